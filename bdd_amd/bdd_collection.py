@@ -1,0 +1,257 @@
+"""Flat BDD interchange format + closed-form QBDD builders.
+
+The storage is bit-compatible with the reference's ``BDD::bdd_collection``
+(reference: include/bdd_collection/bdd_collection.h:14-36,122-288): a flat array of
+``bdd_instruction{size_t lo, hi, index}`` with ABSOLUTE lo/hi indices, one
+``bdd_delimiters`` entry per BDD, nodes grouped by variable in BDD order and the two
+terminals (index == TOPSINK / BOTSINK) last.  This is the *input type* of the hot path
+(SURVEY.md §8 a-0); the HIP library consumes it through ``bddmma_create``.
+
+The builders restate the canned constraints of the reference
+(src/bdd_collection/bdd_collection.cpp:2039-2134 ``simplex_constraint``,
+``not_all_false_constraint`` followed by ``make_qbdd`` :1670-1812) in closed form so
+that benchmark instances can be generated without any reference code on the GPU box.
+tests/test_bdd_builders.py checks them node-for-node against oracle/_ref.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TOPSINK = np.uint64(2**64 - 1)
+BOTSINK = np.uint64(2**64 - 2)
+# local placeholders used inside templates (resolved to absolute indices on append)
+_T = -1  # top sink
+_B = -2  # bot sink
+
+
+class BddCollection:
+    """Growable flat QBDD store (reference: BDD::bdd_collection)."""
+
+    def __init__(self):
+        self._chunks = []  # list of (n,3) uint64 arrays with ABSOLUTE indices
+        self._delims = [np.zeros(1, dtype=np.uint64)]
+        self._n = 0
+        self._nb = 0
+
+    # ------------------------------------------------------------------ access
+    @property
+    def instr(self) -> np.ndarray:
+        if len(self._chunks) != 1:
+            self._chunks = [np.concatenate(self._chunks, axis=0) if self._chunks else np.zeros((0, 3), np.uint64)]
+        return self._chunks[0]
+
+    @property
+    def delims(self) -> np.ndarray:
+        if len(self._delims) != 1:
+            self._delims = [np.concatenate(self._delims)]
+        return self._delims[0]
+
+    def nr_bdds(self) -> int:
+        return self._nb
+
+    def nr_bdd_nodes(self) -> int:
+        return self._n
+
+    def nr_variables(self) -> int:
+        ins = self.instr
+        nt = ins[:, 2] < BOTSINK
+        return int(ins[nt, 2].max()) + 1 if nt.any() else 0
+
+    def variables(self, b: int) -> list:
+        d = self.delims
+        idx = self.instr[int(d[b]):int(d[b + 1]), 2]
+        idx = idx[idx < BOTSINK]
+        out = []
+        for v in idx.tolist():
+            if not out or out[-1] != v:
+                out.append(v)
+        return out
+
+    # ---------------------------------------------------------------- building
+    def _append_local(self, lo, hi, var_of_node, n_bdds, nodes_per_bdd, top_first):
+        """Append n_bdds BDDs that share one local template.
+
+        lo/hi: (n_bdds, nodes_per_bdd) int64 local child indices (or _T/_B);
+        var_of_node: (n_bdds, nodes_per_bdd) uint64 global variable ids.
+        Two terminals are appended after the nodes of every BDD.
+        """
+        per = nodes_per_bdd + 2
+        base = self._n + np.arange(n_bdds, dtype=np.int64)[:, None] * per
+        top_local = nodes_per_bdd + (0 if top_first else 1)
+        bot_local = nodes_per_bdd + (1 if top_first else 0)
+
+        def resolve(x):
+            x = np.where(x == _T, top_local, x)
+            x = np.where(x == _B, bot_local, x)
+            return (x + base).astype(np.uint64)
+
+        out = np.empty((n_bdds, per, 3), dtype=np.uint64)
+        out[:, :nodes_per_bdd, 0] = resolve(lo)
+        out[:, :nodes_per_bdd, 1] = resolve(hi)
+        out[:, :nodes_per_bdd, 2] = var_of_node
+        out[:, top_local, :] = TOPSINK
+        out[:, bot_local, :] = BOTSINK
+        self._chunks.append(out.reshape(-1, 3))
+        self._delims.append((self._n + (np.arange(n_bdds, dtype=np.int64) + 1) * per).astype(np.uint64))
+        first = self._nb
+        self._n += n_bdds * per
+        self._nb += n_bdds
+        return first
+
+    def add_simplex(self, variables) -> int:
+        """sum_i x_i = 1  (bdd_collection.cpp:2039-2103).  variables: (n,) or (n_bdds, n)."""
+        v = np.atleast_2d(np.asarray(variables, dtype=np.uint64))
+        nb, n = v.shape
+        if n == 1:
+            lo = np.full((nb, 1), _B, np.int64)
+            hi = np.full((nb, 1), _T, np.int64)
+            return self._append_local(lo, hi, v, nb, 1, top_first=False)
+        nn = 2 * n - 1
+        lo = np.empty(nn, np.int64)
+        hi = np.empty(nn, np.int64)
+        layer = np.empty(nn, np.int64)
+        lo[0], hi[0], layer[0] = 1, 2, 0
+        for i in range(1, n - 1):
+            a, c = 2 * i - 1, 2 * i  # sum == 0, sum == 1
+            lo[a], hi[a] = 2 * i + 1, 2 * i + 2
+            lo[c], hi[c] = 2 * i + 2, _B
+            layer[a] = layer[c] = i
+        a, c = 2 * n - 3, 2 * n - 2
+        lo[a], hi[a] = _B, _T
+        lo[c], hi[c] = _T, _B
+        layer[a] = layer[c] = n - 1
+        return self._append_local(np.broadcast_to(lo, (nb, nn)), np.broadcast_to(hi, (nb, nn)), v[:, layer], nb, nn,
+                                  top_first=False)
+
+    def add_covering(self, variables) -> int:
+        """sum_i x_i >= 1 as the QBDD that not_all_false_constraint(n) + make_qbdd yields
+        (bdd_collection.cpp:2105-2134, :1670-1812; SURVEY.md §8c dump for n = 4)."""
+        v = np.atleast_2d(np.asarray(variables, dtype=np.uint64))
+        nb, n = v.shape
+        if n == 1:
+            lo = np.full((nb, 1), _B, np.int64)
+            hi = np.full((nb, 1), _T, np.int64)
+            return self._append_local(lo, hi, v, nb, 1, top_first=True)
+        nn = 2 * n - 1
+        lo = np.empty(nn, np.int64)
+        hi = np.empty(nn, np.int64)
+        layer = np.empty(nn, np.int64)
+        lo[0], hi[0], layer[0] = 1, 2, 0
+        for i in range(1, n - 1):
+            a, c = 2 * i - 1, 2 * i  # uncovered, covered
+            lo[a], hi[a] = 2 * i + 1, 2 * i + 2
+            lo[c], hi[c] = 2 * i + 2, 2 * i + 2
+            layer[a] = layer[c] = i
+        a, c = 2 * n - 3, 2 * n - 2
+        lo[a], hi[a] = _B, _T
+        lo[c], hi[c] = _T, _T
+        layer[a] = layer[c] = n - 1
+        return self._append_local(np.broadcast_to(lo, (nb, nn)), np.broadcast_to(hi, (nb, nn)), v[:, layer], nb, nn,
+                                  top_first=True)
+
+    def add_linear(self, coefficients, ineq: str, rhs: int, variables) -> int:
+        """sum_i a_i x_i {<=,=,>=} rhs as the canonical (minimal) QBDD over `variables` in the
+        given order — the function the reference builds with bdd_converter + make_qbdd
+        (bdd_preprocessor.cpp:196-226).  Returns the BDD number, or raises on a constraint that is
+        trivially true/false (the reference skips / throws, :213-216)."""
+        a = [int(c) for c in coefficients]
+        vs = [int(x) for x in variables]
+        n = len(a)
+        assert n == len(vs) and n > 0
+        cmp = {"<=": lambda s: s <= rhs, "=": lambda s: s == rhs, ">=": lambda s: s >= rhs,
+               "<": lambda s: s < rhs, ">": lambda s: s > rhs}[ineq]
+        # level-wise reachable partial sums
+        levels = [{0}]
+        for i in range(n):
+            nxt = set()
+            for s in levels[i]:
+                nxt.add(s)
+                nxt.add(s + a[i])
+            levels.append(nxt)
+        # bottom-up canonical ids: id -1 = top, -2 = bot, else index into level's unique table
+        T, Bt = _T, _B
+        cur = {s: (T if cmp(s) else Bt) for s in levels[n]}
+        tables = [None] * n  # per level: list of (lo_id, hi_id)
+        for i in range(n - 1, -1, -1):
+            uniq = {}
+            tab = []
+            new = {}
+            for s in sorted(levels[i]):
+                key = (cur[s], cur[s + a[i]])
+                if key == (Bt, Bt):
+                    new[s] = Bt
+                    continue
+                if key not in uniq:
+                    uniq[key] = len(tab)
+                    tab.append(key)
+                new[s] = uniq[key]
+            tables[i] = tab
+            cur = new
+        root = cur[0]
+        if root == Bt:
+            raise ValueError("constraint is infeasible")
+        # T appears as a child only at the last level, so a sub-function that is constant TRUE below
+        # level i keeps explicit nodes on every level (QBDD: no level skipping).
+        if all(cmp(s) for s in levels[n]):
+            raise ValueError("constraint is trivially true")
+        # drop nodes unreachable from the root after bot-pruning
+        reach = [set() for _ in range(n)]
+        reach[0].add(root)
+        for i in range(n - 1):
+            for k in reach[i]:
+                for ch in tables[i][k]:
+                    if ch >= 0:
+                        reach[i + 1].add(ch)
+        remap = []
+        offs = []
+        total = 0
+        for i in range(n):
+            order = sorted(reach[i])
+            remap.append({k: j for j, k in enumerate(order)})
+            offs.append(total)
+            total += len(order)
+        lo = np.empty(total, np.int64)
+        hi = np.empty(total, np.int64)
+        layer = np.empty(total, np.int64)
+        for i in range(n):
+            for k, j in remap[i].items():
+                l, h = tables[i][k]
+                lo[offs[i] + j] = l if l < 0 else offs[i + 1] + remap[i + 1][l]
+                hi[offs[i] + j] = h if h < 0 else offs[i + 1] + remap[i + 1][h]
+                layer[offs[i] + j] = i
+        v = np.asarray(vs, dtype=np.uint64)[None, :]
+        return self._append_local(lo[None, :], hi[None, :], v[:, layer], 1, total, top_first=False)
+
+    def add_cardinality(self, variables, k: int) -> int:
+        """sum_i x_i = k (bdd_collection::cardinality_constraint)."""
+        return self.add_linear([1] * len(variables), "=", k, variables)
+
+    def append(self, other: "BddCollection") -> None:
+        ins = other.instr.copy()
+        nt = ins[:, 2] < BOTSINK
+        ins[nt, 0] += np.uint64(self._n)
+        ins[nt, 1] += np.uint64(self._n)
+        self._chunks.append(ins)
+        self._delims.append(other.delims[1:] + np.uint64(self._n))
+        self._n += other._n
+        self._nb += other._nb
+
+    def rebase(self, var_map) -> None:
+        """bdd_collection::rebase: variable i -> var_map[i] for every BDD."""
+        vm = np.asarray(var_map, dtype=np.uint64)
+        ins = self.instr
+        nt = ins[:, 2] < BOTSINK
+        ins[nt, 2] = vm[ins[nt, 2].astype(np.int64)]
+
+    # ------------------------------------------------------------- evaluation
+    def evaluate(self, b: int, x) -> bool:
+        """bdd_collection::evaluate (bdd_collection.h:293-311)."""
+        ins = self.instr
+        i = int(self.delims[b])
+        while True:
+            lo, hi, idx = (int(t) for t in ins[i])
+            if idx == int(TOPSINK):
+                return True
+            if idx == int(BOTSINK):
+                return False
+            i = hi if x[idx] else lo

@@ -1,0 +1,188 @@
+"""0/1 ILP model, a reader for the .lp subset the reference parses, and ILP -> QBDD conversion.
+
+Mirrors (host-side, Python) the input stage either side of the hot path:
+  * ``ILP`` / ``parse_lp``: reference ``LPMP::ILP_input`` + the PEGTL grammar in
+    src/ILP/ILP_parser.cpp:24-140 (``Minimize``, objective terms, ``Subject To``, optionally
+    named rows, ``Bounds`` / ``Binaries`` sections ignored, ``End``).  Variable indices are
+    assigned in order of first appearance, objective first (ILP_parser.cpp:246-254, :316-327).
+  * ``to_bdd_collection``: ``bdd_preprocessor::add_ilp`` (src/bdd_conversion/bdd_preprocessor.cpp:123-336)
+    for linear rows: simplex rows -> ``simplex_constraint`` (:172-188), everything else ->
+    canonical QBDD over the row's variables in the order they are written (:190-226).
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+
+from .bdd_collection import BddCollection
+
+
+@dataclass
+class Constraint:
+    coefficients: List[int]
+    variables: List[int]
+    ineq: str  # "<=", "=", ">="
+    rhs: int
+    name: str = ""
+
+    def is_simplex(self) -> bool:
+        # ILP_input::constraint::is_simplex, src/ILP/ILP_input.cpp:81-93
+        return self.ineq == "=" and self.rhs != 0 and all(c == self.rhs for c in self.coefficients)
+
+
+@dataclass
+class ILP:
+    var_names: List[str] = field(default_factory=list)
+    objective: List[float] = field(default_factory=list)
+    constraints: List[Constraint] = field(default_factory=list)
+    constant: float = 0.0
+    _index: dict = field(default_factory=dict, repr=False)
+
+    def var(self, name: str) -> int:
+        i = self._index.get(name)
+        if i is None:
+            i = len(self.var_names)
+            self._index[name] = i
+            self.var_names.append(name)
+            self.objective.append(0.0)
+        return i
+
+    def nr_variables(self) -> int:
+        return len(self.var_names)
+
+    def add_constraint(self, terms, ineq, rhs, name=""):
+        """terms: iterable of (coeff, var_name_or_index)."""
+        cs, vs = [], []
+        for c, v in terms:
+            cs.append(int(c))
+            vs.append(self.var(v) if isinstance(v, str) else int(v))
+        self.constraints.append(Constraint(cs, vs, ineq, int(rhs), name))
+
+    def evaluate(self, x) -> float:
+        return float(np.dot(self.objective, x)) + self.constant
+
+    def feasible(self, x) -> bool:
+        for c in self.constraints:
+            s = sum(a * int(x[v]) for a, v in zip(c.coefficients, c.variables))
+            ok = s <= c.rhs if c.ineq == "<=" else (s == c.rhs if c.ineq == "=" else s >= c.rhs)
+            if not ok:
+                return False
+        return True
+
+    def write_lp(self) -> str:
+        def term(c, name, first):
+            sign = "-" if c < 0 else ("" if first else "+")
+            mag = abs(c)
+            mag_s = repr(mag) if isinstance(mag, float) and mag != int(mag) else str(int(mag))
+            return f"{sign} {mag_s} {name}".strip()
+
+        lines = ["Minimize"]
+        obj = [term(c, n, i == 0) for i, (c, n) in enumerate(zip(self.objective, self.var_names))]
+        for i in range(0, len(obj), 8):
+            lines.append(" ".join(obj[i:i + 8]))
+        lines.append("Subject To")
+        for c in self.constraints:
+            lhs = " ".join(term(a, self.var_names[v], i == 0) for i, (a, v) in enumerate(zip(c.coefficients, c.variables)))
+            pre = f"{c.name}: " if c.name else ""
+            lines.append(f"{pre}{lhs} {c.ineq} {c.rhs}")
+        lines.append("End")
+        return "\n".join(lines) + "\n"
+
+
+_NUM = r"(?:\d+\.?\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?)"
+_VAR = r"[A-Za-z][A-Za-z0-9_\-/(){},#;\[\].']*"
+_TERM = re.compile(rf"\s*([+-])?\s*({_NUM})?\s*\*?\s*({_VAR})")
+_INEQ = re.compile(r"(<=|>=|=)")
+_SECTION = re.compile(r"^\s*(bounds|binaries|binary|generals|general|coalesce)\s*$", re.I)
+
+
+def _parse_terms(s: str, what: str):
+    terms, pos = [], 0
+    s = s.strip()
+    while pos < len(s):
+        m = _TERM.match(s, pos)
+        if not m or m.end() == pos:
+            rest = s[pos:].strip()
+            if not rest:
+                break
+            raise ValueError(f"cannot parse {what} near '{rest[:40]}'")
+        sign = -1.0 if m.group(1) == "-" else 1.0
+        coeff = float(m.group(2)) if m.group(2) is not None else 1.0
+        terms.append((sign * coeff, m.group(3)))
+        pos = m.end()
+    return terms
+
+
+def parse_lp(text: str) -> ILP:
+    """Parse the .lp subset of the reference's ILP_parser (src/ILP/ILP_parser.cpp:24-140)."""
+    lines = [ln for ln in text.splitlines() if not ln.lstrip().startswith("\\")]
+    body = "\n".join(lines)
+    m = re.search(r"^\s*(Minimize|Minimise|min)\s*$", body, re.I | re.M)
+    if not m:
+        raise ValueError("LP text has no 'Minimize' line")
+    st = re.search(r"^\s*Subject To\s*$|^\s*s\.t\.\s*$|^\s*st\s*$", body[m.end():], re.I | re.M)
+    if not st:
+        raise ValueError("LP text has no 'Subject To' line")
+    obj_text = body[m.end(): m.end() + st.start()]
+    rest = body[m.end() + st.end():]
+    ilp = ILP()
+    obj_text = re.sub(r"^\s*[A-Za-z_][\w]*\s*:", "", obj_text.strip())  # optional objective name
+    # a trailing constant (sign number with no variable) is the objective constant
+    mconst = re.search(rf"([+-])\s*({_NUM})\s*$", obj_text)
+    if mconst and not re.search(rf"{_VAR}\s*$", obj_text):
+        ilp.constant = float(mconst.group(2)) * (-1.0 if mconst.group(1) == "-" else 1.0)
+        obj_text = obj_text[: mconst.start()]
+    for c, name in _parse_terms(obj_text.replace("\n", " "), "objective"):
+        ilp.objective[ilp.var(name)] += c
+    # constraints: a row may span several lines; it ends at the line holding the relation + rhs
+    pending = ""
+    for ln in rest.splitlines():
+        s = ln.strip()
+        if not s:
+            continue
+        if re.match(r"^end\s*$", s, re.I) or _SECTION.match(s):
+            break
+        pending = (pending + " " + s).strip()
+        mi = _INEQ.search(pending)
+        if not mi:
+            continue
+        rhs_s = pending[mi.end():].strip()
+        if not re.fullmatch(rf"[+-]?\s*{_NUM}", rhs_s):
+            continue  # rhs not complete yet
+        lhs = pending[: mi.start()]
+        name = ""
+        mn = re.match(r"^\s*([^\s:]+)\s*:", lhs)
+        if mn:
+            name = mn.group(1)
+            lhs = lhs[mn.end():]
+        terms = _parse_terms(lhs, "constraint")
+        rhs = float(rhs_s.replace(" ", ""))
+        if rhs != int(rhs) or any(c != int(c) for c, _ in terms):
+            raise ValueError("only integer constraint coefficients are supported (as the reference, ILP_parser.cpp:262-300)")
+        ilp.add_constraint([(int(c), n) for c, n in terms], mi.group(1), int(rhs), name)
+        pending = ""
+    if pending:
+        raise ValueError(f"incomplete constraint: '{pending[:60]}'")
+    return ilp
+
+
+def to_bdd_collection(ilp: ILP) -> BddCollection:
+    """bdd_preprocessor::add_ilp for linear rows (bdd_preprocessor.cpp:165-226).
+    Rows that are trivially true are skipped (:213-214); infeasible rows raise (:215-216)."""
+    col = BddCollection()
+    for c in ilp.constraints:
+        if len(set(c.variables)) != len(c.variables):
+            raise ValueError(f"constraint '{c.name}' repeats a variable")
+        if c.is_simplex():
+            col.add_simplex(c.variables)
+            continue
+        try:
+            col.add_linear(c.coefficients, c.ineq, c.rhs, c.variables)
+        except ValueError as e:
+            if "trivially true" in str(e):
+                continue
+            raise RuntimeError("problem is infeasible") from e
+    return col

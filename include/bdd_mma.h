@@ -1,0 +1,216 @@
+/*
+ * bdd_mma.h — C-ABI of the MI355X-native parallel deferred min-marginal-averaging
+ * (MMA) solver over BDDs.
+ *
+ * This is the drop-in boundary for the reference's GPU relaxation solver
+ * `LPMP::bdd_cuda_parallel_mma<REAL>` and its base `LPMP::bdd_cuda_base<REAL>`
+ * (reference: include/bdd_solver/bdd_cuda_parallel_mma.h:7-52,
+ * include/bdd_solver/bdd_cuda_base.h:58-229).  The reference has no FFI for this
+ * path; the boundary is a compile-time "solver concept" selected by
+ * `"relaxation solver": "cuda parallel mma"` (src/bdd_solver/bdd_solver.cpp:164-176).
+ * Every entry point below names the reference member function it replaces.
+ *
+ * Conventions
+ *  - Nothing but POD crosses the ABI.  All device memory is owned by the handle.
+ *  - Every call returns BDDMMA_OK (0) or a negative error code; the message is
+ *    available from bddmma_last_error().  No C++ exception crosses the ABI.
+ *  - `precision` is BDDMMA_F32 or BDDMMA_F64; "REAL" below means that type.
+ *    Buffers declared `void*` hold REAL elements of the handle's precision.
+ *  - `on_device` != 0 means the buffer is a device pointer on the handle's GPU
+ *    (the reference's thrust::device_vector overloads); 0 means host memory.
+ *  - One handle per problem; handles are independent (own stream, own buffers)
+ *    so one host thread/process per GPU is safe (reference: single stream,
+ *    device 0 hard-coded, include/cuda_utils.h:111-114).
+ *  - Layers: one layer per (BDD, variable) pair = one dual variable.  Terminal
+ *    layers carry no information and are not exposed: nr_layers() equals the
+ *    reference CPU solver's nr_layers() (bdd_parallel_mma_base.cpp:1398-1402),
+ *    i.e. the reference GPU nr_layers() minus nr_bdds().  Per-layer vectors are
+ *    in the solver's internal layer order; bddmma_layer_variables /
+ *    bddmma_layer_bdds give the (variable, BDD) of every entry.
+ */
+#ifndef BDD_MMA_H
+#define BDD_MMA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDDMMA_OK 0
+#define BDDMMA_ERR_INVALID_ARGUMENT (-1)
+#define BDDMMA_ERR_INVALID_BDD (-2)   /* not a QBDD / malformed collection */
+#define BDDMMA_ERR_DEVICE (-3)        /* HIP runtime error */
+#define BDDMMA_ERR_STATE (-4)         /* call not valid in current solver state */
+#define BDDMMA_ERR_UNSUPPORTED (-5)
+#define BDDMMA_ERR_IO (-6)
+
+#define BDDMMA_F32 0
+#define BDDMMA_F64 1
+
+/* Bit-identical to BDD::bdd_instruction {size_t lo, hi, index}
+ * (reference: include/bdd_collection/bdd_collection.h:14-36).  `lo`/`hi` are
+ * ABSOLUTE indices into the instruction array; terminals have
+ * index == BDDMMA_TOPSINK / BDDMMA_BOTSINK. */
+typedef struct bddmma_instruction {
+    uint64_t lo;
+    uint64_t hi;
+    uint64_t index;
+} bddmma_instruction;
+
+#define BDDMMA_TOPSINK UINT64_MAX
+#define BDDMMA_BOTSINK (UINT64_MAX - 1)
+
+typedef struct bddmma_solver bddmma_solver;
+
+/* Tunables of the device layout (0 = default). */
+typedef struct bddmma_options {
+    uint32_t pack_width;       /* max #nodes of one hop inside a wave-sized BDD pack (default 128) */
+    uint32_t wide_pack_width;  /* max #nodes of one hop inside a workgroup-sized pack (default 4096) */
+    uint32_t deterministic;    /* 1: delta accumulation by per-variable gather (bit-reproducible) */
+    uint32_t reserved[5];
+} bddmma_options;
+
+/* ---- construction ------------------------------------------------------- */
+
+/* Replaces bdd_cuda_parallel_mma<REAL>(const BDD::bdd_collection&, const std::vector<double>& costs_hi)
+ * (src/bdd_solver/bdd_cuda_parallel_mma.cu:7-17, bdd_cuda_base.cu:31-53).
+ * `bdd_delims` has n_bdds+1 entries: BDD b occupies instr[bdd_delims[b] .. bdd_delims[b+1]),
+ * nodes grouped by variable in BDD order, the two terminals last (either order).
+ * Every BDD must be a reordered QBDD (bdd_cuda_base.cu:98-99).
+ * costs_hi may be NULL (n_costs = 0): all costs zero. */
+int bddmma_create(bddmma_solver** out, int precision, int device,
+                  const bddmma_instruction* instr, const uint64_t* bdd_delims, uint64_t n_bdds,
+                  const double* costs_hi, uint64_t n_costs, const bddmma_options* opts);
+void bddmma_destroy(bddmma_solver* s);
+
+/* Error text of the last failed call on `s`; with s == NULL the last failed bddmma_create. */
+const char* bddmma_last_error(const bddmma_solver* s);
+
+/* ---- sizes (bdd_cuda_base.h:98-116) -------------------------------------- */
+uint64_t bddmma_nr_variables(const bddmma_solver* s);
+uint64_t bddmma_nr_bdds(const bddmma_solver* s);
+uint64_t bddmma_nr_layers(const bddmma_solver* s);      /* non-terminal layers = #dual variables */
+uint64_t bddmma_nr_bdd_nodes(const bddmma_solver* s);   /* incl. 2 terminals per BDD, as the reference counts */
+uint64_t bddmma_nr_hops(const bddmma_solver* s);        /* length of the longest BDD */
+uint64_t bddmma_nr_packs(const bddmma_solver* s);
+int bddmma_precision(const bddmma_solver* s);
+int bddmma_device(const bddmma_solver* s);
+/* nr_bdds(var): int32[nr_variables] (get_num_bdds_per_var, bdd_cuda_base.h:166) */
+int bddmma_num_bdds_per_var(const bddmma_solver* s, int32_t* out);
+/* (variable, bdd) of every layer in internal layer order (get_primal_variable_index / get_bdd_index) */
+int bddmma_layer_variables(const bddmma_solver* s, int32_t* out);
+int bddmma_layer_bdds(const bddmma_solver* s, int32_t* out);
+/* nodes / layers per hop (get_cum_nr_bdd_nodes_per_hop_dist etc., non-cumulative, nr_hops entries) */
+int bddmma_nodes_per_hop(const bddmma_solver* s, uint64_t* out);
+int bddmma_layers_per_hop(const bddmma_solver* s, uint64_t* out);
+
+/* ---- costs -------------------------------------------------------------- */
+/* update_costs(cost_delta_0, cost_delta_1) (bdd_cuda_base.cu:476-558): cost[layer] += c[var]/nr_bdds(var).
+ * n_lo / n_hi may be 0 (that side untouched) or <= nr_variables; layers of variables >= n are
+ * SET to 0 as in the reference (bdd_cuda_base.cu:465-469).  elem_precision: type of lo/hi buffers. */
+int bddmma_update_costs(bddmma_solver* s, const void* lo, uint64_t n_lo, const void* hi, uint64_t n_hi,
+                        int elem_precision, int on_device);
+/* set_cost(c, var) (bdd_cuda_base.cu:441-455): hi cost of all layers of `var` += c/nr_bdds(var). */
+int bddmma_set_cost(bddmma_solver* s, double c, uint64_t var);
+/* get_solver_costs / set_solver_costs (bdd_cuda_base.cu:1308-1344): REAL[nr_layers] each. */
+int bddmma_get_solver_costs(const bddmma_solver* s, void* lo, void* hi, void* deferred_mm_diff, int on_device);
+int bddmma_set_solver_costs(bddmma_solver* s, const void* lo, const void* hi, const void* deferred_mm_diff, int on_device);
+/* compute_primal_objective_vec (bdd_cuda_base.cu:1352-1362): out[var] = sum over layers of var (hi - lo). */
+int bddmma_primal_objective_vec(bddmma_solver* s, void* out, int on_device);
+
+/* ---- plain sweeps ------------------------------------------------------- */
+int bddmma_forward_run(bddmma_solver* s);   /* bdd_cuda_base.cu:588-612 */
+int bddmma_backward_run(bddmma_solver* s);  /* bdd_cuda_base.cu:669-713 (without path costs) */
+/* lower_bound() (bdd_cuda_base.cu:1243-1251): sum of root costs-from-terminal, accumulated in double. */
+int bddmma_lower_bound(bddmma_solver* s, double* lb);
+/* lower_bound_per_bdd (bdd_cuda_base.cu:1253-1259): REAL[nr_bdds], indexed by BDD number. */
+int bddmma_lower_bound_per_bdd(bddmma_solver* s, void* out, int on_device);
+
+/* ---- parallel MMA (bdd_cuda_parallel_mma.cu) ------------------------------ */
+/* iteration(omega) (:142-153): forward_mm, normalize_delta, backward_mm, normalize_delta on the
+ * solver's own deferred delta. Asynchronous: returns once queued on the handle's stream. */
+int bddmma_iteration(bddmma_solver* s, double omega);
+/* n iterations back to back without host synchronisation. */
+int bddmma_iterations(bddmma_solver* s, double omega, uint64_t n);
+/* forward_mm(omega, delta_lo_hi) / backward_mm (:207-257, :301-346): delta is REAL[2*nr_variables],
+ * interleaved {lo,hi}; read as the values to add, overwritten with the un-normalised sums. */
+int bddmma_forward_mm(bddmma_solver* s, double omega, void* delta_lo_hi, int on_device);
+int bddmma_backward_mm(bddmma_solver* s, double omega, void* delta_lo_hi, int on_device);
+/* normalize_delta (:410-430): delta[i] /= nr_bdds(i/2). */
+int bddmma_normalize_delta(const bddmma_solver* s, void* delta_lo_hi, int on_device);
+/* distribute_delta() (bdd_cuda_base.cu:1396-1436). */
+int bddmma_distribute_delta(bddmma_solver* s);
+/* the solver's deferred delta_lo_hi_ (REAL[2*nr_variables]) */
+int bddmma_get_delta(const bddmma_solver* s, void* out, int on_device);
+
+/* ---- min-marginals and per-BDD solutions -------------------------------- */
+/* min_marginals_cuda(get_sorted) (bdd_cuda_base.cu:716-749): var int32[nr_layers], mm0/mm1 REAL[nr_layers].
+ * sorted != 0: ordered by (variable, bdd) as primal_variable_sorting_order_ (bdd_cuda_base.cu:379-391). */
+int bddmma_min_marginals(bddmma_solver* s, int sorted, int32_t* var, void* mm0, void* mm1, int on_device);
+/* bdds_solution_vec() (bdd_cuda_base.cu:1139-1202): char[nr_layers] argmin path per BDD, internal
+ * layer order (sorted = 0) or (variable,bdd) order (sorted = 1, as bdds_solution(), :1204-1233). */
+int bddmma_bdds_solution(bddmma_solver* s, int sorted, char* sol, int on_device);
+
+/* ---- L-BFGS support (lbfgs.h:22-27) --------------------------------------- */
+/* net_solver_costs() (bdd_cuda_parallel_mma.cu:432-463): hi - lo + deferred mm diff, REAL[nr_layers]. */
+int bddmma_net_solver_costs(const bddmma_solver* s, void* out, int on_device);
+/* make_dual_feasible(g) (bdd_cuda_base.cu:1261-1303): g[layer] -= mean over layers of the same variable. */
+int bddmma_make_dual_feasible(const bddmma_solver* s, void* g, int on_device);
+/* gradient_step(g, step) (bdd_cuda_parallel_mma.h:62-77): hi += step * g. */
+int bddmma_gradient_step(bddmma_solver* s, const void* g, double step_size, int on_device);
+
+/* L-BFGS outer solver wrapping a handle (lbfgs.h:35-111, lbfgs_impl.h). */
+typedef struct bddmma_lbfgs bddmma_lbfgs;
+typedef struct bddmma_lbfgs_params {
+    int32_t history_size;                   /* "history size", default 5 */
+    double init_step_size;                  /* "initial step size", default 1e-6 */
+    double req_rel_lb_increase;             /* "required relative lb increase", default 1e-6 */
+    double step_size_decrease_factor;       /* default 0.8 */
+    double step_size_increase_factor;       /* default 1.1 */
+} bddmma_lbfgs_params;
+int bddmma_lbfgs_create(bddmma_lbfgs** out, bddmma_solver* s, const bddmma_lbfgs_params* p);
+void bddmma_lbfgs_destroy(bddmma_lbfgs* l);
+int bddmma_lbfgs_iteration(bddmma_lbfgs* l);       /* lbfgs::iteration(), lbfgs_impl.h:137-157 */
+int bddmma_lbfgs_update_costs(bddmma_lbfgs* l, const void* lo, uint64_t n_lo, const void* hi, uint64_t n_hi,
+                              int elem_precision, int on_device);  /* lbfgs_impl.h:353-364: also drops history */
+
+/* ---- run_solver (include/run_solver_util.h:10-77) ------------------------- */
+typedef struct bddmma_run_result {
+    uint64_t iterations;
+    double lb_initial;
+    double lb_final;
+    double seconds;
+    int32_t stop_reason; /* 0 max iter, 1 time limit, 2 min improvement, 3 improvement slope, 4 infeasible */
+} bddmma_run_result;
+int bddmma_run_solver(bddmma_solver* s, bddmma_lbfgs* lbfgs_or_null, uint64_t max_iter, double tolerance,
+                      double improvement_slope, double time_limit, int verbose, bddmma_run_result* res);
+
+/* ---- checkpoint (bdd_cuda_base.cu:1486-1550) ------------------------------ */
+int bddmma_save(const bddmma_solver* s, const char* path);
+int bddmma_load(bddmma_solver** out, int device, const char* path);
+
+/* ---- measurement ---------------------------------------------------------- */
+int bddmma_synchronize(bddmma_solver* s);
+/* Kernel classes timed with hipEvents on the handle's stream when profiling is on. */
+#define BDDMMA_K_FORWARD_MM 0
+#define BDDMMA_K_BACKWARD_MM 1
+#define BDDMMA_K_FINISH_DELTA 2
+#define BDDMMA_K_OTHER 3
+#define BDDMMA_K_COUNT 4
+typedef struct bddmma_profile {
+    uint64_t launches[BDDMMA_K_COUNT];
+    double total_ms[BDDMMA_K_COUNT];
+} bddmma_profile;
+int bddmma_set_profiling(bddmma_solver* s, int on);  /* resets the counters */
+int bddmma_get_profile(bddmma_solver* s, bddmma_profile* out);  /* synchronises */
+/* Run n iterations bracketed by hipEvents on the handle's stream; *ms = elapsed device time. */
+int bddmma_time_iterations(bddmma_solver* s, double omega, uint64_t n, double* ms);
+/* HBM bytes held by the handle. */
+uint64_t bddmma_device_bytes(const bddmma_solver* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BDD_MMA_H */
