@@ -131,7 +131,8 @@ class BddCollection:
         if n == 1:
             lo = np.full((nb, 1), _B, np.int64)
             hi = np.full((nb, 1), _T, np.int64)
-            return self._append_local(lo, hi, v, nb, 1, top_first=True)
+            # a single-node not_all_false BDD already is a QBDD: make_qbdd is skipped, sinks stay bot, top
+            return self._append_local(lo, hi, v, nb, 1, top_first=False)
         nn = 2 * n - 1
         lo = np.empty(nn, np.int64)
         hi = np.empty(nn, np.int64)
@@ -202,6 +203,13 @@ class BddCollection:
                 for ch in tables[i][k]:
                     if ch >= 0:
                         reach[i + 1].add(ch)
+        # A variable the function does not depend on is absent from the reference's BDD: the reduced
+        # BDD built by bdd_mgr does not contain it and make_qbdd only fills in variables that occur.
+        # Such a variable has lo == hi on every node of its level; f is then the row without that term.
+        dead = [i for i in range(n) if all(tables[i][k][0] == tables[i][k][1] for k in reach[i])]
+        if dead:
+            keep = [i for i in range(n) if i not in set(dead)]
+            return self.add_linear([a[i] for i in keep], ineq, rhs, [vs[i] for i in keep])
         remap = []
         offs = []
         total = 0

@@ -1,0 +1,134 @@
+"""ctypes binding of the C-ABI library (include/bdd_mma.h).
+
+This is the binding a maintainer of a Python front-end (the reference's `bdd_solver_py`,
+src/bdd_solver/bdd_solver_py.cpp:9-20) would add.  It loads the in-tree
+bdd_amd/csrc/libbdd_mma_hip.so and fails loudly if the library is missing: there is no
+CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbdd_mma_hip.so")
+
+OK = 0
+F32, F64 = 0, 1
+K_FORWARD_MM, K_BACKWARD_MM, K_FINISH_DELTA, K_OTHER, K_COUNT = 0, 1, 2, 3, 4
+
+
+class Options(C.Structure):
+    _fields_ = [("pack_width", C.c_uint32), ("wide_pack_width", C.c_uint32), ("deterministic", C.c_uint32),
+                ("reserved", C.c_uint32 * 5)]
+
+
+class LbfgsParams(C.Structure):
+    _fields_ = [("history_size", C.c_int32), ("init_step_size", C.c_double), ("req_rel_lb_increase", C.c_double),
+                ("step_size_decrease_factor", C.c_double), ("step_size_increase_factor", C.c_double)]
+
+
+class RunResult(C.Structure):
+    _fields_ = [("iterations", C.c_uint64), ("lb_initial", C.c_double), ("lb_final", C.c_double),
+                ("seconds", C.c_double), ("stop_reason", C.c_int32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("launches", C.c_uint64 * K_COUNT), ("total_ms", C.c_double * K_COUNT)]
+
+
+# every symbol include/bdd_mma.h declares: name -> (restype, argtypes)
+_V, _U64, _I, _D = C.c_void_p, C.c_uint64, C.c_int, C.c_double
+SIGNATURES = {
+    "bddmma_create": (_I, [C.POINTER(_V), _I, _I, _V, _V, _U64, _V, _U64, C.POINTER(Options)]),
+    "bddmma_destroy": (None, [_V]),
+    "bddmma_last_error": (C.c_char_p, [_V]),
+    "bddmma_nr_variables": (_U64, [_V]),
+    "bddmma_nr_bdds": (_U64, [_V]),
+    "bddmma_nr_layers": (_U64, [_V]),
+    "bddmma_nr_bdd_nodes": (_U64, [_V]),
+    "bddmma_nr_hops": (_U64, [_V]),
+    "bddmma_nr_packs": (_U64, [_V]),
+    "bddmma_precision": (_I, [_V]),
+    "bddmma_device": (_I, [_V]),
+    "bddmma_num_bdds_per_var": (_I, [_V, _V]),
+    "bddmma_layer_variables": (_I, [_V, _V]),
+    "bddmma_layer_bdds": (_I, [_V, _V]),
+    "bddmma_nodes_per_hop": (_I, [_V, _V]),
+    "bddmma_layers_per_hop": (_I, [_V, _V]),
+    "bddmma_update_costs": (_I, [_V, _V, _U64, _V, _U64, _I, _I]),
+    "bddmma_set_cost": (_I, [_V, _D, _U64]),
+    "bddmma_get_solver_costs": (_I, [_V, _V, _V, _V, _I]),
+    "bddmma_set_solver_costs": (_I, [_V, _V, _V, _V, _I]),
+    "bddmma_primal_objective_vec": (_I, [_V, _V, _I]),
+    "bddmma_forward_run": (_I, [_V]),
+    "bddmma_backward_run": (_I, [_V]),
+    "bddmma_lower_bound": (_I, [_V, C.POINTER(_D)]),
+    "bddmma_lower_bound_per_bdd": (_I, [_V, _V, _I]),
+    "bddmma_iteration": (_I, [_V, _D]),
+    "bddmma_iterations": (_I, [_V, _D, _U64]),
+    "bddmma_forward_mm": (_I, [_V, _D, _V, _I]),
+    "bddmma_backward_mm": (_I, [_V, _D, _V, _I]),
+    "bddmma_normalize_delta": (_I, [_V, _V, _I]),
+    "bddmma_distribute_delta": (_I, [_V]),
+    "bddmma_get_delta": (_I, [_V, _V, _I]),
+    "bddmma_set_delta": (_I, [_V, _V, _I]),
+    "bddmma_min_marginals": (_I, [_V, _I, _V, _V, _V, _I]),
+    "bddmma_bdds_solution": (_I, [_V, _I, _V, _I]),
+    "bddmma_net_solver_costs": (_I, [_V, _V, _I]),
+    "bddmma_make_dual_feasible": (_I, [_V, _V, _I]),
+    "bddmma_gradient_step": (_I, [_V, _V, _D, _I]),
+    "bddmma_lbfgs_create": (_I, [C.POINTER(_V), _V, C.POINTER(LbfgsParams)]),
+    "bddmma_lbfgs_destroy": (None, [_V]),
+    "bddmma_lbfgs_iteration": (_I, [_V]),
+    "bddmma_lbfgs_update_costs": (_I, [_V, _V, _U64, _V, _U64, _I, _I]),
+    "bddmma_run_solver": (_I, [_V, _V, _U64, _D, _D, _D, _I, C.POINTER(RunResult)]),
+    "bddmma_save": (_I, [_V, C.c_char_p]),
+    "bddmma_load": (_I, [C.POINTER(_V), _I, C.c_char_p]),
+    "bddmma_synchronize": (_I, [_V]),
+    "bddmma_set_profiling": (_I, [_V, _I]),
+    "bddmma_get_profile": (_I, [_V, C.POINTER(Profile)]),
+    "bddmma_time_iterations": (_I, [_V, _D, _U64, C.POINTER(_D)]),
+    "bddmma_device_bytes": (_U64, [_V]),
+    "bddmma_layout_create": (_I, [C.POINTER(_V), _V, _V, _U64, C.POINTER(Options)]),
+    "bddmma_layout_destroy": (None, [_V]),
+    "bddmma_layout_size": (_U64, [_V, _I]),
+    "bddmma_layout_copy": (_I, [_V, _I, _V]),
+}
+
+_lib = None
+
+
+def build(verbose: bool = False) -> None:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("building libbdd_mma_hip.so failed:\n" + out.stdout + out.stderr)
+    if verbose:
+        print(out.stdout)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `make -C bdd_amd/csrc` (or __graft_entry__.build()); "
+                               "bdd_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+class BddMmaError(RuntimeError):
+    pass
+
+
+def check(rc: int, handle=None):
+    if rc != OK:
+        msg = lib().bddmma_last_error(handle)
+        raise BddMmaError(f"bdd_mma error {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,636 @@
+// bdd_mma_hip.hip — solver object + C-ABI (include/bdd_mma.h) of the MI355X-native
+// parallel deferred min-marginal-averaging solver.  gfx950 only; there is no CPU fallback:
+// every compute entry point fails with BDDMMA_ERR_DEVICE when no HIP device is usable.
+//
+// Mirrors LPMP::bdd_cuda_parallel_mma<REAL> / bdd_cuda_base<REAL>
+// (reference: src/bdd_solver/bdd_cuda_parallel_mma.cu, src/bdd_solver/bdd_cuda_base.cu).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/bdd_mma.h"
+#include "kernels.hpp"
+#include "layout.hpp"
+#include "solver.hpp"
+
+namespace bddmma {
+
+thread_local std::string g_create_error;
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            err = std::string(#expr) + ": " + hipGetErrorString(e_);                                   \
+            return BDDMMA_ERR_DEVICE;                                                                  \
+        }                                                                                              \
+    } while (0)
+
+static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+template <typename REAL>
+struct SolverT final : SolverBase {
+    // device buffers
+    uint32_t* d_nwords = nullptr;
+    uint64_t* d_wwords = nullptr;
+    REAL *d_F = nullptr, *d_T = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_mm = nullptr;
+    int32_t *d_var = nullptr, *d_bdd = nullptr, *d_nbdds = nullptr;
+    uint32_t *d_var_ptr = nullptr, *d_var_layers = nullptr, *d_root_slot = nullptr;
+    REAL *d_delta_a = nullptr, *d_delta_b = nullptr;  // solver's own deferred delta (in / accumulator)
+    REAL *d_delta_c = nullptr, *d_delta_d = nullptr;  // scratch for the explicit forward_mm/backward_mm API
+    double *d_lb_partial = nullptr, *d_lb = nullptr;
+    REAL *d_tmp0 = nullptr, *d_tmp1 = nullptr;        // per-layer scratch (min-marginals, sorted outputs)
+    char* d_sol = nullptr;
+    struct PackBufs {
+        uint32_t *pack_hop_ptr = nullptr, *hop_node_off = nullptr, *hop_layer_off = nullptr;
+        uint8_t* pack_steps = nullptr;
+        uint32_t n_packs = 0;
+    } nb_, wb_;
+    uint32_t wide_lds = 0;
+
+    std::vector<void*> allocs;
+
+    ~SolverT() override
+    {
+        if (device >= 0) (void)hipSetDevice(device);
+        for (void* p : allocs) (void)hipFree(p);
+        for (auto& e : ev_pool) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        if (ev_t0) (void)hipEventDestroy(ev_t0);
+        if (ev_t1) (void)hipEventDestroy(ev_t1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    template <typename T>
+    int dalloc(T** p, uint64_t n)
+    {
+        const uint64_t bytes = std::max<uint64_t>(n, 1) * sizeof(T);
+        HIPCHK(hipMalloc((void**)p, bytes));
+        allocs.push_back(*p);
+        dev_bytes += bytes;
+        return BDDMMA_OK;
+    }
+    template <typename T>
+    int upload(T** p, const std::vector<T>& h)
+    {
+        int rc = dalloc(p, h.size());
+        if (rc) return rc;
+        if (!h.empty()) HIPCHK(hipMemcpyAsync(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+        return BDDMMA_OK;
+    }
+    int upload_packs(PackBufs& b, const PackSet& ps)
+    {
+        b.n_packs = ps.n_packs();
+        int rc;
+        if ((rc = upload(&b.pack_hop_ptr, ps.pack_hop_ptr))) return rc;
+        if ((rc = upload(&b.hop_node_off, ps.hop_node_off))) return rc;
+        if ((rc = upload(&b.hop_layer_off, ps.hop_layer_off))) return rc;
+        if ((rc = upload(&b.pack_steps, ps.pack_steps))) return rc;
+        return BDDMMA_OK;
+    }
+
+    int init(const HostLayout& L, const bddmma_options* opts)
+    {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&ev_t0));
+        HIPCHK(hipEventCreate(&ev_t1));
+        n_vars = L.n_vars; n_bdds = L.n_bdds; n_layers = L.n_layers; n_hops = L.n_hops;
+        n_input_nodes = L.n_input_nodes; n_slots = L.n_slots; pack_width = L.pack_width;
+        wide_pack_width = L.wide_pack_width;
+        nodes_per_hop = L.nodes_per_hop; layers_per_hop = L.layers_per_hop;
+        h_nbdds = L.num_bdds_per_var; h_var_ptr = L.var_ptr;
+        h_layer_var = L.layer_var; h_layer_bdd = L.layer_bdd;
+        deterministic = opts && opts->deterministic;
+        int rc;
+        if ((rc = upload(&d_nwords, L.narrow_words))) return rc;
+        if ((rc = upload(&d_wwords, L.wide_words))) return rc;
+        if ((rc = upload(&d_var, L.layer_var))) return rc;
+        if ((rc = upload(&d_bdd, L.layer_bdd))) return rc;
+        if ((rc = upload(&d_nbdds, L.num_bdds_per_var))) return rc;
+        if ((rc = upload(&d_var_ptr, L.var_ptr))) return rc;
+        if ((rc = upload(&d_var_layers, L.var_layers))) return rc;
+        if ((rc = upload(&d_root_slot, L.bdd_root_slot))) return rc;
+        if ((rc = upload_packs(nb_, L.narrow))) return rc;
+        if ((rc = upload_packs(wb_, L.wide))) return rc;
+        wide_slot_base = L.narrow_slots;
+        if ((rc = dalloc(&d_F, n_slots))) return rc;
+        if ((rc = dalloc(&d_T, n_slots))) return rc;
+        if ((rc = dalloc(&d_lo, n_layers))) return rc;
+        if ((rc = dalloc(&d_hi, n_layers))) return rc;
+        if ((rc = dalloc(&d_mm, n_layers))) return rc;
+        if ((rc = dalloc(&d_tmp0, n_layers))) return rc;
+        if ((rc = dalloc(&d_tmp1, n_layers))) return rc;
+        if ((rc = dalloc(&d_sol, n_layers))) return rc;
+        if ((rc = dalloc(&d_delta_a, 2 * n_vars))) return rc;
+        if ((rc = dalloc(&d_delta_b, 2 * n_vars))) return rc;
+        if ((rc = dalloc(&d_delta_c, 2 * n_vars))) return rc;
+        if ((rc = dalloc(&d_delta_d, 2 * n_vars))) return rc;
+        if ((rc = dalloc(&d_lb_partial, nb_.n_packs + wb_.n_packs))) return rc;
+        if ((rc = dalloc(&d_lb, 1))) return rc;
+        HIPCHK(hipMemsetAsync(d_F, 0, n_slots * sizeof(REAL), stream));
+        HIPCHK(hipMemsetAsync(d_T, 0, n_slots * sizeof(REAL), stream));
+        HIPCHK(hipMemsetAsync(d_lo, 0, n_layers * sizeof(REAL), stream));
+        HIPCHK(hipMemsetAsync(d_hi, 0, n_layers * sizeof(REAL), stream));
+        HIPCHK(hipMemsetAsync(d_mm, 0, n_layers * sizeof(REAL), stream));  // bdd_cuda_base.cu:45
+        for (REAL* p : {d_delta_a, d_delta_b, d_delta_c, d_delta_d}) HIPCHK(hipMemsetAsync(p, 0, 2 * n_vars * sizeof(REAL), stream));
+        if (wb_.n_packs) {
+            wide_lds = (uint32_t)wide_lds_bytes(sizeof(REAL), wide_pack_width, true);
+            if (wide_lds > 160 * 1024) {
+                err = "wide_pack_width needs " + std::to_string(wide_lds) + " B of LDS (> 160 KiB)";
+                return BDDMMA_ERR_UNSUPPORTED;
+            }
+#define SET_LDS(K) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds))
+            SET_LDS((k_fwd_wide<REAL, FWD_PLAIN>));
+            SET_LDS((k_fwd_wide<REAL, FWD_SOLVE>));
+            SET_LDS((k_fwd_wide<REAL, FWD_SOLUTION>));
+            SET_LDS((k_bwd_wide<REAL, BWD_PLAIN>));
+            SET_LDS((k_bwd_wide<REAL, BWD_SOLVE>));
+            SET_LDS((k_bwd_wide<REAL, BWD_MARGINALS>));
+#undef SET_LDS
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        return BDDMMA_OK;
+    }
+
+    // ---------------------------------------------------------------------------- launches
+    DevPtrs<REAL> ptrs(const REAL* din, REAL* dout) const
+    {
+        DevPtrs<REAL> d;
+        d.nwords = d_nwords; d.wwords = d_wwords; d.wide_slot_base = wide_slot_base;
+        d.F = d_F; d.T = d_T; d.lo = d_lo; d.hi = d_hi; d.mm = d_mm; d.var = d_var;
+        d.delta_in = din; d.delta_out = dout; d.lb_partial = d_lb_partial;
+        d.mm0_out = d_tmp0; d.mm1_out = d_tmp1; d.sol_out = d_sol;
+        return d;
+    }
+    static PackDev pdev(const PackBufs& b, uint32_t lb_base)
+    {
+        return PackDev{b.pack_hop_ptr, b.hop_node_off, b.hop_layer_off, b.pack_steps, b.n_packs, lb_base};
+    }
+
+    template <int MODE>
+    int launch_fwd(const REAL* din, REAL* dout, REAL omega, int kclass)
+    {
+        DevPtrs<REAL> d = ptrs(din, dout);
+        prof_begin(kclass);
+        if (nb_.n_packs) {
+            const PackDev pk = pdev(nb_, 0);
+            const dim3 grid(8 * cdiv(nb_.n_packs, 8)), block(64);
+            switch (pack_width) {
+                case 64: hipLaunchKernelGGL((k_fwd_narrow<REAL, 1, MODE>), grid, block, 0, stream, d, pk, omega); break;
+                case 128: hipLaunchKernelGGL((k_fwd_narrow<REAL, 2, MODE>), grid, block, 0, stream, d, pk, omega); break;
+                default: hipLaunchKernelGGL((k_fwd_narrow<REAL, 4, MODE>), grid, block, 0, stream, d, pk, omega); break;
+            }
+        }
+        if (wb_.n_packs) {
+            const PackDev pk = pdev(wb_, nb_.n_packs);
+            hipLaunchKernelGGL((k_fwd_wide<REAL, MODE>), dim3(wb_.n_packs), dim3(WIDE_THREADS), wide_lds, stream, d, pk, omega, wide_pack_width);
+        }
+        prof_end(kclass);
+        HIPCHK(hipGetLastError());
+        return BDDMMA_OK;
+    }
+    template <int MODE>
+    int launch_bwd(const REAL* din, REAL* dout, REAL omega, int kclass)
+    {
+        DevPtrs<REAL> d = ptrs(din, dout);
+        prof_begin(kclass);
+        if (nb_.n_packs) {
+            const PackDev pk = pdev(nb_, 0);
+            const dim3 grid(8 * cdiv(nb_.n_packs, 8)), block(64);
+            switch (pack_width) {
+                case 64: hipLaunchKernelGGL((k_bwd_narrow<REAL, 1, MODE>), grid, block, 0, stream, d, pk, omega); break;
+                case 128: hipLaunchKernelGGL((k_bwd_narrow<REAL, 2, MODE>), grid, block, 0, stream, d, pk, omega); break;
+                default: hipLaunchKernelGGL((k_bwd_narrow<REAL, 4, MODE>), grid, block, 0, stream, d, pk, omega); break;
+            }
+        }
+        if (wb_.n_packs) {
+            const PackDev pk = pdev(wb_, nb_.n_packs);
+            hipLaunchKernelGGL((k_bwd_wide<REAL, MODE>), dim3(wb_.n_packs), dim3(WIDE_THREADS), wide_lds, stream, d, pk, omega, wide_pack_width);
+        }
+        prof_end(kclass);
+        HIPCHK(hipGetLastError());
+        return BDDMMA_OK;
+    }
+    int finish_delta(REAL* din, REAL* dout)
+    {
+        // deterministic mode: the pass did not accumulate; gather per variable from mm first
+        if (deterministic) {
+            prof_begin(BDDMMA_K_FINISH_DELTA);
+            hipLaunchKernelGGL((k_delta_gather<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm, d_var_ptr, d_var_layers, dout, (uint32_t)n_vars);
+            prof_end(BDDMMA_K_FINISH_DELTA);
+        }
+        prof_begin(BDDMMA_K_FINISH_DELTA);
+        hipLaunchKernelGGL((k_finish_delta<REAL>), dim3(cdiv(2 * n_vars, 256)), dim3(256), 0, stream, din, dout, d_nbdds, (uint32_t)(2 * n_vars));
+        prof_end(BDDMMA_K_FINISH_DELTA);
+        HIPCHK(hipGetLastError());
+        return BDDMMA_OK;
+    }
+
+    // ---------------------------------------------------------------------------- SolverBase
+    int forward_run() override
+    {
+        if (fwd_valid) return BDDMMA_OK;
+        HIPCHK(hipSetDevice(device));
+        int rc = launch_fwd<FWD_PLAIN>(nullptr, nullptr, REAL(0), BDDMMA_K_OTHER);
+        if (rc) return rc;
+        fwd_valid = true;
+        return BDDMMA_OK;
+    }
+    int backward_run() override
+    {
+        if (bwd_valid) return BDDMMA_OK;
+        HIPCHK(hipSetDevice(device));
+        int rc = launch_bwd<BWD_PLAIN>(nullptr, nullptr, REAL(0), BDDMMA_K_OTHER);
+        if (rc) return rc;
+        bwd_valid = true;
+        return BDDMMA_OK;
+    }
+    int lower_bound(double* lb) override
+    {
+        int rc = backward_run();
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_lb_reduce, dim3(1), dim3(1024), 0, stream, d_lb_partial, nb_.n_packs + wb_.n_packs, d_lb);
+        HIPCHK(hipMemcpyAsync(lb, d_lb, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return BDDMMA_OK;
+    }
+    int lower_bound_per_bdd(void* out, int on_device) override
+    {
+        int rc = backward_run();
+        if (rc) return rc;
+        REAL* tmp = nullptr;
+        REAL* dst = (REAL*)out;
+        if (!on_device) { HIPCHK(hipMalloc((void**)&tmp, n_bdds * sizeof(REAL))); dst = tmp; }
+        hipLaunchKernelGGL((k_lb_per_bdd<REAL>), dim3(cdiv(n_bdds, 256)), dim3(256), 0, stream, d_T, d_root_slot, dst, (uint32_t)n_bdds);
+        if (!on_device) {
+            hipError_t e = hipMemcpyAsync(out, tmp, n_bdds * sizeof(REAL), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            (void)hipFree(tmp);
+            HIPCHK(e);
+        }
+        return BDDMMA_OK;
+    }
+
+    int mma_forward(REAL omega, REAL* din, REAL* dout)
+    {
+        int rc;
+        if (!bwd_valid && (rc = backward_run())) return rc;  // bdd_cuda_parallel_mma.cu:211-212
+        rc = launch_fwd<FWD_SOLVE>(din, deterministic ? nullptr : dout, omega, BDDMMA_K_FORWARD_MM);
+        if (rc) return rc;
+        fwd_valid = true;
+        bwd_valid = false;
+        return BDDMMA_OK;
+    }
+    int mma_backward(REAL omega, REAL* din, REAL* dout)
+    {
+        if (!fwd_valid) {
+            err = "backward_mm requires a valid forward state (call forward_mm first)";  // assert at :304
+            return BDDMMA_ERR_STATE;
+        }
+        int rc = launch_bwd<BWD_SOLVE>(din, deterministic ? nullptr : dout, omega, BDDMMA_K_BACKWARD_MM);
+        if (rc) return rc;
+        fwd_valid = false;
+        bwd_valid = true;
+        return BDDMMA_OK;
+    }
+    int iteration(double omega) override
+    {
+        HIPCHK(hipSetDevice(device));
+        int rc;
+        // delta_a = deferred delta (normalised), delta_b = accumulator (zero between passes)
+        if ((rc = mma_forward((REAL)omega, d_delta_a, d_delta_b))) return rc;
+        if ((rc = finish_delta(d_delta_a, d_delta_b))) return rc;
+        if ((rc = mma_backward((REAL)omega, d_delta_a, d_delta_b))) return rc;
+        if ((rc = finish_delta(d_delta_a, d_delta_b))) return rc;
+        return BDDMMA_OK;
+    }
+    int explicit_mm(bool forward, double omega, void* delta, int on_device)
+    {
+        HIPCHK(hipSetDevice(device));
+        const size_t bytes = 2 * n_vars * sizeof(REAL);
+        HIPCHK(hipMemcpyAsync(d_delta_c, delta, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemsetAsync(d_delta_d, 0, bytes, stream));
+        int rc = forward ? mma_forward((REAL)omega, d_delta_c, d_delta_d) : mma_backward((REAL)omega, d_delta_c, d_delta_d);
+        if (rc) return rc;
+        if (deterministic)
+            hipLaunchKernelGGL((k_delta_gather<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm, d_var_ptr, d_var_layers, d_delta_d, (uint32_t)n_vars);
+        HIPCHK(hipMemcpyAsync(delta, d_delta_d, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return BDDMMA_OK;
+    }
+    int forward_mm(double omega, void* delta, int on_device) override { return explicit_mm(true, omega, delta, on_device); }
+    int backward_mm(double omega, void* delta, int on_device) override { return explicit_mm(false, omega, delta, on_device); }
+
+    int normalize_delta(void* delta, int on_device) override
+    {
+        HIPCHK(hipSetDevice(device));
+        const size_t bytes = 2 * n_vars * sizeof(REAL);
+        REAL* p = (REAL*)delta;
+        if (!on_device) { p = d_delta_c; HIPCHK(hipMemcpyAsync(p, delta, bytes, hipMemcpyHostToDevice, stream)); }
+        hipLaunchKernelGGL((k_normalize_delta<REAL>), dim3(cdiv(2 * n_vars, 256)), dim3(256), 0, stream, p, d_nbdds, (uint32_t)(2 * n_vars));
+        if (!on_device) HIPCHK(hipMemcpyAsync(delta, p, bytes, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return BDDMMA_OK;
+    }
+    int distribute_delta() override
+    {
+        HIPCHK(hipSetDevice(device));
+        hipLaunchKernelGGL((k_distribute_delta<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lo, d_hi, d_mm, (uint32_t)n_layers);
+        HIPCHK(hipMemsetAsync(d_delta_a, 0, 2 * n_vars * sizeof(REAL), stream));  // bdd_cuda_base.cu:1428
+        fwd_valid = bwd_valid = false;
+        HIPCHK(hipGetLastError());
+        return BDDMMA_OK;
+    }
+    int get_delta(void* out, int on_device) override
+    {
+        HIPCHK(hipMemcpyAsync(out, d_delta_a, 2 * n_vars * sizeof(REAL), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return BDDMMA_OK;
+    }
+
+    int set_delta(const void* in, int on_device) override
+    {
+        HIPCHK(hipMemcpyAsync(d_delta_a, in, 2 * n_vars * sizeof(REAL), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return BDDMMA_OK;
+    }
+
+    template <typename TIN>
+    int update_side(REAL* cost, const void* c, uint64_t n, int on_device)
+    {
+        if (n == 0) return BDDMMA_OK;
+        if (n > n_vars) { err = "cost vector longer than nr_variables()"; return BDDMMA_ERR_INVALID_ARGUMENT; }
+        const TIN* dc = (const TIN*)c;
+        TIN* tmp = nullptr;
+        if (!on_device) {
+            HIPCHK(hipMalloc((void**)&tmp, n * sizeof(TIN)));
+            hipError_t e = hipMemcpyAsync(tmp, c, n * sizeof(TIN), hipMemcpyHostToDevice, stream);
+            if (e != hipSuccess) { (void)hipFree(tmp); HIPCHK(e); }
+            dc = tmp;
+        }
+        hipLaunchKernelGGL((k_update_costs<REAL, TIN>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, cost, d_var, d_nbdds, dc, n, (uint32_t)n_layers);
+        if (tmp) { HIPCHK(hipStreamSynchronize(stream)); (void)hipFree(tmp); }
+        return BDDMMA_OK;
+    }
+    int update_costs(const void* lo, uint64_t n_lo, const void* hi, uint64_t n_hi, int elem_precision, int on_device) override
+    {
+        HIPCHK(hipSetDevice(device));
+        int rc;
+        if (elem_precision == BDDMMA_F64) {
+            if ((rc = update_side<double>(d_lo, lo, n_lo, on_device))) return rc;
+            if ((rc = update_side<double>(d_hi, hi, n_hi, on_device))) return rc;
+        } else {
+            if ((rc = update_side<float>(d_lo, lo, n_lo, on_device))) return rc;
+            if ((rc = update_side<float>(d_hi, hi, n_hi, on_device))) return rc;
+        }
+        fwd_valid = bwd_valid = false;
+        HIPCHK(hipGetLastError());
+        return BDDMMA_OK;
+    }
+    int set_cost(double c, uint64_t var) override
+    {
+        if (var >= n_vars) { err = "variable out of range"; return BDDMMA_ERR_INVALID_ARGUMENT; }
+        HIPCHK(hipSetDevice(device));
+        const uint32_t k0 = h_var_ptr[var], k1 = h_var_ptr[var + 1];
+        if (k1 > k0) {
+            const REAL cc = REAL(c / (double)(k1 - k0));
+            hipLaunchKernelGGL((k_set_cost<REAL>), dim3(cdiv(k1 - k0, 64)), dim3(64), 0, stream, d_hi, d_var_layers, k0, k1, cc);
+        }
+        fwd_valid = bwd_valid = false;
+        HIPCHK(hipGetLastError());
+        return BDDMMA_OK;
+    }
+    int copy_out(void* dst, const void* src, size_t bytes, int on_device) const
+    {
+        std::string& err = const_cast<std::string&>(this->err);
+        if (!dst) return BDDMMA_OK;
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return BDDMMA_OK;
+    }
+    int get_solver_costs(void* lo, void* hi, void* mm, int on_device) override
+    {
+        int rc;
+        if ((rc = copy_out(lo, d_lo, n_layers * sizeof(REAL), on_device))) return rc;
+        if ((rc = copy_out(hi, d_hi, n_layers * sizeof(REAL), on_device))) return rc;
+        return copy_out(mm, d_mm, n_layers * sizeof(REAL), on_device);
+    }
+    int set_solver_costs(const void* lo, const void* hi, const void* mm, int on_device) override
+    {
+        const hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        if (lo) HIPCHK(hipMemcpyAsync(d_lo, lo, n_layers * sizeof(REAL), k, stream));
+        if (hi) HIPCHK(hipMemcpyAsync(d_hi, hi, n_layers * sizeof(REAL), k, stream));
+        if (mm) HIPCHK(hipMemcpyAsync(d_mm, mm, n_layers * sizeof(REAL), k, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        fwd_valid = bwd_valid = false;
+        return BDDMMA_OK;
+    }
+    int primal_objective_vec(void* out, int on_device) override
+    {
+        HIPCHK(hipSetDevice(device));
+        REAL* dst = on_device ? (REAL*)out : d_delta_c;  // 2V scratch is large enough
+        hipLaunchKernelGGL((k_primal_objective<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_lo, d_hi, d_var_ptr, d_var_layers, dst, (uint32_t)n_vars);
+        if (!on_device) return copy_out(out, dst, n_vars * sizeof(REAL), 0);
+        HIPCHK(hipStreamSynchronize(stream));
+        return BDDMMA_OK;
+    }
+    int min_marginals(int sorted, int32_t* var, void* mm0, void* mm1, int on_device) override
+    {
+        HIPCHK(hipSetDevice(device));
+        int rc;
+        if ((rc = forward_run())) return rc;  // bdd_cuda_base.cu:720
+        if ((rc = launch_bwd<BWD_MARGINALS>(nullptr, nullptr, REAL(0), BDDMMA_K_OTHER))) return rc;
+        bwd_valid = true;
+        const hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        if (!sorted) {
+            if (var) HIPCHK(hipMemcpyAsync(var, d_var, n_layers * sizeof(int32_t), k, stream));
+            if (mm0) HIPCHK(hipMemcpyAsync(mm0, d_tmp0, n_layers * sizeof(REAL), k, stream));
+            if (mm1) HIPCHK(hipMemcpyAsync(mm1, d_tmp1, n_layers * sizeof(REAL), k, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            return BDDMMA_OK;
+        }
+        // gather by primal_variable_sorting_order_ (:737-746); d_mm must stay intact, so use temporaries
+        REAL *s0 = nullptr, *s1 = nullptr;
+        int32_t* sv = nullptr;
+        HIPCHK(hipMalloc((void**)&s0, std::max<uint64_t>(n_layers, 1) * sizeof(REAL)));
+        HIPCHK(hipMalloc((void**)&s1, std::max<uint64_t>(n_layers, 1) * sizeof(REAL)));
+        HIPCHK(hipMalloc((void**)&sv, std::max<uint64_t>(n_layers, 1) * sizeof(int32_t)));
+        const dim3 g(cdiv(n_layers, 256)), b(256);
+        hipLaunchKernelGGL((k_gather<REAL>), g, b, 0, stream, d_tmp0, d_var_layers, s0, (uint32_t)n_layers);
+        hipLaunchKernelGGL((k_gather<REAL>), g, b, 0, stream, d_tmp1, d_var_layers, s1, (uint32_t)n_layers);
+        hipLaunchKernelGGL(k_gather_var, g, b, 0, stream, d_var, d_var_layers, sv, (uint32_t)n_layers);
+        hipError_t e = hipSuccess;
+        if (var && e == hipSuccess) e = hipMemcpyAsync(var, sv, n_layers * sizeof(int32_t), k, stream);
+        if (mm0 && e == hipSuccess) e = hipMemcpyAsync(mm0, s0, n_layers * sizeof(REAL), k, stream);
+        if (mm1 && e == hipSuccess) e = hipMemcpyAsync(mm1, s1, n_layers * sizeof(REAL), k, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(s0); (void)hipFree(s1); (void)hipFree(sv);
+        HIPCHK(e);
+        return BDDMMA_OK;
+    }
+    int bdds_solution(int sorted, char* sol, int on_device) override
+    {
+        HIPCHK(hipSetDevice(device));
+        int rc;
+        if ((rc = backward_run())) return rc;
+        HIPCHK(hipMemsetAsync(d_sol, 0, n_layers, stream));
+        if ((rc = launch_fwd<FWD_SOLUTION>(nullptr, nullptr, REAL(0), BDDMMA_K_OTHER))) return rc;
+        fwd_valid = true;  // the solution sweep recomputes and stores cost-from-root
+        const hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        if (!sorted) {
+            HIPCHK(hipMemcpyAsync(sol, d_sol, n_layers, k, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            return BDDMMA_OK;
+        }
+        char* s = nullptr;
+        HIPCHK(hipMalloc((void**)&s, std::max<uint64_t>(n_layers, 1)));
+        hipLaunchKernelGGL((k_gather<char>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_sol, d_var_layers, s, (uint32_t)n_layers);
+        hipError_t e = hipMemcpyAsync(sol, s, n_layers, k, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(s);
+        HIPCHK(e);
+        return BDDMMA_OK;
+    }
+    int net_solver_costs(void* out, int on_device) override
+    {
+        HIPCHK(hipSetDevice(device));
+        REAL* dst = on_device ? (REAL*)out : d_tmp0;
+        hipLaunchKernelGGL((k_net_costs<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lo, d_hi, d_mm, dst, (uint32_t)n_layers);
+        if (!on_device) return copy_out(out, dst, n_layers * sizeof(REAL), 0);
+        HIPCHK(hipGetLastError());
+        return BDDMMA_OK;
+    }
+    int make_dual_feasible(void* g, int on_device) override
+    {
+        HIPCHK(hipSetDevice(device));
+        REAL* p = (REAL*)g;
+        if (!on_device) { p = d_tmp0; HIPCHK(hipMemcpyAsync(p, g, n_layers * sizeof(REAL), hipMemcpyHostToDevice, stream)); }
+        hipLaunchKernelGGL((k_make_dual_feasible<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, p, d_var_ptr, d_var_layers, (uint32_t)n_vars);
+        if (!on_device) return copy_out(g, p, n_layers * sizeof(REAL), 0);
+        HIPCHK(hipGetLastError());
+        return BDDMMA_OK;
+    }
+    int gradient_step(const void* g, double step, int on_device) override
+    {
+        HIPCHK(hipSetDevice(device));
+        const REAL* p = (const REAL*)g;
+        if (!on_device) { HIPCHK(hipMemcpyAsync(d_tmp0, g, n_layers * sizeof(REAL), hipMemcpyHostToDevice, stream)); p = d_tmp0; }
+        hipLaunchKernelGGL((k_gradient_step<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_hi, p, REAL(step), (uint32_t)n_layers);
+        fwd_valid = bwd_valid = false;
+        HIPCHK(hipGetLastError());
+        return BDDMMA_OK;
+    }
+    void* stream_handle() override { return (void*)stream; }
+};
+
+// ---------------------------------------------------------------------------------------------
+int SolverBase::synchronize()
+{
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(stream));
+    return BDDMMA_OK;
+}
+
+void SolverBase::prof_begin(int kclass)
+{
+    if (!profiling) return;
+    if (ev_used == ev_pool.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { profiling = false; return; }
+        ev_pool.push_back({a, b});
+        ev_class.push_back(kclass);
+    }
+    ev_class[ev_used] = kclass;
+    (void)hipEventRecord(ev_pool[ev_used].first, stream);
+}
+void SolverBase::prof_end(int)
+{
+    if (!profiling) return;
+    (void)hipEventRecord(ev_pool[ev_used].second, stream);
+    ++ev_used;
+}
+int SolverBase::set_profiling(int on)
+{
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(stream));
+    profiling = on != 0;
+    ev_used = 0;
+    return BDDMMA_OK;
+}
+int SolverBase::get_profile(bddmma_profile* out)
+{
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(stream));
+    std::memset(out, 0, sizeof(*out));
+    for (size_t i = 0; i < ev_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
+        out->launches[ev_class[i]]++;
+        out->total_ms[ev_class[i]] += ms;
+    }
+    return BDDMMA_OK;
+}
+int SolverBase::time_iterations(double omega, uint64_t n, double* ms)
+{
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipEventRecord(ev_t0, stream));
+    for (uint64_t i = 0; i < n; ++i) {
+        int rc = iteration(omega);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(ev_t1, stream));
+    HIPCHK(hipEventSynchronize(ev_t1));
+    float f = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, ev_t0, ev_t1));
+    *ms = f;
+    return BDDMMA_OK;
+}
+
+int create_solver(SolverBase** out, int precision, int device, const HostLayout& L, const bddmma_options* opts, std::string& err)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        err = std::string("no HIP device available (") + (e == hipSuccess ? "device count 0" : hipGetErrorString(e)) +
+              "); this library has no CPU fallback";
+        return BDDMMA_ERR_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        err = "device index out of range";
+        return BDDMMA_ERR_INVALID_ARGUMENT;
+    }
+    std::unique_ptr<SolverBase> s;
+    int rc;
+    if (precision == BDDMMA_F32) {
+        auto* t = new SolverT<float>();
+        s.reset(t);
+        t->precision = precision; t->device = device;
+        rc = t->init(L, opts);
+    } else if (precision == BDDMMA_F64) {
+        auto* t = new SolverT<double>();
+        s.reset(t);
+        t->precision = precision; t->device = device;
+        rc = t->init(L, opts);
+    } else {
+        err = "precision must be BDDMMA_F32 or BDDMMA_F64";
+        return BDDMMA_ERR_INVALID_ARGUMENT;
+    }
+    if (rc) {
+        err = s->err;
+        return rc;
+    }
+    *out = s.release();
+    return BDDMMA_OK;
+}
+
+}  // namespace bddmma

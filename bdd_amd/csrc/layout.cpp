@@ -1,0 +1,340 @@
+// layout.cpp — see layout.hpp.
+#include "layout.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <limits>
+
+namespace bddmma {
+
+namespace {
+
+inline bool is_top(const bddmma_instruction& i) { return i.index == BDDMMA_TOPSINK; }
+inline bool is_bot(const bddmma_instruction& i) { return i.index == BDDMMA_BOTSINK; }
+inline bool is_term(const bddmma_instruction& i) { return is_top(i) || is_bot(i); }
+
+struct PackBuilder {
+    // Greedy first-fit in input order: a BDD joins the current pack if, at every hop, its layer
+    // fits below `width` slots without straddling a `group`-slot boundary (group = 64 for narrow
+    // packs so that a layer lives inside one wavefront group; 0 = no such rule).
+    uint32_t width, group;
+    std::vector<uint32_t> used;     // slots used per hop in the open pack
+    std::vector<uint32_t> nlayers;  // layers per hop in the open pack
+    uint32_t maxw = 0;
+    bool open = false;
+
+    // closed packs
+    std::vector<uint32_t> pack_first_bdd;      // index into `order`
+    std::vector<uint32_t> pack_hop_ptr;        // into flat_used / flat_nlayers
+    std::vector<uint32_t> flat_used, flat_nlayers;
+    std::vector<uint8_t> pack_steps;
+
+    static uint8_t steps_for(uint32_t w)
+    {
+        uint8_t s = 0;
+        while ((1u << s) < w) ++s;
+        return s;
+    }
+    void close()
+    {
+        if (!open) return;
+        pack_hop_ptr.push_back((uint32_t)flat_used.size());
+        flat_used.insert(flat_used.end(), used.begin(), used.end());
+        flat_nlayers.insert(flat_nlayers.end(), nlayers.begin(), nlayers.end());
+        pack_steps.push_back(steps_for(maxw));
+        used.clear();
+        nlayers.clear();
+        maxw = 0;
+        open = false;
+    }
+    uint32_t place(uint32_t u, uint32_t w) const
+    {
+        if (group && (u % group) + w > group) u = (u + group - 1) / group * group;
+        return u;
+    }
+    // widths[0..n) = layer widths of the BDD.  Writes the slot position of every layer to pos[].
+    void add(uint32_t order_idx, const uint32_t* widths, uint32_t n, uint32_t* pos)
+    {
+        if (open) {
+            bool fits = true;
+            for (uint32_t h = 0; h < n && fits; ++h) {
+                const uint32_t u = h < used.size() ? used[h] : 0;
+                if (place(u, widths[h]) + widths[h] > width) fits = false;
+            }
+            if (!fits) close();
+        }
+        if (!open) {
+            open = true;
+            pack_first_bdd.push_back(order_idx);
+        }
+        if (used.size() < n) {
+            used.resize(n, 0);
+            nlayers.resize(n, 0);
+        }
+        for (uint32_t h = 0; h < n; ++h) {
+            const uint32_t p = place(used[h], widths[h]);
+            pos[h] = p;
+            used[h] = p + widths[h];
+            nlayers[h]++;
+            maxw = std::max(maxw, widths[h]);
+        }
+    }
+    void finish(uint32_t n_order)
+    {
+        close();
+        pack_first_bdd.push_back(n_order);
+        pack_hop_ptr.push_back((uint32_t)flat_used.size());
+    }
+    uint32_t n_packs() const { return (uint32_t)pack_first_bdd.size() - 1; }
+};
+
+}  // namespace
+
+int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
+                 const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps)
+{
+    L = HostLayout();
+    if (!instr || !delims || n_bdds == 0) {
+        err = "empty BDD collection";
+        return BDDMMA_ERR_INVALID_ARGUMENT;
+    }
+    uint32_t W = opts && opts->pack_width ? opts->pack_width : 128;
+    uint32_t WW = opts && opts->wide_pack_width ? opts->wide_pack_width : 2048;
+    if (W != 64 && W != 128 && W != 256) {
+        err = "pack_width must be 64, 128 or 256";
+        return BDDMMA_ERR_INVALID_ARGUMENT;
+    }
+    if (WW < 64 || WW > 4096) {
+        err = "wide_pack_width must be in [64, 4096]";
+        return BDDMMA_ERR_INVALID_ARGUMENT;
+    }
+    L.pack_width = W;
+    L.wide_pack_width = WW;
+    L.n_bdds = n_bdds;
+    L.n_input_nodes = delims[n_bdds] - delims[0];
+
+    // ---- pass 1: parse + validate every BDD (bdd_cuda_base.cu:86-144) ------------------------
+    std::vector<uint64_t> lay_first;   // first instruction of every input layer (BDD-major)
+    std::vector<uint32_t> bdd_lay_ptr(n_bdds + 1, 0);
+    std::vector<uint32_t> bdd_maxw(n_bdds, 0);
+    uint64_t max_var = 0;
+    for (uint64_t b = 0; b < n_bdds; ++b) {
+        const uint64_t d0 = delims[b], d1 = delims[b + 1];
+        bdd_lay_ptr[b] = (uint32_t)lay_first.size();
+        if (d1 < d0 + 3) {
+            err = "BDD " + std::to_string(b) + " has fewer than 3 entries";
+            return BDDMMA_ERR_INVALID_BDD;
+        }
+        const bddmma_instruction& t0 = instr[d1 - 2];
+        const bddmma_instruction& t1 = instr[d1 - 1];
+        if (!((is_top(t0) && is_bot(t1)) || (is_bot(t0) && is_top(t1)))) {
+            err = "BDD " + std::to_string(b) + ": the last two entries must be the top and bot sinks";
+            return BDDMMA_ERR_INVALID_BDD;
+        }
+        uint64_t prev = BDDMMA_BOTSINK - 7;
+        for (uint64_t i = d0; i < d1 - 2; ++i) {
+            if (is_term(instr[i])) {
+                err = "BDD " + std::to_string(b) + ": terminal entry before the end";
+                return BDDMMA_ERR_INVALID_BDD;
+            }
+            if (instr[i].index != prev) {
+                lay_first.push_back(i);
+                prev = instr[i].index;
+                max_var = std::max(max_var, prev);
+            }
+        }
+        if (lay_first.size() > std::numeric_limits<uint32_t>::max() - 2) {
+            err = "too many layers";
+            return BDDMMA_ERR_UNSUPPORTED;
+        }
+    }
+    bdd_lay_ptr[n_bdds] = (uint32_t)lay_first.size();
+    const uint32_t Lin = (uint32_t)lay_first.size();
+    lay_first.push_back(0);  // sentinel slot, patched per BDD below
+    if (max_var >= (uint64_t)std::numeric_limits<int32_t>::max()) {
+        err = "variable index too large";
+        return BDDMMA_ERR_UNSUPPORTED;
+    }
+    L.n_vars = max_var + 1;
+    L.n_layers = Lin;
+    L.num_bdds_per_var.assign(L.n_vars, 0);
+
+    auto layer_end = [&](uint64_t b, uint32_t l) -> uint64_t {
+        return (l + 1 < bdd_lay_ptr[b + 1]) ? lay_first[l + 1] : delims[b + 1] - 2;
+    };
+    {
+        std::vector<uint64_t> last_bdd(L.n_vars, std::numeric_limits<uint64_t>::max());
+        for (uint64_t b = 0; b < n_bdds; ++b) {
+            const uint64_t d1 = delims[b + 1];
+            const uint32_t l0 = bdd_lay_ptr[b], l1 = bdd_lay_ptr[b + 1];
+            if (layer_end(b, l0) - lay_first[l0] != 1) {
+                err = "BDD " + std::to_string(b) + " does not have exactly one root node";
+                return BDDMMA_ERR_INVALID_BDD;
+            }
+            for (uint32_t l = l0; l < l1; ++l) {
+                const uint64_t f = lay_first[l], e = layer_end(b, l);
+                const uint64_t v = instr[f].index;
+                if (last_bdd[v] == b) {
+                    err = "BDD " + std::to_string(b) + " is not reordered: variable " + std::to_string(v) + " appears in two layers";
+                    return BDDMMA_ERR_INVALID_BDD;
+                }
+                last_bdd[v] = b;
+                L.num_bdds_per_var[v]++;
+                bdd_maxw[b] = std::max<uint32_t>(bdd_maxw[b], (uint32_t)(e - f));
+                const bool last = (l + 1 == l1);
+                const uint64_t nf = last ? 0 : lay_first[l + 1], ne = last ? 0 : layer_end(b, l + 1);
+                for (uint64_t i = f; i < e; ++i) {
+                    for (int side = 0; side < 2; ++side) {
+                        const uint64_t c = side ? instr[i].hi : instr[i].lo;
+                        if (c >= d1 || c < delims[b]) {
+                            err = "BDD " + std::to_string(b) + ": child index out of range";
+                            return BDDMMA_ERR_INVALID_BDD;
+                        }
+                        if (is_bot(instr[c])) continue;
+                        if (is_top(instr[c])) {
+                            if (!last) {
+                                err = "BDD " + std::to_string(b) + " is not a QBDD: arc to the top sink skips variables";
+                                return BDDMMA_ERR_INVALID_BDD;
+                            }
+                            continue;
+                        }
+                        if (last || c < nf || c >= ne) {
+                            err = "BDD " + std::to_string(b) + " is not a QBDD: arc does not go to the next variable's layer";
+                            return BDDMMA_ERR_INVALID_BDD;
+                        }
+                    }
+                }
+            }
+            L.n_hops = std::max<uint64_t>(L.n_hops, l1 - l0);
+        }
+    }
+
+    // ---- pass 2: narrow / wide classification and greedy pack formation ----------------------
+    const uint32_t narrow_limit = std::min<uint32_t>(NARROW_MAX_LAYER_WIDTH, W);
+    std::vector<uint32_t> order_n, order_w;
+    for (uint64_t b = 0; b < n_bdds; ++b) {
+        if (bdd_maxw[b] <= narrow_limit) order_n.push_back((uint32_t)b);
+        else if (bdd_maxw[b] <= WW) order_w.push_back((uint32_t)b);
+        else {
+            err = "BDD " + std::to_string(b) + " has a layer of " + std::to_string(bdd_maxw[b]) +
+                  " nodes; widest supported layer is " + std::to_string(WW) + " (wide_pack_width)";
+            return BDDMMA_ERR_UNSUPPORTED;
+        }
+    }
+    std::vector<uint32_t> lay_pos(Lin);  // slot position of every input layer inside its (pack,hop)
+    PackBuilder pn{W, 64}, pw{WW, 0};
+    std::vector<uint32_t> widths;
+    auto form = [&](PackBuilder& pb, const std::vector<uint32_t>& order) {
+        for (uint32_t k = 0; k < order.size(); ++k) {
+            const uint64_t b = order[k];
+            const uint32_t l0 = bdd_lay_ptr[b], n = bdd_lay_ptr[b + 1] - l0;
+            widths.resize(n);
+            for (uint32_t h = 0; h < n; ++h) widths[h] = (uint32_t)(layer_end(b, l0 + h) - lay_first[l0 + h]);
+            pb.add(k, widths.data(), n, &lay_pos[l0]);
+        }
+        pb.finish((uint32_t)order.size());
+    };
+    form(pn, order_n);
+    form(pw, order_w);
+
+    // ---- pass 3: emit ----------------------------------------------------------------------
+    uint64_t total_slots = 0;
+    for (uint32_t u : pn.flat_used) total_slots += u;
+    const uint64_t narrow_slots = total_slots;
+    for (uint32_t u : pw.flat_used) total_slots += u;
+    if (total_slots >= std::numeric_limits<uint32_t>::max()) {
+        err = "more than 2^32 node slots";
+        return BDDMMA_ERR_UNSUPPORTED;
+    }
+    L.n_slots = total_slots;
+    L.narrow_slots = (uint32_t)narrow_slots;
+    L.narrow_words.assign(narrow_slots, NW_PAD_WORD);
+    L.wide_words.assign(total_slots - narrow_slots, 0);
+    L.layer_var.assign(Lin, 0);
+    L.layer_bdd.assign(Lin, 0);
+    L.bdd_root_slot.assign(n_bdds, 0);
+    L.nodes_per_hop.assign(L.n_hops, 0);
+    L.layers_per_hop.assign(L.n_hops, 0);
+    if (keep_debug_maps) L.slot_to_instr.assign(total_slots, std::numeric_limits<uint64_t>::max());
+    std::vector<uint32_t> in_layer_to_internal(Lin);
+
+    uint32_t slot_cursor = 0, layer_cursor = 0;
+    auto emit = [&](PackBuilder& pb, const std::vector<uint32_t>& order, PackSet& ps, bool wide) {
+        const uint32_t P = pb.n_packs();
+        ps.pack_hop_ptr.resize(P + 1);
+        ps.pack_steps = pb.pack_steps;
+        std::vector<uint32_t> lcount;
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint32_t q0 = pb.pack_hop_ptr[p], q1 = pb.pack_hop_ptr[p + 1];
+            ps.pack_hop_ptr[p] = (uint32_t)ps.hop_node_off.size();
+            const uint32_t H = q1 - q0;
+            const uint32_t base_q = (uint32_t)ps.hop_node_off.size();
+            for (uint32_t h = 0; h < H; ++h) {
+                ps.hop_node_off.push_back(slot_cursor);
+                ps.hop_layer_off.push_back(layer_cursor);
+                slot_cursor += pb.flat_used[q0 + h];
+                layer_cursor += pb.flat_nlayers[q0 + h];
+            }
+            lcount.assign(H, 0);
+            for (uint32_t k = pb.pack_first_bdd[p]; k < pb.pack_first_bdd[p + 1]; ++k) {
+                const uint64_t b = order[k];
+                const uint32_t l0 = bdd_lay_ptr[b], n = bdd_lay_ptr[b + 1] - l0;
+                for (uint32_t h = 0; h < n; ++h) {
+                    const uint32_t l = l0 + h;
+                    const uint64_t f = lay_first[l], e = layer_end(b, l);
+                    const uint32_t lloc = lcount[h]++;
+                    const uint32_t lg = ps.hop_layer_off[base_q + h] + lloc;
+                    in_layer_to_internal[l] = lg;
+                    L.layer_var[lg] = (int32_t)instr[f].index;
+                    L.layer_bdd[lg] = (int32_t)b;
+                    L.nodes_per_hop[h] += e - f;
+                    L.layers_per_hop[h] += 1;
+                    const bool last = (h + 1 == n);
+                    const uint64_t nf = last ? 0 : lay_first[l + 1];
+                    const uint32_t npos = last ? 0 : lay_pos[l + 1];
+                    for (uint64_t i = f; i < e; ++i) {
+                        const uint32_t j = lay_pos[l] + (uint32_t)(i - f);
+                        const uint32_t slot = ps.hop_node_off[base_q + h] + j;
+                        if (h == 0) L.bdd_root_slot[b] = slot;
+                        if (keep_debug_maps) L.slot_to_instr[slot] = i;
+                        uint64_t ch[2];
+                        for (int side = 0; side < 2; ++side) {
+                            const uint64_t c = side ? instr[i].hi : instr[i].lo;
+                            if (is_bot(instr[c])) ch[side] = wide ? WW_BOT : NW_BOT;
+                            else if (is_top(instr[c])) ch[side] = wide ? WW_TOP : NW_TOP;
+                            else ch[side] = npos + (c - nf);
+                        }
+                        if (wide) {
+                            L.wide_words[slot - narrow_slots] =
+                                ch[0] | (ch[1] << WW_CHILD_BITS) | ((uint64_t)lloc << (2 * WW_CHILD_BITS)) | (i == f ? WW_HEAD : 0);
+                        } else {
+                            L.narrow_words[slot] = (uint32_t)ch[0] | ((uint32_t)ch[1] << NW_CHILD_BITS) |
+                                                   (lloc << (2 * NW_CHILD_BITS)) | (i == f ? NW_HEAD : 0);
+                        }
+                    }
+                }
+            }
+        }
+        ps.pack_hop_ptr[P] = (uint32_t)ps.hop_node_off.size();
+        ps.hop_node_off.push_back(slot_cursor);
+        ps.hop_layer_off.push_back(layer_cursor);
+    };
+    emit(pn, order_n, L.narrow, false);
+    emit(pw, order_w, L.wide, true);
+    L.n_nodes = L.n_input_nodes - 2 * n_bdds;
+
+    // ---- variable -> layers CSR, sorted by (variable, bdd) (bdd_cuda_base.cu:379-391) ---------
+    L.var_ptr.assign(L.n_vars + 1, 0);
+    for (uint64_t v = 0; v < L.n_vars; ++v) L.var_ptr[v + 1] = L.var_ptr[v] + (uint32_t)L.num_bdds_per_var[v];
+    L.var_layers.assign(Lin, 0);
+    {
+        std::vector<uint32_t> cursor(L.var_ptr.begin(), L.var_ptr.end() - 1);
+        for (uint32_t l = 0; l < Lin; ++l) {  // input layers are BDD-major => stable by bdd
+            const uint32_t lg = in_layer_to_internal[l];
+            L.var_layers[cursor[L.layer_var[lg]]++] = lg;
+        }
+    }
+    return BDDMMA_OK;
+}
+
+}  // namespace bddmma

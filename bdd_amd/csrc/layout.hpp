@@ -1,0 +1,93 @@
+// layout.hpp — host-side device-layout builder for the parallel-MMA hot path.
+//
+// Replaces the layout stage of the reference's GPU solver constructor
+// (bdd_cuda_base.cu:31-46,55-391: initialize / populate_bdd_nodes / reorder_bdd_nodes /
+// compress_bdd_nodes_to_layer / reorder_within_bdd_layers / set_special_nodes_* /
+// find_primal_variable_ordering).  The reference sorts all nodes of all BDDs hop-major so
+// that one kernel launch per hop can sweep them; that forces a grid-wide barrier (a kernel
+// boundary) per hop.  Here BDDs are grouped into *packs*: a pack is a set of BDDs that one
+// wavefront (narrow pack) or one workgroup (wide pack) walks hop by hop with the frontier in
+// LDS, so a whole pass is ONE launch.  Inside a pack the nodes are stored hop-major SoA, so
+// the 64 lanes of a wave read consecutive addresses at every hop.
+//
+// Pure C++ (no HIP): unit-testable on a CPU-only box through the bddmma_layout_* debug ABI.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/bdd_mma.h"
+
+namespace bddmma {
+
+// ---- narrow node word (uint32) -------------------------------------------------------------
+//  bits  0..9   lo child: local index inside the NEXT hop of the same pack, or NW_BOT / NW_TOP
+//  bits 10..19  hi child
+//  bits 20..29  layer index local to (pack, hop)
+//  bit  30      head: first node of its layer
+//  bit  31      padding slot (no node)
+constexpr uint32_t NW_CHILD_BITS = 10;
+constexpr uint32_t NW_CHILD_MASK = (1u << NW_CHILD_BITS) - 1;
+constexpr uint32_t NW_BOT = NW_CHILD_MASK;      // 1023
+constexpr uint32_t NW_TOP = NW_CHILD_MASK - 1;  // 1022
+constexpr uint32_t NW_HEAD = 1u << 30;
+constexpr uint32_t NW_PAD = 1u << 31;
+constexpr uint32_t NW_PAD_WORD = NW_PAD | NW_HEAD | (NW_BOT << NW_CHILD_BITS) | NW_BOT;
+constexpr uint32_t NARROW_MAX_LAYER_WIDTH = 64;  // a layer never straddles a 64-lane group
+constexpr uint32_t NARROW_MAX_PACK_WIDTH = 256;  // 64 * R, R <= 4
+
+// ---- wide node word (uint64) ---------------------------------------------------------------
+//  bits  0..20  lo child (local index in next hop) or WW_BOT / WW_TOP
+//  bits 21..41  hi child
+//  bits 42..62  layer index local to (pack, hop)
+//  bit  63      head
+constexpr uint32_t WW_CHILD_BITS = 21;
+constexpr uint64_t WW_CHILD_MASK = (1ull << WW_CHILD_BITS) - 1;
+constexpr uint64_t WW_BOT = WW_CHILD_MASK;
+constexpr uint64_t WW_TOP = WW_CHILD_MASK - 1;
+constexpr uint64_t WW_HEAD = 1ull << 63;
+
+struct PackSet {
+    // one entry per pack (+1): index of the pack's first (pack,hop) record
+    std::vector<uint32_t> pack_hop_ptr;
+    // one entry per (pack,hop) (+1): global offsets into the node / layer arrays
+    std::vector<uint32_t> hop_node_off;
+    std::vector<uint32_t> hop_layer_off;
+    // per pack: number of shuffle-halving steps a segmented min needs = ceil(log2(max layer width))
+    std::vector<uint8_t> pack_steps;
+    uint32_t n_packs() const { return pack_hop_ptr.empty() ? 0 : (uint32_t)pack_hop_ptr.size() - 1; }
+};
+
+struct HostLayout {
+    uint64_t n_bdds = 0, n_vars = 0, n_hops = 0;
+    uint64_t n_input_nodes = 0;   // incl. terminals (reference nr_bdd_nodes())
+    uint64_t n_slots = 0;         // node slots in the device arrays (non-terminal nodes + padding)
+    uint64_t n_nodes = 0;         // non-terminal nodes
+    uint64_t n_layers = 0;        // non-terminal layers
+    uint32_t pack_width = 0, wide_pack_width = 0;
+
+    PackSet narrow, wide;
+    uint32_t narrow_slots = 0;        // slots [0, narrow_slots) belong to narrow packs
+    std::vector<uint32_t> narrow_words;  // [narrow_slots]
+    std::vector<uint64_t> wide_words;    // [n_slots - narrow_slots]
+
+    // per layer (internal order: pack-major, hop-major, BDD order inside the pack)
+    std::vector<int32_t> layer_var, layer_bdd;
+    // per variable
+    std::vector<int32_t> num_bdds_per_var;
+    // CSR variable -> layers, sorted by (variable, bdd): var_ptr[V+1], var_layers[L]
+    // (= primal_variable_sorting_order_, bdd_cuda_base.cu:379-391)
+    std::vector<uint32_t> var_ptr, var_layers;
+    // per BDD: internal layer index of its first layer is not contiguous; root slot:
+    std::vector<uint32_t> bdd_root_slot;
+    // per hop statistics (over all packs)
+    std::vector<uint64_t> nodes_per_hop, layers_per_hop;
+    // slot -> input instruction index (debug / round-trip tests), UINT64_MAX for padding
+    std::vector<uint64_t> slot_to_instr;
+};
+
+// Returns BDDMMA_OK or an error code; `err` receives the message.
+int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
+                 const bddmma_options* opts, HostLayout& out, std::string& err, bool keep_debug_maps);
+
+}  // namespace bddmma

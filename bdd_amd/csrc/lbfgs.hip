@@ -1,0 +1,325 @@
+// lbfgs.hip — L-BFGS outer loop around the HIP parallel-MMA solver.
+//
+// Mirrors LPMP::lbfgs<bdd_cuda_parallel_mma<REAL>, device_vector<REAL>, REAL, device_vector<char>, true>
+// (reference: include/bdd_solver/lbfgs.h:35-111, src/bdd_solver/lbfgs_impl.h:45-419).
+// The reference's device branches are compiled out (`#ifdef CUDACC`, lbfgs_impl.h:59...303) and its
+// alpha history is pushed uninitialised (:251-263), so bit-parity with it is undefined; this file
+// implements the maths those lines intend: the standard two-loop recursion with
+//   s_k = x_k - x_{k-1},  y_k = g_{k-1} - g_k,  rho_inv_k = <s_k, y_k>  (kept only if > 1e-8),
+//   initial H diagonal rho_inv_last / (1e-8 + |y_last|^2) folded into the first beta,
+// the step-size search of :159-224 and the mma/lbfgs switch of :409-417.
+// Vectors stay on the device; dot products are two-stage deterministic reductions.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/bdd_mma.h"
+#include "kernels.hpp"
+#include "solver.hpp"
+
+using namespace bddmma;
+
+struct bddmma_lbfgs {
+    bddmma_solver* s = nullptr;
+    bddmma_lbfgs_params p{};
+    std::string err;
+    virtual ~bddmma_lbfgs() {}
+    virtual int iteration() = 0;
+    virtual void flush() = 0;
+};
+
+namespace {
+
+#define LHIP(expr)                                                                 \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            err = std::string(#expr) + ": " + hipGetErrorString(e_);               \
+            return BDDMMA_ERR_DEVICE;                                              \
+        }                                                                          \
+    } while (0)
+
+template <typename REAL>
+struct Lbfgs final : bddmma_lbfgs {
+    struct Hist {
+        REAL* s = nullptr;
+        char* y = nullptr;
+        double rho_inv = 0;
+    };
+    std::deque<Hist> history;
+    std::vector<void*> allocs;
+    REAL *prev_x = nullptr, *cur_x = nullptr, *dir = nullptr;
+    char *prev_g = nullptr, *cur_g = nullptr;
+    double *d_partial = nullptr, *d_scalar = nullptr;
+    std::deque<double> lb_history;
+    double step_size = 0;
+    int unsuccessful = 0;
+    bool prev_stored = false;
+    uint32_t n = 0;
+    hipStream_t st = nullptr;
+
+    ~Lbfgs() override
+    {
+        (void)hipSetDevice(s->impl->device);
+        for (void* q : allocs) (void)hipFree(q);
+        for (auto& h : history) { (void)hipFree(h.s); (void)hipFree(h.y); }
+    }
+    template <typename T>
+    int alloc(T** q, size_t cnt)
+    {
+        LHIP(hipMalloc((void**)q, (cnt ? cnt : 1) * sizeof(T)));
+        allocs.push_back(*q);
+        return 0;
+    }
+    int init()
+    {
+        SolverBase* b = s->impl;
+        LHIP(hipSetDevice(b->device));
+        n = (uint32_t)b->n_layers;
+        st = (hipStream_t)b->stream_handle();
+        step_size = p.init_step_size;
+        int rc;
+        if ((rc = alloc(&prev_x, n)) || (rc = alloc(&cur_x, n)) || (rc = alloc(&dir, n)) || (rc = alloc(&prev_g, n)) ||
+            (rc = alloc(&cur_g, n)) || (rc = alloc(&d_partial, 1024)) || (rc = alloc(&d_scalar, 1)))
+            return rc;
+        return 0;
+    }
+    void flush() override  // flush_lbfgs_states, lbfgs_impl.h:318-326
+    {
+        unsuccessful = 0;
+        for (auto& h : history) { (void)hipFree(h.s); (void)hipFree(h.y); }
+        history.clear();
+        prev_stored = false;
+    }
+    template <typename TA, typename TB>
+    int dot(const TA* a, const TB* b, double* out)
+    {
+        const uint32_t blocks = std::min<uint32_t>(1024, (n + 255) / 256 ? (n + 255) / 256 : 1);
+        hipLaunchKernelGGL((k_dot<TA, TB>), dim3(blocks), dim3(256), 0, st, a, b, d_partial, n);
+        hipLaunchKernelGGL(k_lb_reduce, dim3(1), dim3(1024), 0, st, d_partial, blocks, d_scalar);
+        LHIP(hipMemcpyAsync(out, d_scalar, sizeof(double), hipMemcpyDeviceToHost, st));
+        LHIP(hipStreamSynchronize(st));
+        return 0;
+    }
+    dim3 grid() const { return dim3((n + 255) / 256 ? (n + 255) / 256 : 1); }
+
+    int lower_bound(double* lb)
+    {
+        int rc = s->impl->lower_bound(lb);
+        if (rc) err = s->impl->err;
+        return rc;
+    }
+
+    // store_iterate, lbfgs_impl.h:45-135
+    int store_iterate()
+    {
+        SolverBase* b = s->impl;
+        int rc = b->net_solver_costs(cur_x, 1);
+        if (rc) { err = b->err; return rc; }
+        if (!prev_stored) {
+            LHIP(hipMemcpyAsync(prev_x, cur_x, n * sizeof(REAL), hipMemcpyDeviceToDevice, st));
+            LHIP(hipMemcpyAsync(prev_g, cur_g, n, hipMemcpyDeviceToDevice, st));
+            prev_stored = true;
+            return 0;
+        }
+        Hist h;
+        LHIP(hipMalloc((void**)&h.s, (n ? n : 1) * sizeof(REAL)));
+        LHIP(hipMalloc((void**)&h.y, n ? n : 1));
+        hipLaunchKernelGGL((k_diff<REAL, REAL>), grid(), dim3(256), 0, st, h.s, cur_x, prev_x, n);   // x_k - x_{k-1}
+        hipLaunchKernelGGL((k_diff<char, char>), grid(), dim3(256), 0, st, h.y, prev_g, cur_g, n);   // g_{k-1} - g_k
+        if ((rc = dot(h.s, h.y, &h.rho_inv))) { (void)hipFree(h.s); (void)hipFree(h.y); return rc; }
+        if (h.rho_inv > 1e-8) {
+            history.push_back(h);
+            if ((int)history.size() > p.history_size) {
+                (void)hipFree(history.front().s);
+                (void)hipFree(history.front().y);
+                history.pop_front();
+            }
+        } else {
+            (void)hipFree(h.s);
+            (void)hipFree(h.y);
+            prev_stored = false;
+        }
+        LHIP(hipMemcpyAsync(prev_x, cur_x, n * sizeof(REAL), hipMemcpyDeviceToDevice, st));
+        LHIP(hipMemcpyAsync(prev_g, cur_g, n, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+
+    bool update_possible() const { return (int)history.size() >= p.history_size && unsuccessful <= 5; }  // :334-340
+
+    // compute_update_direction, :226-316
+    int compute_direction()
+    {
+        hipLaunchKernelGGL((k_fill<REAL>), grid(), dim3(256), 0, st, dir, REAL(0), (uint64_t)n);
+        hipLaunchKernelGGL((k_axpy<REAL, char>), grid(), dim3(256), 0, st, dir, cur_g, REAL(1), n);  // direction = grad_f
+        std::vector<double> alpha(history.size());
+        int rc;
+        for (int i = (int)history.size() - 1; i >= 0; --i) {
+            double sd;
+            if ((rc = dot(history[i].s, dir, &sd))) return rc;
+            alpha[i] = sd / history[i].rho_inv;
+            hipLaunchKernelGGL((k_axpy<REAL, char>), grid(), dim3(256), 0, st, dir, history[i].y, REAL(-alpha[i]), n);
+        }
+        double last_y_norm;
+        if ((rc = dot(history.back().y, history.back().y, &last_y_norm))) return rc;
+        const double h_diag = history.back().rho_inv / (1e-8 + last_y_norm);
+        for (size_t i = 0; i < history.size(); ++i) {
+            double rho = 1.0 / history[i].rho_inv;
+            if (i == 0) rho *= h_diag;
+            double yd;
+            if ((rc = dot(history[i].y, dir, &yd))) return rc;
+            const double beta = rho * yd;
+            hipLaunchKernelGGL((k_axpy<REAL, REAL>), grid(), dim3(256), 0, st, dir, history[i].s, REAL(alpha[i] - beta), n);
+        }
+        LHIP(hipGetLastError());
+        return 0;
+    }
+
+    // search_step_size_and_apply, :159-224
+    int search_step_size_and_apply()
+    {
+        SolverBase* b = s->impl;
+        double lb_pre;
+        int rc;
+        if ((rc = lower_bound(&lb_pre))) return rc;
+        const int m = p.history_size;
+        auto rel_change = [&](double* out) -> int {
+            double lb;
+            int r = lower_bound(&lb);
+            if (r) return r;
+            const double cur_inc = lb - lb_pre;
+            const double past_inc = *(lb_history.rbegin() + m - 2) - *(lb_history.rbegin() + m - 1);
+            *out = cur_inc / (1e-9 + past_inc);
+            return 0;
+        };
+        double prev_step = 0.0;
+        auto apply = [&](double new_step) -> int {
+            const double net = new_step - prev_step;
+            if (net != 0.0) {
+                int r = b->gradient_step(dir, net, 1);
+                if (r) { err = b->err; return r; }
+            }
+            prev_step = new_step;
+            return 0;
+        };
+        size_t num_updates = 0;
+        double cur = 0.0, best_step = 0.0, best_impr = 0.0;
+        do {
+            if ((rc = apply(step_size))) return rc;
+            if ((rc = rel_change(&cur))) return rc;
+            if (best_impr < cur) { best_impr = cur; best_step = step_size; }
+            if (cur <= 0.0) step_size *= p.step_size_decrease_factor;
+            else if (cur < p.req_rel_lb_increase) step_size *= p.step_size_increase_factor;
+            if (num_updates > 5) {
+                if (best_impr > p.req_rel_lb_increase / 10.0) {
+                    if ((rc = apply(best_step))) return rc;
+                } else {
+                    if ((rc = apply(0.0))) return rc;
+                    unsuccessful += 1;
+                }
+                return 0;
+            }
+            num_updates++;
+        } while (cur < p.req_rel_lb_increase);
+        if (num_updates == 1 && unsuccessful == 0) step_size *= p.step_size_increase_factor;
+        unsuccessful = 0;
+        return 0;
+    }
+
+    // iteration(), :137-157
+    int iteration() override
+    {
+        SolverBase* b = s->impl;
+        LHIP(hipSetDevice(b->device));
+        int rc;
+        double lb;
+        if (lb_history.empty()) {
+            if ((rc = lower_bound(&lb))) return rc;
+            lb_history.push_back(lb);
+        }
+        if ((rc = b->bdds_solution(0, cur_g, 1))) { err = b->err; return rc; }
+        if ((rc = store_iterate())) return rc;
+        if (update_possible() && (int)lb_history.size() >= p.history_size) {
+            if ((rc = compute_direction())) return rc;
+            if ((rc = b->make_dual_feasible(dir, 1))) { err = b->err; return rc; }
+            if ((rc = search_step_size_and_apply())) return rc;
+        }
+        if ((rc = b->iteration(0.5))) { err = b->err; return rc; }
+        if ((rc = lower_bound(&lb))) return rc;
+        lb_history.push_back(lb);
+        if (lb_history.size() > (size_t)std::max(64, p.history_size + 2)) lb_history.pop_front();
+        return 0;
+    }
+};
+
+thread_local std::string g_lbfgs_error;
+
+}  // namespace
+
+extern "C" {
+
+int bddmma_lbfgs_create(bddmma_lbfgs** out, bddmma_solver* s, const bddmma_lbfgs_params* p)
+{
+    if (!out || !s || !s->impl) return BDDMMA_ERR_INVALID_ARGUMENT;
+    bddmma_lbfgs_params q;
+    q.history_size = 5;                 // lbfgs.h:29-33
+    q.init_step_size = 1e-6;
+    q.req_rel_lb_increase = 1e-6;
+    q.step_size_decrease_factor = 0.8;
+    q.step_size_increase_factor = 1.1;
+    if (p) {
+        if (p->history_size > 0) q.history_size = p->history_size;
+        if (p->init_step_size > 0) q.init_step_size = p->init_step_size;
+        if (p->req_rel_lb_increase > 0) q.req_rel_lb_increase = p->req_rel_lb_increase;
+        if (p->step_size_decrease_factor > 0) q.step_size_decrease_factor = p->step_size_decrease_factor;
+        if (p->step_size_increase_factor > 0) q.step_size_increase_factor = p->step_size_increase_factor;
+    }
+    // lbfgs_impl.h:27-31
+    if (q.history_size < 2 || q.step_size_decrease_factor >= 1.0 || q.step_size_increase_factor <= 1.0) {
+        s->impl->err = "invalid L-BFGS parameters";
+        return BDDMMA_ERR_INVALID_ARGUMENT;
+    }
+    bddmma_lbfgs* l = nullptr;
+    int rc;
+    if (s->impl->precision == BDDMMA_F32) {
+        auto* t = new Lbfgs<float>();
+        t->s = s; t->p = q;
+        rc = t->init();
+        l = t;
+    } else {
+        auto* t = new Lbfgs<double>();
+        t->s = s; t->p = q;
+        rc = t->init();
+        l = t;
+    }
+    if (rc) {
+        s->impl->err = l->err;
+        delete l;
+        return rc;
+    }
+    *out = l;
+    return BDDMMA_OK;
+}
+
+void bddmma_lbfgs_destroy(bddmma_lbfgs* l) { delete l; }
+
+int bddmma_lbfgs_iteration(bddmma_lbfgs* l)
+{
+    if (!l) return BDDMMA_ERR_INVALID_ARGUMENT;
+    int rc = l->iteration();
+    if (rc) l->s->impl->err = l->err;
+    return rc;
+}
+
+int bddmma_lbfgs_update_costs(bddmma_lbfgs* l, const void* lo, uint64_t n_lo, const void* hi, uint64_t n_hi,
+                              int elem_precision, int on_device)
+{
+    if (!l) return BDDMMA_ERR_INVALID_ARGUMENT;
+    l->flush();  // lbfgs_impl.h:343-364
+    return l->s->impl->update_costs(lo, n_lo, hi, n_hi, elem_precision, on_device);
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+// solver.hpp — precision-erased solver interface behind the C-ABI (include/bdd_mma.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/bdd_mma.h"
+#include "layout.hpp"
+
+namespace bddmma {
+
+struct SolverBase {
+    int precision = BDDMMA_F32, device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    uint64_t n_vars = 0, n_bdds = 0, n_layers = 0, n_hops = 0, n_input_nodes = 0, n_slots = 0;
+    uint32_t pack_width = 0, wide_pack_width = 0, wide_slot_base = 0;
+    uint64_t dev_bytes = 0;
+    bool fwd_valid = false, bwd_valid = false;  // forward_state_valid_ / backward_state_valid_ (bdd_cuda_base.h:205-206)
+    bool deterministic = false;
+    std::vector<uint64_t> nodes_per_hop, layers_per_hop;
+    std::vector<int32_t> h_nbdds, h_layer_var, h_layer_bdd;
+    std::vector<uint32_t> h_var_ptr;
+    uint32_t n_packs_narrow = 0, n_packs_wide = 0;
+    // checkpoint support: the input collection is kept so that save() can re-create the layout
+    std::vector<bddmma_instruction> saved_instr;
+    std::vector<uint64_t> saved_delims;
+    bddmma_options saved_opts{};
+
+    // profiling: one hipEvent pair per launch group on `stream`
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int> ev_class;
+    size_t ev_used = 0;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+
+    virtual ~SolverBase() {}
+    virtual int forward_run() = 0;
+    virtual int backward_run() = 0;
+    virtual int lower_bound(double* lb) = 0;
+    virtual int lower_bound_per_bdd(void* out, int on_device) = 0;
+    virtual int iteration(double omega) = 0;
+    virtual int forward_mm(double omega, void* delta, int on_device) = 0;
+    virtual int backward_mm(double omega, void* delta, int on_device) = 0;
+    virtual int normalize_delta(void* delta, int on_device) = 0;
+    virtual int distribute_delta() = 0;
+    virtual int get_delta(void* out, int on_device) = 0;
+    virtual int set_delta(const void* in, int on_device) = 0;
+    virtual int update_costs(const void* lo, uint64_t n_lo, const void* hi, uint64_t n_hi, int elem_precision, int on_device) = 0;
+    virtual int set_cost(double c, uint64_t var) = 0;
+    virtual int get_solver_costs(void* lo, void* hi, void* mm, int on_device) = 0;
+    virtual int set_solver_costs(const void* lo, const void* hi, const void* mm, int on_device) = 0;
+    virtual int primal_objective_vec(void* out, int on_device) = 0;
+    virtual int min_marginals(int sorted, int32_t* var, void* mm0, void* mm1, int on_device) = 0;
+    virtual int bdds_solution(int sorted, char* sol, int on_device) = 0;
+    virtual int net_solver_costs(void* out, int on_device) = 0;
+    virtual int make_dual_feasible(void* g, int on_device) = 0;
+    virtual int gradient_step(const void* g, double step, int on_device) = 0;
+    virtual void* stream_handle() = 0;
+
+    int synchronize();
+    void prof_begin(int kclass);
+    void prof_end(int kclass);
+    int set_profiling(int on);
+    int get_profile(bddmma_profile* out);
+    int time_iterations(double omega, uint64_t n, double* ms);
+};
+
+int create_solver(SolverBase** out, int precision, int device, const HostLayout& L, const bddmma_options* opts, std::string& err);
+
+}  // namespace bddmma
+
+// the opaque C handle
+struct bddmma_solver {
+    bddmma::SolverBase* impl = nullptr;
+};

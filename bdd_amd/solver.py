@@ -1,0 +1,278 @@
+"""Host-side mirror of the reference solver classes for the `cuda parallel mma` path.
+
+`bdd_hip_parallel_mma` has the public surface of `LPMP::bdd_cuda_parallel_mma<REAL>` +
+`bdd_cuda_base<REAL>` (reference: include/bdd_solver/bdd_cuda_parallel_mma.h:7-52,
+include/bdd_solver/bdd_cuda_base.h:58-229) — same method names, argument meaning and error
+behaviour — so the parity tests read like test/test_cuda_parallel_mma.cu and
+test/test_bdd_cuda_*.cpp.  All compute happens in the HIP library behind the C-ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .bdd_collection import BddCollection
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class bdd_hip_parallel_mma:
+    """Drop-in for bdd_cuda_parallel_mma<REAL> (value_type = float | double)."""
+
+    def __init__(self, bdd_col: BddCollection, costs_hi=None, precision: str = "double", device: int = 0,
+                 pack_width: int = 0, wide_pack_width: int = 0, deterministic: bool = False, _handle=None):
+        self._L = capi.lib()
+        self.value_type = {"double": np.float64, "float": np.float32, "single": np.float32}[precision]
+        self._prec = capi.F64 if self.value_type == np.float64 else capi.F32
+        if _handle is not None:
+            self._h = _handle
+            return
+        instr = np.ascontiguousarray(bdd_col.instr, dtype=np.uint64)
+        delims = np.ascontiguousarray(bdd_col.delims, dtype=np.uint64)
+        opts = capi.Options(pack_width, wide_pack_width, 1 if deterministic else 0)
+        h = C.c_void_p()
+        costs = None if costs_hi is None else np.ascontiguousarray(costs_hi, dtype=np.float64)
+        rc = self._L.bddmma_create(C.byref(h), self._prec, device, _ptr(instr), _ptr(delims), bdd_col.nr_bdds(),
+                                   _ptr(costs), 0 if costs is None else costs.size, C.byref(opts))
+        capi.check(rc, None)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.bddmma_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        capi.check(rc, self._h)
+
+    # ---- sizes (bdd_cuda_base.h:98-116)
+    def nr_variables(self): return int(self._L.bddmma_nr_variables(self._h))
+    def nr_layers(self): return int(self._L.bddmma_nr_layers(self._h))
+    def nr_bdd_nodes(self): return int(self._L.bddmma_nr_bdd_nodes(self._h))
+    def nr_hops(self): return int(self._L.bddmma_nr_hops(self._h))
+    def nr_packs(self): return int(self._L.bddmma_nr_packs(self._h))
+    def device_bytes(self): return int(self._L.bddmma_device_bytes(self._h))
+
+    def nr_bdds(self, var=None):
+        if var is None:
+            return int(self._L.bddmma_nr_bdds(self._h))
+        return int(self.get_num_bdds_per_var()[var])
+
+    def get_num_bdds_per_var(self):
+        out = np.zeros(self.nr_variables(), np.int32)
+        self._ck(self._L.bddmma_num_bdds_per_var(self._h, _ptr(out)))
+        return out
+
+    def get_primal_variable_index(self):
+        out = np.zeros(self.nr_layers(), np.int32)
+        self._ck(self._L.bddmma_layer_variables(self._h, _ptr(out)))
+        return out
+
+    def get_bdd_index(self):
+        out = np.zeros(self.nr_layers(), np.int32)
+        self._ck(self._L.bddmma_layer_bdds(self._h, _ptr(out)))
+        return out
+
+    def nodes_per_hop(self):
+        out = np.zeros(self.nr_hops(), np.uint64)
+        self._ck(self._L.bddmma_nodes_per_hop(self._h, _ptr(out)))
+        return out
+
+    def layers_per_hop(self):
+        out = np.zeros(self.nr_hops(), np.uint64)
+        self._ck(self._L.bddmma_layers_per_hop(self._h, _ptr(out)))
+        return out
+
+    def bdd_major_order(self):
+        """Permutation taking internal layer order to BDD-major order (bdd ascending, hop ascending):
+        the layer order of the reference CPU solver (bdd_parallel_mma_base.cpp:75-170)."""
+        return np.argsort(self.get_bdd_index(), kind="stable")
+
+    # ---- costs
+    def update_costs(self, cost_delta_0, cost_delta_1):
+        lo = np.ascontiguousarray(cost_delta_0, dtype=np.float64)
+        hi = np.ascontiguousarray(cost_delta_1, dtype=np.float64)
+        self._ck(self._L.bddmma_update_costs(self._h, _ptr(lo), lo.size, _ptr(hi), hi.size, capi.F64, 0))
+
+    def set_cost(self, c, var):
+        self._ck(self._L.bddmma_set_cost(self._h, float(c), int(var)))
+
+    def get_solver_costs(self):
+        n = self.nr_layers()
+        lo, hi, mm = (np.zeros(n, self.value_type) for _ in range(3))
+        self._ck(self._L.bddmma_get_solver_costs(self._h, _ptr(lo), _ptr(hi), _ptr(mm), 0))
+        return lo, hi, mm
+
+    def set_solver_costs(self, lo, hi, mm):
+        lo, hi, mm = (np.ascontiguousarray(x, dtype=self.value_type) for x in (lo, hi, mm))
+        self._ck(self._L.bddmma_set_solver_costs(self._h, _ptr(lo), _ptr(hi), _ptr(mm), 0))
+
+    def get_primal_objective_vector_host(self):
+        out = np.zeros(self.nr_variables(), self.value_type)
+        self._ck(self._L.bddmma_primal_objective_vec(self._h, _ptr(out), 0))
+        return out
+
+    # ---- sweeps
+    def forward_run(self): self._ck(self._L.bddmma_forward_run(self._h))
+    def backward_run(self): self._ck(self._L.bddmma_backward_run(self._h))
+
+    def lower_bound(self) -> float:
+        lb = C.c_double()
+        self._ck(self._L.bddmma_lower_bound(self._h, C.byref(lb)))
+        return lb.value
+
+    def lower_bound_per_bdd(self):
+        out = np.zeros(self.nr_bdds(), self.value_type)
+        self._ck(self._L.bddmma_lower_bound_per_bdd(self._h, _ptr(out), 0))
+        return out
+
+    # ---- parallel mma
+    def iteration(self, omega=0.5):
+        self._ck(self._L.bddmma_iteration(self._h, float(omega)))
+
+    def iterations(self, n, omega=0.5):
+        self._ck(self._L.bddmma_iterations(self._h, float(omega), int(n)))
+
+    def forward_mm(self, omega, delta_lo_hi):
+        assert delta_lo_hi.dtype == self.value_type and delta_lo_hi.size == 2 * self.nr_variables()
+        self._ck(self._L.bddmma_forward_mm(self._h, float(omega), _ptr(delta_lo_hi), 0))
+
+    def backward_mm(self, omega, delta_lo_hi):
+        assert delta_lo_hi.dtype == self.value_type and delta_lo_hi.size == 2 * self.nr_variables()
+        self._ck(self._L.bddmma_backward_mm(self._h, float(omega), _ptr(delta_lo_hi), 0))
+
+    def normalize_delta(self, delta_lo_hi):
+        self._ck(self._L.bddmma_normalize_delta(self._h, _ptr(delta_lo_hi), 0))
+
+    def distribute_delta(self):
+        self._ck(self._L.bddmma_distribute_delta(self._h))
+
+    def get_delta(self):
+        out = np.zeros(2 * self.nr_variables(), self.value_type)
+        self._ck(self._L.bddmma_get_delta(self._h, _ptr(out), 0))
+        return out
+
+    # ---- min-marginals / solutions
+    def min_marginals_cuda(self, get_sorted=True):
+        n = self.nr_layers()
+        var = np.zeros(n, np.int32)
+        mm0, mm1 = np.zeros(n, self.value_type), np.zeros(n, self.value_type)
+        self._ck(self._L.bddmma_min_marginals(self._h, 1 if get_sorted else 0, _ptr(var), _ptr(mm0), _ptr(mm1), 0))
+        return var, mm0, mm1
+
+    def min_marginals(self):
+        """two_dim_variable_array<array<double,2>>[var][bdd] (bdd_cuda_base.cu:751-786) as a list of (k,2) arrays."""
+        var, mm0, mm1 = self.min_marginals_cuda(True)
+        nb = self.get_num_bdds_per_var()
+        ptr = np.concatenate([[0], np.cumsum(nb)])
+        return [np.stack([mm0[ptr[v]:ptr[v + 1]], mm1[ptr[v]:ptr[v + 1]]], axis=1).astype(np.float64)
+                for v in range(self.nr_variables())]
+
+    def bdds_solution_vec(self):
+        out = np.zeros(self.nr_layers(), np.int8)
+        self._ck(self._L.bddmma_bdds_solution(self._h, 0, _ptr(out), 0))
+        return out
+
+    def bdds_solution(self):
+        out = np.zeros(self.nr_layers(), np.int8)
+        self._ck(self._L.bddmma_bdds_solution(self._h, 1, _ptr(out), 0))
+        nb = self.get_num_bdds_per_var()
+        ptr = np.concatenate([[0], np.cumsum(nb)])
+        return [out[ptr[v]:ptr[v + 1]].astype(np.float64) for v in range(self.nr_variables())]
+
+    # ---- L-BFGS support
+    def net_solver_costs(self):
+        out = np.zeros(self.nr_layers(), self.value_type)
+        self._ck(self._L.bddmma_net_solver_costs(self._h, _ptr(out), 0))
+        return out
+
+    def make_dual_feasible(self, d):
+        assert d.dtype == self.value_type and d.size == self.nr_layers()
+        self._ck(self._L.bddmma_make_dual_feasible(self._h, _ptr(d), 0))
+
+    def gradient_step(self, g, step_size):
+        g = np.ascontiguousarray(g, dtype=self.value_type)
+        self._ck(self._L.bddmma_gradient_step(self._h, _ptr(g), float(step_size), 0))
+
+    # ---- checkpoint (bdd_cuda_base.cu:1486-1550; pickle in bdd_cuda_parallel_mma_py.cu:15-38)
+    def save(self, path: str):
+        self._ck(self._L.bddmma_save(self._h, path.encode()))
+
+    @classmethod
+    def load(cls, path: str, device: int = 0):
+        L = capi.lib()
+        h = C.c_void_p()
+        capi.check(L.bddmma_load(C.byref(h), device, path.encode()), None)
+        prec = "double" if L.bddmma_precision(h) == capi.F64 else "float"
+        return cls(None, precision=prec, _handle=h)
+
+    # ---- measurement
+    def synchronize(self): self._ck(self._L.bddmma_synchronize(self._h))
+    def set_profiling(self, on: bool): self._ck(self._L.bddmma_set_profiling(self._h, 1 if on else 0))
+
+    def get_profile(self):
+        p = capi.Profile()
+        self._ck(self._L.bddmma_get_profile(self._h, C.byref(p)))
+        return {"launches": list(p.launches), "total_ms": list(p.total_ms)}
+
+    def time_iterations(self, n, omega=0.5) -> float:
+        ms = C.c_double()
+        self._ck(self._L.bddmma_time_iterations(self._h, float(omega), int(n), C.byref(ms)))
+        return ms.value
+
+
+class bdd_hip_lbfgs:
+    """lbfgs<bdd_cuda_parallel_mma<REAL>, ...> (include/bdd_solver/lbfgs.h:35-111) over a HIP solver."""
+
+    def __init__(self, solver: bdd_hip_parallel_mma, history_size=5, init_step_size=1e-6, req_rel_lb_increase=1e-6,
+                 step_size_decrease_factor=0.8, step_size_increase_factor=1.1):
+        self.solver = solver
+        self._L = capi.lib()
+        p = capi.LbfgsParams(history_size, init_step_size, req_rel_lb_increase, step_size_decrease_factor,
+                             step_size_increase_factor)
+        h = C.c_void_p()
+        capi.check(self._L.bddmma_lbfgs_create(C.byref(h), solver._h, C.byref(p)), solver._h)
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.bddmma_lbfgs_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def iteration(self):
+        capi.check(self._L.bddmma_lbfgs_iteration(self._h), self.solver._h)
+
+    def lower_bound(self):
+        return self.solver.lower_bound()
+
+    def update_costs(self, lo, hi):
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        capi.check(self._L.bddmma_lbfgs_update_costs(self._h, _ptr(lo), lo.size, _ptr(hi), hi.size, capi.F64, 0),
+                   self.solver._h)
+
+
+def run_solver(solver, max_iter=1000, tolerance=1e-6, improvement_slope=1e-9, time_limit=3600.0, verbose=False,
+               lbfgs: bdd_hip_lbfgs = None):
+    """run_solver<SOLVER>() of include/run_solver_util.h:10-77 (executed inside the library)."""
+    L = capi.lib()
+    res = capi.RunResult()
+    base = solver.solver if isinstance(solver, bdd_hip_lbfgs) else solver
+    lb = solver if isinstance(solver, bdd_hip_lbfgs) else lbfgs
+    capi.check(L.bddmma_run_solver(base._h, lb._h if lb else None, int(max_iter), float(tolerance),
+                                   float(improvement_slope), float(time_limit), 1 if verbose else 0, C.byref(res)), base._h)
+    return dict(iterations=int(res.iterations), lb_initial=res.lb_initial, lb_final=res.lb_final,
+                seconds=res.seconds, stop_reason=int(res.stop_reason))

@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py — parallel-MMA iterations/s on the BASELINE.json workload, with roofline + CPU baseline.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" is one iteration() of the solver = forward_mm + normalize + backward_mm + normalize over
+the whole instance (reference: bdd_cuda_parallel_mma.cu:142-153).  Workload: random set cover,
+row size 10, V = 1e6, B = 5e5 -> 10.5 M BDD nodes (BASELINE.json configs[2], the configuration the
+metric is quoted on).  Multi-GPU: independent instances, one per GPU, no collective on the data
+path ("replicas only"); `value` = iterations of all ranks / max-over-ranks time.
+Inputs are resident in HBM before the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "HBM3E peak BW")
+
+
+def algorithmic_bytes_per_pass(sizes, R):
+    """12 N' + 2R N + (5R+4) L' + (8R+4) V  (one forward_mm or backward_mm sweep)."""
+    return 12 * sizes["N_nt"] + 2 * R * sizes["N"] + (5 * R + 4) * sizes["L_nt"] + (8 * R + 4) * sizes["V"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--precision", default="float", choices=["float", "double"])
+    ap.add_argument("--vars", type=int, default=1_000_000)
+    ap.add_argument("--rows", type=int, default=500_000)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--pack-width", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--deterministic", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+
+    from bdd_amd.instances import random_set_cover, set_cover_sizes
+    from bdd_amd.solver import bdd_hip_parallel_mma
+
+    sizes = set_cover_sizes(args.vars, args.rows, args.k)
+    col, costs = random_set_cover(args.vars, args.rows, args.k, seed=12345 + rank)
+    solver = bdd_hip_parallel_mma(col, costs, precision=args.precision, device=local_rank,
+                                  pack_width=args.pack_width, deterministic=args.deterministic)
+    R = 4 if args.precision == "float" else 8
+    solver.iterations(args.warmup)
+    solver.synchronize()
+    solver.set_profiling(True)  # hipEvent pairs around every launch on the solver's stream
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    solver.iterations(args.steps)
+    solver.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    prof = solver.get_profile()
+    solver.set_profiling(False)
+    lb = solver.lower_bound()
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        its = world * args.steps / dt
+        names = ["forward_mm", "backward_mm", "finish_delta", "other"]
+        avg_ms = [prof["total_ms"][i] / max(prof["launches"][i], 1) for i in range(4)]
+        dom = 0 if avg_ms[0] >= avg_ms[1] else 1
+        bytes_pass = algorithmic_bytes_per_pass(sizes, R)
+        achieved = bytes_pass / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
+        out = {
+            "metric": "parallel-MMA iterations/sec, 10M BDD nodes, 1 GPU (+ achieved HBM GB/s in roofline)",
+            "value": its,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "float" else "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"random set cover, row size {args.k}, V={args.vars}, B={args.rows}: "
+                            f"{sizes['N']} BDD nodes (BASELINE.json configs[2]); one independent instance per GPU",
+                "precision": args.precision,
+                "omega": 0.5,
+                "pack_width": args.pack_width or 128,
+                "packs": solver.nr_packs(),
+                "hops": solver.nr_hops(),
+                "delta_accumulation": "gather (deterministic)" if args.deterministic else "atomicAdd",
+                "hbm_resident_bytes": solver.device_bytes(),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": names[dom],
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_pass,
+                "avg_launch_ms": {names[i]: avg_ms[i] for i in range(3)},
+                "whole_iteration_GBs": 2 * bytes_pass * its / world / 1e9,
+            },
+            "lower_bound_after": {"iterations": args.warmup + args.steps, "value": lb},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(col, costs, args, sizes)
+        print(json.dumps(out), flush=True)
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(col, costs, args, sizes):
+    """The CPU restatement of the reference's `parallel mma` (oracle/, OpenMP over BDDs) timed on this
+    box's host cores on the same instance — rank 0, bounded to ~args.cpu_seconds of work."""
+    from bdd_amd.solver import bdd_hip_parallel_mma
+    from oracle.oracle import Oracle
+
+    cores = os.cpu_count() or 1
+    o = Oracle(col, costs, args.precision, threads=cores)
+    o.iteration()  # warm-up (first touch, backward_run)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        o.iteration()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or n >= 200:
+            break
+    cpu_lb = o.lower_bound()
+    g = bdd_hip_parallel_mma(col, costs, precision=args.precision, pack_width=args.pack_width)
+    g.iterations(n + 1)
+    gpu_lb = g.lower_bound()
+    return {
+        "value": n / el,
+        "unit": "iterations/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n} iterations of the same {sizes['N']}-node instance after 1 warm-up iteration, "
+                  f"oracle/mma_oracle.c with OpenMP over BDDs ({cores} threads), {args.precision}",
+        "lb_after": {"iterations": n + 1, "cpu": cpu_lb, "gpu": gpu_lb,
+                     "rel_diff": abs(cpu_lb - gpu_lb) / max(abs(cpu_lb), 1e-300)},
+    }
+
+
+if __name__ == "__main__":
+    main()

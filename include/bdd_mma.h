@@ -66,8 +66,8 @@ typedef struct bddmma_solver bddmma_solver;
 
 /* Tunables of the device layout (0 = default). */
 typedef struct bddmma_options {
-    uint32_t pack_width;       /* max #nodes of one hop inside a wave-sized BDD pack (default 128) */
-    uint32_t wide_pack_width;  /* max #nodes of one hop inside a workgroup-sized pack (default 4096) */
+    uint32_t pack_width;       /* max #nodes of one hop inside a wave-sized BDD pack: 64, 128 (default) or 256 */
+    uint32_t wide_pack_width;  /* max #nodes of one hop inside a workgroup-sized pack (default 2048; <= 2048 for F64, <= 4096 for F32) */
     uint32_t deterministic;    /* 1: delta accumulation by per-variable gather (bit-reproducible) */
     uint32_t reserved[5];
 } bddmma_options;
@@ -144,6 +144,7 @@ int bddmma_normalize_delta(const bddmma_solver* s, void* delta_lo_hi, int on_dev
 int bddmma_distribute_delta(bddmma_solver* s);
 /* the solver's deferred delta_lo_hi_ (REAL[2*nr_variables]) */
 int bddmma_get_delta(const bddmma_solver* s, void* out, int on_device);
+int bddmma_set_delta(bddmma_solver* s, const void* in, int on_device);
 
 /* ---- min-marginals and per-BDD solutions -------------------------------- */
 /* min_marginals_cuda(get_sorted) (bdd_cuda_base.cu:716-749): var int32[nr_layers], mm0/mm1 REAL[nr_layers].
@@ -209,6 +210,14 @@ int bddmma_get_profile(bddmma_solver* s, bddmma_profile* out);  /* synchronises 
 int bddmma_time_iterations(bddmma_solver* s, double omega, uint64_t n, double* ms);
 /* HBM bytes held by the handle. */
 uint64_t bddmma_device_bytes(const bddmma_solver* s);
+
+/* ---- host-only layout inspection (no GPU needed; used by the CPU test-suite) ------------- */
+typedef struct bddmma_layout bddmma_layout;
+int bddmma_layout_create(bddmma_layout** out, const bddmma_instruction* instr, const uint64_t* bdd_delims,
+                         uint64_t n_bdds, const bddmma_options* opts);
+void bddmma_layout_destroy(bddmma_layout* l);
+uint64_t bddmma_layout_size(const bddmma_layout* l, int what);
+int bddmma_layout_copy(const bddmma_layout* l, int which, void* out);
 
 #ifdef __cplusplus
 }

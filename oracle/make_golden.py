@@ -1,0 +1,113 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own compiled code (oracle/_ref).
+
+Run in the build container (needs /root/reference):  python oracle/make_golden.py
+Every fixture holds inputs (flat BDD arrays built by the reference's bdd_collection, costs) and
+expected outputs produced by the reference's node arithmetic (bdd_branch_instruction.h) driven by
+oracle/ref_driver.cpp:
+  * `delta_trace`  : the CPU<->GPU parity protocol of test/test_cuda_parallel_mma.cu:13-103 —
+                     10x { forward_mm(0.5, d); backward_mm(0.5, d) } with d NOT normalised in between;
+                     shape (10, 2, 2V)
+  * `lb_trace`     : lower bound after every backward_mm of that protocol, shape (10,)
+  * `iter_lb`      : lower bound after each of 20 iteration() calls on a fresh solver, shape (20,)
+  * `lb_init`      : lower bound right after update_costs
+Fixtures are data only; no reference source text is stored.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bdd_amd.ilp import ILP  # noqa: E402
+from bdd_amd.instances import GRID_3X3, LONG_CHAIN, SHORT_CHAIN, assignment_ilp, mrf_ilp  # noqa: E402
+from oracle.oracle import RefCollection, RefMma  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def ref_collection_from_ilp(ilp: ILP) -> RefCollection:
+    rc = RefCollection()
+    for c in ilp.constraints:
+        if c.is_simplex():
+            rc.add_simplex(c.variables)
+        else:
+            r = rc.add_linear(c.coefficients, c.ineq, c.rhs, c.variables)
+            assert r >= 0, "trivial/infeasible constraint"
+    return rc
+
+
+def record(name, rc: RefCollection, costs):
+    col = rc.export()
+    out = dict(instr=col.instr, delims=col.delims, costs=np.asarray(costs, np.float64))
+    for prec, dt in (("f64", np.float64), ("f32", np.float32)):
+        m = RefMma(rc, "double" if prec == "f64" else "float")
+        V = m.nr_variables()
+        c = np.zeros(V)
+        c[: len(costs)] = costs
+        m.update_costs([], c)
+        out[f"lb_init_{prec}"] = m.lower_bound()
+        d = np.zeros(2 * V, dt)
+        trace = np.zeros((10, 2, 2 * V), dt)
+        lbs = np.zeros(10)
+        for it in range(10):
+            m.forward_mm(0.5, d)
+            trace[it, 0] = d
+            lbs[it] = m.backward_mm(0.5, d)
+            trace[it, 1] = d
+        out[f"delta_trace_{prec}"] = trace
+        out[f"lb_trace_{prec}"] = lbs
+        m2 = RefMma(rc, "double" if prec == "f64" else "float")
+        m2.update_costs([], c)
+        out[f"iter_lb_{prec}"] = np.array([m2.iteration() for _ in range(20)])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "V", V, "bdds", rc.nr_bdds(), "lb_init", out["lb_init_f64"], "iter_lb[-1]", out["iter_lb_f64"][-1])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ilp = assignment_ilp(3)
+    record("matching_3x3_diag", ref_collection_from_ilp(ilp), ilp.objective)
+    c = -np.ones((3, 3)); c[:, 0] = -2
+    ilp = assignment_ilp(3, c)
+    record("matching_3x3_first_row", ref_collection_from_ilp(ilp), ilp.objective)
+    ilp = assignment_ilp(8)
+    record("matching_8x8", ref_collection_from_ilp(ilp), ilp.objective)
+    # 3-row set cover of test/test_loose_covering_problem.cpp:8-22
+    rc = RefCollection()
+    for row in ([0, 1, 3], [0, 2, 4], [1, 2, 5]):
+        rc.add_covering(row)
+    record("loose_covering", rc, np.ones(6))
+    for nm, P in (("mrf_short_chain", SHORT_CHAIN), ("mrf_long_chain", LONG_CHAIN), ("mrf_grid_3x3", GRID_3X3)):
+        ilp = mrf_ilp(**P)
+        record(nm, ref_collection_from_ilp(ilp), ilp.objective)
+    # random set cover with variable gaps (some variables in no BDD), mixed row sizes
+    rng = np.random.Generator(np.random.PCG64(7))
+    rc = RefCollection()
+    V = 60
+    for _ in range(45):
+        k = int(rng.integers(2, 9))
+        rc.add_covering(np.sort(rng.choice(V - 5, size=k, replace=False)))
+    costs = rng.uniform(1, 10, V)
+    col = rc.export()
+    used = np.zeros(V, bool)
+    used[col.instr[col.instr[:, 2] < 2**63, 2].astype(int)] = True
+    costs[~used] = 0
+    record("random_cover_small", rc, costs[: col.nr_variables()])
+    # knapsack-like rows with wider layers + cardinality rows
+    rc = RefCollection()
+    rng = np.random.Generator(np.random.PCG64(11))
+    V = 24
+    for _ in range(10):
+        k = int(rng.integers(4, 10))
+        vs = np.sort(rng.choice(V, size=k, replace=False))
+        co = rng.integers(1, 6, size=k)
+        rhs = int(co.sum() // 2)
+        rc.add_linear(co, "<=" if rng.random() < 0.5 else ">=", rhs, vs)
+    for _ in range(4):
+        vs = np.sort(rng.choice(V, size=5, replace=False))
+        rc.add_cardinality(vs, 2)
+    record("knapsack_mixed", rc, rng.normal(0, 3, V).round(2))
+
+
+if __name__ == "__main__":
+    main()

@@ -289,7 +289,8 @@ void ref_col_export(void* c, uint64_t* instr, uint64_t* delims)
     for (size_t b = 0; b < col.nr_bdds(); ++b) {
         delims[b] = k;
         const size_t off = col.offset(b);
-        for (auto it = col.cbegin(b); it != col.cend(b); ++it, ++k) {
+        const bdd_instruction* it = col.cbegin(b);  // cend() stops before the two terminals
+        for (size_t i = 0; i < col.nr_bdd_nodes(b); ++i, ++it, ++k) {
             // re-base absolute indices to the exported (dense) array
             instr[3 * k + 0] = it->is_terminal() ? it->lo : it->lo - off + delims[b];
             instr[3 * k + 1] = it->is_terminal() ? it->hi : it->hi - off + delims[b];

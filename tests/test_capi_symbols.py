@@ -1,0 +1,30 @@
+"""The C-ABI library loads and exports every symbol include/bdd_mma.h declares — CPU only, no compute."""
+import os
+import re
+
+from bdd_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bdd_mma.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bddmma_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    L = capi.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 50
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/bdd_mma.h but not exported"
+        assert s in capi.SIGNATURES, f"{s} has no ctypes signature in bdd_amd/capi.py"
+    assert set(capi.SIGNATURES) <= set(syms)
+
+
+def test_null_handles_are_rejected():
+    L = capi.lib()
+    assert L.bddmma_iteration(None, 0.5) == -1
+    assert L.bddmma_nr_variables(None) == 0
+    assert L.bddmma_last_error(None) is not None

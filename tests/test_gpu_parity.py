@@ -1,0 +1,320 @@
+"""HIP path vs the CPU oracle / reference golden traces / reference known answers — needs an MI355X.
+
+Everything goes through the C-ABI (bdd_amd.solver -> ctypes -> libbdd_mma_hip.so).
+Tolerances: the reference's own CPU<->GPU test uses 1e-6 absolute on every delta and lower bound in
+double (test/test_cuda_parallel_mma.cu:72-99); BASELINE.json asks for 1e-5 relative on the lower
+bound after equal iterations.  Double runs here are held to 1e-9, float runs to 1e-5 relative.
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from bdd_amd import BddCollection, parse_lp, to_bdd_collection
+from bdd_amd.instances import GRID_3X3, LONG_CHAIN, SHORT_CHAIN, assignment_ilp, mrf_ilp, random_set_cover
+from bdd_amd.solver import bdd_hip_lbfgs, bdd_hip_parallel_mma, run_solver
+from oracle.oracle import Oracle
+from test_oracle_kat import SIMPLEX_KATS
+from util import GOLDEN, load_golden, pad_costs, suffix
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"double": dict(abs=1e-9, rel=1e-9), "float": dict(abs=2e-4, rel=1e-5)}
+
+
+def close(a, b, precision, scale=1.0):
+    t = TOL[precision]
+    return abs(a - b) <= t["abs"] * max(1.0, scale) + t["rel"] * abs(b)
+
+
+# ---------------------------------------------------------------- reference known answers
+@pytest.mark.parametrize("lp,nv,nb,lb", SIMPLEX_KATS + [(assignment_ilp(3).write_lp(), 9, 6, -6.0)])
+def test_bdd_cuda_base_kats(lp, nv, nb, lb):
+    # test/test_bdd_cuda_base.cpp:49-115: bdd_cuda_base<float>, set_cost per variable, exact lower bound
+    ilp = parse_lp(lp)
+    s = bdd_hip_parallel_mma(to_bdd_collection(ilp), precision="float")
+    assert s.nr_variables() == nv and s.nr_bdds() == nb
+    for i, c in enumerate(ilp.objective):
+        s.set_cost(c, i)
+    assert s.lower_bound() == lb
+
+
+def test_min_marginals_two_simplex():
+    # test/test_bdd_cuda_min_marginals.cpp:17-36
+    ilp = parse_lp(SIMPLEX_KATS[1][0])
+    s = bdd_hip_parallel_mma(to_bdd_collection(ilp), precision="float")
+    s.update_costs([], ilp.objective)
+    mms = s.min_marginals()
+    assert len(mms) == 6 and all(m.shape == (1, 2) for m in mms)
+    expect = [(1, 2), (1, 1), (1, 1), (1, 0), (0, 1), (3, 0)]
+    for m, e in zip(mms, expect):
+        assert tuple(m[0]) == e
+
+
+@pytest.mark.parametrize("P,kat", [(SHORT_CHAIN, 1.0), (LONG_CHAIN, -9.0), (GRID_3X3, -8.0), ("matching", -6.0)])
+def test_200_iterations_kats_and_reparametrisation(P, kat):
+    # test/test_bdd_cuda_parallel_mma.cu:197-247: 200 iteration()s, distribute_delta(), final LB,
+    # primal objective vector equals the ILP objective before and after (1e-12 there, double)
+    ilp = assignment_ilp(3) if P == "matching" else mrf_ilp(**P)
+    col = to_bdd_collection(ilp)
+    s = bdd_hip_parallel_mma(col, ilp.objective, precision="double")
+    np.testing.assert_allclose(s.get_primal_objective_vector_host(), ilp.objective, atol=1e-12)
+    for _ in range(200):
+        s.iteration()
+    s.distribute_delta()
+    assert abs(s.lower_bound() - kat) < 1e-9
+    np.testing.assert_allclose(s.get_primal_objective_vector_host(), ilp.objective, atol=1e-9)
+
+
+# ---------------------------------------------------------------- reference traces (oracle/_ref)
+@pytest.mark.parametrize("name", GOLDEN)
+@pytest.mark.parametrize("precision", ["double", "float"])
+@pytest.mark.parametrize("pack_width", [64, 128, 256])
+def test_parity_protocol(name, precision, pack_width):
+    """test/test_cuda_parallel_mma.cu:13-103 against traces of the reference's CPU node arithmetic."""
+    col, z = load_golden(name)
+    sfx = suffix(precision)
+    s = bdd_hip_parallel_mma(col, precision=precision, pack_width=pack_width)
+    V = s.nr_variables()
+    o = Oracle(col, None, precision)
+    assert V == o.nr_variables() and s.nr_bdds() == o.nr_bdds() and s.nr_layers() == o.nr_layers()
+    np.testing.assert_array_equal(s.get_num_bdds_per_var(), o.nr_bdds_per_var())
+    assert close(s.lower_bound(), 0.0, precision)  # before cost update
+    s.update_costs([], pad_costs(z["costs"], V))
+    scale = float(np.abs(z["costs"]).max())
+    assert close(s.lower_bound(), float(z[f"lb_init_{sfx}"]), precision, scale)
+    d = np.zeros(2 * V, s.value_type)
+    t = TOL[precision]
+    for it in range(10):
+        s.forward_mm(0.5, d)
+        np.testing.assert_allclose(d, z[f"delta_trace_{sfx}"][it, 0], atol=t["abs"] * scale, rtol=t["rel"])
+        s.backward_mm(0.5, d)
+        np.testing.assert_allclose(d, z[f"delta_trace_{sfx}"][it, 1], atol=t["abs"] * scale, rtol=t["rel"])
+        assert close(s.lower_bound(), float(z[f"lb_trace_{sfx}"][it]), precision, scale)
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+@pytest.mark.parametrize("precision", ["double", "float"])
+def test_iteration_trajectory(name, precision):
+    col, z = load_golden(name)
+    sfx = suffix(precision)
+    s = bdd_hip_parallel_mma(col, pad_costs(z["costs"], col.nr_variables()), precision=precision)
+    scale = float(np.abs(z["costs"]).max())
+    prev = s.lower_bound()
+    for it in range(20):
+        s.iteration()
+        lb = s.lower_bound()
+        assert close(lb, float(z[f"iter_lb_{sfx}"][it]), precision, scale)
+        assert lb >= prev - TOL[precision]["abs"] * scale * 10
+        prev = lb
+
+
+def test_backward_mm_needs_forward_state():
+    col, z = load_golden("loose_covering")
+    s = bdd_hip_parallel_mma(col, z["costs"])
+    d = np.zeros(2 * s.nr_variables())
+    from bdd_amd.capi import BddMmaError
+    with pytest.raises(BddMmaError, match="forward"):
+        s.backward_mm(0.5, d)  # assert(forward_state_valid_), bdd_cuda_parallel_mma.cu:304
+
+
+# ---------------------------------------------------------------- vs the oracle on seeded instances
+def oracle_layer_perm(s, o):
+    """internal layer order -> oracle (BDD-major) order"""
+    perm = s.bdd_major_order()
+    var, bdd = o.layer_info()
+    np.testing.assert_array_equal(s.get_primal_variable_index()[perm], var)
+    np.testing.assert_array_equal(s.get_bdd_index()[perm], bdd)
+    return perm
+
+
+@pytest.mark.parametrize("precision", ["double", "float"])
+@pytest.mark.parametrize("pack_width", [64, 128])
+def test_random_cover_vs_oracle(precision, pack_width):
+    col, costs = random_set_cover(3000, 2500, 8, seed=5)
+    s = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=pack_width)
+    o = Oracle(col, costs, precision)
+    assert s.nr_packs() > 8
+    assert close(s.lower_bound(), o.lower_bound(), precision, 10)
+    np.testing.assert_allclose(s.lower_bound_per_bdd(), o.lower_bound_per_bdd(), rtol=TOL[precision]["rel"], atol=TOL[precision]["abs"])
+    for _ in range(15):
+        s.iteration(); o.iteration()
+        assert close(s.lower_bound(), o.lower_bound(), precision, 10)
+    perm = oracle_layer_perm(s, o)
+    # costs after 15 iterations agree layer by layer
+    lo, hi, _ = s.get_solver_costs()
+    olo, ohi = o.get_costs()
+    np.testing.assert_allclose(lo[perm], olo, rtol=1e-4 if precision == "float" else 1e-9, atol=1e-3 if precision == "float" else 1e-9)
+    np.testing.assert_allclose(hi[perm], ohi, rtol=1e-4 if precision == "float" else 1e-9, atol=1e-3 if precision == "float" else 1e-9)
+
+
+def test_min_marginals_and_solution_vs_oracle():
+    col, z = load_golden("knapsack_mixed")
+    costs = pad_costs(z["costs"], col.nr_variables())
+    s = bdd_hip_parallel_mma(col, costs, precision="double")
+    o = Oracle(col, costs, "double")
+    for _ in range(3):
+        s.iteration(); o.iteration()
+    s.distribute_delta(); o.distribute_delta()
+    perm = oracle_layer_perm(s, o)
+    var, mm0, mm1 = s.min_marginals_cuda(get_sorted=False)
+    omm = o.min_marginals()
+    np.testing.assert_allclose(mm0[perm], omm[:, 0], atol=1e-9)
+    np.testing.assert_allclose(mm1[perm], omm[:, 1], atol=1e-9)
+    # sorted output: ordered by (variable, bdd)
+    svar, s0, s1 = s.min_marginals_cuda(get_sorted=True)
+    assert np.all(np.diff(svar) >= 0)
+    order = np.lexsort((s.get_bdd_index(), s.get_primal_variable_index()))
+    np.testing.assert_array_equal(svar, s.get_primal_variable_index()[order])
+    np.testing.assert_allclose(s0, mm0[order]); np.testing.assert_allclose(s1, mm1[order])
+    # per-BDD argmin path: feasible for its BDD and attains the BDD's lower bound (test_bdd_cuda_base_sol.cpp:30-86)
+    sol = s.bdds_solution_vec()
+    lo, hi, _ = s.get_solver_costs()
+    lbs = s.lower_bound_per_bdd()
+    bdd = s.get_bdd_index(); v = s.get_primal_variable_index()
+    for b in range(s.nr_bdds()):
+        m = bdd == b
+        x = np.zeros(s.nr_variables()); x[v[m]] = sol[m]
+        assert col.evaluate(b, x)
+        assert abs(np.where(sol[m] == 1, hi[m], lo[m]).sum() - lbs[b]) < 1e-9
+
+
+@pytest.mark.parametrize("precision", ["double", "float"])
+def test_wide_packs_vs_oracle(precision):
+    rng = np.random.Generator(np.random.PCG64(21))
+    col = BddCollection()
+    V = 40
+    for _ in range(6):
+        k = int(rng.integers(16, 22))
+        vs = np.sort(rng.choice(V, size=k, replace=False))
+        co = rng.integers(1, 40, size=k)
+        col.add_linear(co, "<=", int(co.sum() // 2), vs)
+    for _ in range(30):
+        col.add_covering(np.sort(rng.choice(V, size=5, replace=False)))
+    costs = rng.normal(0, 3, col.nr_variables()).round(3)
+    s = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=64, wide_pack_width=512)
+    o = Oracle(col, costs, precision)
+    assert close(s.lower_bound(), o.lower_bound(), precision, 100)
+    for _ in range(12):
+        s.iteration(); o.iteration()
+        assert close(s.lower_bound(), o.lower_bound(), precision, 100)
+    perm = oracle_layer_perm(s, o)
+    _, mm0, mm1 = s.min_marginals_cuda(False)
+    s2 = bdd_hip_parallel_mma(col, costs, precision=precision)  # fresh: compare plain min-marginals
+    o2 = Oracle(col, costs, precision)
+    _, a0, a1 = s2.min_marginals_cuda(False)
+    om = o2.min_marginals()
+    p2 = oracle_layer_perm(s2, o2)
+    np.testing.assert_allclose(a0[p2], om[:, 0], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(a1[p2], om[:, 1], rtol=1e-5, atol=1e-4)
+    sol = s2.bdds_solution_vec()
+    for b in range(6):
+        m = s2.get_bdd_index() == b
+        x = np.zeros(col.nr_variables()); x[s2.get_primal_variable_index()[m]] = sol[m]
+        assert col.evaluate(b, x)
+
+
+def test_deterministic_mode_is_bit_reproducible_and_agrees():
+    col, costs = random_set_cover(3000, 2500, 8, seed=9)
+    runs = []
+    for _ in range(2):
+        s = bdd_hip_parallel_mma(col, costs, precision="float", deterministic=True)
+        s.iterations(10)
+        runs.append((s.lower_bound(), s.get_delta().copy(), s.get_solver_costs()[1].copy()))
+    assert runs[0][0] == runs[1][0]
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    np.testing.assert_array_equal(runs[0][2], runs[1][2])
+    s = bdd_hip_parallel_mma(col, costs, precision="float")
+    s.iterations(10)
+    assert abs(s.lower_bound() - runs[0][0]) <= 1e-5 * abs(runs[0][0])
+
+
+def test_dual_ops_vs_numpy():
+    col, costs = random_set_cover(500, 400, 6, seed=2)
+    s = bdd_hip_parallel_mma(col, costs, precision="double")
+    s.iterations(3)
+    lo, hi, mm = s.get_solver_costs()
+    np.testing.assert_allclose(s.net_solver_costs(), hi - lo + mm, atol=1e-12)  # bdd_cuda_parallel_mma.cu:432-446
+    rng = np.random.Generator(np.random.PCG64(1))
+    g = rng.normal(size=s.nr_layers())
+    v = s.get_primal_variable_index()
+    g2 = g.copy()
+    s.make_dual_feasible(g2)
+    sums = np.zeros(s.nr_variables()); np.add.at(sums, v, g)
+    cnt = np.maximum(s.get_num_bdds_per_var(), 1)
+    np.testing.assert_allclose(g2, g - (sums / cnt)[v], atol=1e-12)
+    lb0 = s.lower_bound()
+    s.gradient_step(g2, 1e-3)
+    lo2, hi2, _ = s.get_solver_costs()
+    np.testing.assert_allclose(hi2, hi + 1e-3 * g2, atol=1e-12)
+    np.testing.assert_array_equal(lo2, lo)
+    assert s.lower_bound() != lb0
+    # set_solver_costs restores the state exactly
+    s.set_solver_costs(lo, hi, mm)
+    assert abs(s.lower_bound() - lb0) < 1e-9
+
+
+def test_save_load_roundtrip():
+    # test/test_bdd_cuda_base_serialization.cpp:52-76: counts and lower bound survive
+    col, costs = random_set_cover(500, 400, 6, seed=3)
+    s = bdd_hip_parallel_mma(col, costs, precision="double")
+    s.iterations(4)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "solver.bin")
+        s.save(path)
+        t = bdd_hip_parallel_mma.load(path)
+    assert (t.nr_variables(), t.nr_bdds(), t.nr_layers()) == (s.nr_variables(), s.nr_bdds(), s.nr_layers())
+    assert t.lower_bound() == s.lower_bound()
+    np.testing.assert_array_equal(t.get_delta(), s.get_delta())
+    s.iterations(3); t.iterations(3)
+    assert abs(t.lower_bound() - s.lower_bound()) < 1e-9
+
+
+def test_run_solver_and_lbfgs():
+    col, costs = random_set_cover(3000, 2500, 8, seed=13)
+    s = bdd_hip_parallel_mma(col, costs, precision="double")
+    res = run_solver(s, max_iter=60, tolerance=1e-9, improvement_slope=0.0, time_limit=100)
+    assert res["iterations"] == 60 or res["stop_reason"] == 2
+    assert res["lb_final"] >= res["lb_initial"] - 1e-9
+    o = Oracle(col, costs, "double")
+    for _ in range(res["iterations"]):
+        o.iteration()
+    assert abs(res["lb_final"] - o.lower_bound()) <= 1e-9 * abs(o.lower_bound())
+    # L-BFGS: lower bound never decreases (assert at lbfgs_impl.h:403) and ends at least as high as plain MMA
+    s2 = bdd_hip_parallel_mma(col, costs, precision="double")
+    l = bdd_hip_lbfgs(s2)
+    prev = s2.lower_bound()
+    for _ in range(60):
+        l.iteration()
+        lb = l.lower_bound()
+        assert lb >= prev - 1e-6
+        prev = lb
+    assert prev >= res["lb_final"] - 1e-4 * abs(res["lb_final"])
+
+
+# ---------------------------------------------------------------- BASELINE.json full size, size-independent properties
+@pytest.mark.parametrize("n_vars,n_rows", [(100_000, 50_000), (1_000_000, 500_000)])
+def test_full_size_properties(n_vars, n_rows):
+    col, costs = random_set_cover(n_vars, n_rows, 10, seed=12345)
+    assert col.nr_bdd_nodes() == n_rows * 21
+    sf = bdd_hip_parallel_mma(col, costs, precision="float")
+    sd = bdd_hip_parallel_mma(col, costs, precision="double")
+    lbs = []
+    for _ in range(10):
+        sf.iteration(); sd.iteration()
+        lf, ld = sf.lower_bound(), sd.lower_bound()
+        assert abs(lf - ld) <= 1e-5 * abs(ld)            # float vs double agree (~1e-11 on CPU)
+        lbs.append(ld)
+    assert all(b >= a - 1e-9 * abs(a) for a, b in zip(lbs, lbs[1:]))  # MMA is monotone
+    assert lbs[-1] <= costs.sum() + 1e-6                  # x = 1 is feasible for a covering problem
+    # reparametrisation invariance: sum over BDDs of (hi - lo) per variable is the objective
+    sd.distribute_delta()
+    np.testing.assert_allclose(sd.get_primal_objective_vector_host(), costs, atol=1e-9)
+    # per-BDD lower bounds add up to the lower bound (checksum of checksums)
+    assert abs(sd.lower_bound_per_bdd().sum() - sd.lower_bound()) <= 1e-9 * abs(sd.lower_bound())
+    if n_rows <= 50_000:
+        o = Oracle(col, costs, "double", threads=os.cpu_count() or 1)
+        for _ in range(10):
+            o.iteration()
+        assert abs(lbs[-1] - o.lower_bound()) <= 1e-9 * abs(o.lower_bound())

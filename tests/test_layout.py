@@ -1,0 +1,178 @@
+"""Device-layout builder (bdd_amd/csrc/layout.cpp) through the host-only debug ABI — CPU only.
+
+Decodes the pack / hop / node-word arrays back into a graph and checks it is the input BDD
+collection (same children, same variables), plus the structural invariants the kernels rely on.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from bdd_amd import BddCollection, capi, to_bdd_collection
+from bdd_amd.instances import assignment_ilp, random_set_cover
+from util import GOLDEN, load_golden
+
+TOP = np.uint64(2**64 - 1)
+BOT = np.uint64(2**64 - 2)
+
+
+class Layout:
+    def __init__(self, col, pack_width=0, wide_pack_width=0):
+        L = capi.lib()
+        instr = np.ascontiguousarray(col.instr, dtype=np.uint64)
+        delims = np.ascontiguousarray(col.delims, dtype=np.uint64)
+        h = C.c_void_p()
+        opts = capi.Options(pack_width, wide_pack_width, 0)
+        rc = L.bddmma_layout_create(C.byref(h), instr.ctypes.data_as(C.c_void_p), delims.ctypes.data_as(C.c_void_p),
+                                    col.nr_bdds(), C.byref(opts))
+        capi.check(rc, None)
+        self.L, self.h = L, h
+        sz = lambda w: int(L.bddmma_layout_size(h, w))
+        self.n_slots, self.narrow_slots, self.n_layers = sz(0), sz(1), sz(2)
+        self.np_n, self.np_w, self.n_hops, self.n_vars = sz(3), sz(4), sz(5), sz(6)
+        rec_n, rec_w = sz(7), sz(8)
+
+        def get(which, n, dt):
+            a = np.zeros(max(n, 1), dt)
+            capi.check(L.bddmma_layout_copy(h, which, a.ctypes.data_as(C.c_void_p)), None)
+            return a[:n]
+        self.nwords = get(0, self.narrow_slots, np.uint32)
+        self.wwords = get(1, self.n_slots - self.narrow_slots, np.uint64)
+        self.slot_to_instr = get(2, self.n_slots, np.uint64)
+        self.layer_var = get(3, self.n_layers, np.int32)
+        self.layer_bdd = get(4, self.n_layers, np.int32)
+        self.sets = []
+        for base, P, rec in ((5, self.np_n, rec_n), (9, self.np_w, rec_w)):
+            self.sets.append(dict(pack_hop_ptr=get(base, P + 1 if P else 0, np.uint32),
+                                  hop_node_off=get(base + 1, rec + 1 if P else 0, np.uint32),
+                                  hop_layer_off=get(base + 2, rec + 1 if P else 0, np.uint32),
+                                  steps=get(base + 3, P, np.uint8), P=P))
+        self.var_ptr = get(13, self.n_vars + 1, np.uint32)
+        self.var_layers = get(14, self.n_layers, np.uint32)
+        self.root_slot = get(15, col.nr_bdds(), np.uint32)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.bddmma_layout_destroy(self.h)
+
+    def decode(self):
+        """-> dict slot -> (lo_slot|'T'|'B', hi_slot|..., layer_global, head)"""
+        out = {}
+        for wide, S in enumerate(self.sets):
+            for p in range(S["P"]):
+                q0, q1 = int(S["pack_hop_ptr"][p]), int(S["pack_hop_ptr"][p + 1])
+                for q in range(q0, q1):
+                    nb, ne = int(S["hop_node_off"][q]), int(S["hop_node_off"][q + 1])
+                    lb = int(S["hop_layer_off"][q])
+                    for j in range(ne - nb):
+                        slot = nb + j
+                        if wide:
+                            w = int(self.wwords[slot - self.narrow_slots])
+                            lo, hi, l = w & 0x1FFFFF, (w >> 21) & 0x1FFFFF, (w >> 42) & 0x1FFFFF
+                            head, pad, BOTC, TOPC = bool(w >> 63), False, 0x1FFFFF, 0x1FFFFE
+                        else:
+                            w = int(self.nwords[slot])
+                            lo, hi, l = w & 1023, (w >> 10) & 1023, (w >> 20) & 1023
+                            head, pad, BOTC, TOPC = bool((w >> 30) & 1), bool(w >> 31), 1023, 1022
+                        if pad:
+                            continue
+                        assert q + 1 < q1 or (lo >= TOPC and hi >= TOPC), "last hop must only reach terminals"
+                        cv = lambda c: "B" if c == BOTC else ("T" if c == TOPC else ne + c)
+                        out[slot] = (cv(lo), cv(hi), lb + l, head, (wide, p, q - q0, j))
+        return out
+
+
+def check_roundtrip(col, **kw):
+    lay = Layout(col, **kw)
+    dec = lay.decode()
+    ins = col.instr
+    n_nonterm = int((ins[:, 2] < BOT).sum())
+    assert len(dec) == n_nonterm == lay.n_slots - sum(1 for s in range(lay.n_slots) if s not in dec)
+    inv = {int(lay.slot_to_instr[s]): s for s in dec}
+    assert len(inv) == n_nonterm
+    seen_heads = {}
+    for s, (lo, hi, lg, head, where) in dec.items():
+        i = int(lay.slot_to_instr[s])
+        for side, c in ((0, lo), (1, hi)):
+            ci = int(ins[i, side])
+            if ins[ci, 2] == TOP:
+                assert c == "T"
+            elif ins[ci, 2] == BOT:
+                assert c == "B"
+            else:
+                assert c == inv[ci]
+        assert lay.layer_var[lg] == int(ins[i, 2])
+        seen_heads[lg] = seen_heads.get(lg, 0) + (1 if head else 0)
+        if not where[0]:  # narrow: a layer never straddles a 64-lane group
+            pass
+    assert all(v == 1 for v in seen_heads.values()) and len(seen_heads) == lay.n_layers
+    # nodes of one layer are contiguous slots inside one 64-group (narrow)
+    by_layer = {}
+    for s, (_, _, lg, _, where) in dec.items():
+        by_layer.setdefault(lg, []).append((s, where))
+    for lg, lst in by_layer.items():
+        slots = sorted(s for s, _ in lst)
+        assert slots == list(range(slots[0], slots[0] + len(slots)))
+        if not lst[0][1][0]:
+            js = [w[3] for _, w in lst]
+            assert min(js) // 64 == max(js) // 64
+    # var CSR sorted by (var, bdd)
+    for v in range(lay.n_vars):
+        ls = lay.var_layers[lay.var_ptr[v]:lay.var_ptr[v + 1]]
+        assert all(lay.layer_var[l] == v for l in ls)
+        b = lay.layer_bdd[ls]
+        assert np.all(b[1:] > b[:-1])
+    # roots
+    d = col.delims.astype(np.int64)
+    for b in range(col.nr_bdds()):
+        assert int(lay.slot_to_instr[lay.root_slot[b]]) == d[b]
+    return lay
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+@pytest.mark.parametrize("pw", [64, 128, 256])
+def test_roundtrip_golden(name, pw):
+    col, _ = load_golden(name)
+    check_roundtrip(col, pack_width=pw)
+
+
+def test_roundtrip_many_packs_and_wide():
+    col, _ = random_set_cover(400, 300, 6, seed=1)
+    lay = check_roundtrip(col, pack_width=64)
+    assert lay.np_n > 1 and lay.np_w == 0
+    # a knapsack row with a wide layer goes to a wide pack
+    col2 = BddCollection()
+    co = [27, 32, 1, 32, 19, 21, 25, 12, 39, 3, 11, 15, 23, 16, 6, 2, 1, 2]  # widest layer: 97 nodes
+    col2.add_linear(co, "<=", sum(co) // 2, list(range(18)))
+    col2.add_covering([0, 5, 9])
+    lay2 = check_roundtrip(col2, pack_width=64)
+    assert lay2.np_w == 1 and lay2.np_n == 1
+
+
+def test_layout_rejects_bad_input():
+    L = capi.lib()
+    col = BddCollection()
+    col.add_simplex([0, 1, 2])
+    ins = col.instr.copy()
+    ins[0, 0] = 3  # root lo -> node of layer 2: skips a layer
+    bad = BddCollection(); bad._chunks = [ins]; bad._delims = [col.delims]; bad._n = col._n; bad._nb = 1
+    with pytest.raises(capi.BddMmaError, match="QBDD"):
+        Layout(bad)
+    with pytest.raises(capi.BddMmaError):
+        Layout(col, pack_width=100)
+    # wider than the widest supported layer
+    col3 = BddCollection()
+    co = [27, 32, 1, 32, 19, 21, 25, 12, 39, 3, 11, 15, 23, 16, 6, 2, 1, 2]
+    col3.add_linear(co, "<=", sum(co) // 2, list(range(18)))
+    with pytest.raises(capi.BddMmaError, match="widest supported"):
+        Layout(col3, wide_pack_width=64)
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from bdd_amd.solver import bdd_hip_parallel_mma
+    ilp = assignment_ilp(3)
+    with pytest.raises(capi.BddMmaError, match="no CPU fallback"):
+        bdd_hip_parallel_mma(to_bdd_collection(ilp), ilp.objective)

@@ -1,0 +1,45 @@
+"""Shared helpers of the test-suite."""
+import glob
+import os
+
+import numpy as np
+
+from bdd_amd.bdd_collection import BddCollection
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    col = BddCollection()
+    col._chunks = [z["instr"].astype(np.uint64)]
+    col._delims = [z["delims"].astype(np.uint64)]
+    col._n = int(z["instr"].shape[0])
+    col._nb = int(z["delims"].shape[0]) - 1
+    return col, z
+
+
+def pad_costs(costs, n):
+    c = np.zeros(n)
+    c[: len(costs)] = costs
+    return c
+
+
+def suffix(precision):
+    return "f64" if precision == "double" else "f32"
+
+
+def same_function(col_a, b_a, col_b, b_b, n_vars, max_enum=14):
+    """Do two BDDs represent the same Boolean function over their variables?"""
+    va = col_a.variables(b_a)
+    assert va == col_b.variables(b_b)
+    k = len(va)
+    assert k <= max_enum
+    x = [0] * n_vars
+    for m in range(1 << k):
+        for i, v in enumerate(va):
+            x[v] = (m >> i) & 1
+        if col_a.evaluate(b_a, x) != col_b.evaluate(b_b, x):
+            return False
+    return True
