@@ -44,7 +44,7 @@ struct SolverT final : SolverBase {
     int32_t *d_var = nullptr, *d_bdd = nullptr, *d_nbdds = nullptr;
     uint32_t *d_var_ptr = nullptr, *d_var_layers = nullptr, *d_root_slot = nullptr;
     REAL *d_delta_a = nullptr, *d_delta_b = nullptr;  // solver's own deferred delta (in / accumulator)
-    REAL *d_delta_c = nullptr, *d_delta_d = nullptr;  // scratch for the explicit forward_mm/backward_mm API
+    REAL *d_delta_c = nullptr, *d_delta_d = nullptr, *d_delta_e = nullptr;  // scratch for the explicit forward_mm/backward_mm API
     double *d_lb_partial = nullptr, *d_lb = nullptr;
     REAL *d_tmp0 = nullptr, *d_tmp1 = nullptr;        // per-layer scratch (min-marginals, sorted outputs)
     char* d_sol = nullptr;
@@ -132,9 +132,10 @@ struct SolverT final : SolverBase {
         if ((rc = dalloc(&d_tmp1, n_layers))) return rc;
         if ((rc = dalloc(&d_sol, n_layers))) return rc;
         if ((rc = dalloc(&d_delta_a, 2 * n_vars))) return rc;
-        if ((rc = dalloc(&d_delta_b, 2 * n_vars))) return rc;
+        if ((rc = dalloc(&d_delta_b, (uint64_t)N_XCD * 2 * n_vars))) return rc;
         if ((rc = dalloc(&d_delta_c, 2 * n_vars))) return rc;
-        if ((rc = dalloc(&d_delta_d, 2 * n_vars))) return rc;
+        if ((rc = dalloc(&d_delta_d, (uint64_t)N_XCD * 2 * n_vars))) return rc;
+        if ((rc = dalloc(&d_delta_e, 2 * n_vars))) return rc;
         if ((rc = dalloc(&d_lb_partial, nb_.n_packs + wb_.n_packs))) return rc;
         if ((rc = dalloc(&d_lb, 1))) return rc;
         HIPCHK(hipMemsetAsync(d_F, 0, n_slots * sizeof(REAL), stream));
@@ -142,7 +143,8 @@ struct SolverT final : SolverBase {
         HIPCHK(hipMemsetAsync(d_lo, 0, n_layers * sizeof(REAL), stream));
         HIPCHK(hipMemsetAsync(d_hi, 0, n_layers * sizeof(REAL), stream));
         HIPCHK(hipMemsetAsync(d_mm, 0, n_layers * sizeof(REAL), stream));  // bdd_cuda_base.cu:45
-        for (REAL* p : {d_delta_a, d_delta_b, d_delta_c, d_delta_d}) HIPCHK(hipMemsetAsync(p, 0, 2 * n_vars * sizeof(REAL), stream));
+        for (REAL* p : {d_delta_a, d_delta_c, d_delta_e}) HIPCHK(hipMemsetAsync(p, 0, 2 * n_vars * sizeof(REAL), stream));
+        for (REAL* p : {d_delta_b, d_delta_d}) HIPCHK(hipMemsetAsync(p, 0, (size_t)N_XCD * 2 * n_vars * sizeof(REAL), stream));
         if (wb_.n_packs) {
             wide_lds = (uint32_t)wide_lds_bytes(sizeof(REAL), wide_pack_width, true);
             if (wide_lds > 160 * 1024) {
@@ -168,7 +170,7 @@ struct SolverT final : SolverBase {
         DevPtrs<REAL> d;
         d.nwords = d_nwords; d.wwords = d_wwords; d.wide_slot_base = wide_slot_base;
         d.F = d_F; d.T = d_T; d.lo = d_lo; d.hi = d_hi; d.mm = d_mm; d.var = d_var;
-        d.delta_in = din; d.delta_out = dout; d.lb_partial = d_lb_partial;
+        d.delta_in = din; d.delta_out = dout; d.delta_stride = (uint32_t)(2 * n_vars); d.lb_partial = d_lb_partial;
         d.mm0_out = d_tmp0; d.mm1_out = d_tmp1; d.sol_out = d_sol;
         return d;
     }
@@ -230,7 +232,7 @@ struct SolverT final : SolverBase {
             prof_end(BDDMMA_K_FINISH_DELTA);
         }
         prof_begin(BDDMMA_K_FINISH_DELTA);
-        hipLaunchKernelGGL((k_finish_delta<REAL>), dim3(cdiv(2 * n_vars, 256)), dim3(256), 0, stream, din, dout, d_nbdds, (uint32_t)(2 * n_vars));
+        hipLaunchKernelGGL((k_finish_delta<REAL>), dim3(cdiv(2 * n_vars, 256)), dim3(256), 0, stream, din, dout, d_nbdds, (uint32_t)(2 * n_vars), deterministic ? 1 : N_XCD);
         prof_end(BDDMMA_K_FINISH_DELTA);
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
@@ -319,12 +321,14 @@ struct SolverT final : SolverBase {
         HIPCHK(hipSetDevice(device));
         const size_t bytes = 2 * n_vars * sizeof(REAL);
         HIPCHK(hipMemcpyAsync(d_delta_c, delta, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemsetAsync(d_delta_d, 0, bytes, stream));
+        HIPCHK(hipMemsetAsync(d_delta_d, 0, (size_t)N_XCD * bytes, stream));
         int rc = forward ? mma_forward((REAL)omega, d_delta_c, d_delta_d) : mma_backward((REAL)omega, d_delta_c, d_delta_d);
         if (rc) return rc;
         if (deterministic)
-            hipLaunchKernelGGL((k_delta_gather<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm, d_var_ptr, d_var_layers, d_delta_d, (uint32_t)n_vars);
-        HIPCHK(hipMemcpyAsync(delta, d_delta_d, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+            hipLaunchKernelGGL((k_delta_gather<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm, d_var_ptr, d_var_layers, d_delta_e, (uint32_t)n_vars);
+        else
+            hipLaunchKernelGGL((k_sum_slices<REAL>), dim3(cdiv(2 * n_vars, 256)), dim3(256), 0, stream, d_delta_e, d_delta_d, (uint32_t)(2 * n_vars), N_XCD);
+        HIPCHK(hipMemcpyAsync(delta, d_delta_e, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         return BDDMMA_OK;
     }
