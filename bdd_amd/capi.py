@@ -21,7 +21,7 @@ K_FORWARD_MM, K_BACKWARD_MM, K_FINISH_DELTA, K_OTHER, K_COUNT = 0, 1, 2, 3, 4
 
 class Options(C.Structure):
     _fields_ = [("pack_width", C.c_uint32), ("wide_pack_width", C.c_uint32), ("deterministic", C.c_uint32),
-                ("reserved", C.c_uint32 * 5)]
+                ("vars_per_bin", C.c_uint32), ("stage_cap", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 class LbfgsParams(C.Structure):
@@ -90,6 +90,7 @@ SIGNATURES = {
     "bddmma_set_profiling": (_I, [_V, _I]),
     "bddmma_get_profile": (_I, [_V, C.POINTER(Profile)]),
     "bddmma_time_iterations": (_I, [_V, _D, _U64, C.POINTER(_D)]),
+    "bddmma_time_kernel": (_I, [_V, _I, _U64, C.POINTER(_D)]),
     "bddmma_device_bytes": (_U64, [_V]),
     "bddmma_layout_create": (_I, [C.POINTER(_V), _V, _V, _U64, C.POINTER(Options)]),
     "bddmma_layout_destroy": (None, [_V]),

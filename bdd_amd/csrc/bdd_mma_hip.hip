@@ -40,11 +40,18 @@ struct SolverT final : SolverBase {
     // device buffers
     uint32_t* d_nwords = nullptr;
     uint64_t* d_wwords = nullptr;
-    REAL *d_F = nullptr, *d_T = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_mm = nullptr;
+    REAL *d_F = nullptr, *d_T = nullptr, *d_lohi = nullptr;  // d_lohi: {lo, hi} per layer, interleaved
+    REAL* d_lo = nullptr;  // = d_lohi     (stride 2)
+    REAL* d_hi = nullptr;  // = d_lohi + 1 (stride 2)
     int32_t *d_var = nullptr, *d_bdd = nullptr, *d_nbdds = nullptr;
     uint32_t *d_var_ptr = nullptr, *d_var_layers = nullptr, *d_root_slot = nullptr;
-    REAL *d_delta_a = nullptr, *d_delta_b = nullptr;  // solver's own deferred delta (in / accumulator)
-    REAL *d_delta_c = nullptr, *d_delta_d = nullptr, *d_delta_e = nullptr;  // scratch for the explicit forward_mm/backward_mm API
+    REAL* d_delta_var = nullptr;    // 2V: the solver's deferred delta_lo_hi_ (normalised), per variable
+    REAL* d_delta_lay = nullptr;    // 2L: the same, broadcast to binned entry order (what the sweeps read)
+    REAL* d_mm_binned = nullptr;    // L : deferred min-marginal differences in binned entry order
+    REAL *d_delta_c = nullptr, *d_delta_lay_c = nullptr;  // scratch for the explicit forward_mm/backward_mm API
+    uint32_t *d_evar = nullptr, *d_lpos = nullptr, *d_vpos = nullptr, *d_bin_ptr = nullptr;
+    uint32_t *d_pack_group_ptr = nullptr, *d_grp_layer_off = nullptr, *d_grp_hop_end = nullptr;
+    uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0, stage_lds = 0, exch_lds = 0, n_narrow_layers = 0;
     double *d_lb_partial = nullptr, *d_lb = nullptr;
     REAL *d_tmp0 = nullptr, *d_tmp1 = nullptr;        // per-layer scratch (min-marginals, sorted outputs)
     char* d_sol = nullptr;
@@ -125,26 +132,48 @@ struct SolverT final : SolverBase {
         wide_slot_base = L.narrow_slots;
         if ((rc = dalloc(&d_F, n_slots))) return rc;
         if ((rc = dalloc(&d_T, n_slots))) return rc;
-        if ((rc = dalloc(&d_lo, n_layers))) return rc;
-        if ((rc = dalloc(&d_hi, n_layers))) return rc;
-        if ((rc = dalloc(&d_mm, n_layers))) return rc;
+        if ((rc = dalloc(&d_lohi, 2 * n_layers + 2))) return rc;
+        d_lo = d_lohi;
+        d_hi = d_lohi + 1;
+        if ((rc = dalloc(&d_mm_binned, n_layers))) return rc;
+        if ((rc = dalloc(&d_delta_lay, 2 * n_layers))) return rc;
+        if ((rc = dalloc(&d_delta_lay_c, 2 * n_layers))) return rc;
+        if ((rc = upload(&d_evar, L.ex.evar))) return rc;
+        if ((rc = upload(&d_lpos, L.ex.lpos))) return rc;
+        if ((rc = upload(&d_vpos, L.ex.vpos))) return rc;
+        if ((rc = upload(&d_bin_ptr, L.ex.bin_ptr))) return rc;
+        if ((rc = upload(&d_pack_group_ptr, L.ex.pack_group_ptr))) return rc;
+        if ((rc = upload(&d_grp_layer_off, L.ex.grp_layer_off))) return rc;
+        if ((rc = upload(&d_grp_hop_end, L.ex.grp_hop_end))) return rc;
+        vars_per_bin = L.ex.vars_per_bin; n_bins = L.ex.n_bins; stage_cap = L.ex.stage_cap;
+        n_narrow_layers = L.ex.grp_layer_off.empty() ? 0 : L.ex.grp_layer_off.back();
+        if (2 * n_layers * sizeof(REAL) >= 0xFFFFFFFFull || n_slots * sizeof(REAL) >= 0xFFFFFFFFull) {
+            err = "instance too large for the 32-bit buffer offsets of the sweep kernels";
+            return BDDMMA_ERR_UNSUPPORTED;
+        }
+        stage_lds = stage_cap * 2 * (uint32_t)sizeof(REAL);
+        exch_lds = vars_per_bin * 2 * (uint32_t)sizeof(double);  // accumulators are double for both precisions
+        if (exch_lds > 160 * 1024 - 1024 || stage_lds > 64 * 1024) {
+            err = "vars_per_bin / stage_cap need more LDS than a CU has";
+            return BDDMMA_ERR_INVALID_ARGUMENT;
+        }
         if ((rc = dalloc(&d_tmp0, n_layers))) return rc;
         if ((rc = dalloc(&d_tmp1, n_layers))) return rc;
         if ((rc = dalloc(&d_sol, n_layers))) return rc;
-        if ((rc = dalloc(&d_delta_a, 2 * n_vars))) return rc;
-        if ((rc = dalloc(&d_delta_b, (uint64_t)N_XCD * 2 * n_vars))) return rc;
+        if ((rc = dalloc(&d_delta_var, 2 * n_vars))) return rc;
         if ((rc = dalloc(&d_delta_c, 2 * n_vars))) return rc;
-        if ((rc = dalloc(&d_delta_d, (uint64_t)N_XCD * 2 * n_vars))) return rc;
-        if ((rc = dalloc(&d_delta_e, 2 * n_vars))) return rc;
         if ((rc = dalloc(&d_lb_partial, nb_.n_packs + wb_.n_packs))) return rc;
         if ((rc = dalloc(&d_lb, 1))) return rc;
         HIPCHK(hipMemsetAsync(d_F, 0, n_slots * sizeof(REAL), stream));
         HIPCHK(hipMemsetAsync(d_T, 0, n_slots * sizeof(REAL), stream));
-        HIPCHK(hipMemsetAsync(d_lo, 0, n_layers * sizeof(REAL), stream));
-        HIPCHK(hipMemsetAsync(d_hi, 0, n_layers * sizeof(REAL), stream));
-        HIPCHK(hipMemsetAsync(d_mm, 0, n_layers * sizeof(REAL), stream));  // bdd_cuda_base.cu:45
-        for (REAL* p : {d_delta_a, d_delta_c, d_delta_e}) HIPCHK(hipMemsetAsync(p, 0, 2 * n_vars * sizeof(REAL), stream));
-        for (REAL* p : {d_delta_b, d_delta_d}) HIPCHK(hipMemsetAsync(p, 0, (size_t)N_XCD * 2 * n_vars * sizeof(REAL), stream));
+        HIPCHK(hipMemsetAsync(d_lohi, 0, 2 * n_layers * sizeof(REAL), stream));
+        HIPCHK(hipMemsetAsync(d_mm_binned, 0, n_layers * sizeof(REAL), stream));  // bdd_cuda_base.cu:45
+        for (REAL* p : {d_delta_var, d_delta_c}) HIPCHK(hipMemsetAsync(p, 0, 2 * n_vars * sizeof(REAL), stream));
+        for (REAL* p : {d_delta_lay, d_delta_lay_c}) HIPCHK(hipMemsetAsync(p, 0, 2 * n_layers * sizeof(REAL), stream));
+#define SET_DYN(K, BYTES) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
+        SET_DYN((k_exchange_reduce<REAL, double, EX_ITER>), exch_lds);
+        SET_DYN((k_exchange_reduce<REAL, double, EX_RAW>), exch_lds);
+#undef SET_DYN
         if (wb_.n_packs) {
             wide_lds = (uint32_t)wide_lds_bytes(sizeof(REAL), wide_pack_width, true);
             if (wide_lds > 160 * 1024) {
@@ -165,32 +194,36 @@ struct SolverT final : SolverBase {
     }
 
     // ---------------------------------------------------------------------------- launches
-    DevPtrs<REAL> ptrs(const REAL* din, REAL* dout) const
+    DevPtrs<REAL> ptrs(const REAL* delta_lay) const
     {
         DevPtrs<REAL> d;
         d.nwords = d_nwords; d.wwords = d_wwords; d.wide_slot_base = wide_slot_base;
-        d.F = d_F; d.T = d_T; d.lo = d_lo; d.hi = d_hi; d.mm = d_mm; d.var = d_var;
-        d.delta_in = din; d.delta_out = dout; d.delta_stride = (uint32_t)(2 * n_vars); d.lb_partial = d_lb_partial;
+        d.F = d_F; d.T = d_T; d.lohi = d_lohi;
+        d.delta_lay = delta_lay; d.mm_binned = d_mm_binned; d.lpos = d_lpos;
+        d.n_slots = (uint32_t)n_slots; d.n_layers = (uint32_t)n_layers; d.n_narrow_layers = n_narrow_layers;
+        d.lb_partial = d_lb_partial;
         d.mm0_out = d_tmp0; d.mm1_out = d_tmp1; d.sol_out = d_sol;
         return d;
     }
-    static PackDev pdev(const PackBufs& b, uint32_t lb_base)
+    PackDev pdev(const PackBufs& b, uint32_t lb_base) const
     {
-        return PackDev{b.pack_hop_ptr, b.hop_node_off, b.hop_layer_off, b.pack_steps, b.n_packs, lb_base};
+        return PackDev{b.pack_hop_ptr, b.hop_node_off, b.hop_layer_off, b.pack_steps,
+                       d_pack_group_ptr, d_grp_layer_off, d_grp_hop_end, b.n_packs, lb_base};
     }
 
     template <int MODE>
-    int launch_fwd(const REAL* din, REAL* dout, REAL omega, int kclass)
+    int launch_fwd(const REAL* delta_lay, REAL omega, int kclass)
     {
-        DevPtrs<REAL> d = ptrs(din, dout);
+        DevPtrs<REAL> d = ptrs(delta_lay);
+        const uint32_t dyn = (MODE == FWD_SOLVE) ? stage_lds : 0;
         prof_begin(kclass);
         if (nb_.n_packs) {
             const PackDev pk = pdev(nb_, 0);
             const dim3 grid(8 * cdiv(nb_.n_packs, 8)), block(64);
             switch (pack_width) {
-                case 64: hipLaunchKernelGGL((k_fwd_narrow<REAL, 1, MODE>), grid, block, 0, stream, d, pk, omega); break;
-                case 128: hipLaunchKernelGGL((k_fwd_narrow<REAL, 2, MODE>), grid, block, 0, stream, d, pk, omega); break;
-                default: hipLaunchKernelGGL((k_fwd_narrow<REAL, 4, MODE>), grid, block, 0, stream, d, pk, omega); break;
+                case 64: hipLaunchKernelGGL((k_fwd_narrow<REAL, 1, MODE>), grid, block, dyn, stream, d, pk, omega); break;
+                case 128: hipLaunchKernelGGL((k_fwd_narrow<REAL, 2, MODE>), grid, block, dyn, stream, d, pk, omega); break;
+                default: hipLaunchKernelGGL((k_fwd_narrow<REAL, 4, MODE>), grid, block, dyn, stream, d, pk, omega); break;
             }
         }
         if (wb_.n_packs) {
@@ -202,17 +235,18 @@ struct SolverT final : SolverBase {
         return BDDMMA_OK;
     }
     template <int MODE>
-    int launch_bwd(const REAL* din, REAL* dout, REAL omega, int kclass)
+    int launch_bwd(const REAL* delta_lay, REAL omega, int kclass)
     {
-        DevPtrs<REAL> d = ptrs(din, dout);
+        DevPtrs<REAL> d = ptrs(delta_lay);
+        const uint32_t dyn = (MODE == BWD_SOLVE) ? stage_lds : 0;
         prof_begin(kclass);
         if (nb_.n_packs) {
             const PackDev pk = pdev(nb_, 0);
             const dim3 grid(8 * cdiv(nb_.n_packs, 8)), block(64);
             switch (pack_width) {
-                case 64: hipLaunchKernelGGL((k_bwd_narrow<REAL, 1, MODE>), grid, block, 0, stream, d, pk, omega); break;
-                case 128: hipLaunchKernelGGL((k_bwd_narrow<REAL, 2, MODE>), grid, block, 0, stream, d, pk, omega); break;
-                default: hipLaunchKernelGGL((k_bwd_narrow<REAL, 4, MODE>), grid, block, 0, stream, d, pk, omega); break;
+                case 64: hipLaunchKernelGGL((k_bwd_narrow<REAL, 1, MODE>), grid, block, dyn, stream, d, pk, omega); break;
+                case 128: hipLaunchKernelGGL((k_bwd_narrow<REAL, 2, MODE>), grid, block, dyn, stream, d, pk, omega); break;
+                default: hipLaunchKernelGGL((k_bwd_narrow<REAL, 4, MODE>), grid, block, dyn, stream, d, pk, omega); break;
             }
         }
         if (wb_.n_packs) {
@@ -223,16 +257,33 @@ struct SolverT final : SolverBase {
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
-    int finish_delta(REAL* din, REAL* dout)
+    // compute_delta + normalize_delta + broadcast to the layers, see kernels.hpp (k_exchange_reduce)
+    void launch_bcast(const REAL* delta_var, REAL* delta_lay)
     {
-        // deterministic mode: the pass did not accumulate; gather per variable from mm first
-        if (deterministic) {
-            prof_begin(BDDMMA_K_FINISH_DELTA);
-            hipLaunchKernelGGL((k_delta_gather<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm, d_var_ptr, d_var_layers, dout, (uint32_t)n_vars);
-            prof_end(BDDMMA_K_FINISH_DELTA);
-        }
+        hipLaunchKernelGGL((k_exchange_bcast<REAL>), dim3(cdiv(cdiv(n_layers, 4), 256)), dim3(256), 0, stream, delta_var, d_evar, delta_lay,
+                           (uint32_t)n_layers, (uint32_t)n_vars);
+    }
+    // un-normalised per-variable sums of the deferred min-marginal differences (compute_delta only)
+    void launch_reduce_raw(REAL* delta_var)
+    {
+        if (deterministic)
+            hipLaunchKernelGGL((k_delta_gather<REAL, false>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr,
+                               d_vpos, delta_var, (uint32_t)n_vars);
+        else
+            hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_RAW>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
+                               d_bin_ptr, d_evar, d_nbdds, delta_var, (REAL*)nullptr, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers);
+    }
+    int exchange()
+    {
         prof_begin(BDDMMA_K_FINISH_DELTA);
-        hipLaunchKernelGGL((k_finish_delta<REAL>), dim3(cdiv(2 * n_vars, 256)), dim3(256), 0, stream, din, dout, d_nbdds, (uint32_t)(2 * n_vars), deterministic ? 1 : N_XCD);
+        if (deterministic) {
+            hipLaunchKernelGGL((k_delta_gather<REAL, true>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr,
+                               d_vpos, d_delta_var, (uint32_t)n_vars);
+            launch_bcast(d_delta_var, d_delta_lay);
+        } else {
+            hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
+                               d_bin_ptr, d_evar, d_nbdds, d_delta_var, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers);
+        }
         prof_end(BDDMMA_K_FINISH_DELTA);
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
@@ -243,7 +294,7 @@ struct SolverT final : SolverBase {
     {
         if (fwd_valid) return BDDMMA_OK;
         HIPCHK(hipSetDevice(device));
-        int rc = launch_fwd<FWD_PLAIN>(nullptr, nullptr, REAL(0), BDDMMA_K_OTHER);
+        int rc = launch_fwd<FWD_PLAIN>(nullptr, REAL(0), BDDMMA_K_OTHER);
         if (rc) return rc;
         fwd_valid = true;
         return BDDMMA_OK;
@@ -252,7 +303,7 @@ struct SolverT final : SolverBase {
     {
         if (bwd_valid) return BDDMMA_OK;
         HIPCHK(hipSetDevice(device));
-        int rc = launch_bwd<BWD_PLAIN>(nullptr, nullptr, REAL(0), BDDMMA_K_OTHER);
+        int rc = launch_bwd<BWD_PLAIN>(nullptr, REAL(0), BDDMMA_K_OTHER);
         if (rc) return rc;
         bwd_valid = true;
         return BDDMMA_OK;
@@ -283,23 +334,23 @@ struct SolverT final : SolverBase {
         return BDDMMA_OK;
     }
 
-    int mma_forward(REAL omega, REAL* din, REAL* dout)
+    int mma_forward(REAL omega, const REAL* delta_lay)
     {
         int rc;
         if (!bwd_valid && (rc = backward_run())) return rc;  // bdd_cuda_parallel_mma.cu:211-212
-        rc = launch_fwd<FWD_SOLVE>(din, deterministic ? nullptr : dout, omega, BDDMMA_K_FORWARD_MM);
+        rc = launch_fwd<FWD_SOLVE>(delta_lay, omega, BDDMMA_K_FORWARD_MM);
         if (rc) return rc;
         fwd_valid = true;
         bwd_valid = false;
         return BDDMMA_OK;
     }
-    int mma_backward(REAL omega, REAL* din, REAL* dout)
+    int mma_backward(REAL omega, const REAL* delta_lay)
     {
         if (!fwd_valid) {
             err = "backward_mm requires a valid forward state (call forward_mm first)";  // assert at :304
             return BDDMMA_ERR_STATE;
         }
-        int rc = launch_bwd<BWD_SOLVE>(din, deterministic ? nullptr : dout, omega, BDDMMA_K_BACKWARD_MM);
+        int rc = launch_bwd<BWD_SOLVE>(delta_lay, omega, BDDMMA_K_BACKWARD_MM);
         if (rc) return rc;
         fwd_valid = false;
         bwd_valid = true;
@@ -309,11 +360,10 @@ struct SolverT final : SolverBase {
     {
         HIPCHK(hipSetDevice(device));
         int rc;
-        // delta_a = deferred delta (normalised), delta_b = accumulator (zero between passes)
-        if ((rc = mma_forward((REAL)omega, d_delta_a, d_delta_b))) return rc;
-        if ((rc = finish_delta(d_delta_a, d_delta_b))) return rc;
-        if ((rc = mma_backward((REAL)omega, d_delta_a, d_delta_b))) return rc;
-        if ((rc = finish_delta(d_delta_a, d_delta_b))) return rc;
+        if ((rc = mma_forward((REAL)omega, d_delta_lay))) return rc;
+        if ((rc = exchange())) return rc;
+        if ((rc = mma_backward((REAL)omega, d_delta_lay))) return rc;
+        if ((rc = exchange())) return rc;
         return BDDMMA_OK;
     }
     int explicit_mm(bool forward, double omega, void* delta, int on_device)
@@ -321,14 +371,11 @@ struct SolverT final : SolverBase {
         HIPCHK(hipSetDevice(device));
         const size_t bytes = 2 * n_vars * sizeof(REAL);
         HIPCHK(hipMemcpyAsync(d_delta_c, delta, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemsetAsync(d_delta_d, 0, (size_t)N_XCD * bytes, stream));
-        int rc = forward ? mma_forward((REAL)omega, d_delta_c, d_delta_d) : mma_backward((REAL)omega, d_delta_c, d_delta_d);
+        launch_bcast(d_delta_c, d_delta_lay_c);  // the caller's delta, as given, to every layer
+        int rc = forward ? mma_forward((REAL)omega, d_delta_lay_c) : mma_backward((REAL)omega, d_delta_lay_c);
         if (rc) return rc;
-        if (deterministic)
-            hipLaunchKernelGGL((k_delta_gather<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm, d_var_ptr, d_var_layers, d_delta_e, (uint32_t)n_vars);
-        else
-            hipLaunchKernelGGL((k_sum_slices<REAL>), dim3(cdiv(2 * n_vars, 256)), dim3(256), 0, stream, d_delta_e, d_delta_d, (uint32_t)(2 * n_vars), N_XCD);
-        HIPCHK(hipMemcpyAsync(delta, d_delta_e, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+        launch_reduce_raw(d_delta_c);
+        HIPCHK(hipMemcpyAsync(delta, d_delta_c, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         return BDDMMA_OK;
     }
@@ -349,22 +396,25 @@ struct SolverT final : SolverBase {
     int distribute_delta() override
     {
         HIPCHK(hipSetDevice(device));
-        hipLaunchKernelGGL((k_distribute_delta<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lo, d_hi, d_mm, (uint32_t)n_layers);
-        HIPCHK(hipMemsetAsync(d_delta_a, 0, 2 * n_vars * sizeof(REAL), stream));  // bdd_cuda_base.cu:1428
+        hipLaunchKernelGGL((k_distribute_delta<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lo, d_hi, d_mm_binned, d_lpos, (uint32_t)n_layers);
+        HIPCHK(hipMemsetAsync(d_delta_var, 0, 2 * n_vars * sizeof(REAL), stream));  // bdd_cuda_base.cu:1428
+        HIPCHK(hipMemsetAsync(d_delta_lay, 0, 2 * n_layers * sizeof(REAL), stream));
         fwd_valid = bwd_valid = false;
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
     int get_delta(void* out, int on_device) override
     {
-        HIPCHK(hipMemcpyAsync(out, d_delta_a, 2 * n_vars * sizeof(REAL), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(out, d_delta_var, 2 * n_vars * sizeof(REAL), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         return BDDMMA_OK;
     }
 
     int set_delta(const void* in, int on_device) override
     {
-        HIPCHK(hipMemcpyAsync(d_delta_a, in, 2 * n_vars * sizeof(REAL), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipMemcpyAsync(d_delta_var, in, 2 * n_vars * sizeof(REAL), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+        launch_bcast(d_delta_var, d_delta_lay);
         HIPCHK(hipStreamSynchronize(stream));
         return BDDMMA_OK;
     }
@@ -425,16 +475,38 @@ struct SolverT final : SolverBase {
     int get_solver_costs(void* lo, void* hi, void* mm, int on_device) override
     {
         int rc;
-        if ((rc = copy_out(lo, d_lo, n_layers * sizeof(REAL), on_device))) return rc;
-        if ((rc = copy_out(hi, d_hi, n_layers * sizeof(REAL), on_device))) return rc;
-        return copy_out(mm, d_mm, n_layers * sizeof(REAL), on_device);
+        std::string& err = const_cast<std::string&>(this->err);
+        HIPCHK(hipSetDevice(device));
+        const dim3 g(cdiv(n_layers, 256)), b(256);
+        if (lo) {
+            hipLaunchKernelGGL((k_strided_copy<REAL>), g, b, 0, stream, d_tmp0, 1u, (const REAL*)d_lo, 2u, (uint32_t)n_layers);
+            if ((rc = copy_out(lo, d_tmp0, n_layers * sizeof(REAL), on_device))) return rc;
+        }
+        if (hi) {
+            hipLaunchKernelGGL((k_strided_copy<REAL>), g, b, 0, stream, d_tmp0, 1u, (const REAL*)d_hi, 2u, (uint32_t)n_layers);
+            if ((rc = copy_out(hi, d_tmp0, n_layers * sizeof(REAL), on_device))) return rc;
+        }
+        if (!mm) return BDDMMA_OK;
+        hipLaunchKernelGGL((k_entries_to_layers<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_mm_binned, d_lpos, d_tmp0, (uint32_t)n_layers);
+        return copy_out(mm, d_tmp0, n_layers * sizeof(REAL), on_device);
     }
     int set_solver_costs(const void* lo, const void* hi, const void* mm, int on_device) override
     {
         const hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-        if (lo) HIPCHK(hipMemcpyAsync(d_lo, lo, n_layers * sizeof(REAL), k, stream));
-        if (hi) HIPCHK(hipMemcpyAsync(d_hi, hi, n_layers * sizeof(REAL), k, stream));
-        if (mm) HIPCHK(hipMemcpyAsync(d_mm, mm, n_layers * sizeof(REAL), k, stream));
+        HIPCHK(hipSetDevice(device));
+        const dim3 g(cdiv(n_layers, 256)), b(256);
+        if (lo) {
+            HIPCHK(hipMemcpyAsync(d_tmp0, lo, n_layers * sizeof(REAL), k, stream));
+            hipLaunchKernelGGL((k_strided_copy<REAL>), g, b, 0, stream, d_lo, 2u, (const REAL*)d_tmp0, 1u, (uint32_t)n_layers);
+        }
+        if (hi) {
+            HIPCHK(hipMemcpyAsync(d_tmp0, hi, n_layers * sizeof(REAL), k, stream));
+            hipLaunchKernelGGL((k_strided_copy<REAL>), g, b, 0, stream, d_hi, 2u, (const REAL*)d_tmp0, 1u, (uint32_t)n_layers);
+        }
+        if (mm) {
+            HIPCHK(hipMemcpyAsync(d_tmp0, mm, n_layers * sizeof(REAL), k, stream));
+            hipLaunchKernelGGL((k_layers_to_entries<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_tmp0, d_lpos, d_mm_binned, (uint32_t)n_layers);
+        }
         HIPCHK(hipStreamSynchronize(stream));
         fwd_valid = bwd_valid = false;
         return BDDMMA_OK;
@@ -453,7 +525,7 @@ struct SolverT final : SolverBase {
         HIPCHK(hipSetDevice(device));
         int rc;
         if ((rc = forward_run())) return rc;  // bdd_cuda_base.cu:720
-        if ((rc = launch_bwd<BWD_MARGINALS>(nullptr, nullptr, REAL(0), BDDMMA_K_OTHER))) return rc;
+        if ((rc = launch_bwd<BWD_MARGINALS>(nullptr, REAL(0), BDDMMA_K_OTHER))) return rc;
         bwd_valid = true;
         const hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
         if (!sorted) {
@@ -463,7 +535,7 @@ struct SolverT final : SolverBase {
             HIPCHK(hipStreamSynchronize(stream));
             return BDDMMA_OK;
         }
-        // gather by primal_variable_sorting_order_ (:737-746); d_mm must stay intact, so use temporaries
+        // gather by primal_variable_sorting_order_ (:737-746)
         REAL *s0 = nullptr, *s1 = nullptr;
         int32_t* sv = nullptr;
         HIPCHK(hipMalloc((void**)&s0, std::max<uint64_t>(n_layers, 1) * sizeof(REAL)));
@@ -488,7 +560,7 @@ struct SolverT final : SolverBase {
         int rc;
         if ((rc = backward_run())) return rc;
         HIPCHK(hipMemsetAsync(d_sol, 0, n_layers, stream));
-        if ((rc = launch_fwd<FWD_SOLUTION>(nullptr, nullptr, REAL(0), BDDMMA_K_OTHER))) return rc;
+        if ((rc = launch_fwd<FWD_SOLUTION>(nullptr, REAL(0), BDDMMA_K_OTHER))) return rc;
         fwd_valid = true;  // the solution sweep recomputes and stores cost-from-root
         const hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
         if (!sorted) {
@@ -509,7 +581,7 @@ struct SolverT final : SolverBase {
     {
         HIPCHK(hipSetDevice(device));
         REAL* dst = on_device ? (REAL*)out : d_tmp0;
-        hipLaunchKernelGGL((k_net_costs<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lo, d_hi, d_mm, dst, (uint32_t)n_layers);
+        hipLaunchKernelGGL((k_net_costs<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lo, d_hi, d_mm_binned, d_lpos, dst, (uint32_t)n_layers);
         if (!on_device) return copy_out(out, dst, n_layers * sizeof(REAL), 0);
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
@@ -535,6 +607,33 @@ struct SolverT final : SolverBase {
         return BDDMMA_OK;
     }
     void* stream_handle() override { return (void*)stream; }
+    int time_kernel(int kind, uint64_t reps, double* ms) override
+    {
+        HIPCHK(hipSetDevice(device));
+        int rc = BDDMMA_OK;
+        auto once = [&]() -> int {
+            switch (kind) {
+                case 0: return launch_fwd<FWD_PLAIN>(nullptr, REAL(0), BDDMMA_K_OTHER);
+                case 1: return launch_bwd<BWD_PLAIN>(nullptr, REAL(0), BDDMMA_K_OTHER);
+                case 2: return launch_fwd<FWD_SOLVE>(d_delta_lay, REAL(0.5), BDDMMA_K_OTHER);
+                case 3: return launch_bwd<BWD_SOLVE>(d_delta_lay, REAL(0.5), BDDMMA_K_OTHER);
+                case 4: return exchange();
+                case 5: launch_bcast(d_delta_c, d_delta_lay_c); return BDDMMA_OK;
+                default: err = "unknown kernel kind"; return BDDMMA_ERR_INVALID_ARGUMENT;
+            }
+        };
+        if ((rc = once())) return rc;  // warm-up
+        HIPCHK(hipEventRecord(ev_t0, stream));
+        for (uint64_t i = 0; i < reps; ++i)
+            if ((rc = once())) return rc;
+        HIPCHK(hipEventRecord(ev_t1, stream));
+        HIPCHK(hipEventSynchronize(ev_t1));
+        float f = 0.f;
+        HIPCHK(hipEventElapsedTime(&f, ev_t0, ev_t1));
+        *ms = f;
+        fwd_valid = bwd_valid = false;
+        return BDDMMA_OK;
+    }
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -57,7 +57,7 @@ int bddmma_create(bddmma_solver** out, int precision, int device, const bddmma_i
     *out = nullptr;
     try {
         HostLayout L;
-        int rc = build_layout(instr, bdd_delims, n_bdds, opts, L, g_err, false);
+        int rc = build_layout(instr, bdd_delims, n_bdds, opts, L, g_err, false, precision == BDDMMA_F64 ? 8 : 4);
         if (rc) return rc;
         SolverBase* impl = nullptr;
         rc = create_solver(&impl, precision, device, L, opts, g_err);
@@ -337,6 +337,10 @@ int bddmma_get_profile(bddmma_solver* s, bddmma_profile* out)
 {
     return guarded(s, [&](SolverBase* b) { return out ? b->get_profile(out) : BDDMMA_ERR_INVALID_ARGUMENT; });
 }
+int bddmma_time_kernel(bddmma_solver* s, int kind, uint64_t reps, double* ms)
+{
+    return guarded(s, [&](SolverBase* b) { return ms ? b->time_kernel(kind, reps, ms) : BDDMMA_ERR_INVALID_ARGUMENT; });
+}
 int bddmma_time_iterations(bddmma_solver* s, double omega, uint64_t n, double* ms)
 {
     return guarded(s, [&](SolverBase* b) { return ms ? b->time_iterations(omega, n, ms) : BDDMMA_ERR_INVALID_ARGUMENT; });
@@ -364,7 +368,8 @@ int bddmma_layout_create(bddmma_layout** out, const bddmma_instruction* instr, c
 }
 void bddmma_layout_destroy(bddmma_layout* l) { delete l; }
 // what: 0 n_slots, 1 narrow_slots, 2 n_layers, 3 narrow packs, 4 wide packs, 5 n_hops, 6 n_vars,
-//       7 narrow (pack,hop) records, 8 wide (pack,hop) records
+//       7 narrow (pack,hop) records, 8 wide (pack,hop) records, 9 bins, 10 vars per bin, 11 stage groups,
+//       12 narrow layers, 13 stage cap
 uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
 {
     const HostLayout& L = l->L;
@@ -378,12 +383,18 @@ uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
         case 6: return L.n_vars;
         case 7: return L.narrow.hop_node_off.empty() ? 0 : L.narrow.hop_node_off.size() - 1;
         case 8: return L.wide.hop_node_off.empty() ? 0 : L.wide.hop_node_off.size() - 1;
+        case 9: return L.ex.n_bins;
+        case 10: return L.ex.vars_per_bin;
+        case 11: return L.ex.grp_hop_end.size();
+        case 12: return L.ex.grp_layer_off.empty() ? 0 : L.ex.grp_layer_off.back();
+        case 13: return L.ex.stage_cap;
         default: return 0;
     }
 }
 // which: 0 narrow_words(u32) 1 wide_words(u64) 2 slot_to_instr(u64) 3 layer_var(i32) 4 layer_bdd(i32)
 //        5/6/7/8 narrow pack_hop_ptr/hop_node_off/hop_layer_off(u32)/pack_steps(u8)   9/10/11/12 wide ...
 //        13 var_ptr(u32) 14 var_layers(u32) 15 bdd_root_slot(u32)
+//        16 bin_ptr(u32) 17 evar(u32) 18 lpos(u32) 19 vpos(u32) 20 pack_group_ptr 21 grp_layer_off 22 grp_hop_end
 int bddmma_layout_copy(const bddmma_layout* l, int which, void* out)
 {
     const HostLayout& L = l->L;
@@ -408,6 +419,13 @@ int bddmma_layout_copy(const bddmma_layout* l, int which, void* out)
         case 13: return cp(L.var_ptr);
         case 14: return cp(L.var_layers);
         case 15: return cp(L.bdd_root_slot);
+        case 16: return cp(L.ex.bin_ptr);
+        case 17: return cp(L.ex.evar);
+        case 18: return cp(L.ex.lpos);
+        case 19: return cp(L.ex.vpos);
+        case 20: return cp(L.ex.pack_group_ptr);
+        case 21: return cp(L.ex.grp_layer_off);
+        case 22: return cp(L.ex.grp_hop_end);
         default: return BDDMMA_ERR_INVALID_ARGUMENT;
     }
 }

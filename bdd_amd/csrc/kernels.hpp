@@ -36,13 +36,14 @@ struct DevPtrs {
     uint32_t wide_slot_base;
     REAL* F;                 // cost from root, per slot
     REAL* T;                 // cost from terminal, per slot
-    REAL* lo;                // per layer
-    REAL* hi;
-    REAL* mm;                // deferred min-marginal difference, per layer
-    const int32_t* var;      // per layer
-    const REAL* delta_in;    // 2V, values to add (already normalised)
-    REAL* delta_out;         // N_XCD x 2V accumulators, one per XCD (nullptr: skip accumulation)
-    uint32_t delta_stride;   // 2V
+    REAL* lohi;              // per layer: {lo, hi} arc costs, interleaved
+    // variable <-> layer exchange arrays in binned entry order (layout.hpp, struct Exchange)
+    const REAL* delta_lay;   // 2 REAL per entry: {delta_lo, delta_hi} of the entry's variable (normalised)
+    REAL* mm_binned;         // 1 REAL per entry: deferred min-marginal difference of the entry's layer
+    const uint32_t* lpos;    // per layer: entry index
+    uint32_t n_slots;        // element counts (buffer descriptors of the narrow kernels)
+    uint32_t n_layers;
+    uint32_t n_narrow_layers;
     double* lb_partial;      // per pack (narrow packs first, then wide)
     REAL* mm0_out;           // BWD_MARGINALS outputs, per layer
     REAL* mm1_out;
@@ -54,9 +55,16 @@ struct PackDev {
     const uint32_t* hop_node_off;
     const uint32_t* hop_layer_off;
     const uint8_t* pack_steps;
+    const uint32_t* pack_group_ptr;  // narrow packs: stage groups
+    const uint32_t* grp_layer_off;
+    const uint32_t* grp_hop_end;
     uint32_t n_packs;
     uint32_t lb_base;  // index of this set's first pack in lb_partial
 };
+
+template <typename REAL> struct Pair;
+template <> struct Pair<float> { using type = float2; };
+template <> struct Pair<double> { using type = double2; };
 
 template <typename REAL> __device__ __forceinline__ REAL inf_v();
 template <> __device__ __forceinline__ float inf_v<float>() { return __builtin_huge_valf(); }
@@ -104,132 +112,319 @@ __device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, unsigned lo
     b = __shfl(b, seg_start);
 }
 
-// Per-XCD accumulators.  The 8 XCD L2s are kept coherent by probes, so float atomics from all XCDs
-// on one 2V-array ping-pong its lines between L2s (measured: 5 M atomicAdd cost 180 us per pass,
-// 2.4x the rest of the sweep).  Each workgroup therefore adds into the accumulator of the XCD it is
-// actually running on (HW_REG_XCC_ID), whose lines only that XCD's L2 ever owns; k_finish_delta
-// sums the N_XCD slices.  Correctness does not depend on the placement: any slice index is valid.
-constexpr int N_XCD = 8;
-__device__ __forceinline__ uint32_t xcc_id()
+// ---- buffer-descriptor memory ops ---------------------------------------------------------------
+// Every per-lane predicate of the narrow kernels is folded into the byte offset of a raw buffer op: an
+// offset past the descriptor's size makes the hardware drop the lane (loads return 0, stores are
+// discarded).  With `if (active) x = p[i]` hipcc emits an exec-masked branch per access; the waitcnt
+// pass then cannot count the outstanding loads and falls back to s_waitcnt vmcnt(0), which drains
+// every prefetch in flight (seen in the ISA of the first pipelined version).  Branch-free buffer ops
+// keep the instruction stream straight-line, so the waits become counted vmcnt(N).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr uint32_t OOB = 0xFFFFFFFFu;
+
+template <typename T>
+__device__ __forceinline__ rsrc_t make_rsrc(const T* p, uint64_t n_elems)
 {
-    return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (N_XCD - 1);  // hwreg(HW_REG_XCC_ID, 0, 4)
+    const uint64_t bytes = n_elems * sizeof(T);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p), 0, (uint32_t)(bytes > 0xFFFFFFFEull ? 0xFFFFFFFEull : bytes), 0x00020000);
+}
+__device__ __forceinline__ uint32_t bload_u32(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
+__device__ __forceinline__ uint32_t bload_u16(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0); }
+__device__ __forceinline__ void bload(float& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
+__device__ __forceinline__ void bload(double& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0)); }
+__device__ __forceinline__ void bload(float2& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0)); }
+__device__ __forceinline__ void bload(double2& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); }
+__device__ __forceinline__ void bstore(float v, rsrc_t r, uint32_t off) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0, 0); }
+__device__ __forceinline__ void bstore(double v, rsrc_t r, uint32_t off)
+{
+    using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, off, 0, 0);
+}
+__device__ __forceinline__ void bstore(float2 v, rsrc_t r, uint32_t off)
+{
+    using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, off, 0, 0);
+}
+__device__ __forceinline__ void bstore(double2 v, rsrc_t r, uint32_t off)
+{
+    using u4 = decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, off, 0, 0);
 }
 
 template <typename REAL>
-__device__ __forceinline__ void accumulate_delta(REAL* delta_out, int v, REAL mm)
+struct NarrowRs {
+    rsrc_t words, T, F, lohi, lpos, dlay, mm;
+    __device__ __forceinline__ explicit NarrowRs(const DevPtrs<REAL>& d)
+    {
+        words = make_rsrc(d.nwords, d.wide_slot_base);
+        T = make_rsrc(d.T, d.n_slots);
+        F = make_rsrc(d.F, d.n_slots);
+        lohi = make_rsrc(d.lohi, 2ull * d.n_layers);
+        lpos = make_rsrc(d.lpos, d.n_layers);
+        dlay = make_rsrc(d.delta_lay, 2ull * d.n_layers);
+        mm = make_rsrc(d.mm_binned, d.n_layers);
+    }
+};
+
+// Stage-group transfer between the binned exchange arrays and LDS.  Staging index = position of the layer
+// inside its group (layers of a group are contiguous), entry index = lpos[layer]; the entry indices stay
+// in registers between the load at the start of the group and the flush at its end.
+constexpr int STAGE_ITERS = 10;  // stage_cap <= 64 * STAGE_ITERS
+
+template <typename REAL>
+__device__ __forceinline__ void stage_load(typename Pair<REAL>::type* sD, uint32_t (&e)[STAGE_ITERS], const NarrowRs<REAL>& rs,
+                                           uint32_t gl0, uint32_t cnt, int lane)
 {
-    // compute_delta_atomic, bdd_cuda_parallel_mma.cu:358-376
-    if (mm > 0) atomicAdd(&delta_out[2 * v + 1], mm);
-    else if (mm < 0) atomicAdd(&delta_out[2 * v], -mm);
+    using P2 = typename Pair<REAL>::type;
+#pragma unroll
+    for (int u = 0; u < STAGE_ITERS; ++u) {
+        const uint32_t i = 64 * u + lane;
+        e[u] = bload_u32(rs.lpos, i < cnt ? (gl0 + i) * 4u : OOB);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        P2 v[STAGE_ITERS / 2];
+#pragma unroll
+        for (int u = 0; u < STAGE_ITERS / 2; ++u) {
+            const int k = half * (STAGE_ITERS / 2) + u;
+            const uint32_t i = 64 * k + lane;
+            bload(v[u], rs.dlay, i < cnt ? e[k] * (uint32_t)sizeof(P2) : OOB);
+        }
+#pragma unroll
+        for (int u = 0; u < STAGE_ITERS / 2; ++u) {
+            const int k = half * (STAGE_ITERS / 2) + u;
+            const uint32_t i = 64 * k + lane;
+            if (i < cnt) sD[i] = v[u];
+        }
+    }
+}
+
+template <typename REAL>
+__device__ __forceinline__ void stage_flush(const typename Pair<REAL>::type* sD, const uint32_t (&e)[STAGE_ITERS], const NarrowRs<REAL>& rs,
+                                            uint32_t cnt, int lane)
+{
+#pragma unroll
+    for (int u = 0; u < STAGE_ITERS; ++u) {
+        const uint32_t i = 64 * u + lane;
+        const REAL m = sD[i < cnt ? i : 0].x;
+        bstore(m, rs.mm, i < cnt ? e[u] * (uint32_t)sizeof(REAL) : OOB);
+    }
 }
 
 // =============================================================================================
 // narrow packs: one wavefront per pack, R groups of 64 slots per hop, no barriers
 // =============================================================================================
+// Window of per-hop offsets kept in LDS.  Reading pk.hop_node_off[q] inside the hop loop compiles to a
+// *vector* global load followed by s_waitcnt vmcnt(0): it serialises two extra memory round trips per
+// hop and drains every prefetch in flight.  Instead 64 consecutive offsets are fetched with one
+// coalesced load and read back with (broadcast) LDS reads, which are counted by lgkmcnt only.
+constexpr uint32_t HOP_WIN = 64;
+struct HopWindow {
+    uint32_t* node;   // LDS [HOP_WIN]
+    uint32_t* layer;  // LDS [HOP_WIN]
+    uint32_t base;    // record index of window slot 0
+    uint32_t q1;      // one past the pack's last hop record (offsets clamp there)
+    __device__ __forceinline__ void fill(const PackDev& pk, uint32_t new_base, int lane)
+    {
+        base = new_base;
+        const uint32_t q = min(new_base + (uint32_t)lane, q1);
+        node[lane] = pk.hop_node_off[q];
+        layer[lane] = pk.hop_layer_off[q];
+        __syncthreads();
+    }
+    __device__ __forceinline__ uint32_t node_off(uint32_t q) const
+    {
+        return __builtin_amdgcn_readfirstlane(node[min(q, q1) - base]);
+    }
+    __device__ __forceinline__ uint32_t layer_off(uint32_t q) const
+    {
+        return __builtin_amdgcn_readfirstlane(layer[min(q, q1) - base]);
+    }
+};
+
+// Per-hop register sets of the software pipeline.  A wave's hop is a chain of dependent memory round
+// trips (node words -> layer costs -> LDS), and with <= 32 waves per CU the sweep was latency-bound
+// (SQ_WAIT_ANY 80 % of wave cycles, 3.9 TB/s).  All addresses of later hops are plain streams, so the
+// words of hop q+2 and the layer data / potentials of hop q+1 are requested while hop q is computed.
+template <typename REAL, int R>
+struct HopLayer {
+    typename Pair<REAL>::type c[R];  // {lo, hi}
+    uint32_t lg[R];
+};
+
+template <typename REAL, int R>
+__device__ __forceinline__ void load_layer(HopLayer<REAL, R>& L, const uint32_t (&w)[R], uint32_t lbase, const NarrowRs<REAL>& rs)
+{
+    using P2 = typename Pair<REAL>::type;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool act = !(w[r] & NW_PAD);
+        L.lg[r] = lbase + ((w[r] >> (2 * NW_CHILD_BITS)) & 1023u);
+        bload(L.c[r], rs.lohi, act ? L.lg[r] * (uint32_t)sizeof(P2) : OOB);
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void load_words(uint32_t (&w)[R], rsrc_t words, uint32_t nb, uint32_t n, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t j = lane + 64 * r;
+        const uint32_t x = bload_u32(words, j < n ? (nb + j) * 4u : OOB);
+        w[r] = (j < n) ? x : NW_PAD_WORD;
+    }
+}
+
+template <typename REAL, int R>
+__device__ __forceinline__ void load_vals(REAL (&v)[R], rsrc_t src, uint32_t nb, uint32_t n, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t j = lane + 64 * r;
+        bload(v[r], src, j < n ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
+    }
+}
+
 template <typename REAL, int R, int MODE>
 __global__ void __launch_bounds__(64) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
 {
     constexpr int W = 64 * R;
+    constexpr bool NEED_T = (MODE != FWD_PLAIN);
+    using P2 = typename Pair<REAL>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    P2* sD = reinterpret_cast<P2*>(dyn_lds);  // staged {delta_lo, delta_hi} of the current stage group; .x is overwritten by mm
     __shared__ REAL sF[2][W];
     __shared__ REAL sT[W];
     __shared__ unsigned char sAct[2][MODE == FWD_SOLUTION ? W : 1];
     const int lane = threadIdx.x;
     const uint32_t p = block_to_pack(blockIdx.x, pk.n_packs);
     if (p >= pk.n_packs) return;
-    if (d.delta_out) d.delta_out += (size_t)xcc_id() * d.delta_stride;
     const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
     const int steps = pk.pack_steps[p];
     const REAL INF = inf_v<REAL>();
-    uint32_t nb = pk.hop_node_off[q0], ne = pk.hop_node_off[q0 + 1];
+    const NarrowRs<REAL> rs(d);
+    __shared__ uint32_t sOffN[HOP_WIN], sOffL[HOP_WIN];
+    // hop_node_off / hop_layer_off have one entry past the last hop of the last pack, so index q1 is
+    // always readable; offsets beyond q1 are clamped (those hops have no nodes for this pack)
+    HopWindow hw{sOffN, sOffL, q0, q1};
+    hw.fill(pk, q0, lane);
+    auto off = [&](uint32_t q) { return hw.node_off(q); };
+    uint32_t nb = off(q0), ne = off(q0 + 1);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t j = lane + 64 * r;
         sF[0][j] = (j < ne - nb) ? REAL(0) : INF;  // every slot of hop 0 is a root (flush_costs_from_root)
         if (MODE == FWD_SOLUTION) sAct[0][j] = (j < ne - nb) ? 1 : 0;
     }
+    // pipeline prologue
+    uint32_t wa[R], wb[R];
+    REAL ta[R];
+    HopLayer<REAL, R> La;
+    load_words<R>(wa, rs.words, nb, ne - nb, lane);
+    {
+        const uint32_t ne2 = off(q0 + 2);
+        load_words<R>(wb, rs.words, ne, ne2 - ne, lane);                     // words of hop q0+1 (none if q0+1 == q1)
+        if (NEED_T) load_vals<REAL, R>(ta, rs.T, ne, ne2 - ne, lane);         // T of hop q0+1
+    }
+    load_layer<REAL, R>(La, wa, hw.layer_off(q0), rs);
     int cur = 0;
-    for (uint32_t q = q0; q < q1; ++q) {
-        const uint32_t n = ne - nb;
-        const bool last = (q + 1 == q1);
-        const uint32_t ne2 = last ? ne : pk.hop_node_off[q + 2];
-        const uint32_t n2 = ne2 - ne;
-        const uint32_t lbase = pk.hop_layer_off[q];
-        uint32_t w[R];
-        REAL f[R], lc[R], hc[R], d0[R], d1[R];
-        int v[R];
-        uint32_t lg[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t j = lane + 64 * r;
-            if (MODE != FWD_PLAIN && j < n2) sT[j] = d.T[ne + j];
-            sF[cur ^ 1][j] = INF;
-            if (MODE == FWD_SOLUTION) sAct[cur ^ 1][j] = 0;
-            w[r] = (j < n) ? d.nwords[nb + j] : NW_PAD_WORD;
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t j = lane + 64 * r;
-            const bool act = !(w[r] & NW_PAD);
-            lg[r] = lbase + ((w[r] >> (2 * NW_CHILD_BITS)) & 1023u);
-            lc[r] = act ? d.lo[lg[r]] : REAL(0);
-            hc[r] = act ? d.hi[lg[r]] : REAL(0);
-            v[r] = (MODE == FWD_SOLVE && act) ? d.var[lg[r]] : 0;
-            f[r] = sF[cur][j];
-        }
+    uint32_t q = q0;
+    const uint32_t g_end = (MODE == FWD_SOLVE) ? pk.pack_group_ptr[p + 1] : 1;
+    for (uint32_t g = (MODE == FWD_SOLVE) ? pk.pack_group_ptr[p] : 0; g < g_end; ++g) {
+        uint32_t gl0 = 0, cnt = 0, qe = q1;
+        uint32_t ent[STAGE_ITERS];
         if (MODE == FWD_SOLVE) {
+            gl0 = pk.grp_layer_off[g];
+            cnt = pk.grp_layer_off[g + 1] - gl0;
+            qe = pk.grp_hop_end[g];
+            stage_load<REAL>(sD, ent, rs, gl0, cnt, lane);  // the group's delta pairs -> LDS
+        }
+        for (; q < qe; ++q) {
+            if (q + 3 >= hw.base + HOP_WIN && hw.base + HOP_WIN <= q1) hw.fill(pk, q, lane);
+            const uint32_t n = ne - nb;
+            const uint32_t ne2 = off(q + 2);
+            const uint32_t n2 = ne2 - ne;
+            // ---- prefetch: layer data of hop q+1 (its words were requested one hop ago), words of hop q+2, T of hop q+2
+            uint32_t wc[R];
+            REAL tb[R];
+            HopLayer<REAL, R> Lb;
+            {
+                const uint32_t ne3 = off(q + 3);
+                load_words<R>(wc, rs.words, ne2, ne3 - ne2, lane);
+                if (NEED_T) load_vals<REAL, R>(tb, rs.T, ne2, ne3 - ne2, lane);
+                const uint32_t lbase_next = hw.layer_off(q + 1);
+                load_layer<REAL, R>(Lb, wb, lbase_next, rs);  // wb is all padding past the last hop: no loads
+            }
+            // ---- LDS set-up of this hop
+            REAL f[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const bool act = !(w[r] & NW_PAD);
-                d0[r] = act ? d.delta_in[2 * v[r]] : REAL(0);
-                d1[r] = act ? d.delta_in[2 * v[r] + 1] : REAL(0);
+                const uint32_t j = lane + 64 * r;
+                if (NEED_T && j < n2) sT[j] = ta[r];
+                sF[cur ^ 1][j] = INF;
+                if (MODE == FWD_SOLUTION) sAct[cur ^ 1][j] = 0;
+                f[r] = sF[cur][j];
             }
-        }
-        __syncthreads();  // one wave: compiles to a wait on the LDS stores above
+            __syncthreads();  // one wave: compiles to a wait on the LDS stores above
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t j = lane + 64 * r;
-            const bool act = !(w[r] & NW_PAD);
-            const uint32_t lo_i = w[r] & NW_CHILD_MASK, hi_i = (w[r] >> NW_CHILD_BITS) & NW_CHILD_MASK;
-            REAL nlo = lc[r], nhi = hc[r];
-            if (MODE == FWD_SOLVE || MODE == FWD_SOLUTION) {
-                const REAL tl = lo_i == NW_BOT ? INF : (lo_i == NW_TOP ? REAL(0) : sT[lo_i]);
-                const REAL th = hi_i == NW_BOT ? INF : (hi_i == NW_TOP ? REAL(0) : sT[hi_i]);
-                if (MODE == FWD_SOLVE) {
-                    REAL m0 = act ? (f[r] + lc[r]) + tl : INF;
-                    REAL m1 = act ? (f[r] + hc[r]) + th : INF;
-                    const unsigned long long heads = __ballot((w[r] & NW_HEAD) != 0);
-                    seg_min2(m0, m1, lane, heads, steps);
-                    const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
-                    nlo = (lc[r] + rmin(mm, REAL(0))) + d0[r];
-                    nhi = (hc[r] + rmin(-mm, REAL(0))) + d1[r];
-                    if (act && (w[r] & NW_HEAD)) {
-                        d.lo[lg[r]] = nlo;
-                        d.hi[lg[r]] = nhi;
-                        d.mm[lg[r]] = mm;
-                        if (d.delta_out) accumulate_delta(d.delta_out, v[r], mm);
-                    }
-                } else {
-                    // compute_bdd_sol_func, bdd_cuda_base.cu:1103-1137 (with the `< 0` fix of SURVEY.md §8)
-                    if (act && sAct[cur][j]) {
-                        const REAL hi_path = f[r] + (th + hc[r]);  // backward_step_with_path_costs, :633-640
-                        const REAL lo_path = f[r] + (tl + lc[r]);
-                        const bool take_lo = (hi_path - lo_path) > 0;
-                        d.sol_out[lg[r]] = take_lo ? 0 : 1;
-                        const uint32_t c = take_lo ? lo_i : hi_i;
-                        if (c < NW_TOP) sAct[cur ^ 1][c] = 1;
+            for (int r = 0; r < R; ++r) {
+                const uint32_t j = lane + 64 * r;
+                const uint32_t w = wa[r];
+                const bool act = !(w & NW_PAD);
+                const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
+                const REAL lc = La.c[r].x, hc = La.c[r].y;
+                REAL nlo = lc, nhi = hc;
+                const uint32_t sl = La.lg[r] - gl0;  // staging index: position of the layer inside its group
+                if (MODE == FWD_SOLVE || MODE == FWD_SOLUTION) {
+                    const REAL tl = lo_i == NW_BOT ? INF : (lo_i == NW_TOP ? REAL(0) : sT[lo_i]);
+                    const REAL th = hi_i == NW_BOT ? INF : (hi_i == NW_TOP ? REAL(0) : sT[hi_i]);
+                    if (MODE == FWD_SOLVE) {
+                        const P2 dd = sD[act ? sl : 0];
+                        REAL m0 = act ? (f[r] + lc) + tl : INF;
+                        REAL m1 = act ? (f[r] + hc) + th : INF;
+                        const unsigned long long heads = __ballot((w & NW_HEAD) != 0);
+                        seg_min2(m0, m1, lane, heads, steps);
+                        const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
+                        nlo = (lc + rmin(mm, REAL(0))) + dd.x;
+                        nhi = (hc + rmin(-mm, REAL(0))) + dd.y;
+                        const bool head = act && (w & NW_HEAD);
+                        P2 nc;
+                        nc.x = nlo;
+                        nc.y = nhi;
+                        bstore(nc, rs.lohi, head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB);
+                        if (head) sD[sl].x = mm;  // every lane of the layer has read its pair above (same wave, in order)
+                    } else {
+                        // compute_bdd_sol_func, bdd_cuda_base.cu:1103-1137 (with the `< 0` fix of SURVEY.md §8)
+                        if (act && sAct[cur][j]) {
+                            const REAL hi_path = f[r] + (th + hc);  // backward_step_with_path_costs, :633-640
+                            const REAL lo_path = f[r] + (tl + lc);
+                            const bool take_lo = (hi_path - lo_path) > 0;
+                            d.sol_out[La.lg[r]] = take_lo ? 0 : 1;
+                            const uint32_t c = take_lo ? lo_i : hi_i;
+                            if (c < NW_TOP) sAct[cur ^ 1][c] = 1;
+                        }
                     }
                 }
+                if (act) {
+                    if (lo_i < NW_TOP) lds_min(&sF[cur ^ 1][lo_i], f[r] + nlo);
+                    if (hi_i < NW_TOP) lds_min(&sF[cur ^ 1][hi_i], f[r] + nhi);
+                }
+                bstore(f[r], rs.F, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
             }
-            if (act) {
-                if (lo_i < NW_TOP) lds_min(&sF[cur ^ 1][lo_i], f[r] + nlo);
-                if (hi_i < NW_TOP) lds_min(&sF[cur ^ 1][hi_i], f[r] + nhi);
-                d.F[nb + j] = f[r];
+            __syncthreads();
+            cur ^= 1;
+            nb = ne;
+            ne = ne2;
+            // ---- rotate the pipeline registers
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                wa[r] = wb[r];
+                wb[r] = wc[r];
+                if (NEED_T) ta[r] = tb[r];
             }
+            La = Lb;
         }
-        __syncthreads();
-        cur ^= 1;
-        nb = ne;
-        ne = ne2;
+        if (MODE == FWD_SOLVE) stage_flush<REAL>(sD, ent, rs, cnt, lane);
     }
 }
 
@@ -237,99 +432,136 @@ template <typename REAL, int R, int MODE>
 __global__ void __launch_bounds__(64) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
 {
     constexpr int W = 64 * R;
+    constexpr bool NEED_F = (MODE != BWD_PLAIN);
+    using P2 = typename Pair<REAL>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    P2* sD = reinterpret_cast<P2*>(dyn_lds);
     __shared__ REAL sT[2][W];
     const int lane = threadIdx.x;
     const uint32_t p = block_to_pack(blockIdx.x, pk.n_packs);
     if (p >= pk.n_packs) return;
-    if (d.delta_out) d.delta_out += (size_t)xcc_id() * d.delta_stride;
     const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
     const int steps = pk.pack_steps[p];
     const REAL INF = inf_v<REAL>();
+    const NarrowRs<REAL> rs(d);
+    __shared__ uint32_t sOffN[HOP_WIN], sOffL[HOP_WIN];
+    HopWindow hw{sOffN, sOffL, q0, q1};
+    hw.fill(pk, q1 + 1 > q0 + HOP_WIN ? q1 + 1 - HOP_WIN : q0, lane);  // window ends at record q1
+    // node range of hop q; hops below q0 (pipeline run-off) are empty
+    auto nb_of = [&](uint32_t q) { return hw.node_off(q); };
+    // pipeline prologue: hop q1-1 fully, words of hop q1-2
+    uint32_t wa[R], wb[R];
+    REAL fa[R], fb[R];
+    HopLayer<REAL, R> La;
+    {
+        const uint32_t nb = nb_of(q1 - 1);
+        const uint32_t n = nb_of(q1) - nb;
+        load_words<R>(wa, rs.words, nb, n, lane);
+        if (NEED_F) load_vals<REAL, R>(fa, rs.F, nb, n, lane);
+        (void)n;
+        const bool has = (q1 - 1 > q0);
+        const uint32_t nb2 = has ? nb_of(q1 - 2) : nb, n2 = has ? nb - nb2 : 0;
+        load_words<R>(wb, rs.words, nb2, n2, lane);
+        if (NEED_F) load_vals<REAL, R>(fb, rs.F, nb2, n2, lane);
+        load_layer<REAL, R>(La, wa, hw.layer_off(q1 - 1), rs);
+    }
     int cur = 0;
-    for (uint32_t q = q1; q-- > q0;) {
-        const uint32_t nb = pk.hop_node_off[q], ne = pk.hop_node_off[q + 1];
-        const uint32_t n = ne - nb;
-        const uint32_t lbase = pk.hop_layer_off[q];
-        uint32_t w[R];
-        REAL f[R], lc[R], hc[R], d0[R], d1[R];
-        int v[R];
-        uint32_t lg[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t j = lane + 64 * r;
-            w[r] = (j < n) ? d.nwords[nb + j] : NW_PAD_WORD;
-            f[r] = (MODE != BWD_PLAIN && j < n) ? d.F[nb + j] : REAL(0);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool act = !(w[r] & NW_PAD);
-            lg[r] = lbase + ((w[r] >> (2 * NW_CHILD_BITS)) & 1023u);
-            lc[r] = act ? d.lo[lg[r]] : REAL(0);
-            hc[r] = act ? d.hi[lg[r]] : REAL(0);
-            v[r] = (MODE == BWD_SOLVE && act) ? d.var[lg[r]] : 0;
-        }
+    uint32_t q = q1;
+    const uint32_t g_first = (MODE == BWD_SOLVE) ? pk.pack_group_ptr[p] : 0;
+    for (uint32_t g = (MODE == BWD_SOLVE) ? pk.pack_group_ptr[p + 1] : 1; g-- > g_first;) {
+        uint32_t gl0 = 0, cnt = 0, qs = q0;
+        uint32_t ent[STAGE_ITERS];
         if (MODE == BWD_SOLVE) {
+            gl0 = pk.grp_layer_off[g];
+            cnt = pk.grp_layer_off[g + 1] - gl0;
+            qs = (g == g_first) ? q0 : pk.grp_hop_end[g - 1];
+            stage_load<REAL>(sD, ent, rs, gl0, cnt, lane);
+            __syncthreads();
+        }
+        while (q > qs) {
+            --q;
+            if (q < hw.base + 2 && hw.base > q0) hw.fill(pk, q + 1 > q0 + HOP_WIN ? q + 1 - HOP_WIN : q0, lane);
+            const uint32_t nb = nb_of(q);
+            // ---- prefetch: layer data of hop q-1, words / F of hop q-2
+            uint32_t wc[R];
+            REAL fc[R];
+            HopLayer<REAL, R> Lb;
+            {
+                const bool has2 = (q >= q0 + 2);
+                const uint32_t nb3 = has2 ? nb_of(q - 2) : nb, n3 = has2 ? nb_of(q - 1) - nb3 : 0;
+                load_words<R>(wc, rs.words, nb3, n3, lane);
+                if (NEED_F) load_vals<REAL, R>(fc, rs.F, nb3, n3, lane);
+                const uint32_t lbase_prev = hw.layer_off(q > q0 ? q - 1 : q);
+                load_layer<REAL, R>(Lb, wb, lbase_prev, rs);  // wb is all padding below the first hop
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const bool act = !(w[r] & NW_PAD);
-                d0[r] = act ? d.delta_in[2 * v[r]] : REAL(0);
-                d1[r] = act ? d.delta_in[2 * v[r] + 1] : REAL(0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t j = lane + 64 * r;
-            const bool act = !(w[r] & NW_PAD);
-            const uint32_t lo_i = w[r] & NW_CHILD_MASK, hi_i = (w[r] >> NW_CHILD_BITS) & NW_CHILD_MASK;
-            const REAL tl = lo_i == NW_BOT ? INF : (lo_i == NW_TOP ? REAL(0) : sT[cur][lo_i]);
-            const REAL th = hi_i == NW_BOT ? INF : (hi_i == NW_TOP ? REAL(0) : sT[cur][hi_i]);
-            REAL t;
-            if (MODE == BWD_SOLVE) {
-                REAL m0 = act ? (f[r] + lc[r]) + tl : INF;
-                REAL m1 = act ? (f[r] + hc[r]) + th : INF;
-                const unsigned long long heads = __ballot((w[r] & NW_HEAD) != 0);
-                seg_min2(m0, m1, lane, heads, steps);
-                const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
-                const REAL nlo = (lc[r] + rmin(mm, REAL(0))) + d0[r];
-                const REAL nhi = (hc[r] + rmin(-mm, REAL(0))) + d1[r];
-                t = rmin(nhi + th, nlo + tl);
-                if (act && (w[r] & NW_HEAD)) {
-                    d.lo[lg[r]] = nlo;
-                    d.hi[lg[r]] = nhi;
-                    d.mm[lg[r]] = mm;
-                    if (d.delta_out) accumulate_delta(d.delta_out, v[r], mm);
-                }
-            } else {
-                const REAL ch = th + hc[r], cl = tl + lc[r];  // backward_step, bdd_cuda_base.cu:646-667
-                t = rmin(ch, cl);
-                if (MODE == BWD_MARGINALS) {
-                    REAL lp = act ? f[r] + cl : INF;  // backward_step_with_path_costs, :633-641
-                    REAL hp = act ? f[r] + ch : INF;
-                    const unsigned long long heads = __ballot((w[r] & NW_HEAD) != 0);
-                    seg_min2(lp, hp, lane, heads, steps);
-                    if (act && (w[r] & NW_HEAD)) {
-                        d.mm0_out[lg[r]] = lp;
-                        d.mm1_out[lg[r]] = hp;
+                const uint32_t j = lane + 64 * r;
+                const uint32_t w = wa[r];
+                const bool act = !(w & NW_PAD);
+                const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
+                const REAL lc = La.c[r].x, hc = La.c[r].y;
+                const uint32_t sl = La.lg[r] - gl0;
+                const REAL tl = lo_i == NW_BOT ? INF : (lo_i == NW_TOP ? REAL(0) : sT[cur][lo_i]);
+                const REAL th = hi_i == NW_BOT ? INF : (hi_i == NW_TOP ? REAL(0) : sT[cur][hi_i]);
+                REAL t;
+                if (MODE == BWD_SOLVE) {
+                    const P2 dd = sD[act ? sl : 0];
+                    REAL m0 = act ? (fa[r] + lc) + tl : INF;
+                    REAL m1 = act ? (fa[r] + hc) + th : INF;
+                    const unsigned long long heads = __ballot((w & NW_HEAD) != 0);
+                    seg_min2(m0, m1, lane, heads, steps);
+                    const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
+                    const REAL nlo = (lc + rmin(mm, REAL(0))) + dd.x;
+                    const REAL nhi = (hc + rmin(-mm, REAL(0))) + dd.y;
+                    t = rmin(nhi + th, nlo + tl);
+                    const bool head = act && (w & NW_HEAD);
+                    P2 nc;
+                    nc.x = nlo;
+                    nc.y = nhi;
+                    bstore(nc, rs.lohi, head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB);
+                    if (head) sD[sl].x = mm;
+                } else {
+                    const REAL ch = th + hc, cl = tl + lc;  // backward_step, bdd_cuda_base.cu:646-667
+                    t = rmin(ch, cl);
+                    if (MODE == BWD_MARGINALS) {
+                        REAL lp = act ? fa[r] + cl : INF;  // backward_step_with_path_costs, :633-641
+                        REAL hp = act ? fa[r] + ch : INF;
+                        const unsigned long long heads = __ballot((w & NW_HEAD) != 0);
+                        seg_min2(lp, hp, lane, heads, steps);
+                        if (act && (w & NW_HEAD)) {
+                            d.mm0_out[La.lg[r]] = lp;
+                            d.mm1_out[La.lg[r]] = hp;
+                        }
                     }
                 }
+                if (act) sT[cur ^ 1][j] = t;
+                bstore(t, rs.T, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
             }
-            if (act) {
-                sT[cur ^ 1][j] = t;
-                d.T[nb + j] = t;
+            __syncthreads();
+            cur ^= 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                wa[r] = wb[r];
+                wb[r] = wc[r];
+                if (NEED_F) {
+                    fa[r] = fb[r];
+                    fb[r] = fc[r];
+                }
             }
+            La = Lb;
         }
-        __syncthreads();
-        cur ^= 1;
+        if (MODE == BWD_SOLVE) stage_flush<REAL>(sD, ent, rs, cnt, lane);
     }
     // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251)
-    const uint32_t n0 = pk.hop_node_off[q0 + 1] - pk.hop_node_off[q0];
+    const uint32_t n0 = nb_of(q0 + 1) - nb_of(q0);
     double s = 0.0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t j = lane + 64 * r;
         if (j < n0) s += (double)sT[cur][j];
     }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    for (int off2 = 32; off2 > 0; off2 >>= 1) s += __shfl_down(s, off2);
     if (lane == 0) d.lb_partial[pk.lb_base + p] = s;
 }
 
@@ -375,7 +607,6 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, Pack
     const uint32_t tid = threadIdx.x;
     const uint32_t p = blockIdx.x;
     if (p >= pk.n_packs) return;
-    if (d.delta_out) d.delta_out += (size_t)xcc_id() * d.delta_stride;
     const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
     const REAL INF = inf_v<REAL>();
     REAL* Fc = s.a;
@@ -402,8 +633,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, Pack
         for (uint32_t l = tid; l < nl; l += WIDE_THREADS) {
             s.m0[l] = INF;
             s.m1[l] = INF;
-            s.lc[l] = d.lo[lbase + l];
-            s.hc[l] = d.hi[lbase + l];
+            s.lc[l] = d.lohi[2 * (size_t)(lbase + l)];
+            s.hc[l] = d.lohi[2 * (size_t)(lbase + l) + 1];
         }
         __syncthreads();
         if (MODE == FWD_SOLVE) {
@@ -427,15 +658,14 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, Pack
             REAL nlo = s.lc[l], nhi = s.hc[l];
             if (MODE == FWD_SOLVE) {
                 const REAL m0 = s.m0[l], m1 = s.m1[l];
-                const int v = d.var[lbase + l];
+                const uint32_t e = d.lpos[lbase + l];
                 const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
-                nlo = (nlo + rmin(mm, REAL(0))) + d.delta_in[2 * v];
-                nhi = (nhi + rmin(-mm, REAL(0))) + d.delta_in[2 * v + 1];
+                nlo = (nlo + rmin(mm, REAL(0))) + d.delta_lay[2 * (size_t)e];
+                nhi = (nhi + rmin(-mm, REAL(0))) + d.delta_lay[2 * (size_t)e + 1];
                 if (w & WW_HEAD) {
-                    d.lo[lbase + l] = nlo;
-                    d.hi[lbase + l] = nhi;
-                    d.mm[lbase + l] = mm;
-                    if (d.delta_out) accumulate_delta(d.delta_out, v, mm);
+                    d.lohi[2 * (size_t)(lbase + l)] = nlo;
+                    d.lohi[2 * (size_t)(lbase + l) + 1] = nhi;
+                    d.mm_binned[e] = mm;
                 }
             } else if (MODE == FWD_SOLUTION) {
                 if (Ac[j]) {
@@ -470,7 +700,6 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
     const uint32_t tid = threadIdx.x;
     const uint32_t p = blockIdx.x;
     if (p >= pk.n_packs) return;
-    if (d.delta_out) d.delta_out += (size_t)xcc_id() * d.delta_stride;
     const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
     const REAL INF = inf_v<REAL>();
     REAL* Tc = s.a;  // T of hop q+1
@@ -483,8 +712,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
         for (uint32_t l = tid; l < nl; l += WIDE_THREADS) {
             s.m0[l] = INF;
             s.m1[l] = INF;
-            s.lc[l] = d.lo[lbase + l];
-            s.hc[l] = d.hi[lbase + l];
+            s.lc[l] = d.lohi[2 * (size_t)(lbase + l)];
+            s.hc[l] = d.lohi[2 * (size_t)(lbase + l) + 1];
         }
         __syncthreads();
         if (MODE != BWD_PLAIN) {
@@ -514,16 +743,15 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
             REAL t;
             if (MODE == BWD_SOLVE) {
                 const REAL m0 = s.m0[l], m1 = s.m1[l];
-                const int v = d.var[lbase + l];
+                const uint32_t e = d.lpos[lbase + l];
                 const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
-                const REAL nlo = (s.lc[l] + rmin(mm, REAL(0))) + d.delta_in[2 * v];
-                const REAL nhi = (s.hc[l] + rmin(-mm, REAL(0))) + d.delta_in[2 * v + 1];
+                const REAL nlo = (s.lc[l] + rmin(mm, REAL(0))) + d.delta_lay[2 * (size_t)e];
+                const REAL nhi = (s.hc[l] + rmin(-mm, REAL(0))) + d.delta_lay[2 * (size_t)e + 1];
                 t = rmin(nhi + th, nlo + tl);
                 if (w & WW_HEAD) {
-                    d.lo[lbase + l] = nlo;
-                    d.hi[lbase + l] = nhi;
-                    d.mm[lbase + l] = mm;
-                    if (d.delta_out) accumulate_delta(d.delta_out, v, mm);
+                    d.lohi[2 * (size_t)(lbase + l)] = nlo;
+                    d.lohi[2 * (size_t)(lbase + l) + 1] = nhi;
+                    d.mm_binned[e] = mm;
                 }
             } else {
                 t = rmin(th + s.hc[l], tl + s.lc[l]);
@@ -555,32 +783,118 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
 // small elementwise / per-variable kernels
 // =============================================================================================
 
-// normalize_delta (bdd_cuda_parallel_mma.cu:410-430) fused with the zero-fill of compute_delta (:384)
-// for the next pass: in[i] = out[i] / nr_bdds(i/2); out[i] = 0.
 template <typename REAL>
-__global__ void k_finish_delta(REAL* __restrict__ delta_in, REAL* __restrict__ delta_out,
-                               const int32_t* __restrict__ nbdds, uint32_t n2, int n_slices)
+__device__ __forceinline__ void lds_add(REAL* p, REAL v)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n2) return;
-    REAL s = 0;
-    for (int x = 0; x < n_slices; ++x) {
-        s += delta_out[(size_t)x * n2 + i];
-        delta_out[(size_t)x * n2 + i] = REAL(0);
-    }
-    const int nb = nbdds[i >> 1];
-    delta_in[i] = nb > 0 ? s / REAL(nb) : REAL(0);
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f32 / ds_add_f64
 }
 
-// sum of the per-XCD slices without normalisation (explicit forward_mm / backward_mm API)
-template <typename REAL>
-__global__ void k_sum_slices(REAL* __restrict__ out, const REAL* __restrict__ slices, uint32_t n2, int n_slices)
+// Exchange kernel: one workgroup per bin of variables; the bin's 2*vars_per_bin accumulators live in LDS.
+//   EX_ITER : compute_delta (bdd_cuda_parallel_mma.cu:358-393) + normalize_delta (:410-430) + broadcast of the
+//             normalised pairs to the bin's entries (what the next sweep adds, :191-197); the per-variable
+//             result is also stored in delta_var (the solver's delta_lo_hi_).
+//   EX_RAW  : compute_delta only — un-normalised sums into delta_var (explicit forward_mm / backward_mm API).
+// The accumulators are ACC-typed: LDS f32 atomics (ds_add_f32) run at half the rate of ds_add_f64 on
+// gfx950 (measured: 33 us vs 16 us for the same 5 M entries), so float solvers accumulate in double
+// and round once per variable.
+enum : int { EX_ITER = 0, EX_RAW = 1 };
+constexpr int EX_THREADS = 1024;
+constexpr int EX_UNROLL = 8;
+
+template <typename REAL, typename ACC, int MODE>
+__global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
+                                                                  const uint32_t* __restrict__ evar, const int32_t* __restrict__ nbdds,
+                                                                  REAL* __restrict__ delta_var, REAL* __restrict__ delta_lay,
+                                                                  uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n2) return;
-    REAL s = 0;
-    for (int x = 0; x < n_slices; ++x) s += slices[(size_t)x * n2 + i];
-    out[i] = s;
+    using P2 = typename Pair<REAL>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    ACC* tile = reinterpret_cast<ACC*>(dyn_lds);
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t v0 = b * vars_per_bin;
+    const uint32_t nv = min(vars_per_bin, n_vars - v0);
+    const uint32_t e0 = bin_ptr[b], e1 = bin_ptr[b + 1];
+    const rsrc_t rmm = make_rsrc(mm_binned, n_entries), rev = make_rsrc(evar, n_entries);
+    for (uint32_t i = tid; i < 2 * nv; i += EX_THREADS) tile[i] = ACC(0);
+    __syncthreads();
+    for (uint32_t base = e0 + tid; base < e1; base += EX_THREADS * EX_UNROLL) {
+        REAL m[EX_UNROLL];
+        uint32_t lv[EX_UNROLL];
+#pragma unroll
+        for (int u = 0; u < EX_UNROLL; ++u) {
+            const uint32_t e = base + u * EX_THREADS;
+            bload(m[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);   // out of range: 0 -> no contribution
+            lv[u] = bload_u32(rev, e < e1 ? e * 4u : OOB);
+        }
+#pragma unroll
+        for (int u = 0; u < EX_UNROLL; ++u) {
+            const uint32_t l = lv[u] - v0;
+            if (m[u] > 0) lds_add(&tile[2 * l + 1], ACC(m[u]));
+            else if (m[u] < 0) lds_add(&tile[2 * l], ACC(-m[u]));
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 2 * nv; i += EX_THREADS) {
+        REAL x = REAL(tile[i]);
+        if (MODE == EX_ITER) {
+            const int nb = nbdds[v0 + (i >> 1)];
+            x = nb > 0 ? x / REAL(nb) : REAL(0);
+            tile[i] = ACC(x);
+        }
+        delta_var[2 * (size_t)v0 + i] = x;
+    }
+    if (MODE != EX_ITER) return;
+    __syncthreads();
+    const rsrc_t rdl = make_rsrc(delta_lay, 2ull * n_entries);
+    for (uint32_t base = e0 + tid; base < e1; base += EX_THREADS * EX_UNROLL) {
+        uint32_t lv[EX_UNROLL];
+#pragma unroll
+        for (int u = 0; u < EX_UNROLL; ++u) {
+            const uint32_t e = base + u * EX_THREADS;
+            lv[u] = bload_u32(rev, e < e1 ? e * 4u : OOB);
+        }
+#pragma unroll
+        for (int u = 0; u < EX_UNROLL; ++u) {
+            const uint32_t e = base + u * EX_THREADS;
+            const uint32_t l = e < e1 ? lv[u] - v0 : 0;
+            P2 pr;
+            pr.x = REAL(tile[2 * l]);
+            pr.y = REAL(tile[2 * l + 1]);
+            bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
+        }
+    }
+}
+
+// Exchange, step B: broadcast the per-variable pairs to every entry (what the next sweep adds to the
+// arc costs, bdd_cuda_parallel_mma.cu:191-197).  Entries of one bin are contiguous, so the pairs of
+// vars_per_bin consecutive variables are re-read from L1/L2 while the writes stream out coalesced.
+// Four entries per thread: one 16-byte index load, four independent pair gathers, 16-byte stores.
+template <typename REAL>
+__global__ void __launch_bounds__(256) k_exchange_bcast(const REAL* __restrict__ delta_var, const uint32_t* __restrict__ evar,
+                                                          REAL* __restrict__ delta_lay, uint32_t n_entries, uint32_t n_vars)
+{
+    using P2 = typename Pair<REAL>::type;
+    const uint32_t e = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= n_entries) return;
+    const rsrc_t rdv = make_rsrc(delta_var, 2ull * n_vars);
+    uint32_t v[4];
+    if (e + 4 <= n_entries) {
+        const uint4 vv = *reinterpret_cast<const uint4*>(evar + e);
+        v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; v[3] = vv.w;
+    } else {
+        for (int u = 0; u < 4; ++u) v[u] = e + u < n_entries ? evar[e + u] : 0xFFFFFFFFu;
+    }
+    P2 pr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bload(pr[u], rdv, v[u] != 0xFFFFFFFFu ? v[u] * (uint32_t)sizeof(P2) : OOB);
+    P2* out = reinterpret_cast<P2*>(delta_lay) + e;
+    if (e + 4 <= n_entries) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) out[u] = pr[u];
+    } else {
+        for (int u = 0; u < 4; ++u)
+            if (e + u < n_entries) out[u] = pr[u];
+    }
 }
 
 template <typename REAL>
@@ -592,22 +906,41 @@ __global__ void k_normalize_delta(REAL* __restrict__ delta, const int32_t* __res
     if (nb > 0) delta[i] /= REAL(nb);
 }
 
-// Deterministic alternative to the atomics of compute_delta: per-variable gather over the
-// (variable,bdd)-sorted layer list (the reduce_by_key variant commented out at :395-407).
-template <typename REAL>
-__global__ void k_delta_gather(const REAL* __restrict__ mm, const uint32_t* __restrict__ var_ptr,
-                               const uint32_t* __restrict__ var_layers, REAL* __restrict__ delta_out, uint32_t n_vars)
+// Deterministic alternative to the LDS atomics of k_exchange: per-variable gather over the
+// (variable,bdd)-sorted entry list (the reduce_by_key variant commented out at bdd_cuda_parallel_mma.cu:395-407).
+template <typename REAL, bool NORMALIZE>
+__global__ void k_delta_gather(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ var_ptr,
+                               const uint32_t* __restrict__ vpos, REAL* __restrict__ delta_var, uint32_t n_vars)
 {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_vars) return;
     REAL lo = 0, hi = 0;
-    for (uint32_t k = var_ptr[v]; k < var_ptr[v + 1]; ++k) {
-        const REAL m = mm[var_layers[k]];
+    const uint32_t k0 = var_ptr[v], k1 = var_ptr[v + 1];
+    for (uint32_t k = k0; k < k1; ++k) {
+        const REAL m = mm_binned[vpos[k]];
         if (m > 0) hi += m;
         else if (m < 0) lo += -m;
     }
-    delta_out[2 * v] = lo;
-    delta_out[2 * v + 1] = hi;
+    if (NORMALIZE && k1 > k0) {
+        lo /= REAL(k1 - k0);
+        hi /= REAL(k1 - k0);
+    }
+    delta_var[2 * (size_t)v] = lo;
+    delta_var[2 * (size_t)v + 1] = hi;
+}
+
+// binned entry order <-> internal layer order (rare elementwise ops, checkpointing)
+template <typename REAL>
+__global__ void k_entries_to_layers(const REAL* __restrict__ binned, const uint32_t* __restrict__ lpos, REAL* __restrict__ out, uint32_t n)
+{
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < n) out[l] = binned[lpos[l]];
+}
+template <typename REAL>
+__global__ void k_layers_to_entries(const REAL* __restrict__ in, const uint32_t* __restrict__ lpos, REAL* __restrict__ binned, uint32_t n)
+{
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < n) binned[lpos[l]] = in[l];
 }
 
 // set_vars_costs_func (bdd_cuda_base.cu:457-474).  The quotient is formed in double and rounded
@@ -620,17 +953,17 @@ __global__ void k_update_costs(REAL* __restrict__ cost, const int32_t* __restric
     if (l >= n_layers) return;
     const int v = var[l];
     if ((uint64_t)v >= n_c) {
-        cost[l] = REAL(0);  // :465-469
+        cost[2 * (size_t)l] = REAL(0);  // :465-469
         return;
     }
-    cost[l] += REAL((double)c[v] / (double)nbdds[v]);
+    cost[2 * (size_t)l] += REAL((double)c[v] / (double)nbdds[v]);
 }
 
 template <typename REAL>
 __global__ void k_set_cost(REAL* __restrict__ hi, const uint32_t* __restrict__ var_layers, uint32_t k0, uint32_t k1, REAL c)
 {
     const uint32_t k = k0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < k1) hi[var_layers[k]] += c;
+    if (k < k1) hi[2 * (size_t)var_layers[k]] += c;
 }
 
 // Deterministic fixed-shape reduction of the per-pack partial lower bounds.
@@ -658,23 +991,25 @@ __global__ void k_lb_per_bdd(const REAL* __restrict__ T, const uint32_t* __restr
 
 // compute_net_costs_func (bdd_cuda_parallel_mma.cu:432-446)
 template <typename REAL>
-__global__ void k_net_costs(const REAL* __restrict__ lo, const REAL* __restrict__ hi, const REAL* __restrict__ mm,
-                            REAL* __restrict__ out, uint32_t n)
+__global__ void k_net_costs(const REAL* __restrict__ lo, const REAL* __restrict__ hi, const REAL* __restrict__ mm_binned,
+                            const uint32_t* __restrict__ lpos, REAL* __restrict__ out, uint32_t n)
 {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < n) out[l] = hi[l] - lo[l] + mm[l];
+    if (l < n) out[l] = hi[2 * (size_t)l] - lo[2 * (size_t)l] + mm_binned[lpos[l]];
 }
 
 // distribute_deffered_mm_diff_func (bdd_cuda_base.cu:1396-1414) + the zero-fill of :1427
 template <typename REAL>
-__global__ void k_distribute_delta(REAL* __restrict__ lo, REAL* __restrict__ hi, REAL* __restrict__ mm, uint32_t n)
+__global__ void k_distribute_delta(REAL* __restrict__ lo, REAL* __restrict__ hi, REAL* __restrict__ mm_binned,
+                                   const uint32_t* __restrict__ lpos, uint32_t n)
 {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= n) return;
-    const REAL m = mm[l];
-    if (m > 0) hi[l] += m;
-    else lo[l] -= m;
-    mm[l] = REAL(0);
+    const uint32_t e = lpos[l];
+    const REAL m = mm_binned[e];
+    if (m > 0) hi[2 * (size_t)l] += m;
+    else lo[2 * (size_t)l] -= m;
+    mm_binned[e] = REAL(0);
 }
 
 // add_scaled_product_func (bdd_cuda_parallel_mma.h:54-60)
@@ -682,7 +1017,7 @@ template <typename REAL>
 __global__ void k_gradient_step(REAL* __restrict__ hi, const REAL* __restrict__ g, REAL step, uint32_t n)
 {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < n) hi[l] = hi[l] + step * g[l];
+    if (l < n) hi[2 * (size_t)l] = hi[2 * (size_t)l] + step * g[l];
 }
 
 // make_dual_feasible (bdd_cuda_base.cu:1261-1303): g[l] -= (sum over layers of var) / nr_bdds(var)
@@ -708,7 +1043,7 @@ __global__ void k_primal_objective(const REAL* __restrict__ lo, const REAL* __re
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_vars) return;
     REAL s = 0;
-    for (uint32_t k = var_ptr[v]; k < var_ptr[v + 1]; ++k) s += hi[var_layers[k]] - lo[var_layers[k]];
+    for (uint32_t k = var_ptr[v]; k < var_ptr[v + 1]; ++k) s += hi[2 * (size_t)var_layers[k]] - lo[2 * (size_t)var_layers[k]];
     out[v] = s;
 }
 
@@ -723,6 +1058,14 @@ static __global__ void k_gather_var(const int32_t* __restrict__ in, const uint32
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[idx[i]];
+}
+
+// dst[i * ds] = src[i * ss]   (interleaved {lo,hi} array <-> the API's separate cost vectors)
+template <typename T>
+__global__ void k_strided_copy(T* __restrict__ dst, uint32_t ds, const T* __restrict__ src, uint32_t ss, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[(size_t)i * ds] = src[(size_t)i * ss];
 }
 
 template <typename T>

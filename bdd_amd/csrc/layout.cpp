@@ -91,7 +91,7 @@ struct PackBuilder {
 }  // namespace
 
 int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
-                 const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps)
+                 const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps, uint32_t real_size)
 {
     L = HostLayout();
     if (!instr || !delims || n_bdds == 0) {
@@ -333,6 +333,75 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
             const uint32_t lg = in_layer_to_internal[l];
             L.var_layers[cursor[L.layer_var[lg]]++] = lg;
         }
+    }
+    // ---- variable <-> layer exchange tables (see layout.hpp, struct Exchange) --------------------
+    {
+        Exchange& X = L.ex;
+        // default bin: as many variables as a 128 KiB LDS tile holds (2 REAL each), but at least ~256 bins
+        // so that the exchange kernel (one workgroup per bin) has enough workgroups to spread over the CUs
+        const uint32_t max_vb = 131072u / (2u * 8u);  // accumulators are double for both precisions
+        (void)real_size;
+        uint32_t auto_vb = (uint32_t)(((L.n_vars + 255) / 256 + 255) / 256 * 256);
+        auto_vb = std::min(std::max(auto_vb, 1024u), max_vb);
+        X.vars_per_bin = opts && opts->vars_per_bin ? opts->vars_per_bin : auto_vb;
+        X.stage_cap = opts && opts->stage_cap ? opts->stage_cap : 640;
+        if (X.vars_per_bin < 64 || X.vars_per_bin > 65536) {
+            err = "vars_per_bin must be in [64, 65536]";
+            return BDDMMA_ERR_INVALID_ARGUMENT;
+        }
+        if (X.stage_cap < W || X.stage_cap > 640) {
+            err = "stage_cap must be in [pack_width, 640]";
+            return BDDMMA_ERR_INVALID_ARGUMENT;
+        }
+        X.n_bins = (uint32_t)((L.n_vars + X.vars_per_bin - 1) / X.vars_per_bin);
+        // stage groups: runs of hops of a narrow pack holding <= stage_cap layers
+        const PackSet& N = L.narrow;
+        const uint32_t Pn = N.n_packs();
+        X.pack_group_ptr.assign(Pn + 1, 0);
+        std::vector<uint32_t> layer_group(Lin, 0);
+        const uint32_t narrow_layers = Pn ? N.hop_layer_off.back() : 0;  // narrow layers come first
+        for (uint32_t p = 0; p < Pn; ++p) {
+            X.pack_group_ptr[p] = (uint32_t)X.grp_hop_end.size();
+            const uint32_t q0 = N.pack_hop_ptr[p], q1 = N.pack_hop_ptr[p + 1];
+            uint32_t acc = 0;
+            for (uint32_t q = q0; q < q1; ++q) {
+                const uint32_t nl = N.hop_layer_off[q + 1] - N.hop_layer_off[q];
+                if (acc + nl > X.stage_cap && acc > 0) {
+                    X.grp_hop_end.push_back(q);
+                    acc = 0;
+                }
+                acc += nl;
+                const uint32_t g = (uint32_t)X.grp_hop_end.size();
+                for (uint32_t l = N.hop_layer_off[q]; l < N.hop_layer_off[q + 1]; ++l) layer_group[l] = g;
+            }
+            X.grp_hop_end.push_back(q1);
+        }
+        X.pack_group_ptr[Pn] = (uint32_t)X.grp_hop_end.size();
+        const uint32_t G = (uint32_t)X.grp_hop_end.size();
+        for (uint32_t l = narrow_layers; l < Lin; ++l) layer_group[l] = G;  // wide layers: one pseudo group, last in every bin
+
+        // a group's layers are contiguous in layer order; entry order: by (bin, group, layer)
+        X.grp_layer_off.assign(G + 1, 0);
+        for (uint32_t l = 0; l < narrow_layers; ++l) X.grp_layer_off[layer_group[l] + 1] = l + 1;
+        for (uint32_t g = 0; g < G; ++g)
+            if (X.grp_layer_off[g + 1] < X.grp_layer_off[g]) X.grp_layer_off[g + 1] = X.grp_layer_off[g];
+        struct Key { uint32_t bin, group, layer; };
+        std::vector<Key> keys(Lin);
+        for (uint32_t l = 0; l < Lin; ++l) keys[l] = Key{(uint32_t)L.layer_var[l] / X.vars_per_bin, layer_group[l], l};
+        // layers are already sorted by (group, layer); a stable sort by bin yields (bin, group, layer)
+        std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.bin < b.bin; });
+        X.bin_ptr.assign(X.n_bins + 1, 0);
+        X.evar.assign(Lin, 0);
+        X.lpos.assign(Lin, 0);
+        for (uint32_t e = 0; e < Lin; ++e) {
+            const Key& k = keys[e];
+            X.bin_ptr[k.bin + 1]++;
+            X.evar[e] = (uint32_t)L.layer_var[k.layer];
+            X.lpos[k.layer] = e;
+        }
+        for (uint32_t b = 0; b < X.n_bins; ++b) X.bin_ptr[b + 1] += X.bin_ptr[b];
+        X.vpos.assign(Lin, 0);
+        for (uint32_t k = 0; k < Lin; ++k) X.vpos[k] = X.lpos[L.var_layers[k]];
     }
     return BDDMMA_OK;
 }

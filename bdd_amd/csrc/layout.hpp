@@ -58,6 +58,30 @@ struct PackSet {
     uint32_t n_packs() const { return pack_hop_ptr.empty() ? 0 : (uint32_t)pack_hop_ptr.size() - 1; }
 };
 
+// Variable <-> layer exchange ("propagation blocking").  Every pass has to broadcast delta[var] to the
+// layers of the variable and reduce mm[layer] back per variable.  Done naively these are two random
+// 4-8 byte accesses per layer into multi-MB arrays — on the 10.5 M-node benchmark they move 3x the
+// bytes of the streamed sweep data.  Instead both directions go through one array in *binned* order:
+//   entry e = (bin of the variable, stage group of the layer, position inside the group)
+// A bin is a contiguous range of `vars_per_bin` variables whose 2 REAL accumulators fit in LDS; a
+// stage group is a run of hops of one narrow pack with <= stage_cap layers.  The sweep kernel loads
+// the delta pairs of the group's layers into LDS (entry index per layer = lpos; the entries of one
+// (bin, group) sit next to each other and next to those of the neighbouring groups, which run on the
+// same XCD at the same time, so the lines are shared in L2), reads / overwrites them by the layer's
+// position inside the group, and writes the min-marginal differences back the same way; the
+// exchange kernel (one workgroup per bin) streams the bin's entries, accumulates per variable in LDS
+// and streams the normalised delta pairs back.  No random global access is left on the hot path.
+struct Exchange {
+    uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0;
+    std::vector<uint32_t> bin_ptr;         // [n_bins+1] first entry of each bin
+    std::vector<uint32_t> evar;            // [L] entry -> variable
+    std::vector<uint32_t> lpos;            // [L] layer -> entry
+    std::vector<uint32_t> vpos;            // [L] (variable,bdd)-sorted position -> entry (deterministic gather)
+    std::vector<uint32_t> pack_group_ptr;  // [narrow packs + 1] first stage group of each narrow pack
+    std::vector<uint32_t> grp_layer_off;   // [G+1] first layer of each group (a group's layers are contiguous)
+    std::vector<uint32_t> grp_hop_end;     // [G] (pack,hop) record index one past the group's last hop
+};
+
 struct HostLayout {
     uint64_t n_bdds = 0, n_vars = 0, n_hops = 0;
     uint64_t n_input_nodes = 0;   // incl. terminals (reference nr_bdd_nodes())
@@ -82,12 +106,14 @@ struct HostLayout {
     std::vector<uint32_t> bdd_root_slot;
     // per hop statistics (over all packs)
     std::vector<uint64_t> nodes_per_hop, layers_per_hop;
+    Exchange ex;
     // slot -> input instruction index (debug / round-trip tests), UINT64_MAX for padding
     std::vector<uint64_t> slot_to_instr;
 };
 
 // Returns BDDMMA_OK or an error code; `err` receives the message.
 int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
-                 const bddmma_options* opts, HostLayout& out, std::string& err, bool keep_debug_maps);
+                 const bddmma_options* opts, HostLayout& out, std::string& err, bool keep_debug_maps,
+                 uint32_t real_size = 4);
 
 }  // namespace bddmma

@@ -60,6 +60,7 @@ struct SolverBase {
     virtual int make_dual_feasible(void* g, int on_device) = 0;
     virtual int gradient_step(const void* g, double step, int on_device) = 0;
     virtual void* stream_handle() = 0;
+    virtual int time_kernel(int kind, uint64_t reps, double* ms) = 0;
 
     int synchronize();
     void prof_begin(int kclass);

@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--rows", type=int, default=500_000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--pack-width", type=int, default=0)
+    ap.add_argument("--vars-per-bin", type=int, default=0)
+    ap.add_argument("--stage-cap", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--deterministic", action="store_true")
@@ -68,7 +70,8 @@ def main():
     sizes = set_cover_sizes(args.vars, args.rows, args.k)
     col, costs = random_set_cover(args.vars, args.rows, args.k, seed=12345 + rank)
     solver = bdd_hip_parallel_mma(col, costs, precision=args.precision, device=local_rank,
-                                  pack_width=args.pack_width, deterministic=args.deterministic)
+                                  pack_width=args.pack_width, deterministic=args.deterministic,
+                                  vars_per_bin=args.vars_per_bin, stage_cap=args.stage_cap)
     R = 4 if args.precision == "float" else 8
     solver.iterations(args.warmup)
     solver.synchronize()
@@ -161,7 +164,8 @@ def cpu_baseline(col, costs, args, sizes):
         if el >= args.cpu_seconds or n >= 200:
             break
     cpu_lb = o.lower_bound()
-    g = bdd_hip_parallel_mma(col, costs, precision=args.precision, pack_width=args.pack_width)
+    g = bdd_hip_parallel_mma(col, costs, precision=args.precision, pack_width=args.pack_width,
+                             vars_per_bin=args.vars_per_bin, stage_cap=args.stage_cap)
     g.iterations(n + 1)
     gpu_lb = g.lower_bound()
     return {

@@ -69,7 +69,9 @@ typedef struct bddmma_options {
     uint32_t pack_width;       /* max #nodes of one hop inside a wave-sized BDD pack: 64, 128 (default) or 256 */
     uint32_t wide_pack_width;  /* max #nodes of one hop inside a workgroup-sized pack (default 2048; <= 2048 for F64, <= 4096 for F32) */
     uint32_t deterministic;    /* 1: delta accumulation by per-variable gather (bit-reproducible) */
-    uint32_t reserved[5];
+    uint32_t vars_per_bin;     /* variables per exchange bin (2*REAL*vars_per_bin bytes of LDS; default 16384 F32 / 8192 F64) */
+    uint32_t stage_cap;        /* max layers of one stage group of a narrow pack (default 640) */
+    uint32_t reserved[3];
 } bddmma_options;
 
 /* ---- construction ------------------------------------------------------- */
@@ -208,6 +210,10 @@ int bddmma_set_profiling(bddmma_solver* s, int on);  /* resets the counters */
 int bddmma_get_profile(bddmma_solver* s, bddmma_profile* out);  /* synchronises */
 /* Run n iterations bracketed by hipEvents on the handle's stream; *ms = elapsed device time. */
 int bddmma_time_iterations(bddmma_solver* s, double omega, uint64_t n, double* ms);
+/* Time `reps` back-to-back launches of one kernel class with hipEvents on the handle's stream
+ * (kernel-level benchmarking; leaves the sweep state invalid).  kind: 0 forward_run sweep, 1 backward_run
+ * sweep, 2 forward_mm sweep, 3 backward_mm sweep, 4 exchange reduce, 5 exchange broadcast. */
+int bddmma_time_kernel(bddmma_solver* s, int kind, uint64_t reps, double* ms);
 /* HBM bytes held by the handle. */
 uint64_t bddmma_device_bytes(const bddmma_solver* s);
 

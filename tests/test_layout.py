@@ -17,12 +17,12 @@ BOT = np.uint64(2**64 - 2)
 
 
 class Layout:
-    def __init__(self, col, pack_width=0, wide_pack_width=0):
+    def __init__(self, col, pack_width=0, wide_pack_width=0, vars_per_bin=0, stage_cap=0):
         L = capi.lib()
         instr = np.ascontiguousarray(col.instr, dtype=np.uint64)
         delims = np.ascontiguousarray(col.delims, dtype=np.uint64)
         h = C.c_void_p()
-        opts = capi.Options(pack_width, wide_pack_width, 0)
+        opts = capi.Options(pack_width, wide_pack_width, 0, vars_per_bin, stage_cap)
         rc = L.bddmma_layout_create(C.byref(h), instr.ctypes.data_as(C.c_void_p), delims.ctypes.data_as(C.c_void_p),
                                     col.nr_bdds(), C.byref(opts))
         capi.check(rc, None)
@@ -50,6 +50,14 @@ class Layout:
         self.var_ptr = get(13, self.n_vars + 1, np.uint32)
         self.var_layers = get(14, self.n_layers, np.uint32)
         self.root_slot = get(15, col.nr_bdds(), np.uint32)
+        self.n_bins, self.vars_per_bin, self.n_groups, self.narrow_layers, self.stage_cap = sz(9), sz(10), sz(11), sz(12), sz(13)
+        self.bin_ptr = get(16, self.n_bins + 1, np.uint32)
+        self.evar = get(17, self.n_layers, np.uint32)
+        self.lpos = get(18, self.n_layers, np.uint32)
+        self.vpos = get(19, self.n_layers, np.uint32)
+        self.pack_group_ptr = get(20, self.np_n + 1 if self.np_n else 0, np.uint32)
+        self.grp_layer_off = get(21, self.n_groups + 1, np.uint32)
+        self.grp_hop_end = get(22, self.n_groups, np.uint32)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -82,8 +90,41 @@ class Layout:
         return out
 
 
+def check_exchange(lay):
+    """Invariants of the variable <-> layer exchange tables (layout.hpp, struct Exchange)."""
+    L, VB = lay.n_layers, lay.vars_per_bin
+    assert sorted(lay.lpos.tolist()) == list(range(L))          # layer -> entry is a permutation
+    assert lay.bin_ptr[0] == 0 and lay.bin_ptr[-1] == L and np.all(np.diff(lay.bin_ptr.astype(np.int64)) >= 0)
+    ebin = np.searchsorted(lay.bin_ptr, np.arange(L), side="right") - 1
+    for l in range(L):
+        e = int(lay.lpos[l])
+        assert int(lay.evar[e]) == int(lay.layer_var[l]) and int(ebin[e]) == int(lay.evar[e]) // VB
+    np.testing.assert_array_equal(lay.vpos, lay.lpos[lay.var_layers])
+    # stage groups tile the hops of every narrow pack and hold <= stage_cap contiguous layers
+    S = lay.sets[0]
+    for p in range(lay.np_n):
+        g0, g1 = int(lay.pack_group_ptr[p]), int(lay.pack_group_ptr[p + 1])
+        q = int(S["pack_hop_ptr"][p])
+        for g in range(g0, g1):
+            qe = int(lay.grp_hop_end[g])
+            assert qe > q
+            l0, l1 = int(S["hop_layer_off"][q]), int(S["hop_layer_off"][qe])
+            assert (int(lay.grp_layer_off[g]), int(lay.grp_layer_off[g + 1])) == (l0, l1)
+            assert 0 < l1 - l0 <= lay.stage_cap
+            # inside one bin the group's entries are consecutive and ordered by layer
+            e = lay.lpos[l0:l1].astype(np.int64)
+            b = ebin[e]
+            for bb in np.unique(b):
+                ee = e[b == bb]
+                assert np.all(np.diff(ee) == 1)
+            q = qe
+        assert q == int(S["pack_hop_ptr"][p + 1])
+    assert int(lay.grp_layer_off[-1]) == lay.narrow_layers
+
+
 def check_roundtrip(col, **kw):
     lay = Layout(col, **kw)
+    check_exchange(lay)
     dec = lay.decode()
     ins = col.instr
     n_nonterm = int((ins[:, 2] < BOT).sum())
@@ -138,8 +179,8 @@ def test_roundtrip_golden(name, pw):
 
 def test_roundtrip_many_packs_and_wide():
     col, _ = random_set_cover(400, 300, 6, seed=1)
-    lay = check_roundtrip(col, pack_width=64)
-    assert lay.np_n > 1 and lay.np_w == 0
+    lay = check_roundtrip(col, pack_width=64, vars_per_bin=64, stage_cap=128)
+    assert lay.np_n > 1 and lay.np_w == 0 and lay.n_bins == 7 and lay.n_groups > lay.np_n
     # a knapsack row with a wide layer goes to a wide pack
     col2 = BddCollection()
     co = [27, 32, 1, 32, 19, 21, 25, 12, 39, 3, 11, 15, 23, 16, 6, 2, 1, 2]  # widest layer: 97 nodes

@@ -1,0 +1,19 @@
+"""Kernel-level micro-benchmark on the GPU box: python tools_kbench.py [--precision float] [--pack-width N] ..."""
+import argparse, sys, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bdd_amd.instances import random_set_cover
+from bdd_amd.solver import bdd_hip_parallel_mma
+ap = argparse.ArgumentParser()
+ap.add_argument("--precision", default="float")
+ap.add_argument("--pack-width", type=int, default=0)
+ap.add_argument("--vars-per-bin", type=int, default=0)
+ap.add_argument("--stage-cap", type=int, default=0)
+ap.add_argument("--vars", type=int, default=1_000_000)
+ap.add_argument("--rows", type=int, default=500_000)
+a = ap.parse_args()
+col, costs = random_set_cover(a.vars, a.rows, 10, seed=12345)
+s = bdd_hip_parallel_mma(col, costs, precision=a.precision, pack_width=a.pack_width, vars_per_bin=a.vars_per_bin, stage_cap=a.stage_cap)
+s.iterations(3)
+names = ["fwd_plain", "bwd_plain", "fwd_solve", "bwd_solve", "exch_reduce", "exch_bcast"]
+print(vars(a))
+print("  ".join(f"{n}={s.time_kernel(k, 30)*1e3:.1f}us" for k, n in enumerate(names)))
