@@ -1,0 +1,175 @@
+// bdd_hip_parallel_mma.hpp — header-only C++ class over the C-ABI (include/bdd_mma.h) that satisfies the
+// reference's relaxation-solver concept, so it can be listed as one more alternative of
+// `bdd_solver::solver_type` (reference: include/bdd_solver/bdd_solver.h:64-69) and constructed where
+// `"relaxation solver": "cuda parallel mma"` is handled (src/bdd_solver/bdd_solver.cpp:164-176).
+// Member names, argument meaning and error behaviour (std::runtime_error) follow
+// LPMP::bdd_cuda_parallel_mma<REAL> / bdd_cuda_base<REAL>.  Needs no HIP headers: device vectors are
+// raw device pointers (`device_ptr<REAL>`) owned by the caller or by the handle.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../../include/bdd_mma.h"
+
+namespace LPMP {
+
+template <typename REAL>
+class bdd_hip_parallel_mma {
+    static_assert(std::is_same<REAL, float>::value || std::is_same<REAL, double>::value, "REAL must be float or double");
+
+   public:
+    using value_type = REAL;
+    static constexpr int precision = std::is_same<REAL, double>::value ? BDDMMA_F64 : BDDMMA_F32;
+
+    bdd_hip_parallel_mma() = default;
+
+    // From the flat storage of BDD::bdd_collection: `instr` = bdd_instructions.data() (bit-identical layout),
+    // `delims` = bdd_delimiters.data().  Mirrors bdd_cuda_parallel_mma(const bdd_collection&, const std::vector<double>&).
+    bdd_hip_parallel_mma(const bddmma_instruction* instr, const uint64_t* delims, size_t nr_bdds,
+                         const std::vector<double>& costs_hi = {}, int device = 0, const bddmma_options* opts = nullptr)
+    {
+        check(bddmma_create(&h_, precision, device, instr, delims, nr_bdds, costs_hi.data(), costs_hi.size(), opts), nullptr);
+    }
+    // Any type with the accessors of BDD::bdd_collection used by the reference constructor
+    // (bdd_cuda_base.cu:55-144): nr_bdds(), nr_bdd_nodes(b), offset(b), operator()(b, i).
+    template <typename BDD_COLLECTION, typename = decltype(std::declval<const BDD_COLLECTION&>().nr_bdds())>
+    explicit bdd_hip_parallel_mma(const BDD_COLLECTION& bdd_col, const std::vector<double>& costs_hi = {}, int device = 0)
+    {
+        std::vector<bddmma_instruction> instr;
+        std::vector<uint64_t> delims(1, 0);
+        for (size_t b = 0; b < bdd_col.nr_bdds(); ++b) {
+            const size_t off = bdd_col.offset(b), base = instr.size();
+            for (size_t i = 0; i < bdd_col.nr_bdd_nodes(b); ++i) {
+                const auto in = bdd_col(b, off + i);
+                const bool term = in.index >= BDDMMA_BOTSINK;
+                instr.push_back({term ? in.lo : in.lo - off + base, term ? in.hi : in.hi - off + base, in.index});
+            }
+            delims.push_back(instr.size());
+        }
+        check(bddmma_create(&h_, precision, device, instr.data(), delims.data(), bdd_col.nr_bdds(), costs_hi.data(), costs_hi.size(), nullptr), nullptr);
+    }
+    ~bdd_hip_parallel_mma() { bddmma_destroy(h_); }
+    bdd_hip_parallel_mma(bdd_hip_parallel_mma&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    bdd_hip_parallel_mma& operator=(bdd_hip_parallel_mma&& o) noexcept
+    {
+        if (this != &o) { bddmma_destroy(h_); h_ = o.h_; o.h_ = nullptr; }
+        return *this;
+    }
+    bdd_hip_parallel_mma(const bdd_hip_parallel_mma&) = delete;
+    bdd_hip_parallel_mma& operator=(const bdd_hip_parallel_mma&) = delete;
+
+    // ---- sizes (bdd_cuda_base.h:98-116)
+    size_t nr_variables() const { return bddmma_nr_variables(h_); }
+    size_t nr_bdds() const { return bddmma_nr_bdds(h_); }
+    size_t nr_layers() const { return bddmma_nr_layers(h_); }
+    size_t nr_bdd_nodes() const { return bddmma_nr_bdd_nodes(h_); }
+    size_t nr_hops() const { return bddmma_nr_hops(h_); }
+    size_t nr_bdds(const size_t var) const
+    {
+        std::vector<int32_t> n(nr_variables());
+        check(bddmma_num_bdds_per_var(h_, n.data()));
+        return n.at(var);
+    }
+
+    // ---- costs (bdd_cuda_base.cu:439-558)
+    void update_costs(const std::vector<REAL>& cost_delta_0, const std::vector<REAL>& cost_delta_1)
+    {
+        check(bddmma_update_costs(h_, cost_delta_0.data(), cost_delta_0.size(), cost_delta_1.data(), cost_delta_1.size(), precision, 0));
+    }
+    void update_costs(const REAL* dev_cost_delta_0, size_t n0, const REAL* dev_cost_delta_1, size_t n1)  // device_vector overload
+    {
+        check(bddmma_update_costs(h_, dev_cost_delta_0, n0, dev_cost_delta_1, n1, precision, 1));
+    }
+    void set_cost(const double c, const size_t var) { check(bddmma_set_cost(h_, c, var)); }
+    std::vector<REAL> get_primal_objective_vector_host()
+    {
+        std::vector<REAL> v(nr_variables());
+        check(bddmma_primal_objective_vec(h_, v.data(), 0));
+        return v;
+    }
+
+    // ---- sweeps and bounds
+    void forward_run() { check(bddmma_forward_run(h_)); }
+    void backward_run() { check(bddmma_backward_run(h_)); }
+    double lower_bound()
+    {
+        double lb;
+        check(bddmma_lower_bound(h_, &lb));
+        return lb;
+    }
+
+    // ---- parallel mma (bdd_cuda_parallel_mma.cu:142-153, 207-257, 301-346, 410-430)
+    void iteration(const REAL omega = 0.5) { check(bddmma_iteration(h_, omega)); }
+    void forward_mm(const REAL omega, std::vector<REAL>& delta_lo_hi) { check(bddmma_forward_mm(h_, omega, delta_lo_hi.data(), 0)); }
+    void backward_mm(const REAL omega, std::vector<REAL>& delta_lo_hi) { check(bddmma_backward_mm(h_, omega, delta_lo_hi.data(), 0)); }
+    void forward_mm(const REAL omega, REAL* dev_delta_lo_hi) { check(bddmma_forward_mm(h_, omega, dev_delta_lo_hi, 1)); }
+    void backward_mm(const REAL omega, REAL* dev_delta_lo_hi) { check(bddmma_backward_mm(h_, omega, dev_delta_lo_hi, 1)); }
+    void normalize_delta(REAL* dev_delta_lo_hi) const { check(bddmma_normalize_delta(h_, dev_delta_lo_hi, 1)); }
+    void distribute_delta() { check(bddmma_distribute_delta(h_)); }
+
+    // ---- min-marginals [var][bdd] -> {mm0, mm1} (bdd_cuda_base.cu:751-786)
+    std::vector<std::vector<std::array<double, 2>>> min_marginals()
+    {
+        const size_t L = nr_layers();
+        std::vector<int32_t> var(L);
+        std::vector<REAL> m0(L), m1(L);
+        check(bddmma_min_marginals(h_, 1, var.data(), m0.data(), m1.data(), 0));
+        std::vector<std::vector<std::array<double, 2>>> out(nr_variables());
+        for (size_t k = 0; k < L; ++k) out[var[k]].push_back({double(m0[k]), double(m1[k])});
+        return out;
+    }
+    std::vector<char> bdds_solution_vec_host()
+    {
+        std::vector<char> s(nr_layers());
+        check(bddmma_bdds_solution(h_, 0, s.data(), 0));
+        return s;
+    }
+
+    // ---- L-BFGS support on device vectors (lbfgs.h:22-27)
+    void net_solver_costs(REAL* dev_out) const { check(bddmma_net_solver_costs(h_, dev_out, 1)); }
+    void bdds_solution_vec(char* dev_out) { check(bddmma_bdds_solution(h_, 0, dev_out, 1)); }
+    void make_dual_feasible(REAL* dev_g) const { check(bddmma_make_dual_feasible(h_, dev_g, 1)); }
+    void gradient_step(const REAL* dev_g, double step_size) { check(bddmma_gradient_step(h_, dev_g, step_size, 1)); }
+
+    void save(const std::string& path) const { check(bddmma_save(h_, path.c_str())); }
+    bddmma_solver* handle() { return h_; }
+
+   private:
+    void check(int rc) const { check(rc, h_); }
+    static void check(int rc, const bddmma_solver* h)
+    {
+        if (rc != BDDMMA_OK) throw std::runtime_error(std::string("bdd_hip_parallel_mma: ") + bddmma_last_error(h));
+    }
+    bddmma_solver* h_ = nullptr;
+};
+
+// lbfgs<bdd_cuda_parallel_mma<REAL>, ...> (include/bdd_solver/lbfgs.h:35-111) over the HIP solver.
+template <typename REAL>
+class bdd_hip_lbfgs_mma {
+   public:
+    bdd_hip_lbfgs_mma(bdd_hip_parallel_mma<REAL>&& s, const bddmma_lbfgs_params* p = nullptr) : solver_(std::move(s))
+    {
+        if (bddmma_lbfgs_create(&l_, solver_.handle(), p) != BDDMMA_OK)
+            throw std::runtime_error(std::string("bdd_hip_lbfgs_mma: ") + bddmma_last_error(solver_.handle()));
+    }
+    ~bdd_hip_lbfgs_mma() { bddmma_lbfgs_destroy(l_); }
+    bdd_hip_lbfgs_mma(const bdd_hip_lbfgs_mma&) = delete;
+    void iteration()
+    {
+        if (bddmma_lbfgs_iteration(l_) != BDDMMA_OK)
+            throw std::runtime_error(std::string("bdd_hip_lbfgs_mma: ") + bddmma_last_error(solver_.handle()));
+    }
+    double lower_bound() { return solver_.lower_bound(); }
+    bdd_hip_parallel_mma<REAL>& solver() { return solver_; }
+
+   private:
+    bdd_hip_parallel_mma<REAL> solver_;
+    bddmma_lbfgs* l_ = nullptr;
+};
+
+}  // namespace LPMP
