@@ -90,14 +90,55 @@ __device__ __forceinline__ uint32_t block_to_pack(uint32_t bid, uint32_t n_packs
     return (bid & 7u) * per + (bid >> 3);
 }
 
-// Segmented min of (a, b) over runs of lanes that belong to one layer, result broadcast to every
-// lane of the run.  `heads` = __ballot(lane is the first node of its layer).
-template <typename REAL>
-__device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, unsigned long long heads, int steps)
+// ---- per-layer min across the lanes of a layer ---------------------------------------------------
+// A layer occupies `len` consecutive lanes starting `pos` lanes below the current one (fields of the
+// node word).  Result: min over the layer, in every lane of the layer.
+__device__ __forceinline__ float dpp_from_next(float v)  // lane i <- lane i+1 (v_mov_b32_dpp wave_shl:1)
 {
-    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-    const unsigned long long above = heads & ~le;
-    const int seg_end = above ? (__ffsll((long long)above) - 1) : 64;
+    const int x = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x130, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_from_prev(float v)  // lane i <- lane i-1 (wave_shr:1)
+{
+    const int x = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double dpp_from_next(double v)
+{
+    const long long x = __builtin_bit_cast(long long, v);
+    const int lo = (int)x, hi = (int)(x >> 32);
+    const unsigned int l2 = (unsigned int)__builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xF, 0xF, false);
+    const unsigned int h2 = (unsigned int)__builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)h2 << 32) | l2);
+}
+__device__ __forceinline__ double dpp_from_prev(double v)
+{
+    const long long x = __builtin_bit_cast(long long, v);
+    const int lo = (int)x, hi = (int)(x >> 32);
+    const unsigned int l2 = (unsigned int)__builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xF, 0xF, false);
+    const unsigned int h2 = (unsigned int)__builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)h2 << 32) | l2);
+}
+
+template <typename REAL>
+__device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, uint32_t pos, uint32_t len, int steps)
+{
+    if (steps <= 1) {
+        // layers of 1 or 2 nodes (simplex / covering / cardinality-1 rows): two DPP moves per value,
+        // no LDS crossbar traffic.  A 2-node layer never straddles the 64-lane group.
+        const REAL a2 = dpp_from_next(a), b2 = dpp_from_next(b);
+        if (pos == 0 && len == 2) {
+            a = rmin(a, a2);
+            b = rmin(b, b2);
+        }
+        const REAL a1 = dpp_from_prev(a), b1 = dpp_from_prev(b);
+        if (pos == 1) {
+            a = a1;
+            b = b1;
+        }
+        return;
+    }
+    const int seg_end = lane - (int)pos + (int)len;
     for (int s = 0; s < steps; ++s) {
         const int off = 1 << s;
         const REAL a2 = __shfl_down(a, off);
@@ -107,9 +148,8 @@ __device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, unsigned lo
             b = rmin(b, b2);
         }
     }
-    const int seg_start = 63 - __clzll((long long)(heads & le));
-    a = __shfl(a, seg_start);
-    b = __shfl(b, seg_start);
+    a = __shfl(a, lane - (int)pos);
+    b = __shfl(b, lane - (int)pos);
 }
 
 // ---- buffer-descriptor memory ops ---------------------------------------------------------------
@@ -249,17 +289,26 @@ struct HopWindow {
 template <typename REAL, int R>
 struct HopLayer {
     typename Pair<REAL>::type c[R];  // {lo, hi}
-    uint32_t lg[R];
+    uint32_t lg[R];                  // global layer index of the lane's node
 };
+
+__device__ __forceinline__ uint32_t nw_pos(uint32_t w) { return (w >> NW_POS_SHIFT) & NW_FIELD6; }
+__device__ __forceinline__ uint32_t nw_len(uint32_t w) { return ((w >> NW_LEN_SHIFT) & NW_FIELD6) + 1; }
+__device__ __forceinline__ bool nw_head(uint32_t w) { return (w & (NW_PAD | (NW_FIELD6 << NW_POS_SHIFT))) == 0; }
 
 template <typename REAL, int R>
 __device__ __forceinline__ void load_layer(HopLayer<REAL, R>& L, const uint32_t (&w)[R], uint32_t lbase, const NarrowRs<REAL>& rs)
 {
     using P2 = typename Pair<REAL>::type;
+    uint32_t base = lbase;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const bool act = !(w[r] & NW_PAD);
-        L.lg[r] = lbase + ((w[r] >> (2 * NW_CHILD_BITS)) & 1023u);
+        // layer index = number of layer heads in the lanes below (minus one for non-head lanes)
+        const unsigned long long heads = __ballot(nw_head(w[r]));
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(heads >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)heads, 0u));
+        L.lg[r] = base + below - (nw_pos(w[r]) != 0 ? 1u : 0u);
+        base += (uint32_t)__popcll(heads);
         bload(L.c[r], rs.lohi, act ? L.lg[r] * (uint32_t)sizeof(P2) : OOB);
     }
 }
@@ -267,11 +316,12 @@ __device__ __forceinline__ void load_layer(HopLayer<REAL, R>& L, const uint32_t 
 template <int R>
 __device__ __forceinline__ void load_words(uint32_t (&w)[R], rsrc_t words, uint32_t nb, uint32_t n, int lane)
 {
+    constexpr uint32_t PADW = nw_pad_word(64 * R);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t j = lane + 64 * r;
         const uint32_t x = bload_u32(words, j < n ? (nb + j) * 4u : OOB);
-        w[r] = (j < n) ? x : NW_PAD_WORD;
+        w[r] = (j < n) ? x : PADW;
     }
 }
 
@@ -293,9 +343,11 @@ __global__ void __launch_bounds__(64) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, 
     using P2 = typename Pair<REAL>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     P2* sD = reinterpret_cast<P2*>(dyn_lds);  // staged {delta_lo, delta_hi} of the current stage group; .x is overwritten by mm
-    __shared__ REAL sF[2][W];
-    __shared__ REAL sT[W];
-    __shared__ unsigned char sAct[2][MODE == FWD_SOLUTION ? W : 1];
+    // +2: constant sink entries at index TOP = W (cost-from-terminal 0) and BOT = W + 1 (+inf);
+    // for sF they are dummy push targets, so sink children need no branch
+    __shared__ REAL sF[2][W + 2];
+    __shared__ REAL sT[W + 2];
+    __shared__ unsigned char sAct[2][MODE == FWD_SOLUTION ? W + 2 : 1];
     const int lane = threadIdx.x;
     const uint32_t p = block_to_pack(blockIdx.x, pk.n_packs);
     if (p >= pk.n_packs) return;
@@ -316,6 +368,7 @@ __global__ void __launch_bounds__(64) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, 
         sF[0][j] = (j < ne - nb) ? REAL(0) : INF;  // every slot of hop 0 is a root (flush_costs_from_root)
         if (MODE == FWD_SOLUTION) sAct[0][j] = (j < ne - nb) ? 1 : 0;
     }
+    if (lane < 2) sT[W + lane] = lane == 0 ? REAL(0) : INF;
     // pipeline prologue
     uint32_t wa[R], wb[R];
     REAL ta[R];
@@ -341,7 +394,7 @@ __global__ void __launch_bounds__(64) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, 
         }
         for (; q < qe; ++q) {
             if (q + 3 >= hw.base + HOP_WIN && hw.base + HOP_WIN <= q1) hw.fill(pk, q, lane);
-            const uint32_t n = ne - nb;
+            (void)0;
             const uint32_t ne2 = off(q + 2);
             const uint32_t n2 = ne2 - ne;
             // ---- prefetch: layer data of hop q+1 (its words were requested one hop ago), words of hop q+2, T of hop q+2
@@ -376,18 +429,17 @@ __global__ void __launch_bounds__(64) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, 
                 REAL nlo = lc, nhi = hc;
                 const uint32_t sl = La.lg[r] - gl0;  // staging index: position of the layer inside its group
                 if (MODE == FWD_SOLVE || MODE == FWD_SOLUTION) {
-                    const REAL tl = lo_i == NW_BOT ? INF : (lo_i == NW_TOP ? REAL(0) : sT[lo_i]);
-                    const REAL th = hi_i == NW_BOT ? INF : (hi_i == NW_TOP ? REAL(0) : sT[hi_i]);
+                    const REAL tl = sT[lo_i];  // sinks: sT[W] = 0, sT[W+1] = +inf
+                    const REAL th = sT[hi_i];
                     if (MODE == FWD_SOLVE) {
                         const P2 dd = sD[act ? sl : 0];
                         REAL m0 = act ? (f[r] + lc) + tl : INF;
                         REAL m1 = act ? (f[r] + hc) + th : INF;
-                        const unsigned long long heads = __ballot((w & NW_HEAD) != 0);
-                        seg_min2(m0, m1, lane, heads, steps);
+                        seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps);
                         const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
                         nlo = (lc + rmin(mm, REAL(0))) + dd.x;
                         nhi = (hc + rmin(-mm, REAL(0))) + dd.y;
-                        const bool head = act && (w & NW_HEAD);
+                        const bool head = nw_head(w);
                         P2 nc;
                         nc.x = nlo;
                         nc.y = nhi;
@@ -400,15 +452,13 @@ __global__ void __launch_bounds__(64) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, 
                             const REAL lo_path = f[r] + (tl + lc);
                             const bool take_lo = (hi_path - lo_path) > 0;
                             d.sol_out[La.lg[r]] = take_lo ? 0 : 1;
-                            const uint32_t c = take_lo ? lo_i : hi_i;
-                            if (c < NW_TOP) sAct[cur ^ 1][c] = 1;
+                            sAct[cur ^ 1][take_lo ? lo_i : hi_i] = 1;  // sink entries are dummies
                         }
                     }
                 }
-                if (act) {
-                    if (lo_i < NW_TOP) lds_min(&sF[cur ^ 1][lo_i], f[r] + nlo);
-                    if (hi_i < NW_TOP) lds_min(&sF[cur ^ 1][hi_i], f[r] + nhi);
-                }
+                // pushes into the sink entries (and from padding lanes, whose children are BOT) land in dummies
+                lds_min(&sF[cur ^ 1][lo_i], f[r] + nlo);
+                lds_min(&sF[cur ^ 1][hi_i], f[r] + nhi);
                 bstore(f[r], rs.F, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
             }
             __syncthreads();
@@ -436,7 +486,7 @@ __global__ void __launch_bounds__(64) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, 
     using P2 = typename Pair<REAL>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     P2* sD = reinterpret_cast<P2*>(dyn_lds);
-    __shared__ REAL sT[2][W];
+    __shared__ REAL sT[2][W + 2];  // +2: sink entries TOP = W (0) and BOT = W + 1 (+inf)
     const int lane = threadIdx.x;
     const uint32_t p = block_to_pack(blockIdx.x, pk.n_packs);
     if (p >= pk.n_packs) return;
@@ -445,6 +495,7 @@ __global__ void __launch_bounds__(64) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, 
     const REAL INF = inf_v<REAL>();
     const NarrowRs<REAL> rs(d);
     __shared__ uint32_t sOffN[HOP_WIN], sOffL[HOP_WIN];
+    if (lane < 4) sT[lane >> 1][W + (lane & 1)] = (lane & 1) ? INF : REAL(0);
     HopWindow hw{sOffN, sOffL, q0, q1};
     hw.fill(pk, q1 + 1 > q0 + HOP_WIN ? q1 + 1 - HOP_WIN : q0, lane);  // window ends at record q1
     // node range of hop q; hops below q0 (pipeline run-off) are empty
@@ -502,20 +553,19 @@ __global__ void __launch_bounds__(64) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, 
                 const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
                 const REAL lc = La.c[r].x, hc = La.c[r].y;
                 const uint32_t sl = La.lg[r] - gl0;
-                const REAL tl = lo_i == NW_BOT ? INF : (lo_i == NW_TOP ? REAL(0) : sT[cur][lo_i]);
-                const REAL th = hi_i == NW_BOT ? INF : (hi_i == NW_TOP ? REAL(0) : sT[cur][hi_i]);
+                const REAL tl = sT[cur][lo_i];  // sinks: [W] = 0, [W+1] = +inf
+                const REAL th = sT[cur][hi_i];
                 REAL t;
                 if (MODE == BWD_SOLVE) {
                     const P2 dd = sD[act ? sl : 0];
                     REAL m0 = act ? (fa[r] + lc) + tl : INF;
                     REAL m1 = act ? (fa[r] + hc) + th : INF;
-                    const unsigned long long heads = __ballot((w & NW_HEAD) != 0);
-                    seg_min2(m0, m1, lane, heads, steps);
+                    seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps);
                     const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
                     const REAL nlo = (lc + rmin(mm, REAL(0))) + dd.x;
                     const REAL nhi = (hc + rmin(-mm, REAL(0))) + dd.y;
                     t = rmin(nhi + th, nlo + tl);
-                    const bool head = act && (w & NW_HEAD);
+                    const bool head = nw_head(w);
                     P2 nc;
                     nc.x = nlo;
                     nc.y = nhi;
@@ -527,9 +577,8 @@ __global__ void __launch_bounds__(64) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, 
                     if (MODE == BWD_MARGINALS) {
                         REAL lp = act ? fa[r] + cl : INF;  // backward_step_with_path_costs, :633-641
                         REAL hp = act ? fa[r] + ch : INF;
-                        const unsigned long long heads = __ballot((w & NW_HEAD) != 0);
-                        seg_min2(lp, hp, lane, heads, steps);
-                        if (act && (w & NW_HEAD)) {
+                        seg_min2(lp, hp, lane, nw_pos(w), nw_len(w), steps);
+                        if (nw_head(w)) {
                             d.mm0_out[La.lg[r]] = lp;
                             d.mm1_out[La.lg[r]] = hp;
                         }

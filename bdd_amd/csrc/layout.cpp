@@ -248,7 +248,7 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
     }
     L.n_slots = total_slots;
     L.narrow_slots = (uint32_t)narrow_slots;
-    L.narrow_words.assign(narrow_slots, NW_PAD_WORD);
+    L.narrow_words.assign(narrow_slots, nw_pad_word(W));
     L.wide_words.assign(total_slots - narrow_slots, 0);
     L.layer_var.assign(Lin, 0);
     L.layer_bdd.assign(Lin, 0);
@@ -300,8 +300,8 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
                         uint64_t ch[2];
                         for (int side = 0; side < 2; ++side) {
                             const uint64_t c = side ? instr[i].hi : instr[i].lo;
-                            if (is_bot(instr[c])) ch[side] = wide ? WW_BOT : NW_BOT;
-                            else if (is_top(instr[c])) ch[side] = wide ? WW_TOP : NW_TOP;
+                            if (is_bot(instr[c])) ch[side] = wide ? WW_BOT : nw_bot(W);
+                            else if (is_top(instr[c])) ch[side] = wide ? WW_TOP : nw_top(W);
                             else ch[side] = npos + (c - nf);
                         }
                         if (wide) {
@@ -309,7 +309,7 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
                                 ch[0] | (ch[1] << WW_CHILD_BITS) | ((uint64_t)lloc << (2 * WW_CHILD_BITS)) | (i == f ? WW_HEAD : 0);
                         } else {
                             L.narrow_words[slot] = (uint32_t)ch[0] | ((uint32_t)ch[1] << NW_CHILD_BITS) |
-                                                   (lloc << (2 * NW_CHILD_BITS)) | (i == f ? NW_HEAD : 0);
+                                                   ((uint32_t)(i - f) << NW_POS_SHIFT) | ((uint32_t)(e - f - 1) << NW_LEN_SHIFT);
                         }
                     }
                 }

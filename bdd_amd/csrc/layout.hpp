@@ -21,18 +21,25 @@
 namespace bddmma {
 
 // ---- narrow node word (uint32) -------------------------------------------------------------
-//  bits  0..9   lo child: local index inside the NEXT hop of the same pack, or NW_BOT / NW_TOP
-//  bits 10..19  hi child
-//  bits 20..29  layer index local to (pack, hop)
-//  bit  30      head: first node of its layer
+//  bits  0..8   lo child: local index inside the NEXT hop of the same pack, or the pack's TOP / BOT code
+//  bits  9..17  hi child
+//  bits 18..23  position of the node inside its layer (0 = head)
+//  bits 24..29  layer width - 1
 //  bit  31      padding slot (no node)
-constexpr uint32_t NW_CHILD_BITS = 10;
+// The sink codes are TOP = pack_width and BOT = pack_width + 1: the kernels keep two constant entries
+// behind the LDS frontier arrays (cost-from-terminal 0 / +inf, dummy push targets), so sink children need
+// no branch.  The layer index local to (pack, hop) is not stored: it is the number of layer heads in the
+// lanes below (v_mbcnt of the head ballot) — segment bounds come from pos / width without mask arithmetic.
+constexpr uint32_t NW_CHILD_BITS = 9;
 constexpr uint32_t NW_CHILD_MASK = (1u << NW_CHILD_BITS) - 1;
-constexpr uint32_t NW_BOT = NW_CHILD_MASK;      // 1023
-constexpr uint32_t NW_TOP = NW_CHILD_MASK - 1;  // 1022
-constexpr uint32_t NW_HEAD = 1u << 30;
+constexpr uint32_t NW_POS_SHIFT = 18, NW_LEN_SHIFT = 24, NW_FIELD6 = 63;
 constexpr uint32_t NW_PAD = 1u << 31;
-constexpr uint32_t NW_PAD_WORD = NW_PAD | NW_HEAD | (NW_BOT << NW_CHILD_BITS) | NW_BOT;
+constexpr uint32_t nw_top(uint32_t pack_width) { return pack_width; }
+constexpr uint32_t nw_bot(uint32_t pack_width) { return pack_width + 1; }
+constexpr uint32_t nw_pad_word(uint32_t pack_width)
+{
+    return NW_PAD | (nw_bot(pack_width) << NW_CHILD_BITS) | nw_bot(pack_width);
+}
 constexpr uint32_t NARROW_MAX_LAYER_WIDTH = 64;  // a layer never straddles a 64-lane group
 constexpr uint32_t NARROW_MAX_PACK_WIDTH = 256;  // 64 * R, R <= 4
 

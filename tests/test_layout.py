@@ -27,6 +27,7 @@ class Layout:
                                     col.nr_bdds(), C.byref(opts))
         capi.check(rc, None)
         self.L, self.h = L, h
+        self.pack_width = pack_width or 128
         sz = lambda w: int(L.bddmma_layout_size(h, w))
         self.n_slots, self.narrow_slots, self.n_layers = sz(0), sz(1), sz(2)
         self.np_n, self.np_w, self.n_hops, self.n_vars = sz(3), sz(4), sz(5), sz(6)
@@ -66,12 +67,15 @@ class Layout:
     def decode(self):
         """-> dict slot -> (lo_slot|'T'|'B', hi_slot|..., layer_global, head)"""
         out = {}
+        widths = {}
+        self.widths = widths
         for wide, S in enumerate(self.sets):
             for p in range(S["P"]):
                 q0, q1 = int(S["pack_hop_ptr"][p]), int(S["pack_hop_ptr"][p + 1])
                 for q in range(q0, q1):
                     nb, ne = int(S["hop_node_off"][q]), int(S["hop_node_off"][q + 1])
                     lb = int(S["hop_layer_off"][q])
+                    lcount = 0
                     for j in range(ne - nb):
                         slot = nb + j
                         if wide:
@@ -80,8 +84,16 @@ class Layout:
                             head, pad, BOTC, TOPC = bool(w >> 63), False, 0x1FFFFF, 0x1FFFFE
                         else:
                             w = int(self.nwords[slot])
-                            lo, hi, l = w & 1023, (w >> 10) & 1023, (w >> 20) & 1023
-                            head, pad, BOTC, TOPC = bool((w >> 30) & 1), bool(w >> 31), 1023, 1022
+                            lo, hi, pos, ln = w & 511, (w >> 9) & 511, (w >> 18) & 63, ((w >> 24) & 63) + 1
+                            pad, TOPC, BOTC = bool(w >> 31), self.pack_width, self.pack_width + 1
+                            head = pos == 0
+                            if not pad:
+                                if head:
+                                    lcount += 1
+                                l = lcount - 1
+                                widths[(q, l)] = ln
+                            else:
+                                l = 0
                         if pad:
                             continue
                         assert q + 1 < q1 or (lo >= TOPC and hi >= TOPC), "last hop must only reach terminals"
@@ -154,6 +166,11 @@ def check_roundtrip(col, **kw):
     for lg, lst in by_layer.items():
         slots = sorted(s for s, _ in lst)
         assert slots == list(range(slots[0], slots[0] + len(slots)))
+        wide, p_, h_, j_ = lst[0][1]
+        if not wide:  # the width field of every node of a narrow layer is the layer's width
+            S = lay.sets[0]
+            q = int(S["pack_hop_ptr"][p_]) + h_
+            assert lay.widths[(q, lg - int(S["hop_layer_off"][q]))] == len(slots)
         if not lst[0][1][0]:
             js = [w[3] for _, w in lst]
             assert min(js) // 64 == max(js) // 64
