@@ -84,6 +84,7 @@ SIGNATURES = {
     "bddmma_lbfgs_iteration": (_I, [_V]),
     "bddmma_lbfgs_update_costs": (_I, [_V, _V, _U64, _V, _U64, _I, _I]),
     "bddmma_run_solver": (_I, [_V, _V, _U64, _D, _D, _D, _I, C.POINTER(RunResult)]),
+    "bddmma_incremental_mm_agreement_rounding": (_I, [_V, _V, _D, _D, _U64, _U64, C.c_uint32, _I, _V, C.POINTER(_I)]),
     "bddmma_save": (_I, [_V, C.c_char_p]),
     "bddmma_load": (_I, [C.POINTER(_V), _I, C.c_char_p]),
     "bddmma_synchronize": (_I, [_V]),

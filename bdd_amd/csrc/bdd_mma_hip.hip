@@ -53,6 +53,7 @@ struct SolverT final : SolverBase {
     uint32_t *d_pack_group_ptr = nullptr, *d_grp_layer_off = nullptr, *d_grp_hop_end = nullptr;
     uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0, stage_lds = 0, exch_lds = 0, n_narrow_layers = 0;
     double *d_lb_partial = nullptr, *d_lb = nullptr;
+    uint32_t* d_counts = nullptr;
     REAL *d_tmp0 = nullptr, *d_tmp1 = nullptr;        // per-layer scratch (min-marginals, sorted outputs)
     char* d_sol = nullptr;
     struct PackBufs {
@@ -164,6 +165,7 @@ struct SolverT final : SolverBase {
         if ((rc = dalloc(&d_delta_c, 2 * n_vars))) return rc;
         if ((rc = dalloc(&d_lb_partial, nb_.n_packs + wb_.n_packs))) return rc;
         if ((rc = dalloc(&d_lb, 1))) return rc;
+        if ((rc = dalloc(&d_counts, 4))) return rc;
         HIPCHK(hipMemsetAsync(d_F, 0, n_slots * sizeof(REAL), stream));
         HIPCHK(hipMemsetAsync(d_T, 0, n_slots * sizeof(REAL), stream));
         HIPCHK(hipMemsetAsync(d_lohi, 0, 2 * n_layers * sizeof(REAL), stream));
@@ -607,6 +609,28 @@ struct SolverT final : SolverBase {
         return BDDMMA_OK;
     }
     void* stream_handle() override { return (void*)stream; }
+    int rounding_round(double delta, uint32_t round, uint32_t seed, uint32_t counts[4], char* sol_host) override
+    {
+        HIPCHK(hipSetDevice(device));
+        int rc;
+        if ((rc = distribute_delta())) return rc;                 // :265
+        if ((rc = forward_run())) return rc;                      // min_marginals_cuda(), :266
+        if ((rc = launch_bwd<BWD_MARGINALS>(nullptr, REAL(0), BDDMMA_K_OTHER))) return rc;
+        bwd_valid = true;
+        HIPCHK(hipMemsetAsync(d_counts, 0, 4 * sizeof(uint32_t), stream));
+        REAL* c0 = d_delta_c;               // 2V scratch: [0,V) cost_delta_0, [V,2V) cost_delta_1
+        REAL* c1 = d_delta_c + n_vars;
+        hipLaunchKernelGGL((k_round_perturb<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_tmp0, d_tmp1, d_var_ptr, d_var_layers,
+                           c0, c1, d_sol, d_counts, (uint32_t)n_vars, delta, round, seed);
+        HIPCHK(hipMemcpyAsync(counts, d_counts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if ((uint64_t)counts[0] + counts[1] == n_vars) {          // all min-marginals agree: read off the solution, :295-305
+            HIPCHK(hipMemcpyAsync(sol_host, d_sol, n_vars, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            return BDDMMA_OK;
+        }
+        return update_costs(c0, n_vars, c1, n_vars, precision, 1);  // :327
+    }
     int time_kernel(int kind, uint64_t reps, double* ms) override
     {
         HIPCHK(hipSetDevice(device));

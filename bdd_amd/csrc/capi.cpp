@@ -259,6 +259,43 @@ int bddmma_run_solver(bddmma_solver* s, bddmma_lbfgs* lbfgs, uint64_t max_iter, 
     });
 }
 
+// incremental_mm_agreement_rounding_cuda (incremental_mm_agreement_rounding_cuda.cu:333-372)
+int bddmma_incremental_mm_agreement_rounding(bddmma_solver* s, bddmma_lbfgs* lbfgs, double init_delta, double delta_growth_rate,
+                                             uint64_t num_itr_lb, uint64_t num_rounds, uint32_t seed, int verbose, char* sol, int* found)
+{
+    if (!sol || !found) return BDDMMA_ERR_INVALID_ARGUMENT;
+    *found = 0;
+    return guarded(s, [&](SolverBase* b) {
+        if (!(delta_growth_rate > 0) || !(init_delta > 0)) {
+            b->err = "rounding: init_delta and delta_growth_rate must be positive";  // asserts at :336-337
+            return BDDMMA_ERR_INVALID_ARGUMENT;
+        }
+        int rc = b->distribute_delta();
+        if (rc) return rc;
+        double lb;
+        if ((rc = b->lower_bound(&lb))) return rc;
+        if (verbose) std::printf("[incremental primal rounding] lower bound after distributing delta: %.10g\n", lb);
+        double cur_delta = init_delta / delta_growth_rate;
+        for (uint64_t round = 0; round < num_rounds; ++round) {
+            cur_delta = std::min(cur_delta * delta_growth_rate, 1e6);
+            uint32_t counts[4];
+            if ((rc = b->rounding_round(cur_delta, (uint32_t)round, seed, counts, sol))) return rc;
+            if (verbose)
+                std::printf("[incremental primal rounding] round %llu, cost delta %g: #ones %u, #zeros %u, #equal %u, #inconsistent %u\n",
+                            (unsigned long long)round, cur_delta, counts[0], counts[1], counts[2], counts[3]);
+            if ((uint64_t)counts[0] + counts[1] == b->n_vars) {
+                *found = 1;
+                return BDDMMA_OK;
+            }
+            bddmma_run_result rr;
+            rc = bddmma_run_solver(s, lbfgs, num_itr_lb, 1e-7, 0.0001, std::numeric_limits<double>::max(), 0, &rr);  // :366
+            if (rc) return rc;
+            if (verbose) std::printf("[incremental primal rounding] lower bound = %.10g\n", rr.lb_final);
+        }
+        return BDDMMA_OK;
+    });
+}
+
 // ---- checkpoint: the layout is a pure function of (collection, options), so the file holds the
 // collection + options + the mutable state (costs, deferred mm, deferred delta).  Mirrors what the
 // reference archives (bdd_cuda_base.cu:1486-1550; cost_from_root/terminal are not saved there either).

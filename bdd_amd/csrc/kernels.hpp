@@ -1096,6 +1096,62 @@ __global__ void k_primal_objective(const REAL* __restrict__ lo, const REAL* __re
     out[v] = s;
 }
 
+// ---- primal rounding by cost perturbation (incremental_mm_agreement_rounding_cuda.cu) -----------------
+// One thread per variable over its (variable,bdd)-sorted layers: sign agreement of the min-marginal
+// differences (mm_diff_direction_func :29-41, fill_mm_type_func :43-65), their sums (compute_mm_sums
+// :110-134) and the cost perturbation of mm_types_transform (:136-205, only_perturb_inconsistent = false).
+// counts[0..3] = #one, #zero, #equal, #inconsistent.  The reference draws its random numbers from
+// thrust::default_random_engine discarded by thread id (:177-181); here a counter-based hash of
+// (variable, round, seed) — statistically equivalent, not bit-identical.
+__device__ __forceinline__ float hash_uniform(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x165667B1u) * 0xC2B2AE3Du;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (float)(x >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+
+template <typename REAL>
+__global__ void k_round_perturb(const REAL* __restrict__ mm0, const REAL* __restrict__ mm1, const uint32_t* __restrict__ var_ptr,
+                                const uint32_t* __restrict__ var_layers, REAL* __restrict__ cost_delta_0, REAL* __restrict__ cost_delta_1,
+                                char* __restrict__ sol, uint32_t* __restrict__ counts, uint32_t n_vars, double delta, uint32_t round,
+                                uint32_t seed)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vars) return;
+    int dmin = 2, dmax = -2;
+    REAL s0 = 0, s1 = 0;
+    for (uint32_t k = var_ptr[v]; k < var_ptr[v + 1]; ++k) {
+        const REAL a = mm0[var_layers[k]], b = mm1[var_layers[k]];
+        const int dir = (a + REAL(1e-6) <= b) ? -1 : ((b + REAL(1e-6) <= a) ? 1 : 0);
+        dmin = min(dmin, dir);
+        dmax = max(dmax, dir);
+        s0 += a;
+        s1 += b;
+    }
+    int type;  // 0 one, 1 zero, 2 equal, 3 inconsistent
+    if (dmin == 2) type = 1;            // variable in no BDD: any value is consistent, take 0
+    else if (dmin > 0) type = 0;
+    else if (dmax < 0) type = 1;
+    else if (dmin == 0 && dmax == 0) type = 2;
+    else type = 3;
+    atomicAdd(&counts[type], 1u);
+    sol[v] = type == 0 ? 1 : 0;
+    REAL c0 = 0, c1 = 0;
+    if (type == 0) c0 = REAL(delta);
+    else if (type == 1) c1 = REAL(delta);
+    else {
+        const float r = (2.0f * hash_uniform(v, round, seed) - 1.0f) * (float)delta;  // U(-delta, delta)
+        const REAL mag = REAL(fabsf(r) * delta);
+        if (type == 2) {
+            if (r < 0.0f) c0 = mag; else c1 = mag;
+        } else {
+            if (s0 < s1) c1 = mag; else c0 = mag;
+        }
+    }
+    cost_delta_0[v] = c0;
+    cost_delta_1[v] = c1;
+}
+
 template <typename T>
 __global__ void k_gather(const T* __restrict__ in, const uint32_t* __restrict__ idx, T* __restrict__ out, uint32_t n)
 {

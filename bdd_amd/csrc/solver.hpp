@@ -61,6 +61,8 @@ struct SolverBase {
     virtual int gradient_step(const void* g, double step, int on_device) = 0;
     virtual void* stream_handle() = 0;
     virtual int time_kernel(int kind, uint64_t reps, double* ms) = 0;
+    // one round of perturb_primal_costs (incremental_mm_agreement_rounding_cuda.cu:262-331); counts = #one,#zero,#equal,#inconsistent
+    virtual int rounding_round(double delta, uint32_t round, uint32_t seed, uint32_t counts[4], char* sol_host) = 0;
 
     int synchronize();
     void prof_begin(int kclass);

@@ -190,6 +190,15 @@ typedef struct bddmma_run_result {
 int bddmma_run_solver(bddmma_solver* s, bddmma_lbfgs* lbfgs_or_null, uint64_t max_iter, double tolerance,
                       double improvement_slope, double time_limit, int verbose, bddmma_run_result* res);
 
+/* ---- primal rounding (src/bdd_solver/incremental_mm_agreement_rounding_cuda.cu:333-372) ------------------
+ * incremental_mm_agreement_rounding_cuda(s, init_delta, delta_growth_rate, num_itr_lb, verbose, num_rounds):
+ * perturbs the costs towards the sign of the min-marginal differences until they agree in every BDD.
+ * sol: char[nr_variables]; *found = 1 if a solution was reconstructed.  The solver's costs stay perturbed
+ * afterwards, as in the reference (bdd_solver.cpp:368 "TODO: reset solver state"). */
+int bddmma_incremental_mm_agreement_rounding(bddmma_solver* s, bddmma_lbfgs* lbfgs_or_null, double init_delta,
+                                             double delta_growth_rate, uint64_t num_itr_lb, uint64_t num_rounds,
+                                             uint32_t seed, int verbose, char* sol, int* found);
+
 /* ---- checkpoint (bdd_cuda_base.cu:1486-1550) ------------------------------ */
 int bddmma_save(const bddmma_solver* s, const char* path);
 int bddmma_load(bddmma_solver** out, int device, const char* path);

@@ -1,0 +1,79 @@
+"""Full `bdd_solver` JSON path on the GPU, against the known answers of the reference's own end-to-end tests."""
+import json
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from bdd_amd.bdd_solver import bdd_solver
+from bdd_amd.instances import GRID_3X3, LONG_CHAIN, assignment_ilp, brute_force_optimum, mrf_ilp
+
+pytestmark = pytest.mark.gpu
+
+TC = {"maximum iterations": 200, "improvement slope": 0.0, "minimum improvement": 0.0, "time limit": 1e10}
+
+
+def cfg(lp, **kw):
+    c = {"precision": "double", "relaxation solver": "cuda parallel mma", "termination criteria": dict(TC), "input": lp}
+    c.update(kw)
+    return c
+
+
+def test_bipartite_matching_kats():
+    # test/test_bdd_bipartite_matching_problem.cpp:8-59 (there with "sequential mma", 20 iterations, 1e-6)
+    s = bdd_solver(cfg(assignment_ilp(3).write_lp()), quiet=True).solve()
+    assert abs(s.lower_bound() - (-6.0)) <= 1e-6
+    c = -np.ones((3, 3)); c[:, 0] = -2
+    s = bdd_solver(cfg(assignment_ilp(3, c).write_lp()), quiet=True).solve()
+    assert abs(s.lower_bound() - (-4.0)) <= 1e-6
+    s = bdd_solver(cfg(assignment_ilp(8).write_lp(), precision="float"), quiet=True).solve()
+    assert abs(s.lower_bound() - (-16.0)) <= 1e-4
+
+
+def test_loose_covering_kat():
+    # test/test_loose_covering_problem.cpp:8-88: LB 1.5; the tightened instance has a larger bound
+    base = "Minimize\nx1 + x2 + x3 + x4 + x5 + x6\nSubject To\nx1 + x2 + x4 >= 1\nx1 + x3 + x5 >= 1\nx2 + x3 + x6 >= 1\n"
+    tail = "Bounds\nBinaries\nx1\nx2\nx3\nx4\nx5\nx6\nEnd\n"
+    s = bdd_solver(cfg(base + tail), quiet=True).solve()
+    assert abs(s.lower_bound() - 1.5) <= 1e-4
+    t = bdd_solver(cfg(base + "x1 + x2 + x3 + x4 + x5 + x6 >= 2\n" + tail), quiet=True).solve()
+    assert t.lower_bound() > 1.5 + 1e-4
+
+
+@pytest.mark.parametrize("solver", ["cuda parallel mma", "lbfgs cuda mma", "cuda lbfgs parallel mma"])
+def test_mrf_end_to_end_with_rounding(solver):
+    ilp = mrf_ilp(**LONG_CHAIN)
+    c = cfg(ilp.write_lp(), **{"relaxation solver": solver,
+                               "perturbation rounding": {"initial perturbation": 0.1, "perturbation growth rate": 1.2,
+                                                         "inner iterations": 50, "outer iterations": 60}})
+    s = bdd_solver(c, quiet=True).solve()
+    assert s.result["lb_final"] >= s.result["lb_initial"] - 1e-9
+    assert abs(s.result["lb_final"] - (-9.0)) < 1e-6          # test_bdd_cuda_parallel_mma.cu:230 (long_mrf_chain)
+    assert s.solution is not None and ilp.feasible(s.solution)
+    assert abs(ilp.evaluate(s.solution) - (-9.0)) < 1e-9       # tree MRF: relaxation tight, rounding recovers the optimum
+
+
+def test_rounding_on_grid_is_feasible_and_bounded():
+    ilp = mrf_ilp(**GRID_3X3)
+    c = cfg(ilp.write_lp(), **{"perturbation rounding": {"inner iterations": 50, "outer iterations": 100}})
+    s = bdd_solver(c, quiet=True).solve()
+    assert s.solution is not None and ilp.feasible(s.solution)
+    assert ilp.evaluate(s.solution) >= s.result["lb_final"] - 1e-6
+
+
+def test_min_marginals_and_normalize():
+    ilp = assignment_ilp(3)
+    s = bdd_solver(cfg(ilp.write_lp(), **{"normalize constraints": True, "print statistics": True}), quiet=True).solve()
+    mm = s.min_marginals()
+    assert len(mm) == 9 and all(m.shape == (2, 2) for m in mm)
+    names, m0, m1 = s.min_marginals_with_variable_names()
+    assert names == ilp.var_names
+
+
+def test_command_line(tmp_path):
+    p = tmp_path / "cfg.json"
+    p.write_text(json.dumps(cfg(assignment_ilp(3).write_lp())))
+    out = subprocess.run([sys.executable, "-m", "bdd_amd.bdd_solver_cl", str(p)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "lower bound = -6" in out.stdout
