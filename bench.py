@@ -122,7 +122,7 @@ def main():
                 "pack_width": args.pack_width or 128,
                 "packs": solver.nr_packs(),
                 "hops": solver.nr_hops(),
-                "delta_accumulation": "gather (deterministic)" if args.deterministic else "atomicAdd",
+                "delta_exchange": "per-variable gather (deterministic)" if args.deterministic else "binned exchange, LDS accumulators",
                 "hbm_resident_bytes": solver.device_bytes(),
             },
             "roofline": {
@@ -132,7 +132,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(names[dom], args),
                 "algorithmic_bytes_per_launch": bytes_pass,
                 "avg_launch_ms": {names[i]: avg_ms[i] for i in range(3)},
                 "whole_iteration_GBs": 2 * bytes_pass * its / world / 1e9,
@@ -147,15 +147,44 @@ def main():
         dist.destroy_process_group()
 
 
+def measured_traffic(kernel, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/<tag>/traffic.json, produced by tools_profile.sh + tools_collect_profiles.py: separate --pmc runs,
+    bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md §HBM).  None when no profile matches."""
+    if (args.vars, args.rows, args.k) != (1_000_000, 500_000, 10) or args.deterministic:
+        return None
+    tag = "r01_f32" if args.precision == "float" else "r01_f64"
+    path = os.path.join(ROOT, "profiles", tag, "traffic.json")
+    if not os.path.exists(path):
+        return None
+    want = "k_fwd_narrow" if kernel == "forward_mm" else "k_bwd_narrow"
+    for name, v in json.load(open(path)).items():
+        if want in name and name.rstrip(">").endswith(", 1"):   # <REAL, R, SOLVE>
+            return v["hbm_bytes"]
+    return None
+
+
 def cpu_baseline(col, costs, args, sizes):
     """The CPU restatement of the reference's `parallel mma` (oracle/, OpenMP over BDDs) timed on this
     box's host cores on the same instance — rank 0, bounded to ~args.cpu_seconds of work."""
     from bdd_amd.solver import bdd_hip_parallel_mma
     from oracle.oracle import Oracle
 
-    cores = os.cpu_count() or 1
-    o = Oracle(col, costs, args.precision, threads=cores)
+    # pick the thread count that is fastest on this box (the per-BDD work items are tiny and the delta
+    # accumulation uses atomics, so all 256 hardware threads of a 2-socket host are not the optimum)
+    ncpu = os.cpu_count() or 1
+    o = Oracle(col, costs, args.precision, threads=min(ncpu, 32))
     o.iteration()  # warm-up (first touch, backward_run)
+    best, cores = 0.0, min(ncpu, 32)
+    for th in sorted({min(ncpu, t) for t in (16, 32, 64, 128, 256)}):
+        o.set_threads(th)
+        t1 = time.perf_counter()
+        o.iteration()
+        rate = 1.0 / (time.perf_counter() - t1)
+        if rate > best:
+            best, cores = rate, th
+    o.set_threads(cores)
+    warm = 1 + len({min(ncpu, t) for t in (16, 32, 64, 128, 256)})
     n, t0 = 0, time.perf_counter()
     while True:
         o.iteration()
@@ -166,16 +195,17 @@ def cpu_baseline(col, costs, args, sizes):
     cpu_lb = o.lower_bound()
     g = bdd_hip_parallel_mma(col, costs, precision=args.precision, pack_width=args.pack_width,
                              vars_per_bin=args.vars_per_bin, stage_cap=args.stage_cap)
-    g.iterations(n + 1)
+    g.iterations(n + warm)
     gpu_lb = g.lower_bound()
     return {
         "value": n / el,
         "unit": "iterations/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{n} iterations of the same {sizes['N']}-node instance after 1 warm-up iteration, "
-                  f"oracle/mma_oracle.c with OpenMP over BDDs ({cores} threads), {args.precision}",
-        "lb_after": {"iterations": n + 1, "cpu": cpu_lb, "gpu": gpu_lb,
+        "sample": f"{n} iterations of the same {sizes['N']}-node instance after {warm} warm-up / thread-count-probe "
+                  f"iterations, oracle/mma_oracle.c with OpenMP over BDDs ({cores} of {ncpu} hardware threads: the "
+                  f"fastest of 16..256), {args.precision}",
+        "lb_after": {"iterations": n + warm, "cpu": cpu_lb, "gpu": gpu_lb,
                      "rel_diff": abs(cpu_lb - gpu_lb) / max(abs(cpu_lb), 1e-300)},
     }
 

@@ -76,6 +76,9 @@ class Oracle:
         except Exception:
             pass
 
+    def set_threads(self, n: int):
+        self._f("oracle_set_num_threads")(self.h, C.c_int(n))
+
     def _u64(self, name):
         f = self._f(name)
         f.restype = C.c_uint64

@@ -320,3 +320,41 @@ def test_full_size_properties(n_vars, n_rows):
         for _ in range(10):
             o.iteration()
         assert abs(lbs[-1] - o.lower_bound()) <= 1e-9 * abs(o.lower_bound())
+
+
+# ---------------------------------------------------------------- long BDDs: hop-window refills and several stage groups per pack
+@pytest.mark.parametrize("precision", ["double", "float"])
+@pytest.mark.parametrize("pack_width,stage_cap", [(64, 64), (128, 640), (256, 256)])
+def test_long_bdds_vs_oracle(precision, pack_width, stage_cap):
+    rng = np.random.Generator(np.random.PCG64(33))
+    V = 700
+    col = BddCollection()
+    col.add_simplex(np.sort(rng.choice(V, size=300, replace=False)))        # 300 hops
+    col.add_covering(np.sort(rng.choice(V, size=200, replace=False)))       # 200 hops
+    col.add_cardinality(np.sort(rng.choice(V, size=90, replace=False)).tolist(), 3)
+    for _ in range(150):                                                    # plus many short rows in the same packs
+        k = int(rng.integers(2, 12))
+        col.add_covering(np.sort(rng.choice(V, size=k, replace=False)))
+    for _ in range(40):
+        k = int(rng.integers(65, 140))                                      # longer than one 64-entry hop window
+        col.add_simplex(np.sort(rng.choice(V, size=k, replace=False)))
+    costs = rng.normal(0, 2, col.nr_variables()).round(3)
+    s = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=pack_width, stage_cap=stage_cap)
+    o = Oracle(col, costs, precision)
+    assert s.nr_hops() == 300
+    assert close(s.lower_bound(), o.lower_bound(), precision, 10)
+    for _ in range(12):
+        s.iteration(); o.iteration()
+        assert close(s.lower_bound(), o.lower_bound(), precision, 10)
+    perm = oracle_layer_perm(s, o)
+    _, a0, a1 = s.min_marginals_cuda(False)
+    om = o.min_marginals()
+    tol = dict(rtol=1e-9, atol=1e-9) if precision == "double" else dict(rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(a0[perm], om[:, 0], **tol)
+    np.testing.assert_allclose(a1[perm], om[:, 1], **tol)
+    sol = s.bdds_solution_vec()
+    bdd, v = s.get_bdd_index(), s.get_primal_variable_index()
+    for b in (0, 1, 2):
+        m = bdd == b
+        x = np.zeros(col.nr_variables()); x[v[m]] = sol[m]
+        assert col.evaluate(b, x)

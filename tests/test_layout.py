@@ -234,3 +234,13 @@ def test_create_without_gpu_fails_loudly():
     ilp = assignment_ilp(3)
     with pytest.raises(capi.BddMmaError, match="no CPU fallback"):
         bdd_hip_parallel_mma(to_bdd_collection(ilp), ilp.objective)
+
+
+def test_roundtrip_long_bdds_many_groups():
+    rng = np.random.Generator(np.random.PCG64(4))
+    col = BddCollection()
+    col.add_simplex(np.sort(rng.choice(500, size=300, replace=False)))
+    for _ in range(60):
+        col.add_covering(np.sort(rng.choice(500, size=int(rng.integers(2, 90)), replace=False)))
+    lay = check_roundtrip(col, pack_width=64, stage_cap=64, vars_per_bin=64)
+    assert lay.n_groups > 10 * lay.np_n and lay.n_hops == 300
