@@ -51,6 +51,9 @@ struct SolverT final : SolverBase {
     REAL *d_delta_c = nullptr, *d_delta_lay_c = nullptr;  // scratch for the explicit forward_mm/backward_mm API
     uint32_t *d_evar = nullptr, *d_lpos = nullptr, *d_vpos = nullptr, *d_bin_ptr = nullptr;
     uint32_t *d_pack_group_ptr = nullptr, *d_grp_layer_off = nullptr, *d_grp_hop_end = nullptr;
+    uint32_t *d_quad_round_ptr = nullptr, *d_cs_ptr = nullptr, *d_cs_entry = nullptr;
+    uint16_t* d_cs_slot = nullptr;
+    uint32_t wpb = 1;
     uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0, stage_lds = 0, exch_lds = 0, n_narrow_layers = 0;
     double *d_lb_partial = nullptr, *d_lb = nullptr;
     uint32_t* d_counts = nullptr;
@@ -146,15 +149,20 @@ struct SolverT final : SolverBase {
         if ((rc = upload(&d_pack_group_ptr, L.ex.pack_group_ptr))) return rc;
         if ((rc = upload(&d_grp_layer_off, L.ex.grp_layer_off))) return rc;
         if ((rc = upload(&d_grp_hop_end, L.ex.grp_hop_end))) return rc;
+        if ((rc = upload(&d_quad_round_ptr, L.ex.quad_round_ptr))) return rc;
+        if ((rc = upload(&d_cs_ptr, L.ex.cs_ptr))) return rc;
+        if ((rc = upload(&d_cs_entry, L.ex.cs_entry))) return rc;
+        if ((rc = upload(&d_cs_slot, L.ex.cs_slot))) return rc;
+        wpb = L.ex.waves_per_block;
         vars_per_bin = L.ex.vars_per_bin; n_bins = L.ex.n_bins; stage_cap = L.ex.stage_cap;
         n_narrow_layers = L.ex.grp_layer_off.empty() ? 0 : L.ex.grp_layer_off.back();
         if (2 * n_layers * sizeof(REAL) >= 0xFFFFFFFFull || n_slots * sizeof(REAL) >= 0xFFFFFFFFull) {
             err = "instance too large for the 32-bit buffer offsets of the sweep kernels";
             return BDDMMA_ERR_UNSUPPORTED;
         }
-        stage_lds = stage_cap * 2 * (uint32_t)sizeof(REAL);
+        stage_lds = L.ex.waves_per_block * stage_cap * 2 * (uint32_t)sizeof(REAL);
         exch_lds = vars_per_bin * 2 * (uint32_t)sizeof(double);  // accumulators are double for both precisions
-        if (exch_lds > 160 * 1024 - 1024 || stage_lds > 64 * 1024) {
+        if (exch_lds > 160 * 1024 - 1024 || stage_lds > 60 * 1024) {
             err = "vars_per_bin / stage_cap need more LDS than a CU has";
             return BDDMMA_ERR_INVALID_ARGUMENT;
         }
@@ -201,7 +209,7 @@ struct SolverT final : SolverBase {
         DevPtrs<REAL> d;
         d.nwords = d_nwords; d.wwords = d_wwords; d.wide_slot_base = wide_slot_base;
         d.F = d_F; d.T = d_T; d.lohi = d_lohi;
-        d.delta_lay = delta_lay; d.mm_binned = d_mm_binned; d.lpos = d_lpos;
+        d.delta_lay = delta_lay; d.mm_binned = d_mm_binned; d.lpos = d_lpos; d.cs_entry = d_cs_entry; d.cs_slot = d_cs_slot;
         d.n_slots = (uint32_t)n_slots; d.n_layers = (uint32_t)n_layers; d.n_narrow_layers = n_narrow_layers;
         d.lb_partial = d_lb_partial;
         d.mm0_out = d_tmp0; d.mm1_out = d_tmp1; d.sol_out = d_sol;
@@ -210,7 +218,7 @@ struct SolverT final : SolverBase {
     PackDev pdev(const PackBufs& b, uint32_t lb_base) const
     {
         return PackDev{b.pack_hop_ptr, b.hop_node_off, b.hop_layer_off, b.pack_steps,
-                       d_pack_group_ptr, d_grp_layer_off, d_grp_hop_end, b.n_packs, lb_base};
+                       d_pack_group_ptr, d_grp_layer_off, d_grp_hop_end, d_quad_round_ptr, d_cs_ptr, stage_cap, b.n_packs, lb_base};
     }
 
     template <int MODE>
@@ -221,12 +229,19 @@ struct SolverT final : SolverBase {
         prof_begin(kclass);
         if (nb_.n_packs) {
             const PackDev pk = pdev(nb_, 0);
-            const dim3 grid(8 * cdiv(nb_.n_packs, 8)), block(64);
+            // SOLVE sweeps: `wpb` packs per workgroup with cooperative staging; the other modes stage nothing
+            const uint32_t w = (MODE == FWD_SOLVE) ? wpb : 1;
+            const dim3 grid(8 * cdiv(cdiv(nb_.n_packs, w), 8)), block(64 * w);
+#define LAUNCH_N(R_, W_) hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
+#define LAUNCH_W(R_) \
+    switch (w) { case 1: LAUNCH_N(R_, 1); break; case 2: LAUNCH_N(R_, 2); break; case 4: LAUNCH_N(R_, 4); break; default: LAUNCH_N(R_, 8); break; }
             switch (pack_width) {
-                case 64: hipLaunchKernelGGL((k_fwd_narrow<REAL, 1, MODE>), grid, block, dyn, stream, d, pk, omega); break;
-                case 128: hipLaunchKernelGGL((k_fwd_narrow<REAL, 2, MODE>), grid, block, dyn, stream, d, pk, omega); break;
-                default: hipLaunchKernelGGL((k_fwd_narrow<REAL, 4, MODE>), grid, block, dyn, stream, d, pk, omega); break;
+                case 64: LAUNCH_W(1); break;
+                case 128: LAUNCH_W(2); break;
+                default: LAUNCH_W(4); break;
             }
+#undef LAUNCH_W
+#undef LAUNCH_N
         }
         if (wb_.n_packs) {
             const PackDev pk = pdev(wb_, nb_.n_packs);
@@ -244,12 +259,19 @@ struct SolverT final : SolverBase {
         prof_begin(kclass);
         if (nb_.n_packs) {
             const PackDev pk = pdev(nb_, 0);
-            const dim3 grid(8 * cdiv(nb_.n_packs, 8)), block(64);
+            // SOLVE sweeps: `wpb` packs per workgroup with cooperative staging; the other modes stage nothing
+            const uint32_t w = (MODE == BWD_SOLVE) ? wpb : 1;
+            const dim3 grid(8 * cdiv(cdiv(nb_.n_packs, w), 8)), block(64 * w);
+#define LAUNCH_N(R_, W_) hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
+#define LAUNCH_W(R_) \
+    switch (w) { case 1: LAUNCH_N(R_, 1); break; case 2: LAUNCH_N(R_, 2); break; case 4: LAUNCH_N(R_, 4); break; default: LAUNCH_N(R_, 8); break; }
             switch (pack_width) {
-                case 64: hipLaunchKernelGGL((k_bwd_narrow<REAL, 1, MODE>), grid, block, dyn, stream, d, pk, omega); break;
-                case 128: hipLaunchKernelGGL((k_bwd_narrow<REAL, 2, MODE>), grid, block, dyn, stream, d, pk, omega); break;
-                default: hipLaunchKernelGGL((k_bwd_narrow<REAL, 4, MODE>), grid, block, dyn, stream, d, pk, omega); break;
+                case 64: LAUNCH_W(1); break;
+                case 128: LAUNCH_W(2); break;
+                default: LAUNCH_W(4); break;
             }
+#undef LAUNCH_W
+#undef LAUNCH_N
         }
         if (wb_.n_packs) {
             const PackDev pk = pdev(wb_, nb_.n_packs);

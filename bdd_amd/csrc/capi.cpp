@@ -406,7 +406,7 @@ int bddmma_layout_create(bddmma_layout** out, const bddmma_instruction* instr, c
 void bddmma_layout_destroy(bddmma_layout* l) { delete l; }
 // what: 0 n_slots, 1 narrow_slots, 2 n_layers, 3 narrow packs, 4 wide packs, 5 n_hops, 6 n_vars,
 //       7 narrow (pack,hop) records, 8 wide (pack,hop) records, 9 bins, 10 vars per bin, 11 stage groups,
-//       12 narrow layers, 13 stage cap
+//       12 narrow layers, 13 stage cap, 14 waves per block, 15 (quad, round) records
 uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
 {
     const HostLayout& L = l->L;
@@ -425,6 +425,8 @@ uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
         case 11: return L.ex.grp_hop_end.size();
         case 12: return L.ex.grp_layer_off.empty() ? 0 : L.ex.grp_layer_off.back();
         case 13: return L.ex.stage_cap;
+        case 14: return L.ex.waves_per_block;
+        case 15: return L.ex.cs_ptr.empty() ? 0 : L.ex.cs_ptr.size() - 1;
         default: return 0;
     }
 }
@@ -432,6 +434,7 @@ uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
 //        5/6/7/8 narrow pack_hop_ptr/hop_node_off/hop_layer_off(u32)/pack_steps(u8)   9/10/11/12 wide ...
 //        13 var_ptr(u32) 14 var_layers(u32) 15 bdd_root_slot(u32)
 //        16 bin_ptr(u32) 17 evar(u32) 18 lpos(u32) 19 vpos(u32) 20 pack_group_ptr 21 grp_layer_off 22 grp_hop_end
+//        23 quad_round_ptr 24 cs_ptr 25 cs_entry(u32) 26 cs_slot(u16)
 int bddmma_layout_copy(const bddmma_layout* l, int which, void* out)
 {
     const HostLayout& L = l->L;
@@ -463,6 +466,10 @@ int bddmma_layout_copy(const bddmma_layout* l, int which, void* out)
         case 20: return cp(L.ex.pack_group_ptr);
         case 21: return cp(L.ex.grp_layer_off);
         case 22: return cp(L.ex.grp_hop_end);
+        case 23: return cp(L.ex.quad_round_ptr);
+        case 24: return cp(L.ex.cs_ptr);
+        case 25: return cp(L.ex.cs_entry);
+        case 26: return cp(L.ex.cs_slot);
         default: return BDDMMA_ERR_INVALID_ARGUMENT;
     }
 }

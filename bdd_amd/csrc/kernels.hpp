@@ -41,6 +41,8 @@ struct DevPtrs {
     const REAL* delta_lay;   // 2 REAL per entry: {delta_lo, delta_hi} of the entry's variable (normalised)
     REAL* mm_binned;         // 1 REAL per entry: deferred min-marginal difference of the entry's layer
     const uint32_t* lpos;    // per layer: entry index
+    const uint32_t* cs_entry;  // cooperative staging: staged item -> entry
+    const uint16_t* cs_slot;   // cooperative staging: staged item -> LDS slot
     uint32_t n_slots;        // element counts (buffer descriptors of the narrow kernels)
     uint32_t n_layers;
     uint32_t n_narrow_layers;
@@ -58,6 +60,9 @@ struct PackDev {
     const uint32_t* pack_group_ptr;  // narrow packs: stage groups
     const uint32_t* grp_layer_off;
     const uint32_t* grp_hop_end;
+    const uint32_t* quad_round_ptr;  // cooperative staging rounds of each quad of packs
+    const uint32_t* cs_ptr;          // first staged item of each (quad, round)
+    uint32_t stage_cap;
     uint32_t n_packs;
     uint32_t lb_base;  // index of this set's first pack in lb_partial
 };
@@ -193,33 +198,37 @@ __device__ __forceinline__ void bstore(double2 v, rsrc_t r, uint32_t off)
 
 template <typename REAL>
 struct NarrowRs {
-    rsrc_t words, T, F, lohi, lpos, dlay, mm;
+    rsrc_t words, T, F, lohi, cse, css, dlay, mm;
     __device__ __forceinline__ explicit NarrowRs(const DevPtrs<REAL>& d)
     {
         words = make_rsrc(d.nwords, d.wide_slot_base);
         T = make_rsrc(d.T, d.n_slots);
         F = make_rsrc(d.F, d.n_slots);
         lohi = make_rsrc(d.lohi, 2ull * d.n_layers);
-        lpos = make_rsrc(d.lpos, d.n_layers);
+        cse = make_rsrc(d.cs_entry, d.n_narrow_layers);
+        css = make_rsrc(d.cs_slot, d.n_narrow_layers);
         dlay = make_rsrc(d.delta_lay, 2ull * d.n_layers);
         mm = make_rsrc(d.mm_binned, d.n_layers);
     }
 };
 
-// Stage-group transfer between the binned exchange arrays and LDS.  Staging index = position of the layer
-// inside its group (layers of a group are contiguous), entry index = lpos[layer]; the entry indices stay
-// in registers between the load at the start of the group and the flush at its end.
+// Cooperative stage transfer between the entry arrays and LDS: the WPB waves of a workgroup sweep WPB
+// consecutive packs; in every round they load the delta pairs of their packs' stage groups together.
+// Staged items are sorted by entry index, so consecutive threads touch consecutive entries — runs of
+// (bin, quad) instead of (bin, pack) length — and scatter them to the owning wave's LDS slots.  The
+// (entry, slot) pairs stay in registers for the write-back of the min-marginal differences.
 constexpr int STAGE_ITERS = 10;  // stage_cap <= 64 * STAGE_ITERS
 
-template <typename REAL>
-__device__ __forceinline__ void stage_load(typename Pair<REAL>::type* sD, uint32_t (&e)[STAGE_ITERS], const NarrowRs<REAL>& rs,
-                                           uint32_t gl0, uint32_t cnt, int lane)
+template <typename REAL, int WPB>
+__device__ __forceinline__ void stage_load(typename Pair<REAL>::type* sD, uint32_t (&e)[STAGE_ITERS], uint32_t (&sl)[STAGE_ITERS],
+                                           const NarrowRs<REAL>& rs, uint32_t c0, uint32_t cnt, uint32_t tid)
 {
     using P2 = typename Pair<REAL>::type;
 #pragma unroll
     for (int u = 0; u < STAGE_ITERS; ++u) {
-        const uint32_t i = 64 * u + lane;
-        e[u] = bload_u32(rs.lpos, i < cnt ? (gl0 + i) * 4u : OOB);
+        const uint32_t i = 64 * WPB * u + tid;
+        e[u] = bload_u32(rs.cse, i < cnt ? (c0 + i) * 4u : OOB);
+        sl[u] = bload_u16(rs.css, i < cnt ? (c0 + i) * 2u : OOB);
     }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -227,26 +236,26 @@ __device__ __forceinline__ void stage_load(typename Pair<REAL>::type* sD, uint32
 #pragma unroll
         for (int u = 0; u < STAGE_ITERS / 2; ++u) {
             const int k = half * (STAGE_ITERS / 2) + u;
-            const uint32_t i = 64 * k + lane;
+            const uint32_t i = 64 * WPB * k + tid;
             bload(v[u], rs.dlay, i < cnt ? e[k] * (uint32_t)sizeof(P2) : OOB);
         }
 #pragma unroll
         for (int u = 0; u < STAGE_ITERS / 2; ++u) {
             const int k = half * (STAGE_ITERS / 2) + u;
-            const uint32_t i = 64 * k + lane;
-            if (i < cnt) sD[i] = v[u];
+            const uint32_t i = 64 * WPB * k + tid;
+            if (i < cnt) sD[sl[k]] = v[u];
         }
     }
 }
 
-template <typename REAL>
-__device__ __forceinline__ void stage_flush(const typename Pair<REAL>::type* sD, const uint32_t (&e)[STAGE_ITERS], const NarrowRs<REAL>& rs,
-                                            uint32_t cnt, int lane)
+template <typename REAL, int WPB>
+__device__ __forceinline__ void stage_flush(const typename Pair<REAL>::type* sD, const uint32_t (&e)[STAGE_ITERS],
+                                            const uint32_t (&sl)[STAGE_ITERS], const NarrowRs<REAL>& rs, uint32_t cnt, uint32_t tid)
 {
 #pragma unroll
     for (int u = 0; u < STAGE_ITERS; ++u) {
-        const uint32_t i = 64 * u + lane;
-        const REAL m = sD[i < cnt ? i : 0].x;
+        const uint32_t i = 64 * WPB * u + tid;
+        const REAL m = sD[i < cnt ? sl[u] : 0].x;
         bstore(m, rs.mm, i < cnt ? e[u] * (uint32_t)sizeof(REAL) : OOB);
     }
 }
@@ -258,6 +267,17 @@ __device__ __forceinline__ void stage_flush(const typename Pair<REAL>::type* sD,
 // *vector* global load followed by s_waitcnt vmcnt(0): it serialises two extra memory round trips per
 // hop and drains every prefetch in flight.  Instead 64 consecutive offsets are fetched with one
 // coalesced load and read back with (broadcast) LDS reads, which are counted by lgkmcnt only.
+// Ordering point for LDS traffic of ONE wave.  The LDS unit executes a wave's DS instructions in order,
+// so a wave that only consumes what it wrote itself needs no hardware barrier — only the compiler must not
+// move LDS accesses across this point.  (In a one-wave workgroup __syncthreads() compiles to the same;
+// with several waves per workgroup it would be a real s_barrier per hop.)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 constexpr uint32_t HOP_WIN = 64;
 struct HopWindow {
     uint32_t* node;   // LDS [HOP_WIN]
@@ -270,7 +290,7 @@ struct HopWindow {
         const uint32_t q = min(new_base + (uint32_t)lane, q1);
         node[lane] = pk.hop_node_off[q];
         layer[lane] = pk.hop_layer_off[q];
-        __syncthreads();
+        wave_sync();
     }
     __device__ __forceinline__ uint32_t node_off(uint32_t q) const
     {
@@ -335,62 +355,82 @@ __device__ __forceinline__ void load_vals(REAL (&v)[R], rsrc_t src, uint32_t nb,
     }
 }
 
-template <typename REAL, int R, int MODE>
-__global__ void __launch_bounds__(64) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
+template <typename REAL, int R, int MODE, int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
 {
     constexpr int W = 64 * R;
     constexpr bool NEED_T = (MODE != FWD_PLAIN);
     using P2 = typename Pair<REAL>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    P2* sD = reinterpret_cast<P2*>(dyn_lds);  // staged {delta_lo, delta_hi} of the current stage group; .x is overwritten by mm
-    // +2: constant sink entries at index TOP = W (cost-from-terminal 0) and BOT = W + 1 (+inf);
+    P2* sD = reinterpret_cast<P2*>(dyn_lds);  // staged {delta_lo, delta_hi} of the workgroup's stage groups; .x is overwritten by mm
+    // per wave; +2: constant sink entries at index TOP = W (cost-from-terminal 0) and BOT = W + 1 (+inf);
     // for sF they are dummy push targets, so sink children need no branch
-    __shared__ REAL sF[2][W + 2];
-    __shared__ REAL sT[W + 2];
-    __shared__ unsigned char sAct[2][MODE == FWD_SOLUTION ? W + 2 : 1];
-    const int lane = threadIdx.x;
-    const uint32_t p = block_to_pack(blockIdx.x, pk.n_packs);
-    if (p >= pk.n_packs) return;
-    const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
-    const int steps = pk.pack_steps[p];
+    __shared__ REAL sF_[WPB][2][W + 2];
+    __shared__ REAL sT_[WPB][W + 2];
+    __shared__ unsigned char sAct_[WPB][2][MODE == FWD_SOLUTION ? W + 2 : 1];
+    __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN];
+    const uint32_t tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int lane = tid & 63;
+    auto& sF = sF_[wave];
+    auto& sT = sT_[wave];
+    auto& sAct = sAct_[wave];
+    const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
+    const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
+    if (quad >= n_quads) return;  // uniform for the workgroup
+    const uint32_t p = quad * WPB + wave;
+    const bool has_pack = p < pk.n_packs;  // the last quad may be partial: such a wave only helps staging
+    const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
+    const int steps = has_pack ? pk.pack_steps[p] : 0;
     const REAL INF = inf_v<REAL>();
     const NarrowRs<REAL> rs(d);
-    __shared__ uint32_t sOffN[HOP_WIN], sOffL[HOP_WIN];
     // hop_node_off / hop_layer_off have one entry past the last hop of the last pack, so index q1 is
     // always readable; offsets beyond q1 are clamped (those hops have no nodes for this pack)
-    HopWindow hw{sOffN, sOffL, q0, q1};
-    hw.fill(pk, q0, lane);
+    HopWindow hw{sOffN_[wave], sOffL_[wave], q0, q1};
     auto off = [&](uint32_t q) { return hw.node_off(q); };
-    uint32_t nb = off(q0), ne = off(q0 + 1);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t j = lane + 64 * r;
-        sF[0][j] = (j < ne - nb) ? REAL(0) : INF;  // every slot of hop 0 is a root (flush_costs_from_root)
-        if (MODE == FWD_SOLUTION) sAct[0][j] = (j < ne - nb) ? 1 : 0;
-    }
-    if (lane < 2) sT[W + lane] = lane == 0 ? REAL(0) : INF;
+    uint32_t nb = 0, ne = 0;
     // pipeline prologue
     uint32_t wa[R], wb[R];
     REAL ta[R];
     HopLayer<REAL, R> La;
-    load_words<R>(wa, rs.words, nb, ne - nb, lane);
-    {
+    if (has_pack) {
+        hw.fill(pk, q0, lane);
+        nb = off(q0);
+        ne = off(q0 + 1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t j = lane + 64 * r;
+            sF[0][j] = (j < ne - nb) ? REAL(0) : INF;  // every slot of hop 0 is a root (flush_costs_from_root)
+            if (MODE == FWD_SOLUTION) sAct[0][j] = (j < ne - nb) ? 1 : 0;
+        }
+        if (lane < 2) sT[W + lane] = lane == 0 ? REAL(0) : INF;
+        load_words<R>(wa, rs.words, nb, ne - nb, lane);
         const uint32_t ne2 = off(q0 + 2);
         load_words<R>(wb, rs.words, ne, ne2 - ne, lane);                     // words of hop q0+1 (none if q0+1 == q1)
         if (NEED_T) load_vals<REAL, R>(ta, rs.T, ne, ne2 - ne, lane);         // T of hop q0+1
+        load_layer<REAL, R>(La, wa, hw.layer_off(q0), rs);
     }
-    load_layer<REAL, R>(La, wa, hw.layer_off(q0), rs);
     int cur = 0;
     uint32_t q = q0;
-    const uint32_t g_end = (MODE == FWD_SOLVE) ? pk.pack_group_ptr[p + 1] : 1;
-    for (uint32_t g = (MODE == FWD_SOLVE) ? pk.pack_group_ptr[p] : 0; g < g_end; ++g) {
+    const uint32_t g0 = (MODE == FWD_SOLVE && has_pack) ? pk.pack_group_ptr[p] : 0;
+    const uint32_t ng = (MODE == FWD_SOLVE && has_pack) ? pk.pack_group_ptr[p + 1] - g0 : 0;
+    const uint32_t r0 = (MODE == FWD_SOLVE) ? pk.quad_round_ptr[quad] : 0;
+    const uint32_t n_rounds = (MODE == FWD_SOLVE) ? pk.quad_round_ptr[quad + 1] - r0 : 1;
+    P2* sDw = sD + (size_t)wave * pk.stage_cap;  // this wave's slots of the staging area
+    for (uint32_t k = 0; k < n_rounds; ++k) {
         uint32_t gl0 = 0, cnt = 0, qe = q1;
-        uint32_t ent[STAGE_ITERS];
+        uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
         if (MODE == FWD_SOLVE) {
-            gl0 = pk.grp_layer_off[g];
-            cnt = pk.grp_layer_off[g + 1] - gl0;
-            qe = pk.grp_hop_end[g];
-            stage_load<REAL>(sD, ent, rs, gl0, cnt, lane);  // the group's delta pairs -> LDS
+            const uint32_t c0 = pk.cs_ptr[r0 + k];
+            cnt = pk.cs_ptr[r0 + k + 1] - c0;
+            stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
+            if (k < ng) {
+                gl0 = pk.grp_layer_off[g0 + k];
+                qe = pk.grp_hop_end[g0 + k];
+            } else {
+                qe = q;  // this pack has no k-th group: no hops in this round
+            }
+            if (WPB > 1) __syncthreads(); else wave_sync();
         }
         for (; q < qe; ++q) {
             if (q + 3 >= hw.base + HOP_WIN && hw.base + HOP_WIN <= q1) hw.fill(pk, q, lane);
@@ -418,7 +458,7 @@ __global__ void __launch_bounds__(64) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, 
                 if (MODE == FWD_SOLUTION) sAct[cur ^ 1][j] = 0;
                 f[r] = sF[cur][j];
             }
-            __syncthreads();  // one wave: compiles to a wait on the LDS stores above
+            wave_sync();  // orders this wave's LDS stores above before the reads below
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t j = lane + 64 * r;
@@ -432,7 +472,7 @@ __global__ void __launch_bounds__(64) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, 
                     const REAL tl = sT[lo_i];  // sinks: sT[W] = 0, sT[W+1] = +inf
                     const REAL th = sT[hi_i];
                     if (MODE == FWD_SOLVE) {
-                        const P2 dd = sD[act ? sl : 0];
+                        const P2 dd = sDw[act ? sl : 0];
                         REAL m0 = act ? (f[r] + lc) + tl : INF;
                         REAL m1 = act ? (f[r] + hc) + th : INF;
                         seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps);
@@ -444,7 +484,7 @@ __global__ void __launch_bounds__(64) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, 
                         nc.x = nlo;
                         nc.y = nhi;
                         bstore(nc, rs.lohi, head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB);
-                        if (head) sD[sl].x = mm;  // every lane of the layer has read its pair above (same wave, in order)
+                        if (head) sDw[sl].x = mm;  // every lane of the layer has read its pair above (same wave, in order)
                     } else {
                         // compute_bdd_sol_func, bdd_cuda_base.cu:1103-1137 (with the `< 0` fix of SURVEY.md §8)
                         if (act && sAct[cur][j]) {
@@ -461,7 +501,7 @@ __global__ void __launch_bounds__(64) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, 
                 lds_min(&sF[cur ^ 1][hi_i], f[r] + nhi);
                 bstore(f[r], rs.F, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
             }
-            __syncthreads();
+            wave_sync();
             cur ^= 1;
             nb = ne;
             ne = ne2;
@@ -474,42 +514,51 @@ __global__ void __launch_bounds__(64) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, 
             }
             La = Lb;
         }
-        if (MODE == FWD_SOLVE) stage_flush<REAL>(sD, ent, rs, cnt, lane);
+        if (MODE == FWD_SOLVE) {
+            if (WPB > 1) __syncthreads(); else wave_sync();
+            stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);  // min-marginal differences of the round -> entry array
+            if (WPB > 1) __syncthreads();                        // the next round overwrites the staging area
+        }
     }
 }
 
-template <typename REAL, int R, int MODE>
-__global__ void __launch_bounds__(64) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
+template <typename REAL, int R, int MODE, int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
 {
     constexpr int W = 64 * R;
     constexpr bool NEED_F = (MODE != BWD_PLAIN);
     using P2 = typename Pair<REAL>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     P2* sD = reinterpret_cast<P2*>(dyn_lds);
-    __shared__ REAL sT[2][W + 2];  // +2: sink entries TOP = W (0) and BOT = W + 1 (+inf)
-    const int lane = threadIdx.x;
-    const uint32_t p = block_to_pack(blockIdx.x, pk.n_packs);
-    if (p >= pk.n_packs) return;
-    const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
-    const int steps = pk.pack_steps[p];
+    __shared__ REAL sT_[WPB][2][W + 2];  // per wave; +2: sink entries TOP = W (0) and BOT = W + 1 (+inf)
+    __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN];
+    const uint32_t tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int lane = tid & 63;
+    auto& sT = sT_[wave];
+    const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
+    const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
+    if (quad >= n_quads) return;
+    const uint32_t p = quad * WPB + wave;
+    const bool has_pack = p < pk.n_packs;
+    const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
+    const int steps = has_pack ? pk.pack_steps[p] : 0;
     const REAL INF = inf_v<REAL>();
     const NarrowRs<REAL> rs(d);
-    __shared__ uint32_t sOffN[HOP_WIN], sOffL[HOP_WIN];
-    if (lane < 4) sT[lane >> 1][W + (lane & 1)] = (lane & 1) ? INF : REAL(0);
-    HopWindow hw{sOffN, sOffL, q0, q1};
-    hw.fill(pk, q1 + 1 > q0 + HOP_WIN ? q1 + 1 - HOP_WIN : q0, lane);  // window ends at record q1
+    HopWindow hw{sOffN_[wave], sOffL_[wave], q0, q1};
     // node range of hop q; hops below q0 (pipeline run-off) are empty
     auto nb_of = [&](uint32_t q) { return hw.node_off(q); };
     // pipeline prologue: hop q1-1 fully, words of hop q1-2
     uint32_t wa[R], wb[R];
     REAL fa[R], fb[R];
     HopLayer<REAL, R> La;
-    {
+    if (has_pack) {
+        if (lane < 4) sT[lane >> 1][W + (lane & 1)] = (lane & 1) ? INF : REAL(0);
+        hw.fill(pk, q1 + 1 > q0 + HOP_WIN ? q1 + 1 - HOP_WIN : q0, lane);  // window ends at record q1
         const uint32_t nb = nb_of(q1 - 1);
         const uint32_t n = nb_of(q1) - nb;
         load_words<R>(wa, rs.words, nb, n, lane);
         if (NEED_F) load_vals<REAL, R>(fa, rs.F, nb, n, lane);
-        (void)n;
         const bool has = (q1 - 1 > q0);
         const uint32_t nb2 = has ? nb_of(q1 - 2) : nb, n2 = has ? nb - nb2 : 0;
         load_words<R>(wb, rs.words, nb2, n2, lane);
@@ -518,16 +567,25 @@ __global__ void __launch_bounds__(64) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, 
     }
     int cur = 0;
     uint32_t q = q1;
-    const uint32_t g_first = (MODE == BWD_SOLVE) ? pk.pack_group_ptr[p] : 0;
-    for (uint32_t g = (MODE == BWD_SOLVE) ? pk.pack_group_ptr[p + 1] : 1; g-- > g_first;) {
+    const uint32_t g0 = (MODE == BWD_SOLVE && has_pack) ? pk.pack_group_ptr[p] : 0;
+    const uint32_t ng = (MODE == BWD_SOLVE && has_pack) ? pk.pack_group_ptr[p + 1] - g0 : 0;
+    const uint32_t r0 = (MODE == BWD_SOLVE) ? pk.quad_round_ptr[quad] : 0;
+    const uint32_t n_rounds = (MODE == BWD_SOLVE) ? pk.quad_round_ptr[quad + 1] - r0 : 1;
+    P2* sDw = sD + (size_t)wave * pk.stage_cap;
+    for (uint32_t k = n_rounds; k-- > 0;) {  // same rounds as the forward sweep, in reverse
         uint32_t gl0 = 0, cnt = 0, qs = q0;
-        uint32_t ent[STAGE_ITERS];
+        uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
         if (MODE == BWD_SOLVE) {
-            gl0 = pk.grp_layer_off[g];
-            cnt = pk.grp_layer_off[g + 1] - gl0;
-            qs = (g == g_first) ? q0 : pk.grp_hop_end[g - 1];
-            stage_load<REAL>(sD, ent, rs, gl0, cnt, lane);
-            __syncthreads();
+            const uint32_t c0 = pk.cs_ptr[r0 + k];
+            cnt = pk.cs_ptr[r0 + k + 1] - c0;
+            stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
+            if (k < ng) {
+                gl0 = pk.grp_layer_off[g0 + k];
+                qs = (k == 0) ? q0 : pk.grp_hop_end[g0 + k - 1];
+            } else {
+                qs = q;  // no k-th group in this pack
+            }
+            if (WPB > 1) __syncthreads(); else wave_sync();
         }
         while (q > qs) {
             --q;
@@ -557,7 +615,7 @@ __global__ void __launch_bounds__(64) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, 
                 const REAL th = sT[cur][hi_i];
                 REAL t;
                 if (MODE == BWD_SOLVE) {
-                    const P2 dd = sD[act ? sl : 0];
+                    const P2 dd = sDw[act ? sl : 0];
                     REAL m0 = act ? (fa[r] + lc) + tl : INF;
                     REAL m1 = act ? (fa[r] + hc) + th : INF;
                     seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps);
@@ -570,7 +628,7 @@ __global__ void __launch_bounds__(64) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, 
                     nc.x = nlo;
                     nc.y = nhi;
                     bstore(nc, rs.lohi, head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB);
-                    if (head) sD[sl].x = mm;
+                    if (head) sDw[sl].x = mm;
                 } else {
                     const REAL ch = th + hc, cl = tl + lc;  // backward_step, bdd_cuda_base.cu:646-667
                     t = rmin(ch, cl);
@@ -587,7 +645,7 @@ __global__ void __launch_bounds__(64) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, 
                 if (act) sT[cur ^ 1][j] = t;
                 bstore(t, rs.T, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
             }
-            __syncthreads();
+            wave_sync();
             cur ^= 1;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -600,8 +658,13 @@ __global__ void __launch_bounds__(64) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, 
             }
             La = Lb;
         }
-        if (MODE == BWD_SOLVE) stage_flush<REAL>(sD, ent, rs, cnt, lane);
+        if (MODE == BWD_SOLVE) {
+            if (WPB > 1) __syncthreads(); else wave_sync();
+            stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
+            if (WPB > 1) __syncthreads();
+        }
     }
+    if (!has_pack) return;
     // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251)
     const uint32_t n0 = nb_of(q0 + 1) - nb_of(q0);
     double s = 0.0;

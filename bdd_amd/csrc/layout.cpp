@@ -400,6 +400,50 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
             X.lpos[k.layer] = e;
         }
         for (uint32_t b = 0; b < X.n_bins; ++b) X.bin_ptr[b + 1] += X.bin_ptr[b];
+        // cooperative staging tables
+        X.waves_per_block = opts && opts->waves_per_block ? opts->waves_per_block : 4;
+        if (X.waves_per_block != 1 && X.waves_per_block != 2 && X.waves_per_block != 4 && X.waves_per_block != 8) {
+            err = "waves_per_block must be 1, 2, 4 or 8";
+            return BDDMMA_ERR_INVALID_ARGUMENT;
+        }
+        if ((uint64_t)X.waves_per_block * X.stage_cap > 65535) {
+            err = "waves_per_block * stage_cap must be < 65536";
+            return BDDMMA_ERR_INVALID_ARGUMENT;
+        }
+        {
+            const uint32_t WPB = X.waves_per_block;
+            const uint32_t n_quads = (Pn + WPB - 1) / WPB;
+            X.quad_round_ptr.assign(n_quads + 1, 0);
+            X.cs_ptr.assign(1, 0);
+            X.cs_entry.reserve(narrow_layers);
+            X.cs_slot.reserve(narrow_layers);
+            std::vector<std::pair<uint32_t, uint16_t>> items;
+            for (uint32_t Q = 0; Q < n_quads; ++Q) {
+                X.quad_round_ptr[Q] = (uint32_t)X.cs_ptr.size() - 1;
+                uint32_t rounds = 0;
+                for (uint32_t w = 0; w < WPB && Q * WPB + w < Pn; ++w) {
+                    const uint32_t p = Q * WPB + w;
+                    rounds = std::max(rounds, X.pack_group_ptr[p + 1] - X.pack_group_ptr[p]);
+                }
+                for (uint32_t k = 0; k < rounds; ++k) {
+                    items.clear();
+                    for (uint32_t w = 0; w < WPB && Q * WPB + w < Pn; ++w) {
+                        const uint32_t p = Q * WPB + w;
+                        const uint32_t g = X.pack_group_ptr[p] + k;
+                        if (g >= X.pack_group_ptr[p + 1]) continue;
+                        for (uint32_t l = X.grp_layer_off[g]; l < X.grp_layer_off[g + 1]; ++l)
+                            items.push_back({X.lpos[l], (uint16_t)(w * X.stage_cap + (l - X.grp_layer_off[g]))});
+                    }
+                    std::sort(items.begin(), items.end());
+                    for (const auto& it : items) {
+                        X.cs_entry.push_back(it.first);
+                        X.cs_slot.push_back(it.second);
+                    }
+                    X.cs_ptr.push_back((uint32_t)X.cs_entry.size());
+                }
+            }
+            X.quad_round_ptr[n_quads] = (uint32_t)X.cs_ptr.size() - 1;
+        }
         X.vpos.assign(Lin, 0);
         for (uint32_t k = 0; k < Lin; ++k) X.vpos[k] = X.lpos[L.var_layers[k]];
     }

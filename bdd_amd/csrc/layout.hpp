@@ -87,6 +87,14 @@ struct Exchange {
     std::vector<uint32_t> pack_group_ptr;  // [narrow packs + 1] first stage group of each narrow pack
     std::vector<uint32_t> grp_layer_off;   // [G+1] first layer of each group (a group's layers are contiguous)
     std::vector<uint32_t> grp_hop_end;     // [G] (pack,hop) record index one past the group's last hop
+    // cooperative staging: `waves_per_block` consecutive narrow packs (a "quad") are swept by one workgroup;
+    // in round k the workgroup stages the k-th stage groups of its packs together, so that the runs it
+    // reads / writes in the entry arrays are (bin, quad)-contiguous instead of (bin, pack)-contiguous
+    uint32_t waves_per_block = 0;
+    std::vector<uint32_t> quad_round_ptr;  // [quads+1] first round record of each quad
+    std::vector<uint32_t> cs_ptr;          // [rounds+1] first staged item of each (quad, round)
+    std::vector<uint32_t> cs_entry;        // [narrow layers] staged item -> entry (ascending inside a round)
+    std::vector<uint16_t> cs_slot;         // [narrow layers] staged item -> LDS slot = wave * stage_cap + (layer - group's first layer)
 };
 
 struct HostLayout {

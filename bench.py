@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--pack-width", type=int, default=0)
     ap.add_argument("--vars-per-bin", type=int, default=0)
     ap.add_argument("--stage-cap", type=int, default=0)
+    ap.add_argument("--wpb", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--deterministic", action="store_true")
@@ -71,7 +72,7 @@ def main():
     col, costs = random_set_cover(args.vars, args.rows, args.k, seed=12345 + rank)
     solver = bdd_hip_parallel_mma(col, costs, precision=args.precision, device=local_rank,
                                   pack_width=args.pack_width, deterministic=args.deterministic,
-                                  vars_per_bin=args.vars_per_bin, stage_cap=args.stage_cap)
+                                  vars_per_bin=args.vars_per_bin, stage_cap=args.stage_cap, waves_per_block=args.wpb)
     R = 4 if args.precision == "float" else 8
     solver.iterations(args.warmup)
     solver.synchronize()
@@ -194,7 +195,7 @@ def cpu_baseline(col, costs, args, sizes):
             break
     cpu_lb = o.lower_bound()
     g = bdd_hip_parallel_mma(col, costs, precision=args.precision, pack_width=args.pack_width,
-                             vars_per_bin=args.vars_per_bin, stage_cap=args.stage_cap)
+                             vars_per_bin=args.vars_per_bin, stage_cap=args.stage_cap, waves_per_block=args.wpb)
     g.iterations(n + warm)
     gpu_lb = g.lower_bound()
     return {

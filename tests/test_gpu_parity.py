@@ -130,10 +130,11 @@ def oracle_layer_perm(s, o):
 
 
 @pytest.mark.parametrize("precision", ["double", "float"])
-@pytest.mark.parametrize("pack_width", [64, 128])
-def test_random_cover_vs_oracle(precision, pack_width):
+@pytest.mark.parametrize("pack_width,wpb", [(64, 4), (128, 4), (128, 1), (128, 8)])
+def test_random_cover_vs_oracle(precision, pack_width, wpb):
     col, costs = random_set_cover(3000, 2500, 8, seed=5)
-    s = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=pack_width)
+    s = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=pack_width, waves_per_block=wpb,
+                             stage_cap=256 if wpb == 8 else 0)
     o = Oracle(col, costs, precision)
     assert s.nr_packs() > 8
     assert close(s.lower_bound(), o.lower_bound(), precision, 10)
@@ -324,8 +325,8 @@ def test_full_size_properties(n_vars, n_rows):
 
 # ---------------------------------------------------------------- long BDDs: hop-window refills and several stage groups per pack
 @pytest.mark.parametrize("precision", ["double", "float"])
-@pytest.mark.parametrize("pack_width,stage_cap", [(64, 64), (128, 640), (256, 256)])
-def test_long_bdds_vs_oracle(precision, pack_width, stage_cap):
+@pytest.mark.parametrize("pack_width,stage_cap,wpb", [(64, 64, 4), (128, 640, 1), (256, 256, 2), (64, 128, 8)])
+def test_long_bdds_vs_oracle(precision, pack_width, stage_cap, wpb):
     rng = np.random.Generator(np.random.PCG64(33))
     V = 700
     col = BddCollection()
@@ -339,7 +340,7 @@ def test_long_bdds_vs_oracle(precision, pack_width, stage_cap):
         k = int(rng.integers(65, 140))                                      # longer than one 64-entry hop window
         col.add_simplex(np.sort(rng.choice(V, size=k, replace=False)))
     costs = rng.normal(0, 2, col.nr_variables()).round(3)
-    s = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=pack_width, stage_cap=stage_cap)
+    s = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=pack_width, stage_cap=stage_cap, waves_per_block=wpb)
     o = Oracle(col, costs, precision)
     assert s.nr_hops() == 300
     assert close(s.lower_bound(), o.lower_bound(), precision, 10)

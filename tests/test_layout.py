@@ -17,12 +17,12 @@ BOT = np.uint64(2**64 - 2)
 
 
 class Layout:
-    def __init__(self, col, pack_width=0, wide_pack_width=0, vars_per_bin=0, stage_cap=0):
+    def __init__(self, col, pack_width=0, wide_pack_width=0, vars_per_bin=0, stage_cap=0, waves_per_block=0):
         L = capi.lib()
         instr = np.ascontiguousarray(col.instr, dtype=np.uint64)
         delims = np.ascontiguousarray(col.delims, dtype=np.uint64)
         h = C.c_void_p()
-        opts = capi.Options(pack_width, wide_pack_width, 0, vars_per_bin, stage_cap)
+        opts = capi.Options(pack_width, wide_pack_width, 0, vars_per_bin, stage_cap, waves_per_block)
         rc = L.bddmma_layout_create(C.byref(h), instr.ctypes.data_as(C.c_void_p), delims.ctypes.data_as(C.c_void_p),
                                     col.nr_bdds(), C.byref(opts))
         capi.check(rc, None)
@@ -59,6 +59,12 @@ class Layout:
         self.pack_group_ptr = get(20, self.np_n + 1 if self.np_n else 0, np.uint32)
         self.grp_layer_off = get(21, self.n_groups + 1, np.uint32)
         self.grp_hop_end = get(22, self.n_groups, np.uint32)
+        self.wpb, n_rounds = sz(14), sz(15)
+        n_quads = (self.np_n + self.wpb - 1) // self.wpb if self.np_n else 0
+        self.quad_round_ptr = get(23, n_quads + 1 if n_quads else 0, np.uint32)
+        self.cs_ptr = get(24, n_rounds + 1, np.uint32)
+        self.cs_entry = get(25, self.narrow_layers, np.uint32)
+        self.cs_slot = get(26, self.narrow_layers, np.uint16)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -132,6 +138,24 @@ def check_exchange(lay):
             q = qe
         assert q == int(S["pack_hop_ptr"][p + 1])
     assert int(lay.grp_layer_off[-1]) == lay.narrow_layers
+    # cooperative staging: every narrow layer is staged exactly once; inside a (quad, round) the items are
+    # sorted by entry and the slot addresses the owning wave's region
+    seen = np.zeros(lay.narrow_layers, bool)
+    inv = np.empty(L, np.int64); inv[lay.lpos] = np.arange(L)
+    for Q in range(len(lay.quad_round_ptr) - 1):
+        for k, r in enumerate(range(int(lay.quad_round_ptr[Q]), int(lay.quad_round_ptr[Q + 1]))):
+            c0, c1 = int(lay.cs_ptr[r]), int(lay.cs_ptr[r + 1])
+            ent = lay.cs_entry[c0:c1].astype(np.int64)
+            assert np.all(np.diff(ent) > 0)
+            layers = inv[ent]
+            for e_layer, slot in zip(layers, lay.cs_slot[c0:c1].astype(np.int64)):
+                w, off = divmod(int(slot), lay.stage_cap)
+                p = Q * lay.wpb + w
+                g = int(lay.pack_group_ptr[p]) + k
+                assert g < int(lay.pack_group_ptr[p + 1]) and int(lay.grp_layer_off[g]) + off == e_layer
+                assert not seen[e_layer]
+                seen[e_layer] = True
+    assert seen.all()
 
 
 def check_roundtrip(col, **kw):
@@ -244,3 +268,5 @@ def test_roundtrip_long_bdds_many_groups():
         col.add_covering(np.sort(rng.choice(500, size=int(rng.integers(2, 90)), replace=False)))
     lay = check_roundtrip(col, pack_width=64, stage_cap=64, vars_per_bin=64)
     assert lay.n_groups > 10 * lay.np_n and lay.n_hops == 300
+    for w in (1, 2, 8):
+        check_roundtrip(col, pack_width=64, stage_cap=64, vars_per_bin=64, waves_per_block=w)

@@ -8,12 +8,13 @@ ap.add_argument("--precision", default="float")
 ap.add_argument("--pack-width", type=int, default=0)
 ap.add_argument("--vars-per-bin", type=int, default=0)
 ap.add_argument("--stage-cap", type=int, default=0)
+ap.add_argument("--wpb", type=int, default=0)
 ap.add_argument("--vars", type=int, default=1_000_000)
 ap.add_argument("--rows", type=int, default=500_000)
 ap.add_argument("--k", type=int, default=10)
 a = ap.parse_args()
 col, costs = random_set_cover(a.vars, a.rows, a.k, seed=12345)
-s = bdd_hip_parallel_mma(col, costs, precision=a.precision, pack_width=a.pack_width, vars_per_bin=a.vars_per_bin, stage_cap=a.stage_cap)
+s = bdd_hip_parallel_mma(col, costs, precision=a.precision, pack_width=a.pack_width, vars_per_bin=a.vars_per_bin, stage_cap=a.stage_cap, waves_per_block=a.wpb)
 s.iterations(3)
 names = ["fwd_plain", "bwd_plain", "fwd_solve", "bwd_solve", "exch_reduce", "exch_bcast"]
 print(vars(a))
