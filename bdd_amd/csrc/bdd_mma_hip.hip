@@ -49,6 +49,7 @@ struct SolverT final : SolverBase {
     REAL* d_delta_lay = nullptr;    // 2L: the same, broadcast to binned entry order (what the sweeps read)
     REAL* d_mm_binned = nullptr;    // L : deferred min-marginal differences in binned entry order
     REAL *d_delta_c = nullptr, *d_delta_lay_c = nullptr;  // scratch for the explicit forward_mm/backward_mm API
+    uint16_t* d_bvar = nullptr;
     uint32_t *d_evar = nullptr, *d_lpos = nullptr, *d_vpos = nullptr, *d_bin_ptr = nullptr;
     uint32_t *d_pack_group_ptr = nullptr, *d_grp_layer_off = nullptr, *d_grp_hop_end = nullptr;
     uint32_t *d_quad_round_ptr = nullptr, *d_cs_ptr = nullptr, *d_cs_entry = nullptr;
@@ -143,6 +144,7 @@ struct SolverT final : SolverBase {
         if ((rc = dalloc(&d_delta_lay, 2 * n_layers))) return rc;
         if ((rc = dalloc(&d_delta_lay_c, 2 * n_layers))) return rc;
         if ((rc = upload(&d_evar, L.ex.evar))) return rc;
+        if ((rc = upload(&d_bvar, L.ex.bvar))) return rc;
         if ((rc = upload(&d_lpos, L.ex.lpos))) return rc;
         if ((rc = upload(&d_vpos, L.ex.vpos))) return rc;
         if ((rc = upload(&d_bin_ptr, L.ex.bin_ptr))) return rc;
@@ -295,7 +297,7 @@ struct SolverT final : SolverBase {
                                d_vpos, delta_var, (uint32_t)n_vars);
         else
             hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_RAW>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
-                               d_bin_ptr, d_evar, d_nbdds, delta_var, (REAL*)nullptr, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers);
+                               d_bin_ptr, d_bvar, d_nbdds, delta_var, (REAL*)nullptr, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers);
     }
     int exchange()
     {
@@ -306,7 +308,7 @@ struct SolverT final : SolverBase {
             launch_bcast(d_delta_var, d_delta_lay);
         } else {
             hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
-                               d_bin_ptr, d_evar, d_nbdds, d_delta_var, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers);
+                               d_bin_ptr, d_bvar, d_nbdds, d_delta_var, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers);
         }
         prof_end(BDDMMA_K_FINISH_DELTA);
         HIPCHK(hipGetLastError());

@@ -166,6 +166,12 @@ __device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, uint32_t po
 // keep the instruction stream straight-line, so the waits become counted vmcnt(N).
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 constexpr uint32_t OOB = 0xFFFFFFFFu;
+#ifndef BDDMMA_LD_AUX
+#define BDDMMA_LD_AUX 0
+#endif
+#ifndef BDDMMA_ST_AUX
+#define BDDMMA_ST_AUX 0
+#endif
 
 template <typename T>
 __device__ __forceinline__ rsrc_t make_rsrc(const T* p, uint64_t n_elems)
@@ -173,22 +179,22 @@ __device__ __forceinline__ rsrc_t make_rsrc(const T* p, uint64_t n_elems)
     const uint64_t bytes = n_elems * sizeof(T);
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p), 0, (uint32_t)(bytes > 0xFFFFFFFEull ? 0xFFFFFFFEull : bytes), 0x00020000);
 }
-__device__ __forceinline__ uint32_t bload_u32(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
+__device__ __forceinline__ uint32_t bload_u32(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, BDDMMA_LD_AUX); }
 __device__ __forceinline__ uint32_t bload_u16(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0); }
-__device__ __forceinline__ void bload(float& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
-__device__ __forceinline__ void bload(double& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0)); }
-__device__ __forceinline__ void bload(float2& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0)); }
+__device__ __forceinline__ void bload(float& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, BDDMMA_LD_AUX)); }
+__device__ __forceinline__ void bload(double& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, BDDMMA_LD_AUX)); }
+__device__ __forceinline__ void bload(float2& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, BDDMMA_LD_AUX)); }
 __device__ __forceinline__ void bload(double2& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); }
-__device__ __forceinline__ void bstore(float v, rsrc_t r, uint32_t off) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0, 0); }
+__device__ __forceinline__ void bstore(float v, rsrc_t r, uint32_t off) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0, BDDMMA_ST_AUX); }
 __device__ __forceinline__ void bstore(double v, rsrc_t r, uint32_t off)
 {
     using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, off, 0, BDDMMA_ST_AUX);
 }
 __device__ __forceinline__ void bstore(float2 v, rsrc_t r, uint32_t off)
 {
     using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, off, 0, BDDMMA_ST_AUX);
 }
 __device__ __forceinline__ void bstore(double2 v, rsrc_t r, uint32_t off)
 {
@@ -915,7 +921,7 @@ constexpr int EX_UNROLL = 8;
 
 template <typename REAL, typename ACC, int MODE>
 __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
-                                                                  const uint32_t* __restrict__ evar, const int32_t* __restrict__ nbdds,
+                                                                  const uint16_t* __restrict__ bvar, const int32_t* __restrict__ nbdds,
                                                                   REAL* __restrict__ delta_var, REAL* __restrict__ delta_lay,
                                                                   uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries)
 {
@@ -926,7 +932,7 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
     const uint32_t v0 = b * vars_per_bin;
     const uint32_t nv = min(vars_per_bin, n_vars - v0);
     const uint32_t e0 = bin_ptr[b], e1 = bin_ptr[b + 1];
-    const rsrc_t rmm = make_rsrc(mm_binned, n_entries), rev = make_rsrc(evar, n_entries);
+    const rsrc_t rmm = make_rsrc(mm_binned, n_entries), rev = make_rsrc(bvar, n_entries);
     for (uint32_t i = tid; i < 2 * nv; i += EX_THREADS) tile[i] = ACC(0);
     __syncthreads();
     for (uint32_t base = e0 + tid; base < e1; base += EX_THREADS * EX_UNROLL) {
@@ -936,11 +942,11 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
         for (int u = 0; u < EX_UNROLL; ++u) {
             const uint32_t e = base + u * EX_THREADS;
             bload(m[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);   // out of range: 0 -> no contribution
-            lv[u] = bload_u32(rev, e < e1 ? e * 4u : OOB);
+            lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
         }
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
-            const uint32_t l = lv[u] - v0;
+            const uint32_t l = lv[u];
             if (m[u] > 0) lds_add(&tile[2 * l + 1], ACC(m[u]));
             else if (m[u] < 0) lds_add(&tile[2 * l], ACC(-m[u]));
         }
@@ -963,12 +969,12 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
             const uint32_t e = base + u * EX_THREADS;
-            lv[u] = bload_u32(rev, e < e1 ? e * 4u : OOB);
+            lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
         }
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
             const uint32_t e = base + u * EX_THREADS;
-            const uint32_t l = e < e1 ? lv[u] - v0 : 0;
+            const uint32_t l = lv[u];
             P2 pr;
             pr.x = REAL(tile[2 * l]);
             pr.y = REAL(tile[2 * l + 1]);

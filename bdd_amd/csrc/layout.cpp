@@ -392,11 +392,13 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
         std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.bin < b.bin; });
         X.bin_ptr.assign(X.n_bins + 1, 0);
         X.evar.assign(Lin, 0);
+        X.bvar.assign(Lin, 0);
         X.lpos.assign(Lin, 0);
         for (uint32_t e = 0; e < Lin; ++e) {
             const Key& k = keys[e];
             X.bin_ptr[k.bin + 1]++;
             X.evar[e] = (uint32_t)L.layer_var[k.layer];
+            X.bvar[e] = (uint16_t)((uint32_t)L.layer_var[k.layer] - k.bin * X.vars_per_bin);
             X.lpos[k.layer] = e;
         }
         for (uint32_t b = 0; b < X.n_bins; ++b) X.bin_ptr[b + 1] += X.bin_ptr[b];

@@ -82,6 +82,7 @@ struct Exchange {
     uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0;
     std::vector<uint32_t> bin_ptr;         // [n_bins+1] first entry of each bin
     std::vector<uint32_t> evar;            // [L] entry -> variable
+    std::vector<uint16_t> bvar;            // [L] entry -> variable index local to its bin (exchange kernel: 2 B instead of 4)
     std::vector<uint32_t> lpos;            // [L] layer -> entry
     std::vector<uint32_t> vpos;            // [L] (variable,bdd)-sorted position -> entry (deterministic gather)
     std::vector<uint32_t> pack_group_ptr;  // [narrow packs + 1] first stage group of each narrow pack

@@ -78,25 +78,14 @@ def main():
     solver.synchronize()
     solver.set_profiling(True)  # hipEvent pairs around every launch on the solver's stream
 
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    solver.iterations(args.steps)
-    solver.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-
+    dt = timed_region(lambda: solver.iterations(args.steps),
+                      lambda: (solver.synchronize(), torch.cuda.synchronize()), dist, local_rank)
     prof = solver.get_profile()
     solver.set_profiling(False)
     lb = solver.lower_bound()
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     if rank == 0:
-        its = world * args.steps / dt
+        its = aggregate_rate(world, args.steps, dt)
         names = ["forward_mm", "backward_mm", "finish_delta", "other"]
         avg_ms = [prof["total_ms"][i] / max(prof["launches"][i], 1) for i in range(4)]
         dom = 0 if avg_ms[0] >= avg_ms[1] else 1
@@ -121,6 +110,7 @@ def main():
                 "precision": args.precision,
                 "omega": 0.5,
                 "pack_width": args.pack_width or 128,
+                "waves_per_block": args.wpb or 4,
                 "packs": solver.nr_packs(),
                 "hops": solver.nr_hops(),
                 "delta_exchange": "per-variable gather (deterministic)" if args.deterministic else "binned exchange, LDS accumulators",
@@ -146,6 +136,37 @@ def main():
     barrier()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def timed_region(run_steps, device_sync, dist, local_rank, backend_device=True):
+    """barrier + device sync, EXACTLY the K steps, device sync + barrier; returns the MAX over ranks of the
+    wall time (the driver's contract).  `dist` is torch.distributed or None (single process)."""
+    import torch
+
+    def barrier():
+        if dist is not None:
+            if backend_device:
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
+
+    barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    run_steps()
+    device_sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend_device else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def aggregate_rate(world, steps, dt):
+    """whole-job throughput: every rank runs its own instance (replicas, no data-path collective)"""
+    return world * steps / dt
 
 
 def measured_traffic(kernel, args):
