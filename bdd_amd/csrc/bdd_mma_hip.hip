@@ -386,6 +386,7 @@ struct SolverT final : SolverBase {
     {
         HIPCHK(hipSetDevice(device));
         int rc;
+        prof_active = profiling && (prof_iter++ % prof_stride == 0);
         if ((rc = mma_forward((REAL)omega, d_delta_lay))) return rc;
         if ((rc = exchange())) return rc;
         if ((rc = mma_backward((REAL)omega, d_delta_lay))) return rc;
@@ -694,7 +695,7 @@ int SolverBase::synchronize()
 
 void SolverBase::prof_begin(int kclass)
 {
-    if (!profiling) return;
+    if (!profiling || !prof_active) return;
     if (ev_used == ev_pool.size()) {
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { profiling = false; return; }
@@ -706,7 +707,7 @@ void SolverBase::prof_begin(int kclass)
 }
 void SolverBase::prof_end(int)
 {
-    if (!profiling) return;
+    if (!profiling || !prof_active) return;
     (void)hipEventRecord(ev_pool[ev_used].second, stream);
     ++ev_used;
 }
@@ -715,6 +716,9 @@ int SolverBase::set_profiling(int on)
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamSynchronize(stream));
     profiling = on != 0;
+    prof_stride = on > 0 ? (uint32_t)on : 1;
+    prof_iter = 0;
+    prof_active = profiling;
     ev_used = 0;
     return BDDMMA_OK;
 }

@@ -31,7 +31,10 @@ struct SolverBase {
     bddmma_options saved_opts{};
 
     // profiling: one hipEvent pair per launch group on `stream`
-    bool profiling = false;
+    bool profiling = false;        // hipEvent pairs are recorded for every `prof_stride`-th iteration only: an event
+    uint32_t prof_stride = 1;      // pair per launch costs ~4 us of stream time (measured: -14 % it/s at stride 1)
+    uint64_t prof_iter = 0;
+    bool prof_active = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<int> ev_class;
     size_t ev_used = 0;

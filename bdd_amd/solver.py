@@ -219,7 +219,9 @@ class bdd_hip_parallel_mma:
 
     # ---- measurement
     def synchronize(self): self._ck(self._L.bddmma_synchronize(self._h))
-    def set_profiling(self, on: bool): self._ck(self._L.bddmma_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, on, stride: int = 1):
+        """record hipEvent pairs around the launches of every `stride`-th iteration (0/False: off)"""
+        self._ck(self._L.bddmma_set_profiling(self._h, int(stride) if on else 0))
 
     def get_profile(self):
         p = capi.Profile()
