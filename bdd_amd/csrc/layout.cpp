@@ -340,7 +340,6 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
         // default bin: as many variables as a 128 KiB LDS tile holds (2 REAL each), but at least ~256 bins
         // so that the exchange kernel (one workgroup per bin) has enough workgroups to spread over the CUs
         const uint32_t max_vb = 131072u / (2u * 8u);  // accumulators are double for both precisions
-        (void)real_size;
         uint32_t auto_vb = (uint32_t)(((L.n_vars + 255) / 256 + 255) / 256 * 256);
         auto_vb = std::min(std::max(auto_vb, 1024u), max_vb);
         X.vars_per_bin = opts && opts->vars_per_bin ? opts->vars_per_bin : auto_vb;
@@ -403,7 +402,11 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
         }
         for (uint32_t b = 0; b < X.n_bins; ++b) X.bin_ptr[b + 1] += X.bin_ptr[b];
         // cooperative staging tables
-        X.waves_per_block = opts && opts->waves_per_block ? opts->waves_per_block : 4;
+        // default: 8 packs per workgroup in float, 4 in double (the staging area is 2*sizeof(REAL) per layer)
+        X.waves_per_block = opts && opts->waves_per_block ? opts->waves_per_block : (real_size == 4 ? 8 : 4);
+        // small instances: keep at least ~512 workgroups so that every CU has work
+        if (!(opts && opts->waves_per_block))
+            while (X.waves_per_block > 1 && Pn / X.waves_per_block < 512) X.waves_per_block /= 2;
         if (X.waves_per_block != 1 && X.waves_per_block != 2 && X.waves_per_block != 4 && X.waves_per_block != 8) {
             err = "waves_per_block must be 1, 2, 4 or 8";
             return BDDMMA_ERR_INVALID_ARGUMENT;

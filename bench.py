@@ -113,7 +113,7 @@ def main():
                 "precision": args.precision,
                 "omega": 0.5,
                 "pack_width": args.pack_width or 128,
-                "waves_per_block": args.wpb or 4,
+                "waves_per_block": args.wpb or (8 if args.precision == "float" else 4),
                 "packs": solver.nr_packs(),
                 "hops": solver.nr_hops(),
                 "delta_exchange": "per-variable gather (deterministic)" if args.deterministic else "binned exchange, LDS accumulators",
