@@ -917,7 +917,7 @@ __device__ __forceinline__ void lds_add(REAL* p, REAL v)
 // and round once per variable.
 enum : int { EX_ITER = 0, EX_RAW = 1 };
 constexpr int EX_THREADS = 1024;
-constexpr int EX_UNROLL = 8;
+constexpr int EX_UNROLL = 12;  // entries per thread and chunk: a bin of <= 12288 entries is one chunk, all loads in flight at once
 
 template <typename REAL, typename ACC, int MODE>
 __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
@@ -933,51 +933,87 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
     const uint32_t nv = min(vars_per_bin, n_vars - v0);
     const uint32_t e0 = bin_ptr[b], e1 = bin_ptr[b + 1];
     const rsrc_t rmm = make_rsrc(mm_binned, n_entries), rev = make_rsrc(bvar, n_entries);
+    const rsrc_t rnb = make_rsrc(nbdds, n_vars);
+    const bool one_chunk = (e1 - e0) <= EX_THREADS * EX_UNROLL;
+    // first chunk: every load of the workgroup is issued before anything is consumed
+    REAL m[EX_UNROLL];
+    uint32_t lv[EX_UNROLL];
+#pragma unroll
+    for (int u = 0; u < EX_UNROLL; ++u) {
+        const uint32_t e = e0 + tid + u * EX_THREADS;
+        bload(m[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);  // out of range: 0 -> no contribution
+        lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
+    }
+    // number of BDDs of the variables this thread normalises (needed only after the accumulation)
+    constexpr int NPT = 8;  // 2 * vars_per_bin <= NPT * EX_THREADS
+    int nb[NPT];
+    if (MODE == EX_ITER) {
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const uint32_t i = tid + k * EX_THREADS;
+            nb[k] = (int)bload_u32(rnb, i < 2 * nv ? (v0 + (i >> 1)) * 4u : OOB);
+        }
+    }
     for (uint32_t i = tid; i < 2 * nv; i += EX_THREADS) tile[i] = ACC(0);
     __syncthreads();
-    for (uint32_t base = e0 + tid; base < e1; base += EX_THREADS * EX_UNROLL) {
-        REAL m[EX_UNROLL];
-        uint32_t lv[EX_UNROLL];
+#pragma unroll
+    for (int u = 0; u < EX_UNROLL; ++u) {
+        if (m[u] > 0) lds_add(&tile[2 * lv[u] + 1], ACC(m[u]));
+        else if (m[u] < 0) lds_add(&tile[2 * lv[u]], ACC(-m[u]));
+    }
+    for (uint32_t base = e0 + EX_THREADS * EX_UNROLL + tid; base < e1; base += EX_THREADS * EX_UNROLL) {  // bins larger than one chunk
+        REAL m2[EX_UNROLL];
+        uint32_t lv2[EX_UNROLL];
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
             const uint32_t e = base + u * EX_THREADS;
-            bload(m[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);   // out of range: 0 -> no contribution
-            lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
+            bload(m2[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
+            lv2[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
         }
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
-            const uint32_t l = lv[u];
-            if (m[u] > 0) lds_add(&tile[2 * l + 1], ACC(m[u]));
-            else if (m[u] < 0) lds_add(&tile[2 * l], ACC(-m[u]));
+            if (m2[u] > 0) lds_add(&tile[2 * lv2[u] + 1], ACC(m2[u]));
+            else if (m2[u] < 0) lds_add(&tile[2 * lv2[u]], ACC(-m2[u]));
         }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < 2 * nv; i += EX_THREADS) {
-        REAL x = REAL(tile[i]);
-        if (MODE == EX_ITER) {
-            const int nb = nbdds[v0 + (i >> 1)];
-            x = nb > 0 ? x / REAL(nb) : REAL(0);
-            tile[i] = ACC(x);
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const uint32_t i = tid + k * EX_THREADS;
+        if (i < 2 * nv) {
+            REAL x = REAL(tile[i]);
+            if (MODE == EX_ITER) {
+                x = nb[k] > 0 ? x / REAL(nb[k]) : REAL(0);
+                tile[i] = ACC(x);
+            }
+            delta_var[2 * (size_t)v0 + i] = x;
         }
-        delta_var[2 * (size_t)v0 + i] = x;
     }
     if (MODE != EX_ITER) return;
     __syncthreads();
     const rsrc_t rdl = make_rsrc(delta_lay, 2ull * n_entries);
-    for (uint32_t base = e0 + tid; base < e1; base += EX_THREADS * EX_UNROLL) {
-        uint32_t lv[EX_UNROLL];
+#pragma unroll
+    for (int u = 0; u < EX_UNROLL; ++u) {  // first chunk: the local variable indices are still in registers
+        const uint32_t e = e0 + tid + u * EX_THREADS;
+        P2 pr;
+        pr.x = REAL(tile[2 * lv[u]]);
+        pr.y = REAL(tile[2 * lv[u] + 1]);
+        bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
+    }
+    if (one_chunk) return;
+    for (uint32_t base = e0 + EX_THREADS * EX_UNROLL + tid; base < e1; base += EX_THREADS * EX_UNROLL) {
+        uint32_t lv2[EX_UNROLL];
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
             const uint32_t e = base + u * EX_THREADS;
-            lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
+            lv2[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
         }
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
             const uint32_t e = base + u * EX_THREADS;
-            const uint32_t l = lv[u];
             P2 pr;
-            pr.x = REAL(tile[2 * l]);
-            pr.y = REAL(tile[2 * l + 1]);
+            pr.x = REAL(tile[2 * lv2[u]]);
+            pr.y = REAL(tile[2 * lv2[u] + 1]);
             bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
         }
     }
