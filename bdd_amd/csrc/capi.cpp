@@ -426,6 +426,7 @@ uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
         case 12: return L.ex.grp_layer_off.empty() ? 0 : L.ex.grp_layer_off.back();
         case 13: return L.ex.stage_cap;
         case 14: return L.ex.waves_per_block;
+        case 16: return L.pack_width;
         case 15: return L.ex.cs_ptr.empty() ? 0 : L.ex.cs_ptr.size() - 1;
         default: return 0;
     }

@@ -90,8 +90,27 @@ struct PackBuilder {
 
 }  // namespace
 
+static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
+                          const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps, uint32_t real_size);
+
 int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
                  const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps, uint32_t real_size)
+{
+    int rc = build_layout_w(instr, delims, n_bdds, opts, L, err, keep_debug_maps, real_size);
+    // Few packs (small instance, or few but long BDDs): a sweep is then bound by the latency of one pack's
+    // hop chain, so prefer more, narrower packs.  Only when the caller left pack_width open.
+    if (rc == BDDMMA_OK && !(opts && opts->pack_width) && L.narrow.n_packs() < 2048 && L.narrow.n_packs() > 0) {
+        bddmma_options o = opts ? *opts : bddmma_options{};
+        o.pack_width = 64;
+        HostLayout L2;
+        std::string err2;
+        if (build_layout_w(instr, delims, n_bdds, &o, L2, err2, keep_debug_maps, real_size) == BDDMMA_OK) L = std::move(L2);
+    }
+    return rc;
+}
+
+static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
+                          const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps, uint32_t real_size)
 {
     L = HostLayout();
     if (!instr || !delims || n_bdds == 0) {

@@ -27,8 +27,8 @@ class Layout:
                                     col.nr_bdds(), C.byref(opts))
         capi.check(rc, None)
         self.L, self.h = L, h
-        self.pack_width = pack_width or 128
         sz = lambda w: int(L.bddmma_layout_size(h, w))
+        self.pack_width = sz(16)
         self.n_slots, self.narrow_slots, self.n_layers = sz(0), sz(1), sz(2)
         self.np_n, self.np_w, self.n_hops, self.n_vars = sz(3), sz(4), sz(5), sz(6)
         rec_n, rec_w = sz(7), sz(8)
