@@ -14,6 +14,7 @@ Inputs are resident in HBM before the timed region starts.
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -185,7 +186,8 @@ def measured_traffic(kernel, args):
         return None
     want = "k_fwd_narrow" if kernel == "forward_mm" else "k_bwd_narrow"
     for name, v in json.load(open(path)).items():
-        if want in name and name.rstrip(">").endswith(", 1"):   # <REAL, R, SOLVE>
+        m = re.search(want + r"<\w+, \d+, (\d+), \d+>", name)   # <REAL, R, MODE, waves per block>; MODE 1 = solve
+        if m and m.group(1) == "1":
             return v["hbm_bytes"]
     return None
 
