@@ -234,6 +234,130 @@ class BddCollection:
         """sum_i x_i = k (bdd_collection::cardinality_constraint)."""
         return self.add_linear([1] * len(variables), "=", k, variables)
 
+    # ---------------------------------------------------------------- splitting
+    def layer_widths(self, b: int) -> list:
+        """#nodes per variable layer of BDD b (bdd_collection::layer_widths, bdd_collection.h:195)."""
+        d = self.delims
+        idx = self.instr[int(d[b]):int(d[b + 1]) - 2, 2]
+        if idx.size == 0:
+            return []
+        starts = np.flatnonzero(np.concatenate(([True], idx[1:] != idx[:-1])))
+        return np.diff(np.concatenate((starts, [idx.size]))).tolist()
+
+    def remove(self, bdd_nrs) -> None:
+        """bdd_collection::remove (bdd_collection.h:200-203): drop the listed BDDs, compacting the storage."""
+        drop = sorted(set(int(b) for b in bdd_nrs))
+        if not drop:
+            return
+        ins, d = self.instr, self.delims.astype(np.int64)
+        keep = [b for b in range(self._nb) if b not in set(drop)]
+        chunks, delims, pos = [], [0], 0
+        for b in keep:
+            part = ins[d[b]:d[b + 1]].copy()
+            nt = part[:, 2] < BOTSINK
+            shift = np.int64(pos) - d[b]
+            part[nt, 0] = (part[nt, 0].astype(np.int64) + shift).astype(np.uint64)
+            part[nt, 1] = (part[nt, 1].astype(np.int64) + shift).astype(np.uint64)
+            chunks.append(part)
+            pos += part.shape[0]
+            delims.append(pos)
+        self._chunks = [np.concatenate(chunks, axis=0)] if chunks else []
+        self._delims = [np.asarray(delims, dtype=np.uint64)]
+        self._n, self._nb = pos, len(keep)
+
+    def split_qbdd(self, b: int, chunk_size: int, aux_var_start: int, with_implication_bdd: bool = False):
+        """Cut a long QBDD into chunks of <= chunk_size variable layers that are coupled through auxiliary
+        one-hot variables (bdd_collection::split_qbdd, src/bdd_collection/bdd_collection.cpp:507-949).
+
+        For a cut in front of a layer with w nodes, w fresh variables a_0..a_{w-1} say which node the path
+        crosses.  The chunk after the cut starts with a triangular "head" over a_0..a_{w-1} that accepts exactly
+        the one-hot assignments and enters node j of the layer for the j-th of them; the chunk before the cut
+        ends, behind every node j of the cut layer, in a "tail" chain over the same variables that accepts
+        only the matching one-hot assignment.  Output BDDs are appended (the original stays; callers remove
+        it, bdd_preprocessor.cpp:393-412); node order and terminal order (bot, top) are the reference's, and
+        tests/test_bdd_builders.py compares node-for-node with oracle/_ref.
+
+        Returns (new BDD numbers, next free auxiliary variable).  A cut layer of width 1 — asserted against
+        by the reference (:583) — gets one auxiliary variable that has to be 1.
+        """
+        if with_implication_bdd:
+            raise NotImplementedError("split_qbdd: the optional implication BDD (bdd_collection.cpp:801-941) is not built")
+        assert chunk_size > 0
+        d = self.delims
+        off = int(d[b])
+        n_nodes = int(d[b + 1]) - off - 2
+        ins = self.instr[off:off + n_nodes + 2].astype(np.int64, copy=True)   # sink markers wrap to -1 / -2
+        widths = self.layer_widths(b)
+        n_layers = len(widths)
+        if n_layers <= chunk_size:
+            return [b], aux_var_start
+        loff = np.concatenate(([0], np.cumsum(widths))).tolist()             # local offsets of the layers, [n_layers] = n_nodes
+        n_chunks = (n_layers + chunk_size - 1) // chunk_size
+        aux = [aux_var_start]
+        for c in range(1, n_chunks - 1):
+            aux.append(aux[-1] + widths[c * chunk_size])
+        top_local, bot_local = off + n_nodes, off + n_nodes + 1
+        if int(ins[n_nodes, 2]) != -1:                                       # terminal order of the input: (bot, top)
+            top_local, bot_local = bot_local, top_local
+
+        new_nrs = []
+        for c in range(n_chunks):
+            first, last = c * chunk_size, min((c + 1) * chunk_size, n_layers) - 1
+            w_head = widths[first] if c > 0 else 0
+            w_tail = widths[last + 1] if c + 1 < n_chunks else 0
+            n_head = w_head * (w_head + 1) // 2
+            n_chunk = loff[last + 1] - loff[first]
+            n_tail = (w_tail * (w_tail + 1) // 2 + w_tail - 1) if w_tail else 0
+            BOT, TOP = n_head + n_chunk + n_tail, n_head + n_chunk + n_tail + 1
+            lo, hi, var = [], [], []
+
+            def emit(v, l, h):
+                var.append(v); lo.append(l); hi.append(h)
+
+            # head: row i has i+1 nodes; node (i, j) is "j-th candidate still open after a_0..a_{i-1}"
+            head = lambda i, j: i * (i + 1) // 2 + j
+            for i in range(w_head):
+                a = aux[c - 1] + i
+                lastrow = i + 1 == w_head
+                for j in range(i + 1):
+                    if not lastrow:
+                        emit(a, head(i + 1, 0), head(i + 1, 1)) if j == 0 else emit(a, head(i + 1, j + 1), BOT)
+                    else:
+                        emit(a, BOT, n_head + j) if j == 0 else emit(a, n_head + j, BOT)
+            # the chunk's own nodes, children shifted; children in layer last+1 land on the tail's first row
+            shift = n_head - loff[first]
+            for u in range(loff[first], loff[last + 1]):
+                l, h, v = (int(t) for t in ins[u])
+                cl = TOP if l == top_local else BOT if l == bot_local else l - off + shift
+                ch = TOP if h == top_local else BOT if h == bot_local else h - off + shift
+                emit(v, cl, ch)
+            # tail
+            if w_tail == 1:
+                emit(aux[c], BOT, TOP)
+            elif w_tail > 1:
+                W, base = w_tail, n_head + n_chunk
+                tail = lambda i, j: base + (j if i == 0 else W + W * (i - 1) + j - (i - 1) * (i - 2) // 2)
+                for j in range(W):
+                    emit(aux[c], BOT, tail(1, W - 1)) if j + 1 == W else emit(aux[c], tail(1, j), BOT)
+                for i in range(1, W - 1):
+                    n_row = W - i + 1
+                    for j in range(n_row):
+                        if j + 1 == n_row:
+                            emit(aux[c] + i, tail(i + 1, W - i - 1), BOT)
+                        elif j + 2 == n_row:
+                            emit(aux[c] + i, BOT, tail(i + 1, j))
+                        else:
+                            emit(aux[c] + i, tail(i + 1, j), BOT)
+                emit(aux[c] + W - 1, BOT, TOP)
+                emit(aux[c] + W - 1, TOP, BOT)
+            n = len(var)
+            assert n == BOT, (n, BOT)
+            lo = np.where(np.asarray(lo) == TOP, _T, np.where(np.asarray(lo) == BOT, _B, np.asarray(lo)))
+            hi = np.where(np.asarray(hi) == TOP, _T, np.where(np.asarray(hi) == BOT, _B, np.asarray(hi)))
+            new_nrs.append(self._append_local(lo[None, :].astype(np.int64), hi[None, :].astype(np.int64),
+                                              np.asarray(var, dtype=np.uint64)[None, :], 1, n, top_first=False))
+        return new_nrs, aux[-1] + widths[(n_chunks - 1) * chunk_size]
+
     def append(self, other: "BddCollection") -> None:
         ins = other.instr.copy()
         nt = ins[:, 2] < BOTSINK

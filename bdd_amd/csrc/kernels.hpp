@@ -1285,6 +1285,16 @@ __global__ void k_fill(T* __restrict__ p, T v, uint64_t n)
     if (i < n) p[i] = v;
 }
 
+// STREAM triad a = b + s*c with 16-byte accesses, grid-stride: the HBM ceiling bench.py quotes the sweep against
+static __global__ void __launch_bounds__(256) k_stream_triad(float4* __restrict__ a, const float4* __restrict__ b,
+                                                      const float4* __restrict__ c, float s, uint64_t n4)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float4 x = b[i], y = c[i];
+        a[i] = make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w);
+    }
+}
+
 // L-BFGS vector helpers (lbfgs_impl.h two-loop recursion; thrust::inner_product / transform there)
 template <typename TA, typename TB>
 __global__ void k_dot(const TA* __restrict__ a, const TB* __restrict__ b, double* __restrict__ partial, uint32_t n)

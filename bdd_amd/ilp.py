@@ -186,3 +186,58 @@ def to_bdd_collection(ilp: ILP) -> BddCollection:
                 continue
             raise RuntimeError("problem is infeasible") from e
     return col
+
+
+# --------------------------------------------------------------------------------------- long-BDD splitting
+# bdd_preprocessor.cpp:25-31 takes (SM count * max threads per SM) / 10 as the number of BDD nodes the device
+# works on concurrently; the same figure for MI355X: 256 CUs * 2048 resident work-items / 10.
+MI355X_CONCURRENT_NODES = 256 * 2048 // 10
+
+
+def compute_split_length(col: BddCollection, parallelism: int = MI355X_CONCURRENT_NODES) -> int:
+    """Largest chunk length >= 200 layers for which the hop-wise node counts, folded at that length, keep the
+    device at >= 50 % average occupancy (compute_split_length, bdd_preprocessor.cpp:32-121)."""
+    import numpy as np
+
+    widths = np.zeros(0, dtype=np.int64)
+    for b in range(col.nr_bdds()):
+        w = np.asarray(col.layer_widths(b), dtype=np.int64)
+        if w.size > widths.size:
+            widths = np.concatenate((widths, np.zeros(w.size - widths.size, np.int64)))
+        widths[: w.size] += w
+    if widths.size == 0:
+        return 0
+    widths = np.maximum.accumulate(widths[::-1])[::-1]          # a hop counts as busy as the busiest later hop
+
+    def occupancy(w):
+        return float(np.minimum(w, parallelism).sum()) / parallelism / w.size
+
+    length = int(widths.size)
+    while length >= 200:
+        folded = np.zeros(length, np.int64)
+        for start in range(0, widths.size, length):
+            part = widths[start:start + length]
+            folded[: part.size] += part
+        if occupancy(folded) >= 0.5:
+            break
+        length -= 1
+    return length
+
+
+def split_long_bdds(col: BddCollection, nr_variables: int, split_length: int = None,
+                    with_implication_bdd: bool = False, parallelism: int = MI355X_CONCURRENT_NODES):
+    """The splitting stage of bdd_preprocessor::add_ilp (bdd_preprocessor.cpp:372-415): every BDD with more than
+    `split_length` variables (None: compute_split_length) is replaced by its split_qbdd chunks; auxiliary
+    variables are numbered from `nr_variables`.  Returns (#BDDs split, number of variables afterwards)."""
+    if split_length is None:
+        split_length = compute_split_length(col, parallelism)
+    if split_length <= 0:
+        return 0, nr_variables
+    next_var, removed = nr_variables, []
+    for b in range(col.nr_bdds()):
+        if len(col.layer_widths(b)) > split_length:
+            new_nrs, next_var = col.split_qbdd(b, split_length, next_var, with_implication_bdd)
+            if len(new_nrs) > 1:
+                removed.append(b)
+    col.remove(removed)
+    return len(removed), next_var

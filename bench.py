@@ -88,6 +88,20 @@ def main():
     solver.set_profiling(False)
     lb = solver.lower_bound()
 
+    triad_gbs = lb_rate = None
+    if rank == 0:
+        # outside the timed region: (1) the same loop with the lower bound fetched every iteration, as
+        # run_solver does (one extra plain backward sweep + reduce + 8-byte D2H per iteration); (2) the
+        # STREAM-triad bandwidth of this box (3 x 1 GiB per launch), the measured ceiling next to the 8 TB/s spec
+        n_lb = min(args.steps, 100)
+        solver.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_lb):
+            solver.iteration()
+            solver.lower_bound()
+        lb_rate = n_lb / (time.perf_counter() - t0)
+        triad_gbs = 3 * (1 << 30) / (solver.time_kernel(6, 20) * 1e-3) / 1e9
+
     if rank == 0:
         its = aggregate_rate(world, args.steps, dt)
         names = ["forward_mm", "backward_mm", "finish_delta", "other"]
@@ -132,7 +146,10 @@ def main():
                 "avg_launch_ms": {names[i]: avg_ms[i] for i in range(3)},
                 "timed_launches": {names[i]: prof["launches"][i] for i in range(3)},
                 "whole_iteration_GBs": 2 * bytes_pass * its / world / 1e9,
+                "stream_triad_GBs": triad_gbs,
+                "frac_of_stream_triad": achieved / triad_gbs if triad_gbs else None,
             },
+            "value_with_lower_bound_every_iteration": lb_rate,
             "lower_bound_after": {"iterations": args.warmup + args.steps, "value": lb},
         }
         if not args.no_cpu_baseline:
@@ -211,8 +228,12 @@ def cpu_baseline(col, costs, args, sizes):
         rate = 1.0 / (time.perf_counter() - t1)
         if rate > best:
             best, cores = rate, th
+    o.set_threads(1)
+    t1 = time.perf_counter()
+    o.iteration()
+    single = 1.0 / (time.perf_counter() - t1)
     o.set_threads(cores)
-    warm = 1 + len({min(ncpu, t) for t in (16, 32, 64, 128, 256)})
+    warm = 2 + len({min(ncpu, t) for t in (16, 32, 64, 128, 256)})
     n, t0 = 0, time.perf_counter()
     while True:
         o.iteration()
@@ -230,6 +251,8 @@ def cpu_baseline(col, costs, args, sizes):
         "unit": "iterations/s",
         "cores": cores,
         "kind": "port",
+        "single_thread_value": single,
+        "value_per_core": n / el / cores,
         "sample": f"{n} iterations of the same {sizes['N']}-node instance after {warm} warm-up / thread-count-probe "
                   f"iterations, oracle/mma_oracle.c with OpenMP over BDDs ({cores} of {ncpu} hardware threads: the "
                   f"fastest of 16..256), {args.precision}",

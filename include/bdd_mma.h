@@ -224,7 +224,10 @@ int bddmma_get_profile(bddmma_solver* s, bddmma_profile* out);  /* synchronises 
 int bddmma_time_iterations(bddmma_solver* s, double omega, uint64_t n, double* ms);
 /* Time `reps` back-to-back launches of one kernel class with hipEvents on the handle's stream
  * (kernel-level benchmarking; leaves the sweep state invalid).  kind: 0 forward_run sweep, 1 backward_run
- * sweep, 2 forward_mm sweep, 3 backward_mm sweep, 4 exchange reduce, 5 exchange broadcast. */
+ * sweep, 2 forward_mm sweep, 3 backward_mm sweep, 4 exchange reduce, 5 exchange broadcast, 6 STREAM triad
+ * a = b + s*c over three temporary arrays of BDDMMA_TRIAD_BYTES each (3 * BDDMMA_TRIAD_BYTES of HBM traffic
+ * per launch: the measured bandwidth ceiling of the box the roofline is quoted next to). */
+#define BDDMMA_TRIAD_BYTES (1ull << 30)
 int bddmma_time_kernel(bddmma_solver* s, int kind, uint64_t reps, double* ms);
 /* HBM bytes held by the handle. */
 uint64_t bddmma_device_bytes(const bddmma_solver* s);

@@ -63,8 +63,26 @@ def record(name, rc: RefCollection, costs):
     print(name, "V", V, "bdds", rc.nr_bdds(), "lb_init", out["lb_init_f64"], "iter_lb[-1]", out["iter_lb_f64"][-1])
 
 
+def record_split(name, build, chunk, aux0):
+    """bdd_collection::split_qbdd of the reference on BDD 0 (then the original removed): input and output storage"""
+    rc = RefCollection()
+    build(rc)
+    before = rc.export()
+    n, next_aux = rc.split_qbdd(0, chunk, aux0)
+    after = rc.export()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), in_instr=before.instr, in_delims=before.delims,
+                        chunk=chunk, aux0=aux0, n_new=n, next_aux=next_aux, out_instr=after.instr, out_delims=after.delims)
+    print(name, "chunks", n, "next aux", next_aux, "nodes", before.nr_bdd_nodes(), "->", after.nr_bdd_nodes())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    record_split("split_covering_10", lambda x: x.add_covering(list(range(10))), 3, 10)
+    record_split("split_simplex_9", lambda x: x.add_simplex(list(range(9))), 4, 20)
+    record_split("split_knapsack_12", lambda x: x.add_linear([1, 2, 3, 2, 1, 3, 2, 1, 2, 3, 1, 2], "<=", 11, list(range(12))), 4, 12)
+    record_split("split_equality_12", lambda x: x.add_linear([1, 2, 3, 2, 1, 3, 2, 1, 2, 3, 1, 2], "=", 9, list(range(0, 24, 2))), 5, 30)
+    record_split("split_cardinality_11", lambda x: x.add_cardinality(list(range(11)), 4), 2, 11)
+    record_split("split_not_needed", lambda x: x.add_covering(list(range(4))), 4, 4)
     ilp = assignment_ilp(3)
     record("matching_3x3_diag", ref_collection_from_ilp(ilp), ilp.objective)
     c = -np.ones((3, 3)); c[:, 0] = -2

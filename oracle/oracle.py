@@ -195,6 +195,14 @@ class RefCollection:
         self.R.ref_col_add_linear.restype = C.c_long
         return int(self.R.ref_col_add_linear(self.h, C.c_size_t(v.size), _p(c), C.c_int(code), C.c_int(rhs), _p(v)))
 
+    def split_qbdd(self, bdd_nr, chunk_size, aux_var_start, with_implication_bdd=False):
+        """reference split_qbdd + removal of the original BDD; -> (#BDDs produced, next free aux variable)"""
+        na = C.c_size_t(0)
+        self.R.ref_col_split_qbdd.restype = C.c_long
+        n = self.R.ref_col_split_qbdd(self.h, C.c_size_t(bdd_nr), C.c_size_t(chunk_size), C.c_size_t(aux_var_start),
+                                      C.c_int(int(with_implication_bdd)), C.byref(na))
+        return int(n), int(na.value)
+
     def nr_bdds(self):
         self.R.ref_col_nr_bdds.restype = C.c_size_t
         return int(self.R.ref_col_nr_bdds(self.h))

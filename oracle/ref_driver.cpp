@@ -272,6 +272,19 @@ long ref_col_add_linear(void* c, size_t n, const int* coeffs, int ineq, int rhs,
     return finish_bdd(col, bdd_nr, vars, n);
 }
 
+// bdd_collection::split_qbdd (bdd_collection.cpp:507-949) on BDD `bdd_nr`, then remove the original as
+// bdd_preprocessor.cpp:393-412 does.  Returns the number of BDDs the split produced (1 = not split, nothing
+// removed); *next_aux receives the next free auxiliary variable.
+long ref_col_split_qbdd(void* c, size_t bdd_nr, size_t chunk_size, size_t aux_var_start, int with_implication,
+                        size_t* next_aux)
+{
+    auto& col = *static_cast<bdd_collection*>(c);
+    const auto [new_nrs, na] = col.split_qbdd(bdd_nr, chunk_size, aux_var_start, with_implication != 0);
+    *next_aux = na;
+    if (new_nrs.size() > 1) col.remove(bdd_nr);
+    return (long)new_nrs.size();
+}
+
 size_t ref_col_nr_bdds(void* c) { return static_cast<bdd_collection*>(c)->nr_bdds(); }
 size_t ref_col_nr_instructions(void* c)
 {

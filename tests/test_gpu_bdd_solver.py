@@ -77,3 +77,37 @@ def test_command_line(tmp_path):
     out = subprocess.run([sys.executable, "-m", "bdd_amd.bdd_solver_cl", str(p)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "lower bound = -6" in out.stdout
+
+
+def long_row_lp(n=60, need=5, seed=3):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.integers(1, 50, n)
+    names = [f"x{i}" for i in range(n)]
+    lp = "Minimize\n" + " + ".join(f"{int(ci)} {v}" for ci, v in zip(c, names)) + "\nSubject To\n"
+    lp += " + ".join(names) + f" >= {need}\n"
+    for i in range(0, n - 1, 7):      # a few short rows so that the instance is not a single BDD
+        lp += f"{names[i]} + {names[i + 1]} <= 1\n"
+    lp += "Bounds\nBinaries\n" + "\n".join(names) + "\nEnd\n"
+    return lp, c
+
+
+def test_split_bdds_same_parity_and_bound():
+    """`"split bdds"` (bdd_solver.cpp:112-123, bdd_preprocessor.cpp:372-415): the long row is cut into chunks
+    coupled by auxiliary variables; GPU and oracle agree on the split instance, and the split relaxation
+    reaches the bound of the un-split one (both decompositions are exact for this instance)."""
+    from oracle.oracle import Oracle
+
+    lp, c = long_row_lp()
+    tc = dict(TC); tc["maximum iterations"] = 3000
+    full = bdd_solver(cfg(lp, **{"termination criteria": tc}), quiet=True).solve()
+    split = bdd_solver(cfg(lp, **{"termination criteria": tc, "split bdds": {"split length": 10}}), quiet=True).solve()
+    assert split.bdd_col.nr_bdds() == full.bdd_col.nr_bdds() + 5
+    assert max(len(split.bdd_col.layer_widths(b)) for b in range(split.bdd_col.nr_bdds())) <= 10 + 2 * 6
+    assert split.solver.nr_variables() > full.solver.nr_variables()
+    costs = np.zeros(split.solver.nr_variables()); costs[: len(c)] = c
+    o = Oracle(split.bdd_col, costs, "double")
+    for _ in range(3000):
+        o.iteration()
+    assert abs(o.lower_bound() - split.lower_bound()) <= 1e-7 * max(1.0, abs(o.lower_bound()))
+    assert split.lower_bound() <= full.lower_bound() + 1e-6
+    assert split.lower_bound() >= full.lower_bound() - 1e-2 * abs(full.lower_bound())

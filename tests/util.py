@@ -7,7 +7,18 @@ import numpy as np
 from bdd_amd.bdd_collection import BddCollection
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+_ALL = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+GOLDEN = [n for n in _ALL if not n.startswith("split_")]        # MMA traces (oracle/make_golden.py: record)
+SPLIT_GOLDEN = [n for n in _ALL if n.startswith("split_")]      # split_qbdd input/output pairs (record_split)
+
+
+def collection_from_arrays(instr, delims):
+    col = BddCollection()
+    col._chunks = [np.asarray(instr).astype(np.uint64)]
+    col._delims = [np.asarray(delims).astype(np.uint64)]
+    col._n = int(instr.shape[0])
+    col._nb = int(delims.shape[0]) - 1
+    return col
 
 
 def load_golden(name):
