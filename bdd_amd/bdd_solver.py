@@ -18,8 +18,8 @@ import time
 
 import numpy as np
 
-from . import capi
-from .ilp import ILP, parse_lp, split_long_bdds, to_bdd_collection
+from . import capi, native
+from .ilp import ILP, parse_lp
 from .solver import bdd_hip_lbfgs, bdd_hip_parallel_mma, run_solver
 
 GPU_MMA = {"cuda parallel mma", "hip parallel mma"}
@@ -82,15 +82,18 @@ class bdd_solver:
     # ------------------------------------------------------------------ transform_to_BDDs (:112-123)
     def transform_to_BDDs(self, ilp: ILP):
         _log("[bdd solver] Compute BDDs", self.quiet)
-        col = to_bdd_collection(ilp)
+        # conversion and splitting run in the C++ input stage (bdd_amd/csrc/host/, include/bdd_ilp.h);
+        # ilp.to_bdd_collection / ilp.split_long_bdds are the same algorithms in Python (tests/test_native_host.py)
+        rows = [(c.coefficients, c.variables, c.ineq, c.rhs) for c in ilp.constraints]
+        split_length = None
         if "split bdds" in self.config:
             sb = self.config["split bdds"] or {}
             # the reference tests contains("implication bdd") and then reads key "implication" (:119); accept both
             if sb.get("implication bdd", sb.get("implication", False)):
                 raise RuntimeError("split bdds: the implication bdd is not available in this backend")
-            n, _ = split_long_bdds(col, max(col.nr_variables(), ilp.nr_variables()), sb.get("split length"))
-            _log(f"[bdd preprocessor] Split {n} BDDs", self.quiet)
-            _log(f"[bdd preprocessor] final #BDDs = {col.nr_bdds()}", self.quiet)
+            split_length = int(sb.get("split length", 0))       # 0: the occupancy rule of compute_split_length
+        col = native.rows_to_bdd_collection(rows, split_length=split_length, nr_variables=ilp.nr_variables())
+        _log(f"[bdd preprocessor] final #BDDs = {col.nr_bdds()}", self.quiet)
         return col
 
     # ------------------------------------------------------------------ construct_solver (:130-267)

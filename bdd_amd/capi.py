@@ -100,6 +100,32 @@ SIGNATURES = {
     "bddmma_layout_copy": (_I, [_V, _I, _V]),
 }
 
+# every symbol include/bdd_ilp.h declares (host-side input stage)
+_I64P, _U64P = C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
+ILP_SIGNATURES = {
+    "bddilp_last_error": (C.c_char_p, []),
+    "bddilp_parse_lp": (_I, [C.c_char_p, C.POINTER(_V)]),
+    "bddilp_destroy": (None, [_V]),
+    "bddilp_nr_variables": (_U64, [_V]),
+    "bddilp_nr_constraints": (_U64, [_V]),
+    "bddilp_variable_name": (C.c_char_p, [_V, _U64]),
+    "bddilp_objective": (_I, [_V, _V, C.POINTER(_D)]),
+    "bddilp_constraint_size": (_U64, [_V, _U64]),
+    "bddilp_constraint": (_I, [_V, _U64, _V, _V, C.POINTER(_I), C.POINTER(C.c_int64)]),
+    "bddilp_constraint_name": (C.c_char_p, [_V, _U64]),
+    "bddilp_normalize": (_I, [_V]),
+    "bddilp_to_bdds": (_I, [_V, _I, _U64, C.POINTER(_V)]),
+    "bddilp_bdds_create": (_I, [C.POINTER(_V)]),
+    "bddilp_bdds_add_row": (_I, [_V, _V, _V, _U64, _I, C.c_int64, C.POINTER(_I)]),
+    "bddilp_bdds_split": (_I, [_V, _U64, _U64, _U64P, _U64P]),
+    "bddilp_bdds_destroy": (None, [_V]),
+    "bddilp_bdds_nr_bdds": (_U64, [_V]),
+    "bddilp_bdds_nr_instructions": (_U64, [_V]),
+    "bddilp_bdds_nr_variables": (_U64, [_V]),
+    "bddilp_bdds_instructions": (_V, [_V]),
+    "bddilp_bdds_delimiters": (_V, [_V]),
+}
+
 _lib = None
 
 
@@ -119,7 +145,7 @@ def lib():
             raise RuntimeError(f"{LIB_PATH} is missing: run `make -C bdd_amd/csrc` (or __graft_entry__.build()); "
                                "bdd_amd has no CPU fallback")
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(ILP_SIGNATURES.items()):
             f = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
             f.restype = res
             f.argtypes = args

@@ -656,20 +656,24 @@ struct SolverT final : SolverBase {
         }
         return update_costs(c0, n_vars, c1, n_vars, precision, 1);  // :327
     }
-    // STREAM triad over three BDDMMA_TRIAD_BYTES arrays allocated for the duration of the call
-    int time_stream_triad(uint64_t reps, double* ms)
+    // STREAM triad / copy over temporary BDDMMA_TRIAD_BYTES arrays (n4 is a multiple of 4 * grid * 256)
+    int time_stream(bool copy, uint64_t reps, double* ms)
     {
         const uint64_t n4 = BDDMMA_TRIAD_BYTES / 16;
-        float4 *a = nullptr, *b = nullptr, *c = nullptr;
+        stream_v4 *a = nullptr, *b = nullptr, *c = nullptr;
         HIPCHK(hipMalloc(&a, BDDMMA_TRIAD_BYTES));
         HIPCHK(hipMalloc(&b, BDDMMA_TRIAD_BYTES));
         HIPCHK(hipMalloc(&c, BDDMMA_TRIAD_BYTES));
         HIPCHK(hipMemsetAsync(b, 0, BDDMMA_TRIAD_BYTES, stream));
         HIPCHK(hipMemsetAsync(c, 0, BDDMMA_TRIAD_BYTES, stream));
-        const unsigned grid = 256 * 16;
-        k_stream_triad<<<grid, 256, 0, stream>>>(a, b, c, 3.0f, n4);
+        const unsigned grid = 16384;
+        auto once = [&]() {
+            if (copy) k_stream<true><<<grid, 256, 0, stream>>>(a, b, c, 3.0f, n4);
+            else k_stream<false><<<grid, 256, 0, stream>>>(a, b, c, 3.0f, n4);
+        };
+        once();
         HIPCHK(hipEventRecord(ev_t0, stream));
-        for (uint64_t i = 0; i < reps; ++i) k_stream_triad<<<grid, 256, 0, stream>>>(a, b, c, 3.0f, n4);
+        for (uint64_t i = 0; i < reps; ++i) once();
         HIPCHK(hipEventRecord(ev_t1, stream));
         HIPCHK(hipEventSynchronize(ev_t1));
         float f = 0.f;
@@ -696,7 +700,7 @@ struct SolverT final : SolverBase {
                 default: err = "unknown kernel kind"; return BDDMMA_ERR_INVALID_ARGUMENT;
             }
         };
-        if (kind == 6) return time_stream_triad(reps, ms);
+        if (kind == 6 || kind == 7) return time_stream(kind == 7, reps, ms);
         if ((rc = once())) return rc;  // warm-up
         HIPCHK(hipEventRecord(ev_t0, stream));
         for (uint64_t i = 0; i < reps; ++i)

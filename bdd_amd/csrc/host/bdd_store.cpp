@@ -1,0 +1,348 @@
+// bdd_store.cpp — see bdd_store.hpp.  Host-only C++17.
+#include "bdd_store.hpp"
+
+#include <algorithm>
+#include <cassert>
+#include <map>
+#include <set>
+
+namespace bddmma_host {
+
+static inline bool is_terminal(const bddmma_instruction& i) { return i.index >= BDDMMA_BOTSINK; }
+
+size_t bdd_store::nr_variables() const
+{
+    uint64_t m = 0;
+    bool any = false;
+    for (const auto& i : instructions)
+        if (!is_terminal(i)) {
+            m = std::max(m, i.index);
+            any = true;
+        }
+    return any ? m + 1 : 0;
+}
+
+std::vector<size_t> bdd_store::variables(size_t b) const
+{
+    std::vector<size_t> out;
+    for (size_t i = delimiters[b]; i + 2 < delimiters[b + 1]; ++i)
+        if (out.empty() || out.back() != instructions[i].index) out.push_back(instructions[i].index);
+    return out;
+}
+
+std::vector<size_t> bdd_store::layer_widths(size_t b) const
+{
+    std::vector<size_t> out;
+    uint64_t prev = BDDMMA_TOPSINK;
+    for (size_t i = delimiters[b]; i + 2 < delimiters[b + 1]; ++i) {
+        if (out.empty() || instructions[i].index != prev) out.push_back(0);
+        ++out.back();
+        prev = instructions[i].index;
+    }
+    return out;
+}
+
+bool bdd_store::evaluate(size_t b, const std::vector<char>& x) const
+{
+    size_t i = delimiters[b];
+    for (;;) {
+        const auto& n = instructions[i];
+        if (n.index == BDDMMA_TOPSINK) return true;
+        if (n.index == BDDMMA_BOTSINK) return false;
+        i = x[n.index] ? n.hi : n.lo;
+    }
+}
+
+size_t bdd_store::append_local(const std::vector<long>& lo, const std::vector<long>& hi, const std::vector<size_t>& var, bool top_first)
+{
+    const size_t n = var.size(), base = instructions.size();
+    const size_t top = base + n + (top_first ? 0 : 1), bot = base + n + (top_first ? 1 : 0);
+    auto abs = [&](long c) -> uint64_t { return c == TOP_LOCAL ? top : c == BOT_LOCAL ? bot : base + (size_t)c; };
+    instructions.reserve(base + n + 2);
+    for (size_t i = 0; i < n; ++i) instructions.push_back({abs(lo[i]), abs(hi[i]), var[i]});
+    const bddmma_instruction t{BDDMMA_TOPSINK, BDDMMA_TOPSINK, BDDMMA_TOPSINK}, f{BDDMMA_BOTSINK, BDDMMA_BOTSINK, BDDMMA_BOTSINK};
+    instructions.push_back(top_first ? t : f);
+    instructions.push_back(top_first ? f : t);
+    delimiters.push_back(instructions.size());
+    return nr_bdds() - 1;
+}
+
+// Two states per level after the first variable: {sum == 0, sum == 1} (simplex) or {uncovered, covered}.
+static void two_state_chain(size_t n, bool covering, std::vector<long>& lo, std::vector<long>& hi, std::vector<size_t>& layer)
+{
+    constexpr long T = -1, B = -2;
+    const size_t nn = 2 * n - 1;
+    lo.assign(nn, 0); hi.assign(nn, 0); layer.assign(nn, 0);
+    lo[0] = 1; hi[0] = 2;
+    for (size_t i = 1; i + 1 < n; ++i) {
+        const size_t a = 2 * i - 1, c = 2 * i;
+        lo[a] = 2 * i + 1; hi[a] = 2 * i + 2;
+        lo[c] = 2 * i + 2; hi[c] = covering ? (long)(2 * i + 2) : B;
+        layer[a] = layer[c] = i;
+    }
+    const size_t a = 2 * n - 3, c = 2 * n - 2;
+    lo[a] = B; hi[a] = T;
+    lo[c] = T; hi[c] = covering ? T : B;
+    layer[a] = layer[c] = n - 1;
+}
+
+size_t bdd_store::add_simplex(const std::vector<size_t>& vars)
+{
+    assert(!vars.empty());
+    if (vars.size() == 1) return append_local({BOT_LOCAL}, {TOP_LOCAL}, vars, false);
+    std::vector<long> lo, hi;
+    std::vector<size_t> layer, var;
+    two_state_chain(vars.size(), false, lo, hi, layer);
+    for (size_t l : layer) var.push_back(vars[l]);
+    return append_local(lo, hi, var, false);
+}
+
+size_t bdd_store::add_covering(const std::vector<size_t>& vars)
+{
+    assert(!vars.empty());
+    // a single-node not_all_false BDD already is a QBDD: make_qbdd is skipped and the sinks stay (bot, top)
+    if (vars.size() == 1) return append_local({BOT_LOCAL}, {TOP_LOCAL}, vars, false);
+    std::vector<long> lo, hi;
+    std::vector<size_t> layer, var;
+    two_state_chain(vars.size(), true, lo, hi, layer);
+    for (size_t l : layer) var.push_back(vars[l]);
+    return append_local(lo, hi, var, true);  // make_qbdd output has the top sink first
+}
+
+row_status bdd_store::add_linear(const std::vector<long>& coeffs, ineq_t ineq, long rhs, const std::vector<size_t>& vars, size_t* bdd_nr)
+{
+    std::vector<long> a = coeffs;
+    std::vector<size_t> vs = vars;
+    assert(a.size() == vs.size() && !a.empty());
+    auto sat = [&](long s) { return ineq == ineq_t::le ? s <= rhs : ineq == ineq_t::eq ? s == rhs : s >= rhs; };
+    constexpr long T = TOP_LOCAL, B = BOT_LOCAL;
+    for (;;) {
+        const size_t n = a.size();
+        // reachable partial sums per level (sorted)
+        std::vector<std::vector<long>> levels(n + 1);
+        levels[0] = {0};
+        for (size_t i = 0; i < n; ++i) {
+            std::vector<long> nxt;
+            nxt.reserve(2 * levels[i].size());
+            for (long s : levels[i]) { nxt.push_back(s); nxt.push_back(s + a[i]); }
+            std::sort(nxt.begin(), nxt.end());
+            nxt.erase(std::unique(nxt.begin(), nxt.end()), nxt.end());
+            levels[i + 1] = std::move(nxt);
+        }
+        bool all_true = true;
+        for (long s : levels[n]) all_true = all_true && sat(s);
+        // bottom-up canonical ids per partial sum: T / B or an index into the level's table of (lo, hi) pairs
+        std::map<long, long> cur;
+        for (long s : levels[n]) cur[s] = sat(s) ? T : B;
+        std::vector<std::vector<std::pair<long, long>>> tables(n);
+        for (size_t i = n; i-- > 0;) {
+            std::map<std::pair<long, long>, long> uniq;
+            std::map<long, long> nw;
+            for (long s : levels[i]) {  // ascending partial sums: first-seen order of the pairs is deterministic
+                const std::pair<long, long> key{cur.at(s), cur.at(s + a[i])};
+                if (key.first == B && key.second == B) { nw[s] = B; continue; }
+                auto it = uniq.find(key);
+                if (it == uniq.end()) {
+                    it = uniq.emplace(key, (long)tables[i].size()).first;
+                    tables[i].push_back(key);
+                }
+                nw[s] = it->second;
+            }
+            cur = std::move(nw);
+        }
+        const long root = cur.at(0);
+        if (root == B) return row_status::infeasible;
+        if (all_true) return row_status::trivially_true;
+        // nodes reachable from the root
+        std::vector<std::set<long>> reach(n);
+        reach[0].insert(root);
+        for (size_t i = 0; i + 1 < n; ++i)
+            for (long k : reach[i]) {
+                if (tables[i][k].first >= 0) reach[i + 1].insert(tables[i][k].first);
+                if (tables[i][k].second >= 0) reach[i + 1].insert(tables[i][k].second);
+            }
+        // variables the function does not depend on (lo == hi on every node of the level) are not in the reference's BDD
+        std::vector<size_t> keep;
+        for (size_t i = 0; i < n; ++i) {
+            bool dead = true;
+            for (long k : reach[i]) dead = dead && tables[i][k].first == tables[i][k].second;
+            if (!dead) keep.push_back(i);
+        }
+        if (keep.size() != n) {
+            std::vector<long> a2;
+            std::vector<size_t> v2;
+            for (size_t i : keep) { a2.push_back(a[i]); v2.push_back(vs[i]); }
+            a.swap(a2); vs.swap(v2);
+            if (a.empty()) return row_status::trivially_true;  // cannot happen for a non-constant function; defensive
+            continue;
+        }
+        std::vector<std::map<long, size_t>> remap(n);
+        std::vector<size_t> offs(n + 1, 0);
+        for (size_t i = 0; i < n; ++i) {
+            size_t j = 0;
+            for (long k : reach[i]) remap[i][k] = j++;
+            offs[i + 1] = offs[i] + reach[i].size();
+        }
+        std::vector<long> lo(offs[n]), hi(offs[n]);
+        std::vector<size_t> var(offs[n]);
+        for (size_t i = 0; i < n; ++i)
+            for (const auto& [k, j] : remap[i]) {
+                const auto [l, h] = tables[i][k];
+                lo[offs[i] + j] = l < 0 ? l : (long)(offs[i + 1] + remap[i + 1].at(l));
+                hi[offs[i] + j] = h < 0 ? h : (long)(offs[i + 1] + remap[i + 1].at(h));
+                var[offs[i] + j] = vs[i];
+            }
+        const size_t nr = append_local(lo, hi, var, false);
+        if (bdd_nr) *bdd_nr = nr;
+        return row_status::ok;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ splitting
+void bdd_store::remove(std::vector<size_t> bdd_nrs)
+{
+    std::sort(bdd_nrs.begin(), bdd_nrs.end());
+    bdd_nrs.erase(std::unique(bdd_nrs.begin(), bdd_nrs.end()), bdd_nrs.end());
+    if (bdd_nrs.empty()) return;
+    std::vector<bddmma_instruction> out;
+    std::vector<uint64_t> nd{0};
+    out.reserve(instructions.size());
+    size_t next = 0;
+    for (size_t b = 0; b < nr_bdds(); ++b) {
+        if (next < bdd_nrs.size() && bdd_nrs[next] == b) { ++next; continue; }
+        const int64_t shift = (int64_t)out.size() - (int64_t)delimiters[b];
+        for (size_t i = delimiters[b]; i < delimiters[b + 1]; ++i) {
+            bddmma_instruction x = instructions[i];
+            if (!is_terminal(x)) { x.lo = (uint64_t)((int64_t)x.lo + shift); x.hi = (uint64_t)((int64_t)x.hi + shift); }
+            out.push_back(x);
+        }
+        nd.push_back(out.size());
+    }
+    instructions.swap(out);
+    delimiters.swap(nd);
+}
+
+std::pair<std::vector<size_t>, size_t> bdd_store::split_qbdd(size_t b, size_t chunk, size_t aux0)
+{
+    assert(chunk > 0);
+    const size_t off = delimiters[b], n_nodes = delimiters[b + 1] - off - 2;
+    const std::vector<size_t> widths = layer_widths(b);
+    const size_t n_layers = widths.size();
+    if (n_layers <= chunk) return {{b}, aux0};
+    std::vector<size_t> loff(n_layers + 1, 0);
+    for (size_t l = 0; l < n_layers; ++l) loff[l + 1] = loff[l] + widths[l];
+    const size_t n_chunks = (n_layers + chunk - 1) / chunk;
+    std::vector<size_t> aux{aux0};
+    for (size_t c = 1; c + 1 < n_chunks; ++c) aux.push_back(aux.back() + widths[c * chunk]);
+    const std::vector<bddmma_instruction> src(instructions.begin() + off, instructions.begin() + off + n_nodes + 2);  // appends below reallocate
+    const size_t top_abs = src[n_nodes].index == BDDMMA_TOPSINK ? off + n_nodes : off + n_nodes + 1;
+    const size_t bot_abs = top_abs == off + n_nodes ? off + n_nodes + 1 : off + n_nodes;
+
+    std::vector<size_t> new_nrs;
+    for (size_t c = 0; c < n_chunks; ++c) {
+        const size_t first = c * chunk, last = std::min((c + 1) * chunk, n_layers) - 1;
+        const size_t w_head = c > 0 ? widths[first] : 0;
+        const size_t w_tail = c + 1 < n_chunks ? widths[last + 1] : 0;
+        const size_t n_head = w_head * (w_head + 1) / 2;
+        const size_t n_chunk = loff[last + 1] - loff[first];
+        const size_t n_tail = w_tail ? w_tail * (w_tail + 1) / 2 + w_tail - 1 : 0;
+        std::vector<long> lo, hi;
+        std::vector<size_t> var;
+        auto emit = [&](size_t v, long l, long h) { var.push_back(v); lo.push_back(l); hi.push_back(h); };
+        // head: row i has i+1 nodes; node (i, j) = "the j-th candidate is still open after a_0 .. a_{i-1}"
+        auto head = [](size_t i, size_t j) { return (long)(i * (i + 1) / 2 + j); };
+        for (size_t i = 0; i < w_head; ++i) {
+            const size_t a = aux[c - 1] + i;
+            const bool last_row = i + 1 == w_head;
+            for (size_t j = 0; j <= i; ++j) {
+                if (!last_row) {
+                    if (j == 0) emit(a, head(i + 1, 0), head(i + 1, 1));
+                    else emit(a, head(i + 1, j + 1), BOT_LOCAL);
+                } else {
+                    if (j == 0) emit(a, BOT_LOCAL, (long)(n_head + j));
+                    else emit(a, (long)(n_head + j), BOT_LOCAL);
+                }
+            }
+        }
+        // the chunk's own nodes; children in layer last+1 land on the first row of the tail
+        const long shift = (long)n_head - (long)loff[first];
+        for (size_t u = loff[first]; u < loff[last + 1]; ++u) {
+            auto child = [&](uint64_t x) -> long {
+                return x == top_abs ? TOP_LOCAL : x == bot_abs ? BOT_LOCAL : (long)(x - off) + shift;
+            };
+            emit(src[u].index, child(src[u].lo), child(src[u].hi));
+        }
+        // tail: behind node j of the cut layer only the matching one-hot assignment of the cut's variables survives
+        if (w_tail == 1) {
+            emit(aux[c], BOT_LOCAL, TOP_LOCAL);  // (the reference asserts w_tail > 1, bdd_collection.cpp:583)
+        } else if (w_tail > 1) {
+            const size_t W = w_tail, base = n_head + n_chunk;
+            auto tail = [&](size_t i, size_t j) {
+                return (long)(base + (i == 0 ? j : W + W * (i - 1) + j - (i - 1) * (i - 2) / 2));
+            };
+            for (size_t j = 0; j < W; ++j) {
+                if (j + 1 == W) emit(aux[c], BOT_LOCAL, tail(1, W - 1));
+                else emit(aux[c], tail(1, j), BOT_LOCAL);
+            }
+            for (size_t i = 1; i + 1 < W; ++i) {
+                const size_t n_row = W - i + 1;
+                for (size_t j = 0; j < n_row; ++j) {
+                    if (j + 1 == n_row) emit(aux[c] + i, tail(i + 1, W - i - 1), BOT_LOCAL);
+                    else if (j + 2 == n_row) emit(aux[c] + i, BOT_LOCAL, tail(i + 1, j));
+                    else emit(aux[c] + i, tail(i + 1, j), BOT_LOCAL);
+                }
+            }
+            emit(aux[c] + W - 1, BOT_LOCAL, TOP_LOCAL);
+            emit(aux[c] + W - 1, TOP_LOCAL, BOT_LOCAL);
+        }
+        assert(var.size() == n_head + n_chunk + n_tail);
+        (void)n_tail;
+        new_nrs.push_back(append_local(lo, hi, var, false));
+    }
+    return {new_nrs, aux.back() + widths[(n_chunks - 1) * chunk]};
+}
+
+size_t bdd_store::compute_split_length(size_t parallelism) const
+{
+    std::vector<size_t> widths;
+    for (size_t b = 0; b < nr_bdds(); ++b) {
+        const auto w = layer_widths(b);
+        if (w.size() > widths.size()) widths.resize(w.size(), 0);
+        for (size_t i = 0; i < w.size(); ++i) widths[i] += w[i];
+    }
+    if (widths.empty()) return 0;
+    for (size_t i = widths.size() - 1; i-- > 0;) widths[i] = std::max(widths[i], widths[i + 1]);
+    auto occupancy = [&](const std::vector<size_t>& w) {
+        double s = 0;
+        for (size_t x : w) s += (double)std::min(x, parallelism) / (double)parallelism;
+        return s / (double)w.size();
+    };
+    size_t length = widths.size();
+    for (; length >= 200; --length) {
+        std::vector<size_t> folded(length, 0);
+        for (size_t i = 0; i < widths.size(); ++i) folded[i % length] += widths[i];
+        if (occupancy(folded) >= 0.5) break;
+    }
+    return length;
+}
+
+std::pair<size_t, size_t> bdd_store::split_long_bdds(size_t nr_vars, size_t split_length, size_t parallelism)
+{
+    if (split_length == 0) split_length = compute_split_length(parallelism);
+    if (split_length == 0) return {0, nr_vars};
+    size_t next = nr_vars;
+    std::vector<size_t> removed;
+    const size_t nb = nr_bdds();
+    for (size_t b = 0; b < nb; ++b) {
+        if (layer_widths(b).size() > split_length) {
+            auto [nrs, na] = split_qbdd(b, split_length, next);
+            next = na;
+            if (nrs.size() > 1) removed.push_back(b);
+        }
+    }
+    const size_t n = removed.size();
+    remove(std::move(removed));
+    return {n, next};
+}
+
+}  // namespace bddmma_host

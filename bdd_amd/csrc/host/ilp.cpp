@@ -1,0 +1,288 @@
+// ilp.cpp — see ilp.hpp.
+#include "ilp.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdlib>
+#include <numeric>
+#include <set>
+#include <sstream>
+
+namespace bddmma_host {
+
+bool constraint::is_simplex() const
+{
+    if (ineq != ineq_t::eq || rhs == 0) return false;
+    for (long c : coefficients)
+        if (c != rhs) return false;
+    return true;
+}
+
+size_t ilp_input::var(const std::string& name)
+{
+    auto it = index_.find(name);
+    if (it != index_.end()) return it->second;
+    const size_t i = var_names.size();
+    index_.emplace(name, i);
+    var_names.push_back(name);
+    objective.push_back(0.0);
+    return i;
+}
+
+double ilp_input::evaluate(const std::vector<char>& x) const
+{
+    double s = constant;
+    for (size_t i = 0; i < objective.size(); ++i) s += objective[i] * (x[i] ? 1.0 : 0.0);
+    return s;
+}
+
+bool ilp_input::feasible(const std::vector<char>& x) const
+{
+    for (const auto& c : constraints) {
+        long s = 0;
+        for (size_t i = 0; i < c.variables.size(); ++i) s += c.coefficients[i] * (x[c.variables[i]] ? 1 : 0);
+        const bool ok = c.ineq == ineq_t::le ? s <= c.rhs : c.ineq == ineq_t::eq ? s == c.rhs : s >= c.rhs;
+        if (!ok) return false;
+    }
+    return true;
+}
+
+void ilp_input::normalize()
+{
+    for (auto& c : constraints) {
+        std::vector<size_t> idx(c.variables.size());
+        std::iota(idx.begin(), idx.end(), 0);
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return c.variables[a] < c.variables[b]; });
+        constraint n = c;
+        for (size_t i = 0; i < idx.size(); ++i) { n.variables[i] = c.variables[idx[i]]; n.coefficients[i] = c.coefficients[idx[i]]; }
+        c = std::move(n);
+    }
+}
+
+static std::string fmt_mag(double m)
+{
+    if (m == std::floor(m) && std::fabs(m) < 1e15) {
+        std::ostringstream o;
+        o << (long long)m;
+        return o.str();
+    }
+    std::ostringstream o;
+    o.precision(17);
+    o << m;
+    return o.str();
+}
+
+std::string ilp_input::write_lp() const
+{
+    auto term = [](double c, const std::string& name, bool first) {
+        std::string s = c < 0 ? "- " : (first ? "" : "+ ");
+        return s + fmt_mag(std::fabs(c)) + " " + name;
+    };
+    std::ostringstream o;
+    o << "Minimize\n";
+    for (size_t i = 0; i < objective.size(); ++i) o << term(objective[i], var_names[i], i == 0) << ((i % 8 == 7 || i + 1 == objective.size()) ? "\n" : " ");
+    o << "Subject To\n";
+    for (const auto& c : constraints) {
+        if (!c.name.empty()) o << c.name << ": ";
+        for (size_t i = 0; i < c.variables.size(); ++i) o << term((double)c.coefficients[i], var_names[c.variables[i]], i == 0) << " ";
+        o << (c.ineq == ineq_t::le ? "<=" : c.ineq == ineq_t::eq ? "=" : ">=") << " " << c.rhs << "\n";
+    }
+    o << "End\n";
+    return o.str();
+}
+
+// ------------------------------------------------------------------------------------------- scanner
+namespace {
+
+bool is_var_start(char c) { return std::isalpha((unsigned char)c); }
+bool is_var_char(char c)
+{
+    return std::isalnum((unsigned char)c) || std::string("_-/(){},#;[].'").find(c) != std::string::npos;
+}
+
+std::string lower(std::string s)
+{
+    for (auto& c : s) c = (char)std::tolower((unsigned char)c);
+    return s;
+}
+
+std::string trim(const std::string& s)
+{
+    size_t a = 0, b = s.size();
+    while (a < b && std::isspace((unsigned char)s[a])) ++a;
+    while (b > a && std::isspace((unsigned char)s[b - 1])) --b;
+    return s.substr(a, b - a);
+}
+
+// number: digits[.digits*][e[+-]digits] | .digits[e..]; returns chars consumed (0 = no number at pos)
+size_t scan_number(const std::string& s, size_t pos, double* out)
+{
+    size_t p = pos;
+    size_t nd = 0;
+    while (p < s.size() && std::isdigit((unsigned char)s[p])) { ++p; ++nd; }
+    if (p < s.size() && s[p] == '.') {
+        size_t q = p + 1, frac = 0;
+        while (q < s.size() && std::isdigit((unsigned char)s[q])) { ++q; ++frac; }
+        if (nd == 0 && frac == 0) return 0;
+        p = q;
+    } else if (nd == 0) {
+        return 0;
+    }
+    if (p < s.size() && (s[p] == 'e' || s[p] == 'E')) {
+        size_t q = p + 1;
+        if (q < s.size() && (s[q] == '+' || s[q] == '-')) ++q;
+        size_t ed = 0;
+        while (q < s.size() && std::isdigit((unsigned char)s[q])) { ++q; ++ed; }
+        if (ed > 0) p = q;
+    }
+    *out = std::strtod(s.substr(pos, p - pos).c_str(), nullptr);
+    return p - pos;
+}
+
+struct term { double coeff; std::string name; };
+
+// [sign] [number] [*] variable ...; a trailing "sign number" without a variable is the constant (objective only)
+std::vector<term> scan_terms(const std::string& s, const char* what, bool allow_constant, double* constant)
+{
+    std::vector<term> out;
+    size_t p = 0;
+    auto skip = [&]() { while (p < s.size() && std::isspace((unsigned char)s[p])) ++p; };
+    for (;;) {
+        skip();
+        if (p >= s.size()) break;
+        const size_t start = p;
+        double sign = 1.0;
+        bool has_sign = false;
+        if (s[p] == '+' || s[p] == '-') { sign = s[p] == '-' ? -1.0 : 1.0; has_sign = true; ++p; }
+        skip();
+        double num = 1.0;
+        const size_t nn = scan_number(s, p, &num);
+        p += nn;
+        skip();
+        if (p < s.size() && s[p] == '*') { ++p; skip(); }
+        if (p < s.size() && is_var_start(s[p])) {
+            const size_t v0 = p;
+            while (p < s.size() && is_var_char(s[p])) ++p;
+            out.push_back({sign * (nn ? num : 1.0), s.substr(v0, p - v0)});
+            continue;
+        }
+        if (allow_constant && has_sign && nn && p >= s.size()) {
+            *constant = sign * num;
+            break;
+        }
+        throw std::runtime_error(std::string("cannot parse ") + what + " near '" + s.substr(start, 40) + "'");
+    }
+    return out;
+}
+
+bool is_keyword_line(const std::string& line, std::initializer_list<const char*> words)
+{
+    const std::string t = lower(trim(line));
+    for (const char* w : words)
+        if (t == w) return true;
+    return false;
+}
+
+}  // namespace
+
+ilp_input parse_lp(const std::string& text)
+{
+    std::vector<std::string> lines;
+    {
+        std::istringstream in(text);
+        std::string ln;
+        while (std::getline(in, ln)) {
+            if (!ln.empty() && ln.back() == '\r') ln.pop_back();
+            const std::string t = trim(ln);
+            if (!t.empty() && t[0] == '\\') continue;  // comment line
+            lines.push_back(ln);
+        }
+    }
+    size_t i_min = lines.size(), i_st = lines.size();
+    for (size_t i = 0; i < lines.size(); ++i)
+        if (is_keyword_line(lines[i], {"minimize", "minimise", "min"})) { i_min = i; break; }
+    if (i_min == lines.size()) throw std::runtime_error("LP text has no 'Minimize' line");
+    for (size_t i = i_min + 1; i < lines.size(); ++i)
+        if (is_keyword_line(lines[i], {"subject to", "s.t.", "st"})) { i_st = i; break; }
+    if (i_st == lines.size()) throw std::runtime_error("LP text has no 'Subject To' line");
+
+    ilp_input ilp;
+    std::string obj;
+    for (size_t i = i_min + 1; i < i_st; ++i) obj += lines[i] + " ";
+    obj = trim(obj);
+    {  // optional objective name "name:"
+        size_t p = 0;
+        if (p < obj.size() && (std::isalpha((unsigned char)obj[p]) || obj[p] == '_')) {
+            size_t q = p;
+            while (q < obj.size() && (std::isalnum((unsigned char)obj[q]) || obj[q] == '_')) ++q;
+            size_t r = q;
+            while (r < obj.size() && std::isspace((unsigned char)obj[r])) ++r;
+            if (r < obj.size() && obj[r] == ':') obj = obj.substr(r + 1);
+        }
+    }
+    for (const auto& t : scan_terms(obj, "objective", true, &ilp.constant)) ilp.objective[ilp.var(t.name)] += t.coeff;
+
+    std::string pending;
+    for (size_t i = i_st + 1; i < lines.size(); ++i) {
+        const std::string s = trim(lines[i]);
+        if (s.empty()) continue;
+        if (is_keyword_line(s, {"end", "bounds", "binaries", "binary", "generals", "general", "coalesce"})) break;
+        pending = trim(pending + " " + s);
+        // relation: first of <=, >=, =
+        size_t rp = std::string::npos, rl = 0;
+        for (size_t p = 0; p < pending.size(); ++p) {
+            if ((pending[p] == '<' || pending[p] == '>') && p + 1 < pending.size() && pending[p + 1] == '=') { rp = p; rl = 2; break; }
+            if (pending[p] == '=') { rp = p; rl = 1; break; }
+        }
+        if (rp == std::string::npos) continue;
+        const std::string rhs_s = trim(pending.substr(rp + rl));
+        double rhs = 0;
+        {  // [+-] number, nothing else — otherwise the right-hand side is not complete yet
+            size_t p = 0;
+            double sign = 1;
+            if (p < rhs_s.size() && (rhs_s[p] == '+' || rhs_s[p] == '-')) { sign = rhs_s[p] == '-' ? -1 : 1; ++p; }
+            while (p < rhs_s.size() && std::isspace((unsigned char)rhs_s[p])) ++p;
+            const size_t nn = scan_number(rhs_s, p, &rhs);
+            if (nn == 0 || p + nn != rhs_s.size()) continue;
+            rhs *= sign;
+        }
+        std::string lhs = pending.substr(0, rp);
+        constraint c;
+        {  // optional row name "name:"
+            const std::string t = trim(lhs);
+            size_t q = 0;
+            while (q < t.size() && !std::isspace((unsigned char)t[q]) && t[q] != ':') ++q;
+            size_t r = q;
+            while (r < t.size() && std::isspace((unsigned char)t[r])) ++r;
+            if (q > 0 && r < t.size() && t[r] == ':') { c.name = t.substr(0, q); lhs = t.substr(r + 1); }
+        }
+        c.ineq = rl == 1 ? ineq_t::eq : pending[rp] == '<' ? ineq_t::le : ineq_t::ge;
+        if (rhs != std::floor(rhs)) throw std::runtime_error("only integer constraint coefficients are supported (as the reference, ILP_parser.cpp:262-300)");
+        c.rhs = (long)rhs;
+        for (const auto& t : scan_terms(lhs, "constraint", false, nullptr)) {
+            if (t.coeff != std::floor(t.coeff)) throw std::runtime_error("only integer constraint coefficients are supported (as the reference, ILP_parser.cpp:262-300)");
+            c.coefficients.push_back((long)t.coeff);
+            c.variables.push_back(ilp.var(t.name));
+        }
+        ilp.constraints.push_back(std::move(c));
+        pending.clear();
+    }
+    if (!pending.empty()) throw std::runtime_error("incomplete constraint: '" + pending.substr(0, 60) + "'");
+    return ilp;
+}
+
+bdd_store to_bdds(const ilp_input& ilp)
+{
+    bdd_store col;
+    for (const auto& c : ilp.constraints) {
+        if (std::set<size_t>(c.variables.begin(), c.variables.end()).size() != c.variables.size())
+            throw std::runtime_error("constraint '" + c.name + "' repeats a variable");
+        if (c.is_simplex()) { col.add_simplex(c.variables); continue; }
+        const row_status st = col.add_linear(c.coefficients, c.ineq, c.rhs, c.variables);
+        if (st == row_status::infeasible) throw std::runtime_error("problem is infeasible");
+    }
+    return col;
+}
+
+}  // namespace bddmma_host

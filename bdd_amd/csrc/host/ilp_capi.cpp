@@ -1,0 +1,107 @@
+// ilp_capi.cpp — extern "C" glue of include/bdd_ilp.h over ilp.hpp / bdd_store.hpp.  No exception crosses the ABI.
+#include <cstring>
+#include <set>
+#include <stdexcept>
+#include <string>
+
+#include "../../../include/bdd_ilp.h"
+#include "ilp.hpp"
+
+using namespace bddmma_host;
+
+struct bddilp { ilp_input ilp; };
+struct bddilp_bdds { bdd_store col; };
+
+static thread_local std::string g_err;
+
+template <typename F>
+static int guarded(int fail_code, F&& f)
+{
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return g_err.find("infeasible") != std::string::npos ? BDDILP_ERR_INFEASIBLE : fail_code;
+    }
+}
+
+extern "C" {
+
+const char* bddilp_last_error(void) { return g_err.c_str(); }
+
+int bddilp_parse_lp(const char* lp_text, bddilp** out)
+{
+    if (!lp_text || !out) { g_err = "null argument"; return BDDILP_ERR_INVALID_ARGUMENT; }
+    return guarded(BDDILP_ERR_PARSE, [&] { *out = new bddilp{parse_lp(lp_text)}; return BDDILP_OK; });
+}
+void bddilp_destroy(bddilp* ilp) { delete ilp; }
+uint64_t bddilp_nr_variables(const bddilp* ilp) { return ilp->ilp.nr_variables(); }
+uint64_t bddilp_nr_constraints(const bddilp* ilp) { return ilp->ilp.constraints.size(); }
+const char* bddilp_variable_name(const bddilp* ilp, uint64_t v) { return v < ilp->ilp.var_names.size() ? ilp->ilp.var_names[v].c_str() : ""; }
+int bddilp_objective(const bddilp* ilp, double* objective, double* constant)
+{
+    if (objective) std::memcpy(objective, ilp->ilp.objective.data(), ilp->ilp.objective.size() * sizeof(double));
+    if (constant) *constant = ilp->ilp.constant;
+    return BDDILP_OK;
+}
+uint64_t bddilp_constraint_size(const bddilp* ilp, uint64_t c) { return c < ilp->ilp.constraints.size() ? ilp->ilp.constraints[c].variables.size() : 0; }
+int bddilp_constraint(const bddilp* ilp, uint64_t c, int64_t* coeffs, uint64_t* vars, int* ineq, int64_t* rhs)
+{
+    if (c >= ilp->ilp.constraints.size()) { g_err = "constraint index out of range"; return BDDILP_ERR_INVALID_ARGUMENT; }
+    const constraint& k = ilp->ilp.constraints[c];
+    for (size_t i = 0; i < k.variables.size(); ++i) {
+        if (coeffs) coeffs[i] = k.coefficients[i];
+        if (vars) vars[i] = k.variables[i];
+    }
+    if (ineq) *ineq = (int)k.ineq;
+    if (rhs) *rhs = k.rhs;
+    return BDDILP_OK;
+}
+const char* bddilp_constraint_name(const bddilp* ilp, uint64_t c) { return c < ilp->ilp.constraints.size() ? ilp->ilp.constraints[c].name.c_str() : ""; }
+int bddilp_normalize(bddilp* ilp) { ilp->ilp.normalize(); return BDDILP_OK; }
+
+int bddilp_to_bdds(const bddilp* ilp, int split, uint64_t split_length, bddilp_bdds** out)
+{
+    if (!ilp || !out) { g_err = "null argument"; return BDDILP_ERR_INVALID_ARGUMENT; }
+    return guarded(BDDILP_ERR_INVALID_ARGUMENT, [&] {
+        auto* b = new bddilp_bdds{to_bdds(ilp->ilp)};
+        if (split) b->col.split_long_bdds(std::max(b->col.nr_variables(), ilp->ilp.nr_variables()), split_length);
+        *out = b;
+        return BDDILP_OK;
+    });
+}
+int bddilp_bdds_create(bddilp_bdds** out) { *out = new bddilp_bdds{}; return BDDILP_OK; }
+int bddilp_bdds_add_row(bddilp_bdds* b, const int64_t* coeffs, const uint64_t* vars, uint64_t n, int ineq, int64_t rhs, int* status)
+{
+    if (!b || !coeffs || !vars || n == 0 || ineq < -1 || ineq > 1) { g_err = "invalid row"; return BDDILP_ERR_INVALID_ARGUMENT; }
+    return guarded(BDDILP_ERR_INVALID_ARGUMENT, [&] {
+        constraint c;
+        c.coefficients.assign(coeffs, coeffs + n);
+        c.variables.assign(vars, vars + n);
+        c.ineq = (ineq_t)ineq;
+        c.rhs = rhs;
+        if (std::set<size_t>(c.variables.begin(), c.variables.end()).size() != c.variables.size()) throw std::runtime_error("constraint repeats a variable");
+        row_status st = row_status::ok;
+        if (c.is_simplex()) b->col.add_simplex(c.variables);
+        else st = b->col.add_linear(c.coefficients, c.ineq, c.rhs, c.variables);
+        if (status) *status = (int)st;
+        return BDDILP_OK;
+    });
+}
+int bddilp_bdds_split(bddilp_bdds* b, uint64_t nr_variables, uint64_t split_length, uint64_t* nr_split, uint64_t* nr_variables_after)
+{
+    return guarded(BDDILP_ERR_INVALID_ARGUMENT, [&] {
+        const auto [n, nv] = b->col.split_long_bdds(nr_variables, split_length);
+        if (nr_split) *nr_split = n;
+        if (nr_variables_after) *nr_variables_after = nv;
+        return BDDILP_OK;
+    });
+}
+void bddilp_bdds_destroy(bddilp_bdds* b) { delete b; }
+uint64_t bddilp_bdds_nr_bdds(const bddilp_bdds* b) { return b->col.nr_bdds(); }
+uint64_t bddilp_bdds_nr_instructions(const bddilp_bdds* b) { return b->col.instructions.size(); }
+uint64_t bddilp_bdds_nr_variables(const bddilp_bdds* b) { return b->col.nr_variables(); }
+const bddmma_instruction* bddilp_bdds_instructions(const bddilp_bdds* b) { return b->col.instructions.data(); }
+const uint64_t* bddilp_bdds_delimiters(const bddilp_bdds* b) { return b->col.delimiters.data(); }
+
+}  // extern "C"

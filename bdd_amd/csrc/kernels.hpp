@@ -1285,13 +1285,27 @@ __global__ void k_fill(T* __restrict__ p, T v, uint64_t n)
     if (i < n) p[i] = v;
 }
 
-// STREAM triad a = b + s*c with 16-byte accesses, grid-stride: the HBM ceiling bench.py quotes the sweep against
-static __global__ void __launch_bounds__(256) k_stream_triad(float4* __restrict__ a, const float4* __restrict__ b,
-                                                      const float4* __restrict__ c, float s, uint64_t n4)
+// STREAM triad a = b + s*c (COPY: a = b): 16-byte non-temporal accesses, 4 independent vectors per thread and
+// trip — the fastest of the variants tried on MI355X (profiles/r01_stream_ceiling.txt).  The measured HBM
+// ceilings bench.py quotes the sweep against.
+typedef float stream_v4 __attribute__((ext_vector_type(4)));
+template <bool COPY>
+static __global__ void __launch_bounds__(256) k_stream(stream_v4* __restrict__ a, const stream_v4* __restrict__ b,
+                                                       const stream_v4* __restrict__ c, float s, uint64_t n4)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) {
-        const float4 x = b[i], y = c[i];
-        a[i] = make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 3 * stride < n4; i += 4 * stride) {
+        stream_v4 x[4], y[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = __builtin_nontemporal_load(&b[i + k * stride]);
+        if (!COPY) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = __builtin_nontemporal_load(&c[i + k * stride]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] += s * y[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(x[k], &a[i + k * stride]);
     }
 }
 

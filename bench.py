@@ -88,7 +88,7 @@ def main():
     solver.set_profiling(False)
     lb = solver.lower_bound()
 
-    triad_gbs = lb_rate = None
+    triad_gbs = copy_gbs = lb_rate = None
     if rank == 0:
         # outside the timed region: (1) the same loop with the lower bound fetched every iteration, as
         # run_solver does (one extra plain backward sweep + reduce + 8-byte D2H per iteration); (2) the
@@ -101,6 +101,7 @@ def main():
             solver.lower_bound()
         lb_rate = n_lb / (time.perf_counter() - t0)
         triad_gbs = 3 * (1 << 30) / (solver.time_kernel(6, 20) * 1e-3) / 1e9
+        copy_gbs = 2 * (1 << 30) / (solver.time_kernel(7, 20) * 1e-3) / 1e9
 
     if rank == 0:
         its = aggregate_rate(world, args.steps, dt)
@@ -147,6 +148,7 @@ def main():
                 "timed_launches": {names[i]: prof["launches"][i] for i in range(3)},
                 "whole_iteration_GBs": 2 * bytes_pass * its / world / 1e9,
                 "stream_triad_GBs": triad_gbs,
+                "stream_copy_GBs": copy_gbs,
                 "frac_of_stream_triad": achieved / triad_gbs if triad_gbs else None,
             },
             "value_with_lower_bound_every_iteration": lb_rate,

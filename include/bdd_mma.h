@@ -226,7 +226,8 @@ int bddmma_time_iterations(bddmma_solver* s, double omega, uint64_t n, double* m
  * (kernel-level benchmarking; leaves the sweep state invalid).  kind: 0 forward_run sweep, 1 backward_run
  * sweep, 2 forward_mm sweep, 3 backward_mm sweep, 4 exchange reduce, 5 exchange broadcast, 6 STREAM triad
  * a = b + s*c over three temporary arrays of BDDMMA_TRIAD_BYTES each (3 * BDDMMA_TRIAD_BYTES of HBM traffic
- * per launch: the measured bandwidth ceiling of the box the roofline is quoted next to). */
+ * per launch), 7 STREAM copy a = b (2 * BDDMMA_TRIAD_BYTES per launch): the measured bandwidth ceilings of the
+ * box the roofline is quoted next to. */
 #define BDDMMA_TRIAD_BYTES (1ull << 30)
 int bddmma_time_kernel(bddmma_solver* s, int kind, uint64_t reps, double* ms);
 /* HBM bytes held by the handle. */

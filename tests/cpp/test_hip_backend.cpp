@@ -1,0 +1,231 @@
+// C++ tests of the drop-in classes (bdd_hip_parallel_mma<REAL>, bdd_hip_lbfgs_mma<REAL>) and of the C++ bdd_solver
+// driver, in the style of the reference's own tests:
+//   test/test_bdd_cuda_base.cpp:8-116, test/test_bdd_cuda_min_marginals.cpp, test/test_cuda_parallel_mma.cu:197-247,
+//   test/test_bdd_bipartite_matching_problem.cpp:8-59, test/test_loose_covering_problem.cpp:8-88.
+// Needs a GPU; run by tests/test_gpu_cpp.py.  Exit code 0 = all passed.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../bdd_amd/csrc/bdd_hip_parallel_mma.hpp"
+#include "../../bdd_amd/csrc/host/bdd_solver.hpp"
+#include "../../bdd_amd/csrc/host/bdd_store.hpp"
+
+using namespace LPMP;
+using bddmma_host::bdd_store;
+
+static int failures = 0;
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) { std::printf("  FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+#define CHECK_NEAR(a, b, tol)                                                                              \
+    do {                                                                                                   \
+        const double a_ = (a), b_ = (b);                                                                   \
+        if (!(std::fabs(a_ - b_) <= (tol))) { std::printf("  FAILED %s:%d: %s = %.12g, expected %.12g\n", __FILE__, __LINE__, #a, a_, b_); ++failures; } \
+    } while (0)
+
+// n x n assignment: 2n simplex rows over n^2 variables (test_bdd_bipartite_matching_problem.cpp)
+static bdd_store matching(size_t n)
+{
+    bdd_store col;
+    for (size_t i = 0; i < n; ++i) {
+        std::vector<size_t> row, colv;
+        for (size_t j = 0; j < n; ++j) { row.push_back(i * n + j); colv.push_back(j * n + i); }
+        col.add_simplex(row);
+        col.add_simplex(colv);
+    }
+    return col;
+}
+
+template <typename REAL>
+static void test_matching_kats()
+{
+    const double tol = sizeof(REAL) == 8 ? 1e-9 : 1e-4;
+    {   // diagonal costs -2, others -1: LB -6 from the start (test_bdd_cuda_base.cpp:114)
+        std::vector<double> c(9, -1.0);
+        c[0] = c[4] = c[8] = -2.0;
+        bdd_hip_parallel_mma<REAL> s(matching(3), c);
+        CHECK(s.nr_variables() == 9 && s.nr_bdds() == 6 && s.nr_layers() == 18);
+        CHECK(s.nr_bdds(4) == 2);
+        CHECK_NEAR(s.lower_bound(), -6.0, tol);
+        for (int i = 0; i < 5; ++i) s.iteration();
+        CHECK_NEAR(s.lower_bound(), -6.0, tol);
+    }
+    {   // first column -2: the exact dyadic trajectory of the CPU parallel mma, optimum -4
+        std::vector<double> c(9, -1.0);
+        c[0] = c[3] = c[6] = -2.0;
+        bdd_hip_parallel_mma<REAL> s(matching(3), c);
+        CHECK_NEAR(s.lower_bound(), -5.0, tol);
+        const double want[] = {-4.78125, -4.3671875, -4.187866210938, -4.103347778320, -4.059029579163};
+        for (double w : want) {
+            s.iteration();
+            CHECK_NEAR(s.lower_bound(), w, sizeof(REAL) == 8 ? 1e-11 : 1e-4);
+        }
+        for (int i = 0; i < 95; ++i) s.iteration();
+        CHECK_NEAR(s.lower_bound(), -4.0, 1e-6);
+    }
+}
+
+template <typename REAL>
+static void test_costs_marginals_solution()
+{
+    // one simplex over 3 variables, costs (1, 2, 3): min-marginals per variable (test_bdd_cuda_min_marginals.cpp pattern)
+    bdd_store col;
+    col.add_simplex({0, 1, 2});
+    bdd_hip_parallel_mma<REAL> s(col);
+    s.set_cost(1.0, 0);
+    s.update_costs(std::vector<REAL>{}, std::vector<REAL>{0, 2, 3});
+    CHECK_NEAR(s.lower_bound(), 1.0, 1e-6);
+    const auto obj = s.get_primal_objective_vector_host();
+    CHECK(obj.size() == 3);
+    CHECK_NEAR(obj[0], 1, 1e-6); CHECK_NEAR(obj[1], 2, 1e-6); CHECK_NEAR(obj[2], 3, 1e-6);
+    const auto mm = s.min_marginals();
+    CHECK(mm.size() == 3 && mm[0].size() == 1);
+    CHECK_NEAR(mm[0][0][0], 2, 1e-6); CHECK_NEAR(mm[0][0][1], 1, 1e-6);   // x0 = 0 -> best is x1 (2); x0 = 1 -> 1
+    CHECK_NEAR(mm[1][0][0], 1, 1e-6); CHECK_NEAR(mm[1][0][1], 2, 1e-6);
+    CHECK_NEAR(mm[2][0][0], 1, 1e-6); CHECK_NEAR(mm[2][0][1], 3, 1e-6);
+    const auto sol = s.bdds_solution_vec_host();
+    CHECK(sol.size() == 3);
+    int ones = 0;
+    for (char x : sol) ones += x;
+    CHECK(ones == 1);
+}
+
+template <typename REAL>
+static void test_explicit_mm_and_distribute()
+{
+    // forward_mm / backward_mm with a caller-held delta, then distribute_delta keeps the sum of costs (test_cuda_parallel_mma.cu:13-103)
+    std::vector<double> c(9, -1.0);
+    c[0] = c[3] = c[6] = -2.0;
+    bdd_hip_parallel_mma<REAL> s(matching(3), c);
+    std::vector<REAL> delta(2 * s.nr_variables(), REAL(0));
+    const double lb0 = s.lower_bound();
+    for (int it = 0; it < 10; ++it) {
+        s.forward_mm(REAL(0.5), delta);
+        for (size_t v = 0; v < s.nr_variables(); ++v) { delta[2 * v] /= s.nr_bdds(v); delta[2 * v + 1] /= s.nr_bdds(v); }
+        s.backward_mm(REAL(0.5), delta);
+        for (size_t v = 0; v < s.nr_variables(); ++v) { delta[2 * v] /= s.nr_bdds(v); delta[2 * v + 1] /= s.nr_bdds(v); }
+    }
+    CHECK(s.lower_bound() >= lb0 - 1e-6);
+    s.distribute_delta();
+    const auto obj = s.get_primal_objective_vector_host();
+    for (size_t v = 0; v < 9; ++v) CHECK_NEAR(obj[v], c[v], sizeof(REAL) == 8 ? 1e-9 : 1e-4);
+}
+
+template <typename REAL>
+static void test_lbfgs_and_move()
+{
+    bdd_store col;
+    for (auto row : std::vector<std::vector<size_t>>{{0, 1, 3}, {0, 2, 4}, {1, 2, 5}}) col.add_covering(row);
+    bdd_hip_parallel_mma<REAL> base(col, std::vector<double>(6, 1.0));
+    bdd_hip_parallel_mma<REAL> moved(std::move(base));   // the variant in bdd_solver.h:64-69 needs movability
+    bdd_hip_lbfgs_mma<REAL> s(std::move(moved));
+    double prev = s.lower_bound();
+    for (int i = 0; i < 60; ++i) {
+        s.iteration();
+        const double lb = s.lower_bound();
+        CHECK(lb >= prev - 1e-5);   // lbfgs_impl.h:403
+        prev = lb;
+    }
+    CHECK_NEAR(prev, 1.5, 1e-3);    // test_loose_covering_problem.cpp: LP bound 1.5
+}
+
+static void test_checkpoint()
+{
+    std::vector<double> c(16, -1.0);
+    bdd_hip_parallel_mma<double> s(matching(4), c);
+    for (int i = 0; i < 3; ++i) s.iteration();
+    const std::string path = "/tmp/bddmma_cpp_test.ckpt";
+    s.save(path);
+    bddmma_solver* h = nullptr;
+    CHECK(bddmma_load(&h, 0, path.c_str()) == BDDMMA_OK);
+    double lb = 0;
+    CHECK(bddmma_lower_bound(h, &lb) == BDDMMA_OK);
+    CHECK_NEAR(lb, s.lower_bound(), 1e-12);
+    bddmma_destroy(h);
+    std::remove(path.c_str());
+}
+
+static void test_driver()
+{
+    const std::string lp = "Minimize\\nx1 + x2 + x3 + x4 + x5 + x6\\nSubject To\\nx1 + x2 + x4 >= 1\\nx1 + x3 + x5 >= 1\\nx2 + x3 + x6 >= 1\\nEnd\\n";
+    for (const char* solver : {"cuda parallel mma", "lbfgs cuda mma"}) {
+        const std::string cfg = std::string("{\"input\": \"") + lp + "\", \"relaxation solver\": \"" + solver +
+                                "\", \"precision\": \"double\", \"termination criteria\": {\"maximum iterations\": 300, \"improvement slope\": 0.0, "
+                                "\"minimum improvement\": 0.0}, \"perturbation rounding\": {\"inner iterations\": 50, \"outer iterations\": 50}}";
+        bddmma_host::bdd_solver s(cfg, true);
+        s.solve();
+        // (the costs stay perturbed after the rounding, as in the reference: bdd_solver.cpp:368; the bound is checked below)
+        CHECK(s.solution().size() == 6);
+        if (s.solution().size() == 6) {
+            CHECK(s.ilp().feasible(s.solution()));
+            CHECK_NEAR(s.solution_objective(), 2.0, 1e-9);   // optimum of the loose covering instance
+        }
+        CHECK(s.min_marginals().size() == 6);
+        const std::string dual_only = std::string("{\"input\": \"") + lp + "\", \"relaxation solver\": \"" + solver +
+                                      "\", \"termination criteria\": {\"maximum iterations\": 300, \"improvement slope\": 0.0, \"minimum improvement\": 0.0}}";
+        bddmma_host::bdd_solver d(dual_only, true);
+        d.solve();
+        CHECK_NEAR(d.lower_bound(), 1.5, 1e-3);   // test_loose_covering_problem.cpp
+    }
+    // a long row cut by "split bdds" gives a valid bound and more BDDs
+    std::string rows = "Minimize\\n";
+    for (int i = 0; i < 40; ++i) rows += (i ? " + " : "") + std::to_string(1 + (i * 7) % 11) + " y" + std::to_string(i);
+    rows += "\\nSubject To\\n";
+    for (int i = 0; i < 40; ++i) rows += (i ? " + y" : "y") + std::to_string(i);
+    rows += " >= 4\\nEnd\\n";
+    const std::string tail = "\", \"termination criteria\": {\"maximum iterations\": 2000, \"improvement slope\": 0.0, \"minimum improvement\": 0.0}";
+    bddmma_host::bdd_solver full("{\"input\": \"" + rows + tail + "}", true), split("{\"input\": \"" + rows + tail + ", \"split bdds\": {\"split length\": 8}}", true);
+    full.solve();
+    split.solve();
+    CHECK(full.bdds().nr_bdds() == 1 && split.bdds().nr_bdds() == 5);
+    CHECK_NEAR(full.lower_bound(), 4.0, 1e-6);                // the four cheapest: costs 1 + (7 i mod 11), i = 0, 11, 22, 33
+    CHECK(split.lower_bound() <= full.lower_bound() + 1e-6);
+    CHECK(split.lower_bound() >= full.lower_bound() - 0.05);
+    // option errors of the reference (bdd_solver.cpp:93, :265, :142)
+    auto throws = [](const std::string& cfg, const std::string& what) {
+        try {
+            bddmma_host::bdd_solver s(cfg, true);
+            s.solve();
+        } catch (const std::exception& e) {
+            return std::string(e.what()).find(what) != std::string::npos;
+        }
+        return false;
+    };
+    CHECK(throws("{\"input\": \"" + lp + "\", \"variable order\": \"spiral\"}", "Variable order spiral unknown"));
+    CHECK(throws("{\"input\": \"" + lp + "\", \"relaxation solver\": \"quantum mma\"}", "relaxation solver quantum mma unknown"));
+    CHECK(throws("{\"input\": \"" + lp + "\", \"precision\": \"half\"}", "precision must be"));
+    CHECK(throws("{}", "no input specified"));
+}
+
+int main()
+{
+    const std::pair<const char*, std::function<void()>> tests[] = {
+        {"matching KATs <double>", test_matching_kats<double>},
+        {"matching KATs <float>", test_matching_kats<float>},
+        {"costs / min-marginals / solution <double>", test_costs_marginals_solution<double>},
+        {"costs / min-marginals / solution <float>", test_costs_marginals_solution<float>},
+        {"explicit forward_mm / backward_mm / distribute_delta <double>", test_explicit_mm_and_distribute<double>},
+        {"explicit forward_mm / backward_mm / distribute_delta <float>", test_explicit_mm_and_distribute<float>},
+        {"L-BFGS wrapper, move construction <double>", test_lbfgs_and_move<double>},
+        {"L-BFGS wrapper, move construction <float>", test_lbfgs_and_move<float>},
+        {"checkpoint", test_checkpoint},
+        {"bdd_solver driver", test_driver},
+    };
+    for (const auto& [name, fn] : tests) {
+        const int before = failures;
+        try {
+            fn();
+        } catch (const std::exception& e) {
+            std::printf("  EXCEPTION: %s\n", e.what());
+            ++failures;
+        }
+        std::printf("[%s] %s\n", failures == before ? " OK " : "FAIL", name);
+    }
+    std::printf("%d failure(s)\n", failures);
+    return failures ? 1 : 0;
+}

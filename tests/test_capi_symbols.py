@@ -7,10 +7,20 @@ from bdd_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "bdd_mma.h")).read()
+def declared_symbols(header="bdd_mma.h", prefix="bddmma_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(bddmma_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_symbol_of_the_host_header_is_exported_and_bound():
+    L = capi.lib()
+    syms = declared_symbols("bdd_ilp.h", "bddilp_")
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/bdd_ilp.h but not exported"
+        assert s in capi.ILP_SIGNATURES, f"{s} has no ctypes signature in bdd_amd/capi.py"
+    assert set(capi.ILP_SIGNATURES) <= set(syms)
 
 
 def test_every_declared_symbol_is_exported_and_bound():

@@ -1,0 +1,106 @@
+"""The C++ host-side input stage (include/bdd_ilp.h: .lp reader, row -> QBDD converter, splitting) against the
+Python specification of the same stage, which tests/test_bdd_builders.py, test_lp_reader.py and test_split_qbdd.py
+pin against the reference — CPU only."""
+import numpy as np
+import pytest
+
+from bdd_amd import native
+from bdd_amd.bdd_collection import BddCollection
+from bdd_amd.ilp import parse_lp, split_long_bdds, to_bdd_collection
+from bdd_amd.instances import GRID_3X3, LONG_CHAIN, SHORT_CHAIN, assignment_ilp, mrf_ilp
+
+LPS = {
+    "covering": "Minimize\nx1 + x2 + x3 + x4 + x5 + x6\nSubject To\nx1 + x2 + x4 >= 1\nx1 + x3 + x5 >= 1\nx2 + x3 + x6 >= 1\n"
+                "Bounds\nBinaries\nx1\nx2\nx3\nx4\nx5\nx6\nEnd\n",
+    "names_and_signs": "\\ a comment\nMinimize\nobj: 2 a - 3.5 b + c_1 - 1e1 d(2) + 4\nSubject To\nr1: a + b + c_1 = 1\n"
+                       "r2: - a + 2 b\n - d(2) <= 1\n3 a - 2 c_1 >= -1\nEnd\n",
+    "multiline": "minimize\n x + y\n + z\nsubject to\n c: x\n + y\n + z >= 2\n x - y = 0\nend\n",
+}
+
+
+def same_ilp(a, b):
+    assert a.var_names == b.var_names
+    np.testing.assert_allclose(a.objective, b.objective, rtol=0, atol=0)
+    assert a.constant == b.constant
+    assert len(a.constraints) == len(b.constraints)
+    for ca, cb in zip(a.constraints, b.constraints):
+        assert (ca.coefficients, ca.variables, ca.ineq, ca.rhs, ca.name) == (cb.coefficients, cb.variables, cb.ineq, cb.rhs, cb.name)
+
+
+@pytest.mark.parametrize("name", sorted(LPS))
+def test_lp_reader_matches_python(name):
+    same_ilp(native.parse_lp(LPS[name]), parse_lp(LPS[name]))
+
+
+@pytest.mark.parametrize("make", [lambda: assignment_ilp(4), lambda: mrf_ilp(**SHORT_CHAIN), lambda: mrf_ilp(**LONG_CHAIN),
+                                  lambda: mrf_ilp(**GRID_3X3)])
+def test_written_lp_round_trips_through_both_readers_and_converters(make):
+    ilp = make()
+    text = ilp.write_lp()
+    same_ilp(native.parse_lp(text), parse_lp(text))
+    want = to_bdd_collection(parse_lp(text))
+    got = native.lp_to_bdd_collection(text)
+    np.testing.assert_array_equal(got.delims, want.delims)
+    np.testing.assert_array_equal(got.instr, want.instr)
+
+
+@pytest.mark.parametrize("bad,match", [("Subject To\nx >= 1\nEnd\n", "Minimize"), ("Minimize\nx\nEnd\n", "Subject To"),
+                                       ("Minimize\nx\nSubject To\nx + 0.5 y >= 1\nEnd\n", "integer"),
+                                       ("Minimize\nx\nSubject To\nx + y >=\nEnd\n", "incomplete")])
+def test_reader_errors(bad, match):
+    with pytest.raises(ValueError, match=match):
+        native.parse_lp(bad)
+    with pytest.raises(ValueError, match=match):
+        parse_lp(bad)
+
+
+def test_random_rows_node_for_node():
+    rng = np.random.Generator(np.random.PCG64(17))
+    rows, want = [], BddCollection()
+    while len(rows) < 150:
+        k = int(rng.integers(1, 11))
+        vs = rng.choice(40, size=k, replace=False)           # unsorted on purpose: the row's own order is the BDD order
+        co = rng.integers(-5, 6, size=k)
+        co[co == 0] = 1
+        rhs = int(rng.integers(co[co < 0].sum() - 1, co[co > 0].sum() + 2))
+        ineq = ["<=", "=", ">="][int(rng.integers(0, 3))]
+        try:
+            if ineq == "=" and rhs != 0 and all(c == rhs for c in co):
+                want.add_simplex(vs)
+            else:
+                want.add_linear(co, ineq, rhs, vs)
+        except ValueError as e:
+            if "infeasible" in str(e):
+                with pytest.raises(RuntimeError, match="infeasible"):
+                    native.rows_to_bdd_collection([(co, vs, ineq, rhs)])
+                continue
+            assert "trivially true" in str(e)                  # skipped by both
+        rows.append((co, vs, ineq, rhs))
+    got = native.rows_to_bdd_collection(rows)
+    assert got.nr_bdds() == want.nr_bdds() > 50
+    np.testing.assert_array_equal(got.delims, want.delims)
+    np.testing.assert_array_equal(got.instr, want.instr)
+
+
+@pytest.mark.parametrize("split_length", [2, 3, 7])
+def test_splitting_node_for_node(split_length):
+    rng = np.random.Generator(np.random.PCG64(23))
+    rows, want = [], BddCollection()
+    for _ in range(12):
+        k = int(rng.integers(5, 16))
+        vs = np.sort(rng.choice(30, size=k, replace=False))
+        co = rng.integers(1, 5, size=k)
+        rows.append((co, vs, "<=", int(co.sum() // 2)))
+        want.add_linear(co, "<=", int(co.sum() // 2), vs)
+    # avoid width-1 cut layers? no: both implementations share the width-1 extension
+    split_long_bdds(want, 30, split_length)
+    got = native.rows_to_bdd_collection(rows, split_length=split_length, nr_variables=30)
+    np.testing.assert_array_equal(got.delims, want.delims)
+    np.testing.assert_array_equal(got.instr, want.instr)
+
+
+def test_infeasible_and_trivial_rows_in_lp():
+    with pytest.raises(RuntimeError, match="infeasible"):
+        native.lp_to_bdd_collection("Minimize\nx + y\nSubject To\nx + y >= 3\nEnd\n")
+    col = native.lp_to_bdd_collection("Minimize\nx + y\nSubject To\nx + y >= 0\nx + y >= 1\nEnd\n")
+    assert col.nr_bdds() == 1

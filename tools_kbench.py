@@ -1,6 +1,9 @@
 """Kernel-level micro-benchmark on the GPU box: python tools_kbench.py [--precision float] [--pack-width N] ..."""
 import argparse, sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bdd_amd import capi
+if os.environ.get("BDDMMA_LIB"):
+    capi.LIB_PATH = os.path.abspath(os.environ["BDDMMA_LIB"])   # experimental builds under build/
 from bdd_amd.instances import random_set_cover
 from bdd_amd.solver import bdd_hip_parallel_mma
 ap = argparse.ArgumentParser()
@@ -19,3 +22,6 @@ s.iterations(3)
 names = ["fwd_plain", "bwd_plain", "fwd_solve", "bwd_solve", "exch_reduce", "exch_bcast"]
 print(vars(a))
 print("  ".join(f"{n}={s.time_kernel(k, 30)*1e3:.1f}us" for k, n in enumerate(names)))
+n = 200
+ms = s.time_iterations(n)
+print(f"  iteration = {ms / n * 1e3:.1f} us  ({n / ms * 1e3:.0f} it/s)   lb = {s.lower_bound():.9g}")
