@@ -64,8 +64,10 @@ struct SolverT final : SolverBase {
         uint32_t *pack_hop_ptr = nullptr, *hop_node_off = nullptr, *hop_layer_off = nullptr;
         uint8_t* pack_steps = nullptr;
         uint32_t n_packs = 0;
-    } nb_, wb_;
+    } nb_, wb_, hb_;  // narrow, wide, huge packs
     uint32_t wide_lds = 0;
+    uint32_t huge_pack_width = 0;
+    unsigned char* d_huge_scratch = nullptr;  // frontier arrays of the huge packs (global memory instead of LDS)
 
     std::vector<void*> allocs;
 
@@ -134,6 +136,9 @@ struct SolverT final : SolverBase {
         if ((rc = upload(&d_root_slot, L.bdd_root_slot))) return rc;
         if ((rc = upload_packs(nb_, L.narrow))) return rc;
         if ((rc = upload_packs(wb_, L.wide))) return rc;
+        if ((rc = upload_packs(hb_, L.huge))) return rc;
+        huge_pack_width = L.huge_pack_width;
+        if (hb_.n_packs && (rc = dalloc(&d_huge_scratch, (size_t)hb_.n_packs * wide_lds_bytes(sizeof(REAL), huge_pack_width, true)))) return rc;
         wide_slot_base = L.narrow_slots;
         if ((rc = dalloc(&d_F, n_slots))) return rc;
         if ((rc = dalloc(&d_T, n_slots))) return rc;
@@ -173,7 +178,7 @@ struct SolverT final : SolverBase {
         if ((rc = dalloc(&d_sol, n_layers))) return rc;
         if ((rc = dalloc(&d_delta_var, 2 * n_vars))) return rc;
         if ((rc = dalloc(&d_delta_c, 2 * n_vars))) return rc;
-        if ((rc = dalloc(&d_lb_partial, nb_.n_packs + wb_.n_packs))) return rc;
+        if ((rc = dalloc(&d_lb_partial, nb_.n_packs + wb_.n_packs + hb_.n_packs))) return rc;
         if ((rc = dalloc(&d_lb, 1))) return rc;
         if ((rc = dalloc(&d_counts, 4))) return rc;
         HIPCHK(hipMemsetAsync(d_F, 0, n_slots * sizeof(REAL), stream));
@@ -247,7 +252,11 @@ struct SolverT final : SolverBase {
         }
         if (wb_.n_packs) {
             const PackDev pk = pdev(wb_, nb_.n_packs);
-            hipLaunchKernelGGL((k_fwd_wide<REAL, MODE>), dim3(wb_.n_packs), dim3(WIDE_THREADS), wide_lds, stream, d, pk, omega, wide_pack_width);
+            hipLaunchKernelGGL((k_fwd_wide<REAL, MODE>), dim3(wb_.n_packs), dim3(WIDE_THREADS), wide_lds, stream, d, pk, omega, wide_pack_width, (unsigned char*)nullptr);
+        }
+        if (hb_.n_packs) {
+            const PackDev pk = pdev(hb_, nb_.n_packs + wb_.n_packs);
+            hipLaunchKernelGGL((k_fwd_wide<REAL, MODE, true>), dim3(hb_.n_packs), dim3(WIDE_THREADS), 0, stream, d, pk, omega, huge_pack_width, d_huge_scratch);
         }
         prof_end(kclass);
         HIPCHK(hipGetLastError());
@@ -277,7 +286,11 @@ struct SolverT final : SolverBase {
         }
         if (wb_.n_packs) {
             const PackDev pk = pdev(wb_, nb_.n_packs);
-            hipLaunchKernelGGL((k_bwd_wide<REAL, MODE>), dim3(wb_.n_packs), dim3(WIDE_THREADS), wide_lds, stream, d, pk, omega, wide_pack_width);
+            hipLaunchKernelGGL((k_bwd_wide<REAL, MODE>), dim3(wb_.n_packs), dim3(WIDE_THREADS), wide_lds, stream, d, pk, omega, wide_pack_width, (unsigned char*)nullptr);
+        }
+        if (hb_.n_packs) {
+            const PackDev pk = pdev(hb_, nb_.n_packs + wb_.n_packs);
+            hipLaunchKernelGGL((k_bwd_wide<REAL, MODE, true>), dim3(hb_.n_packs), dim3(WIDE_THREADS), 0, stream, d, pk, omega, huge_pack_width, d_huge_scratch);
         }
         prof_end(kclass);
         HIPCHK(hipGetLastError());
@@ -338,7 +351,7 @@ struct SolverT final : SolverBase {
     {
         int rc = backward_run();
         if (rc) return rc;
-        hipLaunchKernelGGL(k_lb_reduce, dim3(1), dim3(1024), 0, stream, d_lb_partial, nb_.n_packs + wb_.n_packs, d_lb);
+        hipLaunchKernelGGL(k_lb_reduce, dim3(1), dim3(1024), 0, stream, d_lb_partial, nb_.n_packs + wb_.n_packs + hb_.n_packs, d_lb);
         HIPCHK(hipMemcpyAsync(lb, d_lb, sizeof(double), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         return BDDMMA_OK;

@@ -63,7 +63,7 @@ int bddmma_create(bddmma_solver** out, int precision, int device, const bddmma_i
         rc = create_solver(&impl, precision, device, L, opts, g_err);
         if (rc) return rc;
         impl->n_packs_narrow = L.narrow.n_packs();
-        impl->n_packs_wide = L.wide.n_packs();
+        impl->n_packs_wide = L.wide.n_packs() + L.huge.n_packs();
         impl->saved_instr.assign(instr, instr + bdd_delims[n_bdds]);
         impl->saved_delims.assign(bdd_delims, bdd_delims + n_bdds + 1);
         if (opts) impl->saved_opts = *opts;
@@ -406,7 +406,8 @@ int bddmma_layout_create(bddmma_layout** out, const bddmma_instruction* instr, c
 void bddmma_layout_destroy(bddmma_layout* l) { delete l; }
 // what: 0 n_slots, 1 narrow_slots, 2 n_layers, 3 narrow packs, 4 wide packs, 5 n_hops, 6 n_vars,
 //       7 narrow (pack,hop) records, 8 wide (pack,hop) records, 9 bins, 10 vars per bin, 11 stage groups,
-//       12 narrow layers, 13 stage cap, 14 waves per block, 15 (quad, round) records
+//       12 narrow layers, 13 stage cap, 14 waves per block, 15 (quad, round) records, 16 pack width,
+//       17 huge packs, 18 huge (pack,hop) records, 19 huge pack width
 uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
 {
     const HostLayout& L = l->L;
@@ -427,6 +428,9 @@ uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
         case 13: return L.ex.stage_cap;
         case 14: return L.ex.waves_per_block;
         case 16: return L.pack_width;
+        case 17: return L.huge.n_packs();
+        case 18: return L.huge.hop_node_off.empty() ? 0 : L.huge.hop_node_off.size() - 1;
+        case 19: return L.huge_pack_width;
         case 15: return L.ex.cs_ptr.empty() ? 0 : L.ex.cs_ptr.size() - 1;
         default: return 0;
     }
@@ -435,7 +439,7 @@ uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
 //        5/6/7/8 narrow pack_hop_ptr/hop_node_off/hop_layer_off(u32)/pack_steps(u8)   9/10/11/12 wide ...
 //        13 var_ptr(u32) 14 var_layers(u32) 15 bdd_root_slot(u32)
 //        16 bin_ptr(u32) 17 evar(u32) 18 lpos(u32) 19 vpos(u32) 20 pack_group_ptr 21 grp_layer_off 22 grp_hop_end
-//        23 quad_round_ptr 24 cs_ptr 25 cs_entry(u32) 26 cs_slot(u16)
+//        23 quad_round_ptr 24 cs_ptr 25 cs_entry(u32) 26 cs_slot(u16)   27/28/29/30 huge pack_hop_ptr/hop_node_off/hop_layer_off/pack_steps
 int bddmma_layout_copy(const bddmma_layout* l, int which, void* out)
 {
     const HostLayout& L = l->L;
@@ -471,6 +475,10 @@ int bddmma_layout_copy(const bddmma_layout* l, int which, void* out)
         case 24: return cp(L.ex.cs_ptr);
         case 25: return cp(L.ex.cs_entry);
         case 26: return cp(L.ex.cs_slot);
+        case 27: return cp(L.huge.pack_hop_ptr);
+        case 28: return cp(L.huge.hop_node_off);
+        case 29: return cp(L.huge.hop_layer_off);
+        case 30: return cp(L.huge.pack_steps);
         default: return BDDMMA_ERR_INVALID_ARGUMENT;
     }
 }

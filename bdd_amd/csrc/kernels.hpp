@@ -86,6 +86,23 @@ __device__ __forceinline__ void lds_min(REAL* p, REAL v)
     __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_min_f32 / ds_min_f64
 }
 
+// frontier minimum of the workgroup-per-pack kernels: LDS (ds_min) or, for huge packs whose frontier does not fit
+// in LDS, global scratch memory (L2 atomic; a CAS loop where the hardware has no float minimum)
+template <bool GLOBAL, typename REAL>
+__device__ __forceinline__ void frontier_min(REAL* p, REAL v)
+{
+    if (GLOBAL) __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// values other waves of the workgroup produced with frontier_min: huge packs read them from L2 (the atomics do not
+// update this CU's vector L1)
+template <bool GLOBAL, typename REAL>
+__device__ __forceinline__ REAL frontier_load(const REAL* p)
+{
+    if (GLOBAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
 // XCD-aware block -> pack map: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md),
 // so giving XCD x the contiguous pack range [x*per, (x+1)*per) keeps neighbouring packs — which
 // share variables in structured problems — behind the same 4 MiB L2.
@@ -717,14 +734,15 @@ __device__ __forceinline__ WideLds<REAL> carve_lds(unsigned char* base, uint32_t
     return l;
 }
 
-template <typename REAL, int MODE>
-__global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
+// GLOBAL: the frontier arrays of pack p live at scratch + p * wide_lds_bytes(ww) in global memory (huge packs)
+template <typename REAL, int MODE, bool GLOBAL = false>
+__global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww, unsigned char* scratch = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    WideLds<REAL> s = carve_lds<REAL>(smem, ww);
     const uint32_t tid = threadIdx.x;
     const uint32_t p = blockIdx.x;
     if (p >= pk.n_packs) return;
+    WideLds<REAL> s = carve_lds<REAL>(GLOBAL ? scratch + (size_t)p * wide_lds_bytes(sizeof(REAL), ww, true) : smem, ww);
     const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
     const REAL INF = inf_v<REAL>();
     REAL* Fc = s.a;
@@ -760,11 +778,11 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, Pack
                 const uint64_t w = d.wwords[nb + j - d.wide_slot_base];
                 const uint32_t lo_i = (uint32_t)(w & WW_CHILD_MASK), hi_i = (uint32_t)((w >> WW_CHILD_BITS) & WW_CHILD_MASK);
                 const uint32_t l = (uint32_t)((w >> (2 * WW_CHILD_BITS)) & WW_CHILD_MASK);
-                const REAL f = Fc[j];
+                const REAL f = frontier_load<GLOBAL>(&Fc[j]);
                 const REAL tl = lo_i == WW_BOT ? INF : (lo_i == WW_TOP ? REAL(0) : s.t[lo_i]);
                 const REAL th = hi_i == WW_BOT ? INF : (hi_i == WW_TOP ? REAL(0) : s.t[hi_i]);
-                lds_min(&s.m0[l], (f + s.lc[l]) + tl);
-                lds_min(&s.m1[l], (f + s.hc[l]) + th);
+                frontier_min<GLOBAL>(&s.m0[l], (f + s.lc[l]) + tl);
+                frontier_min<GLOBAL>(&s.m1[l], (f + s.hc[l]) + th);
             }
             __syncthreads();
         }
@@ -772,10 +790,10 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, Pack
             const uint64_t w = d.wwords[nb + j - d.wide_slot_base];
             const uint32_t lo_i = (uint32_t)(w & WW_CHILD_MASK), hi_i = (uint32_t)((w >> WW_CHILD_BITS) & WW_CHILD_MASK);
             const uint32_t l = (uint32_t)((w >> (2 * WW_CHILD_BITS)) & WW_CHILD_MASK);
-            const REAL f = Fc[j];
+            const REAL f = frontier_load<GLOBAL>(&Fc[j]);
             REAL nlo = s.lc[l], nhi = s.hc[l];
             if (MODE == FWD_SOLVE) {
-                const REAL m0 = s.m0[l], m1 = s.m1[l];
+                const REAL m0 = frontier_load<GLOBAL>(&s.m0[l]), m1 = frontier_load<GLOBAL>(&s.m1[l]);
                 const uint32_t e = d.lpos[lbase + l];
                 const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
                 nlo = (nlo + rmin(mm, REAL(0))) + d.delta_lay[2 * (size_t)e];
@@ -797,8 +815,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, Pack
                     if (c < WW_TOP) An[c] = 1;
                 }
             }
-            if (lo_i < WW_TOP) lds_min(&Fn[lo_i], f + nlo);
-            if (hi_i < WW_TOP) lds_min(&Fn[hi_i], f + nhi);
+            if (lo_i < WW_TOP) frontier_min<GLOBAL>(&Fn[lo_i], f + nlo);
+            if (hi_i < WW_TOP) frontier_min<GLOBAL>(&Fn[hi_i], f + nhi);
             d.F[nb + j] = f;
         }
         __syncthreads();
@@ -809,15 +827,15 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, Pack
     }
 }
 
-template <typename REAL, int MODE>
-__global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
+template <typename REAL, int MODE, bool GLOBAL = false>
+__global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww, unsigned char* scratch = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    WideLds<REAL> s = carve_lds<REAL>(smem, ww);
     __shared__ double red[WIDE_THREADS / 64];
     const uint32_t tid = threadIdx.x;
     const uint32_t p = blockIdx.x;
     if (p >= pk.n_packs) return;
+    WideLds<REAL> s = carve_lds<REAL>(GLOBAL ? scratch + (size_t)p * wide_lds_bytes(sizeof(REAL), ww, true) : smem, ww);
     const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
     const REAL INF = inf_v<REAL>();
     REAL* Tc = s.a;  // T of hop q+1
@@ -843,11 +861,11 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
                 const REAL tl = lo_i == WW_BOT ? INF : (lo_i == WW_TOP ? REAL(0) : Tc[lo_i]);
                 const REAL th = hi_i == WW_BOT ? INF : (hi_i == WW_TOP ? REAL(0) : Tc[hi_i]);
                 if (MODE == BWD_SOLVE) {
-                    lds_min(&s.m0[l], (f + s.lc[l]) + tl);
-                    lds_min(&s.m1[l], (f + s.hc[l]) + th);
+                    frontier_min<GLOBAL>(&s.m0[l], (f + s.lc[l]) + tl);
+                    frontier_min<GLOBAL>(&s.m1[l], (f + s.hc[l]) + th);
                 } else {
-                    lds_min(&s.m0[l], f + (tl + s.lc[l]));
-                    lds_min(&s.m1[l], f + (th + s.hc[l]));
+                    frontier_min<GLOBAL>(&s.m0[l], f + (tl + s.lc[l]));
+                    frontier_min<GLOBAL>(&s.m1[l], f + (th + s.hc[l]));
                 }
             }
             __syncthreads();
@@ -860,7 +878,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
             const REAL th = hi_i == WW_BOT ? INF : (hi_i == WW_TOP ? REAL(0) : Tc[hi_i]);
             REAL t;
             if (MODE == BWD_SOLVE) {
-                const REAL m0 = s.m0[l], m1 = s.m1[l];
+                const REAL m0 = frontier_load<GLOBAL>(&s.m0[l]), m1 = frontier_load<GLOBAL>(&s.m1[l]);
                 const uint32_t e = d.lpos[lbase + l];
                 const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
                 const REAL nlo = (s.lc[l] + rmin(mm, REAL(0))) + d.delta_lay[2 * (size_t)e];
@@ -874,8 +892,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
             } else {
                 t = rmin(th + s.hc[l], tl + s.lc[l]);
                 if (MODE == BWD_MARGINALS && (w & WW_HEAD)) {
-                    d.mm0_out[lbase + l] = s.m0[l];
-                    d.mm1_out[lbase + l] = s.m1[l];
+                    d.mm0_out[lbase + l] = frontier_load<GLOBAL>(&s.m0[l]);
+                    d.mm1_out[lbase + l] = frontier_load<GLOBAL>(&s.m1[l]);
                 }
             }
             Tn[j] = t;

@@ -230,18 +230,24 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
 
     // ---- pass 2: narrow / wide classification and greedy pack formation ----------------------
     const uint32_t narrow_limit = std::min<uint32_t>(NARROW_MAX_LAYER_WIDTH, W);
-    std::vector<uint32_t> order_n, order_w;
+    std::vector<uint32_t> order_n, order_w, order_h;
+    uint32_t HW = 0;  // huge packs: one workgroup per pack too, but the frontier lives in global memory
     for (uint64_t b = 0; b < n_bdds; ++b) {
         if (bdd_maxw[b] <= narrow_limit) order_n.push_back((uint32_t)b);
         else if (bdd_maxw[b] <= WW) order_w.push_back((uint32_t)b);
-        else {
+        else if (bdd_maxw[b] < WW_TOP) {
+            order_h.push_back((uint32_t)b);
+            HW = std::max<uint32_t>(HW, (uint32_t)bdd_maxw[b]);
+        } else {
             err = "BDD " + std::to_string(b) + " has a layer of " + std::to_string(bdd_maxw[b]) +
-                  " nodes; widest supported layer is " + std::to_string(WW) + " (wide_pack_width)";
+                  " nodes; the node word addresses " + std::to_string(WW_TOP - 1) + " nodes per hop";
             return BDDMMA_ERR_UNSUPPORTED;
         }
     }
+    HW = (HW + 7u) / 8u * 8u;  // per-pack scratch regions stay 8-byte aligned
+    L.huge_pack_width = HW;
     std::vector<uint32_t> lay_pos(Lin);  // slot position of every input layer inside its (pack,hop)
-    PackBuilder pn{W, 64}, pw{WW, 0};
+    PackBuilder pn{W, 64}, pw{WW, 0}, ph{std::max(HW, 1u), 0};
     std::vector<uint32_t> widths;
     auto form = [&](PackBuilder& pb, const std::vector<uint32_t>& order) {
         for (uint32_t k = 0; k < order.size(); ++k) {
@@ -255,12 +261,14 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     };
     form(pn, order_n);
     form(pw, order_w);
+    form(ph, order_h);
 
     // ---- pass 3: emit ----------------------------------------------------------------------
     uint64_t total_slots = 0;
     for (uint32_t u : pn.flat_used) total_slots += u;
     const uint64_t narrow_slots = total_slots;
     for (uint32_t u : pw.flat_used) total_slots += u;
+    for (uint32_t u : ph.flat_used) total_slots += u;
     if (total_slots >= std::numeric_limits<uint32_t>::max()) {
         err = "more than 2^32 node slots";
         return BDDMMA_ERR_UNSUPPORTED;
@@ -340,6 +348,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     };
     emit(pn, order_n, L.narrow, false);
     emit(pw, order_w, L.wide, true);
+    emit(ph, order_h, L.huge, true);
     L.n_nodes = L.n_input_nodes - 2 * n_bdds;
 
     // ---- variable -> layers CSR, sorted by (variable, bdd) (bdd_cuda_base.cu:379-391) ---------

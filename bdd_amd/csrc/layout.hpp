@@ -106,10 +106,11 @@ struct HostLayout {
     uint64_t n_layers = 0;        // non-terminal layers
     uint32_t pack_width = 0, wide_pack_width = 0;
 
-    PackSet narrow, wide;
+    PackSet narrow, wide, huge;   // huge: BDDs with a layer wider than wide_pack_width (frontier in global memory)
+    uint32_t huge_pack_width = 0;  // largest hop of a huge pack (0: none)
     uint32_t narrow_slots = 0;        // slots [0, narrow_slots) belong to narrow packs
     std::vector<uint32_t> narrow_words;  // [narrow_slots]
-    std::vector<uint64_t> wide_words;    // [n_slots - narrow_slots]
+    std::vector<uint64_t> wide_words;    // [n_slots - narrow_slots]: wide packs, then huge packs
 
     // per layer (internal order: pack-major, hop-major, BDD order inside the pack)
     std::vector<int32_t> layer_var, layer_bdd;

@@ -359,3 +359,47 @@ def test_long_bdds_vs_oracle(precision, pack_width, stage_cap, wpb):
         m = bdd == b
         x = np.zeros(col.nr_variables()); x[v[m]] = sol[m]
         assert col.evaluate(b, x)
+
+
+@pytest.mark.parametrize("precision", ["double", "float"])
+def test_huge_layers_use_the_global_memory_frontier(precision):
+    """BDD layers wider than the LDS frontier of a workgroup (wide_pack_width, default 2048): the 'huge' pack path.
+    Same protocol as the other oracle comparisons: lower bound, iterations, min-marginals, per-BDD argmin."""
+    from bdd_amd import native
+    rng = np.random.Generator(np.random.PCG64(1))
+    n = 28
+    co = rng.integers(1, 5000, size=n)
+    rows = [(co, np.arange(n), "<=", int(co.sum() // 2))]
+    for _ in range(6):                                   # narrow and wide neighbours sharing the variables
+        k = int(rng.integers(3, 9))
+        rows.append((np.ones(k, int), np.sort(rng.choice(n, size=k, replace=False)), ">=", 1))
+    c2 = rng.integers(1, 40, size=n)
+    rows.append((c2, np.arange(n), ">=", int(c2.sum() // 3)))
+    col = native.rows_to_bdd_collection(rows)
+    assert max(col.layer_widths(0)) > 2048
+    costs = rng.normal(0, 5, n).round(3)
+    s = bdd_hip_parallel_mma(col, costs, precision=precision)
+    o = Oracle(col, costs, precision)
+    rel = 1e-9 if precision == "double" else 2e-5
+    assert abs(s.lower_bound() - o.lower_bound()) <= rel * max(1.0, abs(o.lower_bound()))
+    for _ in range(25):
+        s.iteration()
+        o.iteration()
+    lb, ref = s.lower_bound(), o.lower_bound()
+    assert abs(lb - ref) <= rel * max(1.0, abs(ref)), (lb, ref)
+    perm = oracle_layer_perm(s, o)
+    _, mm0, mm1 = s.min_marginals_cuda(get_sorted=False)
+    omm = o.min_marginals()
+    tol = dict(rtol=1e-4, atol=2e-2) if precision == "float" else dict(rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(mm0[perm], omm[:, 0], **tol)
+    np.testing.assert_allclose(mm1[perm], omm[:, 1], **tol)
+    sol = s.bdds_solution_vec()
+    bdd, var = s.get_bdd_index(), s.get_primal_variable_index()
+    for b in range(s.nr_bdds()):
+        x = np.zeros(s.nr_variables()); x[var[bdd == b]] = sol[bdd == b]
+        assert col.evaluate(b, x)
+    # forcing the same instance through small LDS frontiers (more huge packs) gives the same numbers
+    s2 = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=64, wide_pack_width=64)
+    for _ in range(25):
+        s2.iteration()
+    assert abs(s2.lower_bound() - ref) <= rel * max(1.0, abs(ref))

@@ -32,6 +32,7 @@ class Layout:
         self.n_slots, self.narrow_slots, self.n_layers = sz(0), sz(1), sz(2)
         self.np_n, self.np_w, self.n_hops, self.n_vars = sz(3), sz(4), sz(5), sz(6)
         rec_n, rec_w = sz(7), sz(8)
+        self.np_h, rec_h, self.huge_pack_width = sz(17), sz(18), sz(19)
 
         def get(which, n, dt):
             a = np.zeros(max(n, 1), dt)
@@ -43,7 +44,7 @@ class Layout:
         self.layer_var = get(3, self.n_layers, np.int32)
         self.layer_bdd = get(4, self.n_layers, np.int32)
         self.sets = []
-        for base, P, rec in ((5, self.np_n, rec_n), (9, self.np_w, rec_w)):
+        for base, P, rec in ((5, self.np_n, rec_n), (9, self.np_w, rec_w), (27, self.np_h, rec_h)):
             self.sets.append(dict(pack_hop_ptr=get(base, P + 1 if P else 0, np.uint32),
                                   hop_node_off=get(base + 1, rec + 1 if P else 0, np.uint32),
                                   hop_layer_off=get(base + 2, rec + 1 if P else 0, np.uint32),
@@ -242,12 +243,24 @@ def test_layout_rejects_bad_input():
         Layout(bad)
     with pytest.raises(capi.BddMmaError):
         Layout(col, pack_width=100)
-    # wider than the widest supported layer
+
+
+def test_layers_wider_than_the_lds_frontier_form_huge_packs():
+    """A BDD with a layer wider than wide_pack_width is not rejected: it goes to a 'huge' pack, whose frontier
+    the workgroup-per-pack kernels keep in global memory."""
     col3 = BddCollection()
-    co = [27, 32, 1, 32, 19, 21, 25, 12, 39, 3, 11, 15, 23, 16, 6, 2, 1, 2]
+    co = [27, 32, 1, 32, 19, 21, 25, 12, 39, 3, 11, 15, 23, 16, 6, 2, 1, 2]   # widest layer: 97 nodes
     col3.add_linear(co, "<=", sum(co) // 2, list(range(18)))
-    with pytest.raises(capi.BddMmaError, match="widest supported"):
-        Layout(col3, wide_pack_width=64)
+    col3.add_covering([0, 5, 9])
+    lay = check_roundtrip(col3, pack_width=64, wide_pack_width=64)
+    assert (lay.np_n, lay.np_w, lay.np_h) == (1, 0, 1) and lay.huge_pack_width == 104   # 97 rounded up to 8
+    from bdd_amd import native
+    n = 28
+    co = np.random.Generator(np.random.PCG64(1)).integers(1, 5000, size=n)   # widest layer: 7843 nodes
+    col4 = native.rows_to_bdd_collection([(co, np.arange(n), "<=", int(co.sum() // 2)), ([1, 1, 1], [0, 1, 2], "=", 1)])
+    assert max(col4.layer_widths(0)) > 2048
+    lay = Layout(col4)
+    assert (lay.np_n, lay.np_w, lay.np_h) == (1, 0, 1) and lay.huge_pack_width >= max(col4.layer_widths(0))
 
 
 def test_create_without_gpu_fails_loudly():
@@ -270,3 +283,4 @@ def test_roundtrip_long_bdds_many_groups():
     assert lay.n_groups > 10 * lay.np_n and lay.n_hops == 300
     for w in (1, 2, 8):
         check_roundtrip(col, pack_width=64, stage_cap=64, vars_per_bin=64, waves_per_block=w)
+
