@@ -1201,10 +1201,24 @@ __global__ void k_make_dual_feasible(REAL* __restrict__ g, const uint32_t* __res
     if (v >= n_vars) return;
     const uint32_t k0 = var_ptr[v], k1 = var_ptr[v + 1];
     if (k1 == k0) return;
+    // the layers of a variable are scattered over the whole vector: issue the first MAXR gathers together
+    // instead of one dependent round trip per layer (same summation order as the plain loop)
+    constexpr int MAXR = 8;
+    uint32_t idx[MAXR];
+    REAL val[MAXR];
+#pragma unroll
+    for (int u = 0; u < MAXR; ++u) idx[u] = k0 + u < k1 ? var_layers[k0 + u] : 0u;
+#pragma unroll
+    for (int u = 0; u < MAXR; ++u) val[u] = k0 + u < k1 ? g[idx[u]] : REAL(0);
     REAL s = 0;
-    for (uint32_t k = k0; k < k1; ++k) s += g[var_layers[k]];
+#pragma unroll
+    for (int u = 0; u < MAXR; ++u) s += val[u];
+    for (uint32_t k = k0 + MAXR; k < k1; ++k) s += g[var_layers[k]];
     const REAL q = s / REAL(k1 - k0);
-    for (uint32_t k = k0; k < k1; ++k) g[var_layers[k]] -= q;
+#pragma unroll
+    for (int u = 0; u < MAXR; ++u)
+        if (k0 + u < k1) g[idx[u]] = val[u] - q;
+    for (uint32_t k = k0 + MAXR; k < k1; ++k) g[var_layers[k]] -= q;
 }
 
 // compute_primal_objective_vec (bdd_cuda_base.cu:1352-1362)

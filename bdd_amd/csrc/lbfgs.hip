@@ -42,6 +42,53 @@ namespace {
         }                                                                          \
     } while (0)
 
+// Scalars of the two-loop recursion stay on the device (no host round trip per dot product):
+//   sc[i] = alpha_i (i < 32), sc[SC_DOT] = last dot product, sc[SC_YNORM] = |y_last|^2, sc[SC_COEF] = coefficient of the next axpy
+enum : int { SC_DOT = 32, SC_YNORM = 33, SC_COEF = 34, SC_COUNT = 40 };
+// What the last block of a dot product does with the result r (the scalar kernels of the recursion, fused):
+//   FIN_STORE : sc[slot] = r
+//   FIN_ALPHA : alpha_i = r / rho_inv_i ; sc[i] = alpha_i ; sc[SC_COEF] = -alpha_i            (next axpy: d -= alpha_i y_i)
+//   FIN_BETA  : rho = 1 / rho_inv_i (times the initial H diagonal rho_inv_last / (1e-8 + |y_last|^2) for the first);
+//               sc[SC_COEF] = alpha_i - rho r                                                   (next axpy: d += (alpha_i - beta) s_i)
+enum : int { FIN_STORE = 0, FIN_ALPHA = 1, FIN_BETA = 2 };
+struct DotFin {
+    int op, slot, i, first;
+    double rho_inv, rho_inv_last;
+};
+
+// Second stage of a dot product (k_dot leaves one partial sum per block): one block adds the partials in a fixed
+// order — deterministic — and applies `fin`.  (A single-launch variant with a ticket counter was slower: 1024
+// same-address atomics, and __threadfence() writes back the XCD's L2: 23-33 us instead of 12 + 5 us.)
+static __global__ void __launch_bounds__(1024) k_reduce_fin(const double* __restrict__ partial, uint32_t n_partial, double* __restrict__ sc, DotFin fin)
+{
+    __shared__ double red[16];
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_partial; i += blockDim.x) acc += partial[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double r = 0.0;
+    for (uint32_t i = 0; i < blockDim.x / 64; ++i) r += red[i];
+    if (fin.op == FIN_STORE) {
+        sc[fin.slot] = r;
+    } else if (fin.op == FIN_ALPHA) {
+        const double al = r / fin.rho_inv;
+        sc[fin.i] = al;
+        sc[SC_COEF] = -al;
+    } else {
+        double rho = 1.0 / fin.rho_inv;
+        if (fin.first) rho *= fin.rho_inv_last / (1e-8 + sc[SC_YNORM]);
+        sc[SC_COEF] = sc[fin.i] - rho * r;
+    }
+}
+template <typename REAL, typename TX>
+static __global__ void k_axpy_dev(REAL* __restrict__ y, const TX* __restrict__ x, const double* __restrict__ coef, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += REAL(*coef) * REAL(x[i]);
+}
+
 template <typename REAL>
 struct Lbfgs final : bddmma_lbfgs {
     struct Hist {
@@ -50,6 +97,7 @@ struct Lbfgs final : bddmma_lbfgs {
         double rho_inv = 0;
     };
     std::deque<Hist> history;
+    std::vector<Hist> free_slots;  // history_size + 1 preallocated (s, y) pairs: no hipMalloc / hipFree per iteration
     std::vector<void*> allocs;
     REAL *prev_x = nullptr, *cur_x = nullptr, *dir = nullptr;
     char *prev_g = nullptr, *cur_g = nullptr;
@@ -65,7 +113,6 @@ struct Lbfgs final : bddmma_lbfgs {
     {
         (void)hipSetDevice(s->impl->device);
         for (void* q : allocs) (void)hipFree(q);
-        for (auto& h : history) { (void)hipFree(h.s); (void)hipFree(h.y); }
     }
     template <typename T>
     int alloc(T** q, size_t cnt)
@@ -83,26 +130,38 @@ struct Lbfgs final : bddmma_lbfgs {
         step_size = p.init_step_size;
         int rc;
         if ((rc = alloc(&prev_x, n)) || (rc = alloc(&cur_x, n)) || (rc = alloc(&dir, n)) || (rc = alloc(&prev_g, n)) ||
-            (rc = alloc(&cur_g, n)) || (rc = alloc(&d_partial, 1024)) || (rc = alloc(&d_scalar, 1)))
+            (rc = alloc(&cur_g, n)) || (rc = alloc(&d_partial, 1024)) || (rc = alloc(&d_scalar, SC_COUNT)))
             return rc;
+        if (p.history_size >= SC_DOT) { err = "history size must be < 32"; return BDDMMA_ERR_INVALID_ARGUMENT; }
+        for (int i = 0; i < p.history_size + 1; ++i) {
+            Hist h;
+            if ((rc = alloc(&h.s, n)) || (rc = alloc(&h.y, n))) return rc;
+            free_slots.push_back(h);
+        }
         return 0;
     }
     void flush() override  // flush_lbfgs_states, lbfgs_impl.h:318-326
     {
         unsuccessful = 0;
-        for (auto& h : history) { (void)hipFree(h.s); (void)hipFree(h.y); }
+        for (auto& h : history) free_slots.push_back(h);
         history.clear();
         prev_stored = false;
     }
     template <typename TA, typename TB>
     int dot(const TA* a, const TB* b, double* out)
     {
-        const uint32_t blocks = std::min<uint32_t>(1024, (n + 255) / 256 ? (n + 255) / 256 : 1);
-        hipLaunchKernelGGL((k_dot<TA, TB>), dim3(blocks), dim3(256), 0, st, a, b, d_partial, n);
-        hipLaunchKernelGGL(k_lb_reduce, dim3(1), dim3(1024), 0, st, d_partial, blocks, d_scalar);
-        LHIP(hipMemcpyAsync(out, d_scalar, sizeof(double), hipMemcpyDeviceToHost, st));
+        dot_dev(a, b, DotFin{FIN_STORE, SC_DOT, 0, 0, 0.0, 0.0});
+        LHIP(hipMemcpyAsync(out, d_scalar + SC_DOT, sizeof(double), hipMemcpyDeviceToHost, st));
         LHIP(hipStreamSynchronize(st));
         return 0;
+    }
+    // dot product consumed on the device (see DotFin); ordered on the stream, no synchronisation
+    template <typename TA, typename TB>
+    void dot_dev(const TA* a, const TB* b, const DotFin& fin)
+    {
+        const uint32_t blocks = std::min<uint32_t>(1024, (n + 255) / 256 ? (n + 255) / 256 : 1);
+        hipLaunchKernelGGL((k_dot<TA, TB>), dim3(blocks), dim3(256), 0, st, a, b, d_partial, n);
+        hipLaunchKernelGGL(k_reduce_fin, dim3(1), dim3(1024), 0, st, d_partial, blocks, d_scalar, fin);
     }
     dim3 grid() const { return dim3((n + 255) / 256 ? (n + 255) / 256 : 1); }
 
@@ -125,22 +184,19 @@ struct Lbfgs final : bddmma_lbfgs {
             prev_stored = true;
             return 0;
         }
-        Hist h;
-        LHIP(hipMalloc((void**)&h.s, (n ? n : 1) * sizeof(REAL)));
-        LHIP(hipMalloc((void**)&h.y, n ? n : 1));
+        Hist h = free_slots.back();
+        free_slots.pop_back();
         hipLaunchKernelGGL((k_diff<REAL, REAL>), grid(), dim3(256), 0, st, h.s, cur_x, prev_x, n);   // x_k - x_{k-1}
         hipLaunchKernelGGL((k_diff<char, char>), grid(), dim3(256), 0, st, h.y, prev_g, cur_g, n);   // g_{k-1} - g_k
-        if ((rc = dot(h.s, h.y, &h.rho_inv))) { (void)hipFree(h.s); (void)hipFree(h.y); return rc; }
+        if ((rc = dot(h.s, h.y, &h.rho_inv))) { free_slots.push_back(h); return rc; }
         if (h.rho_inv > 1e-8) {
             history.push_back(h);
             if ((int)history.size() > p.history_size) {
-                (void)hipFree(history.front().s);
-                (void)hipFree(history.front().y);
+                free_slots.push_back(history.front());
                 history.pop_front();
             }
         } else {
-            (void)hipFree(h.s);
-            (void)hipFree(h.y);
+            free_slots.push_back(h);
             prev_stored = false;
         }
         LHIP(hipMemcpyAsync(prev_x, cur_x, n * sizeof(REAL), hipMemcpyDeviceToDevice, st));
@@ -150,29 +206,20 @@ struct Lbfgs final : bddmma_lbfgs {
 
     bool update_possible() const { return (int)history.size() >= p.history_size && unsuccessful <= 5; }  // :334-340
 
-    // compute_update_direction, :226-316
+    // compute_update_direction, :226-316 — everything queued on the stream, the scalars never leave the device
     int compute_direction()
     {
         hipLaunchKernelGGL((k_fill<REAL>), grid(), dim3(256), 0, st, dir, REAL(0), (uint64_t)n);
         hipLaunchKernelGGL((k_axpy<REAL, char>), grid(), dim3(256), 0, st, dir, cur_g, REAL(1), n);  // direction = grad_f
-        std::vector<double> alpha(history.size());
-        int rc;
+        const double* coef = d_scalar + SC_COEF;
         for (int i = (int)history.size() - 1; i >= 0; --i) {
-            double sd;
-            if ((rc = dot(history[i].s, dir, &sd))) return rc;
-            alpha[i] = sd / history[i].rho_inv;
-            hipLaunchKernelGGL((k_axpy<REAL, char>), grid(), dim3(256), 0, st, dir, history[i].y, REAL(-alpha[i]), n);
+            dot_dev(history[i].s, dir, DotFin{FIN_ALPHA, 0, i, 0, history[i].rho_inv, 0.0});
+            hipLaunchKernelGGL((k_axpy_dev<REAL, char>), grid(), dim3(256), 0, st, dir, history[i].y, coef, n);
         }
-        double last_y_norm;
-        if ((rc = dot(history.back().y, history.back().y, &last_y_norm))) return rc;
-        const double h_diag = history.back().rho_inv / (1e-8 + last_y_norm);
+        dot_dev(history.back().y, history.back().y, DotFin{FIN_STORE, SC_YNORM, 0, 0, 0.0, 0.0});
         for (size_t i = 0; i < history.size(); ++i) {
-            double rho = 1.0 / history[i].rho_inv;
-            if (i == 0) rho *= h_diag;
-            double yd;
-            if ((rc = dot(history[i].y, dir, &yd))) return rc;
-            const double beta = rho * yd;
-            hipLaunchKernelGGL((k_axpy<REAL, REAL>), grid(), dim3(256), 0, st, dir, history[i].s, REAL(alpha[i] - beta), n);
+            dot_dev(history[i].y, dir, DotFin{FIN_BETA, 0, (int)i, i == 0 ? 1 : 0, history[i].rho_inv, history.back().rho_inv});
+            hipLaunchKernelGGL((k_axpy_dev<REAL, REAL>), grid(), dim3(256), 0, st, dir, history[i].s, coef, n);
         }
         LHIP(hipGetLastError());
         return 0;
