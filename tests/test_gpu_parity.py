@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from bdd_amd import BddCollection, parse_lp, to_bdd_collection
-from bdd_amd.instances import GRID_3X3, LONG_CHAIN, SHORT_CHAIN, assignment_ilp, mrf_ilp, random_set_cover
+from bdd_amd.instances import GRID_3X3, LONG_CHAIN, SHORT_CHAIN, assignment_ilp, brute_force_optimum, mrf_ilp, random_set_cover
 from bdd_amd.solver import bdd_hip_lbfgs, bdd_hip_parallel_mma, run_solver
 from oracle.oracle import Oracle
 from test_oracle_kat import SIMPLEX_KATS
@@ -403,3 +403,71 @@ def test_huge_layers_use_the_global_memory_frontier(precision):
     for _ in range(25):
         s2.iteration()
     assert abs(s2.lower_bound() - ref) <= rel * max(1.0, abs(ref))
+
+
+@pytest.mark.parametrize("precision", ["double", "float"])
+def test_edge_cases_vs_oracle(precision):
+    """Inputs at the edges of the format: duplicated rows, variables no BDD contains, zero costs, unsorted variables
+    with negative coefficients, a cost vector shorter than the number of variables (bdd_cuda_base.cu:465-469)."""
+    col = BddCollection()
+    col.add_simplex([0, 1, 2, 3, 4, 5])
+    col.add_covering([2, 3, 9])
+    col.add_covering([2, 3, 9])                            # duplicate row
+    col.add_linear([2, -1, 3, -2], ">=", 1, [9, 4, 11, 0])  # unsorted variables, negative coefficients; variables 6, 7, 8, 10 are in no BDD
+    col.add_covering([1, 5])
+    V = col.nr_variables()
+    assert V == 12
+    rng = np.random.Generator(np.random.PCG64(5))
+    costs = rng.normal(0, 3, V).round(2)
+    costs[[1, 9]] = 0.0
+    rel = 1e-9 if precision == "double" else 2e-5
+    for c in (costs, costs[:8]):                           # the short vector leaves the tail variables at cost 0
+        s = bdd_hip_parallel_mma(col, c, precision=precision)
+        o = Oracle(col, pad_costs(c, V), precision)
+        assert s.nr_bdds(6) == 0 and s.nr_bdds(2) == 3
+        assert abs(s.lower_bound() - o.lower_bound()) <= rel * max(1.0, abs(o.lower_bound()))
+        for it in range(30):
+            s.iteration(); o.iteration()
+            lb, ref = s.lower_bound(), o.lower_bound()
+            assert np.isfinite(ref) and abs(lb - ref) <= rel * max(1.0, abs(ref)), (it, lb, ref)
+        perm = oracle_layer_perm(s, o)
+        _, mm0, mm1 = s.min_marginals_cuda(get_sorted=False)
+        omm = o.min_marginals()
+        tol = dict(rtol=1e-4, atol=1e-4) if precision == "float" else dict(rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(mm0[perm], omm[:, 0], **tol)
+        np.testing.assert_allclose(mm1[perm], omm[:, 1], **tol)
+
+
+@pytest.mark.parametrize("precision", ["double", "float"])
+def test_forced_variables_keep_the_bound_finite_and_valid(precision):
+    """Single-variable BDDs and rows that fix variables: one arc of every node of such a layer leads to the bot sink, the
+    min-marginal of that side is +inf and the GPU rule applies no update (`mm = 0` unless both are finite,
+    bdd_cuda_parallel_mma.cu:83-84).  The CPU solver instead propagates the fixation as infinite costs
+    (bdd_parallel_mma_base.cpp:844-863), so this is checked by properties, not against the oracle: the bound stays
+    finite, never decreases and never exceeds the optimum."""
+    from bdd_amd.ilp import ILP
+    ilp = ILP()
+    names = [f"x{i}" for i in range(10)]
+    for n in names:
+        ilp.var(n)
+    ilp.objective = [3.0, -1.5, 2.0, 0.5, -2.5, 1.0, -0.5, 4.0, -3.0, 0.25]
+    ilp.add_constraint([(1, "x3")], "=", 1)                                # single-variable simplex: x3 = 1
+    ilp.add_constraint([(1, "x7")], ">=", 1)                               # single-variable covering
+    ilp.add_constraint([(1, "x0"), (1, "x1")], "=", 2)                     # both forced to 1
+    ilp.add_constraint([(1, "x4"), (1, "x5")], "<=", 0)                    # both forced to 0
+    ilp.add_constraint([(1, n) for n in ("x0", "x2", "x4", "x6", "x8")], "<=", 3)
+    ilp.add_constraint([(1, n) for n in ("x1", "x3", "x5", "x7", "x9")], ">=", 3)
+    ilp.add_constraint([(2, "x2"), (-1, "x6"), (1, "x8"), (1, "x9")], ">=", 1)
+    opt = brute_force_optimum(ilp)
+    col = to_bdd_collection(ilp)
+    s = bdd_hip_parallel_mma(col, ilp.objective, precision=precision)
+    prev = s.lower_bound()
+    assert np.isfinite(prev) and prev <= opt + 1e-6
+    for _ in range(200):
+        s.iteration()
+        lb = s.lower_bound()
+        assert np.isfinite(lb) and lb >= prev - (1e-9 if precision == "double" else 1e-4) and lb <= opt + 1e-4
+        prev = lb
+    _, mm0, mm1 = s.min_marginals_cuda(get_sorted=False)
+    var = s.get_primal_variable_index()
+    assert np.isinf(mm0[var == 3]).sum() == 1 and np.all(np.isfinite(mm1[var == 3]))   # x3 = 0 is impossible in its own single-node BDD only
