@@ -154,7 +154,7 @@ def main():
             "value_with_lower_bound_every_iteration": lb_rate,
             "lower_bound_after": {"iterations": args.warmup + args.steps, "value": lb},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(col, costs, args, sizes)
         print(json.dumps(out), flush=True)
     barrier()
