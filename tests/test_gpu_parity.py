@@ -471,3 +471,36 @@ def test_forced_variables_keep_the_bound_finite_and_valid(precision):
     _, mm0, mm1 = s.min_marginals_cuda(get_sorted=False)
     var = s.get_primal_variable_index()
     assert np.isinf(mm0[var == 3]).sum() == 1 and np.all(np.isfinite(mm1[var == 3]))   # x3 = 0 is impossible in its own single-node BDD only
+
+
+def test_independent_handles_interleaved_and_bad_device():
+    """Handles own their stream and buffers (bdd_mma.h: one per problem, one per GPU host thread): two solvers that are
+    stepped alternately, and from two host threads, give exactly the results of running each alone."""
+    import threading
+    col_a, costs_a = random_set_cover(3000, 2000, 6, seed=3)
+    col_b, costs_b = random_set_cover(2500, 1800, 9, seed=4)
+
+    def alone(col, costs, n):
+        s = bdd_hip_parallel_mma(col, costs, precision="double", deterministic=True)
+        s.iterations(n)
+        return s.lower_bound()
+    want_a, want_b = alone(col_a, costs_a, 40), alone(col_b, costs_b, 25)
+    a = bdd_hip_parallel_mma(col_a, costs_a, precision="double", deterministic=True)
+    b = bdd_hip_parallel_mma(col_b, costs_b, precision="double", deterministic=True)
+    for i in range(40):
+        a.iteration()
+        if i < 25:
+            b.iteration()
+    assert a.lower_bound() == want_a and b.lower_bound() == want_b
+    out = {}
+
+    def work(key, col, costs, n):
+        out[key] = alone(col, costs, n)
+    ts = [threading.Thread(target=work, args=("a", col_a, costs_a, 40)), threading.Thread(target=work, args=("b", col_b, costs_b, 25))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert out == {"a": want_a, "b": want_b}
+    with pytest.raises(Exception, match="device"):
+        bdd_hip_parallel_mma(col_a, costs_a, device=63)
