@@ -19,7 +19,7 @@ import time
 import numpy as np
 
 from . import capi, native
-from .ilp import ILP, parse_lp
+from .ilp import ILP, parse_lp, parse_lp_or_opb, parse_opb
 from .solver import bdd_hip_lbfgs, bdd_hip_parallel_mma, run_solver
 
 GPU_MMA = {"cuda parallel mma", "hip parallel mma"}
@@ -61,9 +61,9 @@ class bdd_solver:
         if os.path.exists(inp):
             _log(f"[bdd_solver] Read input file {inp}", self.quiet)
             with open(inp) as f:
-                return parse_lp(f.read())
+                return parse_opb(f.read()) if os.path.splitext(inp)[1] == ".opb" else parse_lp_or_opb(f.read())
         _log("[bdd_solver] Read input string", self.quiet)
-        return parse_lp(inp)
+        return parse_lp_or_opb(inp)      # the reference tries the .lp grammar, then OPB (:59-63)
 
     # ------------------------------------------------------------------ process_ILP (:71-103)
     def process_ILP(self, ilp: ILP):

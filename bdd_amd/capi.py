@@ -105,6 +105,8 @@ _I64P, _U64P = C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
 ILP_SIGNATURES = {
     "bddilp_last_error": (C.c_char_p, []),
     "bddilp_parse_lp": (_I, [C.c_char_p, C.POINTER(_V)]),
+    "bddilp_parse_opb": (_I, [C.c_char_p, C.POINTER(_V)]),
+    "bddilp_parse": (_I, [C.c_char_p, C.POINTER(_V)]),
     "bddilp_destroy": (None, [_V]),
     "bddilp_nr_variables": (_U64, [_V]),
     "bddilp_nr_constraints": (_U64, [_V]),

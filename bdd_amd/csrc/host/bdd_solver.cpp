@@ -66,10 +66,10 @@ ilp_input bdd_solver::read_ILP() const
     const std::string inp = config_["input"].str;
     if (file_exists(inp)) {
         log("[bdd_solver] Read input file " + inp);
-        return parse_lp(slurp(inp));
+        return extension(inp) == ".opb" ? parse_opb(slurp(inp)) : parse_lp_or_opb(slurp(inp));
     }
     log("[bdd_solver] Read input string");
-    return parse_lp(inp);
+    return parse_lp_or_opb(inp);  // the reference tries the .lp grammar, then OPB (:59-63)
 }
 
 void bdd_solver::process_ILP(ilp_input& ilp) const

@@ -272,6 +272,78 @@ ilp_input parse_lp(const std::string& text)
     return ilp;
 }
 
+ilp_input parse_opb(const std::string& text)
+{
+    // drop the leading comment lines, then treat the rest as one stream of `;`-terminated statements
+    std::string body;
+    {
+        std::istringstream in(text);
+        std::string ln;
+        bool header = true;
+        while (std::getline(in, ln)) {
+            if (!ln.empty() && ln.back() == '\r') ln.pop_back();
+            if (header && !trim(ln).empty() && trim(ln)[0] == '*') continue;
+            if (!trim(ln).empty()) header = false;
+            body += ln + " ";
+        }
+    }
+    const std::string t = trim(body);
+    if (t.compare(0, 4, "min:") != 0) throw std::runtime_error("could not read input: OPB text must start with 'min:'");
+    size_t p = t.find(';');
+    if (p == std::string::npos) throw std::runtime_error("could not read input: objective is not terminated by ';'");
+    ilp_input ilp;
+    double dummy = 0;
+    for (const auto& tm : scan_terms(t.substr(4, p - 4), "objective", false, &dummy)) ilp.objective[ilp.var(tm.name)] += tm.coeff;
+    for (;;) {
+        const size_t q = t.find(';', p + 1);
+        if (q == std::string::npos) break;  // `until<eof>`: the remainder is not a complete row
+        const std::string row = trim(t.substr(p + 1, q - p - 1));
+        p = q;
+        if (row.empty()) continue;
+        size_t rp = std::string::npos, rl = 0;
+        for (size_t i = 0; i < row.size(); ++i) {
+            if ((row[i] == '<' || row[i] == '>') && i + 1 < row.size() && row[i + 1] == '=') { rp = i; rl = 2; break; }
+            if (row[i] == '=') { rp = i; rl = 1; break; }
+        }
+        if (rp == std::string::npos) throw std::runtime_error("cannot parse constraint near '" + row.substr(0, 40) + "'");
+        constraint c;
+        c.ineq = rl == 1 ? ineq_t::eq : row[rp] == '<' ? ineq_t::le : ineq_t::ge;
+        {
+            const std::string rhs_s = trim(row.substr(rp + rl));
+            size_t i = 0;
+            long sign = 1;
+            if (i < rhs_s.size() && (rhs_s[i] == '+' || rhs_s[i] == '-')) { sign = rhs_s[i] == '-' ? -1 : 1; ++i; }
+            if (i >= rhs_s.size()) throw std::runtime_error("cannot parse constraint near '" + row.substr(0, 40) + "'");
+            long v = 0;
+            for (; i < rhs_s.size(); ++i) {
+                if (!std::isdigit((unsigned char)rhs_s[i])) throw std::runtime_error("only integer constraint coefficients are supported (OPB_parser.cpp:55)");
+                v = v * 10 + (rhs_s[i] - '0');
+            }
+            c.rhs = sign * v;
+        }
+        for (const auto& tm : scan_terms(row.substr(0, rp), "constraint", false, nullptr)) {
+            if (tm.coeff != std::floor(tm.coeff)) throw std::runtime_error("only integer constraint coefficients are supported (OPB_parser.cpp:47-48)");
+            c.coefficients.push_back((long)tm.coeff);
+            c.variables.push_back(ilp.var(tm.name));
+        }
+        ilp.constraints.push_back(std::move(c));
+    }
+    return ilp;
+}
+
+ilp_input parse_lp_or_opb(const std::string& text)
+{
+    try {
+        return parse_lp(text);
+    } catch (const std::exception& lp_error) {
+        try {
+            return parse_opb(text);
+        } catch (const std::exception&) {
+            throw std::runtime_error(lp_error.what());  // report the .lp diagnosis: it is the primary format
+        }
+    }
+}
+
 bdd_store to_bdds(const ilp_input& ilp)
 {
     bdd_store col;

@@ -45,6 +45,11 @@ private:
 
 // throws std::runtime_error with the offending text on malformed input
 ilp_input parse_lp(const std::string& text);
+// The OPB (pseudo-Boolean) subset of src/ILP/OPB_parser.cpp:23-60: leading `* comment` lines, `min: <terms> ;`, then
+// `<terms> {<=,>=,=} <integer> ;` rows (a row may span lines); whatever follows the last `;` is ignored.
+ilp_input parse_opb(const std::string& text);
+// bdd_solver::read_ILP (bdd_solver.cpp:44-66): try the .lp grammar first, then OPB
+ilp_input parse_lp_or_opb(const std::string& text);
 
 // Rows that are trivially true are skipped (bdd_preprocessor.cpp:213-214); an infeasible row throws (:215-216).
 bdd_store to_bdds(const ilp_input& ilp);

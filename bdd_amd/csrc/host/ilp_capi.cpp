@@ -34,6 +34,16 @@ int bddilp_parse_lp(const char* lp_text, bddilp** out)
     if (!lp_text || !out) { g_err = "null argument"; return BDDILP_ERR_INVALID_ARGUMENT; }
     return guarded(BDDILP_ERR_PARSE, [&] { *out = new bddilp{parse_lp(lp_text)}; return BDDILP_OK; });
 }
+int bddilp_parse_opb(const char* text, bddilp** out)
+{
+    if (!text || !out) { g_err = "null argument"; return BDDILP_ERR_INVALID_ARGUMENT; }
+    return guarded(BDDILP_ERR_PARSE, [&] { *out = new bddilp{parse_opb(text)}; return BDDILP_OK; });
+}
+int bddilp_parse(const char* text, bddilp** out)
+{
+    if (!text || !out) { g_err = "null argument"; return BDDILP_ERR_INVALID_ARGUMENT; }
+    return guarded(BDDILP_ERR_PARSE, [&] { *out = new bddilp{parse_lp_or_opb(text)}; return BDDILP_OK; });
+}
 void bddilp_destroy(bddilp* ilp) { delete ilp; }
 uint64_t bddilp_nr_variables(const bddilp* ilp) { return ilp->ilp.nr_variables(); }
 uint64_t bddilp_nr_constraints(const bddilp* ilp) { return ilp->ilp.constraints.size(); }

@@ -169,6 +169,54 @@ def parse_lp(text: str) -> ILP:
     return ilp
 
 
+def parse_opb(text: str) -> ILP:
+    """The OPB (pseudo-Boolean) subset of the reference's OPB_parser (src/ILP/OPB_parser.cpp:23-60): leading
+    `* comment` lines, `min: <terms> ;`, then `<terms> {<=,>=,=} <integer> ;` rows, which may span lines; whatever
+    follows the last `;` is ignored (`until<eof>`)."""
+    lines, header = [], True
+    for ln in text.splitlines():
+        if header and ln.strip().startswith("*"):
+            continue
+        if ln.strip():
+            header = False
+        lines.append(ln)
+    t = " ".join(lines).strip()
+    if not t.startswith("min:"):
+        raise ValueError("could not read input: OPB text must start with 'min:'")
+    stmts = t[4:].split(";")
+    if len(stmts) < 2:
+        raise ValueError("could not read input: objective is not terminated by ';'")
+    ilp = ILP()
+    for c, name in _parse_terms(stmts[0], "objective"):
+        ilp.objective[ilp.var(name)] += c
+    for row in stmts[1:-1]:                      # the piece after the last ';' is not a complete row
+        row = row.strip()
+        if not row:
+            continue
+        mi = _INEQ.search(row)
+        if not mi:
+            raise ValueError(f"cannot parse constraint near '{row[:40]}'")
+        rhs_s = row[mi.end():].strip()
+        if not re.fullmatch(r"[+-]?\d+", rhs_s):
+            raise ValueError("only integer constraint coefficients are supported (OPB_parser.cpp:55)")
+        terms = _parse_terms(row[: mi.start()], "constraint")
+        if any(c != int(c) for c, _ in terms):
+            raise ValueError("only integer constraint coefficients are supported (OPB_parser.cpp:47-48)")
+        ilp.add_constraint([(int(c), n) for c, n in terms], mi.group(1), int(rhs_s))
+    return ilp
+
+
+def parse_lp_or_opb(text: str) -> ILP:
+    """bdd_solver::read_ILP for strings (bdd_solver.cpp:59-63): the .lp grammar first, then OPB."""
+    try:
+        return parse_lp(text)
+    except ValueError as lp_error:
+        try:
+            return parse_opb(text)
+        except ValueError:
+            raise lp_error
+
+
 def to_bdd_collection(ilp: ILP) -> BddCollection:
     """bdd_preprocessor::add_ilp for linear rows (bdd_preprocessor.cpp:165-226).
     Rows that are trivially true are skipped (:213-214); infeasible rows raise (:215-216)."""

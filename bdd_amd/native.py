@@ -36,11 +36,12 @@ def _collection_from_handle(L, h) -> BddCollection:
     return col
 
 
-def parse_lp(text: str) -> ILP:
-    """ilp.parse_lp through the C++ reader."""
+def parse_lp(text: str, fmt: str = "lp") -> ILP:
+    """ilp.parse_lp / parse_opb / parse_lp_or_opb through the C++ readers (fmt: "lp", "opb" or "auto")."""
     L = capi.lib()
     h = C.c_void_p()
-    _check(L.bddilp_parse_lp(text.encode(), C.byref(h)))
+    fn = {"lp": L.bddilp_parse_lp, "opb": L.bddilp_parse_opb, "auto": L.bddilp_parse}[fmt]
+    _check(fn(text.encode(), C.byref(h)))
     try:
         ilp = ILP()
         V = int(L.bddilp_nr_variables(h))

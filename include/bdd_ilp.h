@@ -36,6 +36,10 @@ const char* bddilp_last_error(void);
 
 /* ILP_parser::parse_string: variables are numbered by first appearance, objective first. */
 int bddilp_parse_lp(const char* lp_text, bddilp** out);
+/* OPB_parser::parse_string (src/ILP/OPB_parser.cpp:23-60, :240-252): `* comments`, `min: terms ;`, `terms rel int ;` rows. */
+int bddilp_parse_opb(const char* opb_text, bddilp** out);
+/* bdd_solver::read_ILP for strings (bdd_solver.cpp:59-63): the .lp grammar first, then OPB. */
+int bddilp_parse(const char* text, bddilp** out);
 void bddilp_destroy(bddilp* ilp);
 uint64_t bddilp_nr_variables(const bddilp* ilp);
 uint64_t bddilp_nr_constraints(const bddilp* ilp);

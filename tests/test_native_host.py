@@ -104,3 +104,36 @@ def test_infeasible_and_trivial_rows_in_lp():
         native.lp_to_bdd_collection("Minimize\nx + y\nSubject To\nx + y >= 3\nEnd\n")
     col = native.lp_to_bdd_collection("Minimize\nx + y\nSubject To\nx + y >= 0\nx + y >= 1\nEnd\n")
     assert col.nr_bdds() == 1
+
+
+OPB = """* #variable= 5 #constraint= 3
+* a comment
+min: +1 x1 -2 x2 +3.5 x3 + x4 - x5 ;
++1 x1 +2 x2 >= 1 ;
+-1 x3 +1 x4
+ +1 x5 = 1 ;
+3 x1 - x5 <= 2;
+"""
+
+
+def test_opb_reader_cpp_python_and_lp_equivalent():
+    from bdd_amd.ilp import parse_lp_or_opb, parse_opb
+    a, b = native.parse_lp(OPB, fmt="opb"), parse_opb(OPB)
+    same_ilp(a, b)
+    assert a.var_names == ["x1", "x2", "x3", "x4", "x5"] and a.objective == [1.0, -2.0, 3.5, 1.0, -1.0]
+    rows = [(c.coefficients, c.variables, c.ineq, c.rhs) for c in a.constraints]
+    assert rows == [([1, 2], [0, 1], ">=", 1), ([-1, 1, 1], [2, 3, 4], "=", 1), ([3, -1], [0, 4], "<=", 2)]
+    lp = "Minimize\nx1 - 2 x2 + 3.5 x3 + x4 - x5\nSubject To\nx1 + 2 x2 >= 1\n- x3 + x4 + x5 = 1\n3 x1 - x5 <= 2\nEnd\n"
+    same_ilp(a, parse_lp(lp))
+    # the driver's fallback: .lp grammar first, then OPB; the .lp diagnosis is reported when both fail
+    same_ilp(native.parse_lp(OPB, fmt="auto"), a)
+    same_ilp(parse_lp_or_opb(OPB), a)
+    same_ilp(native.parse_lp(lp, fmt="auto"), a)
+    for f in (lambda t: native.parse_lp(t, fmt="auto"), parse_lp_or_opb):
+        with pytest.raises(ValueError, match="Minimize"):
+            f("max: x1 ;")
+    for f in (lambda t: native.parse_lp(t, fmt="opb"), parse_opb):
+        with pytest.raises(ValueError, match="min:"):
+            f("x1 + x2 >= 1 ;")
+        with pytest.raises(ValueError, match="integer"):
+            f("min: x1 ;\n x1 + 0.5 x2 >= 1 ;")
