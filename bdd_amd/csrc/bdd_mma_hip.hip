@@ -125,6 +125,13 @@ struct SolverT final : SolverBase {
         h_nbdds = L.num_bdds_per_var; h_var_ptr = L.var_ptr;
         h_layer_var = L.layer_var; h_layer_bdd = L.layer_bdd;
         deterministic = opts && opts->deterministic;
+        // the kernels address every array through a buffer descriptor with 32-bit byte offsets (kernels.hpp: make_rsrc);
+        // an access past 4 GiB would be dropped silently, so refuse such instances up front
+        if ((uint64_t)n_slots * sizeof(REAL) >= (1ull << 32) || 2ull * n_layers * sizeof(REAL) >= (1ull << 32)) {
+            err = "instance too large for 32-bit buffer offsets: " + std::to_string(n_slots) + " node slots, " + std::to_string(n_layers) +
+                  " layers of " + std::to_string(sizeof(REAL)) + "-byte values (each array must stay below 4 GiB)";
+            return BDDMMA_ERR_UNSUPPORTED;
+        }
         int rc;
         if ((rc = upload(&d_nwords, L.narrow_words))) return rc;
         if ((rc = upload(&d_wwords, L.wide_words))) return rc;

@@ -963,7 +963,7 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
         lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
     }
     // number of BDDs of the variables this thread normalises (needed only after the accumulation)
-    constexpr int NPT = 8;  // 2 * vars_per_bin <= NPT * EX_THREADS
+    constexpr int NPT = 16;  // 2 * vars_per_bin <= NPT * EX_THREADS
     int nb[NPT];
     if (MODE == EX_ITER) {
 #pragma unroll

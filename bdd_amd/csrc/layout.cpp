@@ -367,13 +367,13 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         Exchange& X = L.ex;
         // default bin: as many variables as a 128 KiB LDS tile holds (2 REAL each), but at least ~256 bins
         // so that the exchange kernel (one workgroup per bin) has enough workgroups to spread over the CUs
-        const uint32_t max_vb = 4096u;  // k_exchange_reduce: 2 * vars_per_bin <= 8 * 1024 threads; 64 KiB of double accumulators
+        const uint32_t max_vb = 8192u;  // k_exchange_reduce: 2 * vars_per_bin <= 16 * 1024 threads; 128 KiB of double accumulators
         uint32_t auto_vb = (uint32_t)(((L.n_vars + 255) / 256 + 255) / 256 * 256);
         auto_vb = std::min(std::max(auto_vb, 1024u), max_vb);
         X.vars_per_bin = opts && opts->vars_per_bin ? opts->vars_per_bin : auto_vb;
         X.stage_cap = opts && opts->stage_cap ? opts->stage_cap : 640;
-        if (X.vars_per_bin < 64 || X.vars_per_bin > 4096) {
-            err = "vars_per_bin must be in [64, 4096]";
+        if (X.vars_per_bin < 64 || X.vars_per_bin > max_vb) {
+            err = "vars_per_bin must be in [64, 8192]";
             return BDDMMA_ERR_INVALID_ARGUMENT;
         }
         if (X.stage_cap < W || X.stage_cap > 640) {

@@ -130,11 +130,11 @@ def oracle_layer_perm(s, o):
 
 
 @pytest.mark.parametrize("precision", ["double", "float"])
-@pytest.mark.parametrize("pack_width,wpb", [(64, 4), (128, 4), (128, 1), (128, 8)])
-def test_random_cover_vs_oracle(precision, pack_width, wpb):
-    col, costs = random_set_cover(3000, 2500, 8, seed=5)
+@pytest.mark.parametrize("pack_width,wpb,vars_per_bin", [(64, 4, 0), (128, 4, 64), (128, 1, 8192), (128, 8, 0)])
+def test_random_cover_vs_oracle(precision, pack_width, wpb, vars_per_bin):
+    col, costs = random_set_cover(3000 if vars_per_bin != 8192 else 20000, 2500, 8, seed=5)
     s = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=pack_width, waves_per_block=wpb,
-                             stage_cap=256 if wpb == 8 else 0)
+                             stage_cap=256 if wpb == 8 else 0, vars_per_bin=vars_per_bin)
     o = Oracle(col, costs, precision)
     assert s.nr_packs() > 8
     assert close(s.lower_bound(), o.lower_bound(), precision, 10)
