@@ -18,7 +18,7 @@ for f in sorted(glob.glob(f"{src}/pmc_*/pmc_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(f"{dst}/pmc_summary.txt", "w") as out:
-    out.write("# rocprofv3 --pmc, one pass per counter group (tools_profile.sh); mean per dispatch of `python bench.py --steps 10`\n")
+    out.write("# rocprofv3 --pmc, one pass per counter group (tools/profile.sh); mean per dispatch of `python bench.py --steps 10`\n")
     for k, d in sorted(agg.items()):
         if "bddmma" in k:
             out.write(f"{k}: " + json.dumps({c: round(sum(v) / len(v), 1) for c, v in sorted(d.items())}) + f"  dispatches={len(next(iter(d.values())))}\n")

@@ -1,6 +1,6 @@
-"""Kernel-level micro-benchmark on the GPU box: python tools_kbench.py [--precision float] [--pack-width N] ..."""
+"""Kernel-level micro-benchmark on the GPU box: python tools/kbench.py [--precision float] [--pack-width N] ..."""
 import argparse, sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bdd_amd import capi
 if os.environ.get("BDDMMA_LIB"):
     capi.LIB_PATH = os.path.abspath(os.environ["BDDMMA_LIB"])   # experimental builds under build/

@@ -1,10 +1,10 @@
 """BASELINE.json configs[3]: L-BFGS around the HIP parallel-MMA backbone on the 10.5 M-node instance —
 iterations/s and lower bound vs iteration / time, next to plain MMA.  Writes profiles/<tag>_lbfgs_curve.json.
 
-    python tools_lbfgs_curve.py [--precision double] [--iters 150] [--tag r01]
+    python tools/lbfgs_curve.py [--precision double] [--iters 150] [--tag r01]
 """
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bdd_amd.instances import random_set_cover, set_cover_sizes
 from bdd_amd.solver import bdd_hip_lbfgs, bdd_hip_parallel_mma
 

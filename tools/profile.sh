@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (on the GPU box, via gpurun): bash tools_profile.sh <tag> [bench args...]
+# Usage (on the GPU box, via gpurun): bash tools/profile.sh <tag> [bench args...]
 # Writes rocprofv3 kernel-trace stats and PMC passes under gpurun_out/prof_<tag>/.
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp

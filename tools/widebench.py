@@ -1,6 +1,6 @@
 """Wide-pack path micro-benchmark: knapsack rows (layer width up to ~150 nodes)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bdd_amd import BddCollection
 from bdd_amd.solver import bdd_hip_parallel_mma
