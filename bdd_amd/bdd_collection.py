@@ -358,6 +358,23 @@ class BddCollection:
                                               np.asarray(var, dtype=np.uint64)[None, :], 1, n, top_first=False))
         return new_nrs, aux[-1] + widths[(n_chunks - 1) * chunk_size]
 
+    def permute(self, order) -> None:
+        """Reorder the BDDs: new BDD i is old BDD order[i] (storage compacted, child indices re-based)."""
+        order = np.asarray(order, dtype=np.int64)
+        assert sorted(order.tolist()) == list(range(self._nb))
+        ins, d = self.instr, self.delims.astype(np.int64)
+        sizes = (d[1:] - d[:-1])[order]
+        new_d = np.concatenate(([0], np.cumsum(sizes)))
+        # source index of every new instruction, and the shift of its BDD
+        src = np.repeat(d[:-1][order] - new_d[:-1], sizes) + np.arange(new_d[-1])
+        out = ins[src].copy()
+        shift = np.repeat(new_d[:-1] - d[:-1][order], sizes)
+        nt = out[:, 2] < BOTSINK
+        out[nt, 0] = (out[nt, 0].astype(np.int64) + shift[nt]).astype(np.uint64)
+        out[nt, 1] = (out[nt, 1].astype(np.int64) + shift[nt]).astype(np.uint64)
+        self._chunks = [out]
+        self._delims = [new_d.astype(np.uint64)]
+
     def append(self, other: "BddCollection") -> None:
         ins = other.instr.copy()
         nt = ins[:, 2] < BOTSINK

@@ -38,7 +38,9 @@ static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b -
 template <typename REAL>
 struct SolverT final : SolverBase {
     // device buffers
-    uint32_t* d_nwords = nullptr;
+    uint32_t* d_nwords = nullptr;       // distinct pack word sequences (layout.hpp: narrow_words_unique)
+    uint32_t* d_pack_word_off = nullptr;
+    uint32_t n_nwords = 0;
     uint64_t* d_wwords = nullptr;
     REAL *d_F = nullptr, *d_T = nullptr, *d_lohi = nullptr;  // d_lohi: {lo, hi} per layer, interleaved
     REAL* d_lo = nullptr;  // = d_lohi     (stride 2)
@@ -133,7 +135,9 @@ struct SolverT final : SolverBase {
             return BDDMMA_ERR_UNSUPPORTED;
         }
         int rc;
-        if ((rc = upload(&d_nwords, L.narrow_words))) return rc;
+        if ((rc = upload(&d_nwords, L.narrow_words_unique))) return rc;
+        n_nwords = (uint32_t)L.narrow_words_unique.size();
+        if ((rc = upload(&d_pack_word_off, L.narrow_word_off))) return rc;
         if ((rc = upload(&d_wwords, L.wide_words))) return rc;
         if ((rc = upload(&d_var, L.layer_var))) return rc;
         if ((rc = upload(&d_bdd, L.layer_bdd))) return rc;
@@ -221,7 +225,7 @@ struct SolverT final : SolverBase {
     DevPtrs<REAL> ptrs(const REAL* delta_lay) const
     {
         DevPtrs<REAL> d;
-        d.nwords = d_nwords; d.wwords = d_wwords; d.wide_slot_base = wide_slot_base;
+        d.nwords = d_nwords; d.n_nwords = n_nwords; d.wwords = d_wwords; d.wide_slot_base = wide_slot_base;
         d.F = d_F; d.T = d_T; d.lohi = d_lohi;
         d.delta_lay = delta_lay; d.mm_binned = d_mm_binned; d.lpos = d_lpos; d.cs_entry = d_cs_entry; d.cs_slot = d_cs_slot;
         d.n_slots = (uint32_t)n_slots; d.n_layers = (uint32_t)n_layers; d.n_narrow_layers = n_narrow_layers;
@@ -231,7 +235,7 @@ struct SolverT final : SolverBase {
     }
     PackDev pdev(const PackBufs& b, uint32_t lb_base) const
     {
-        return PackDev{b.pack_hop_ptr, b.hop_node_off, b.hop_layer_off, b.pack_steps,
+        return PackDev{b.pack_hop_ptr, b.hop_node_off, b.hop_layer_off, b.pack_steps, d_pack_word_off,
                        d_pack_group_ptr, d_grp_layer_off, d_grp_hop_end, d_quad_round_ptr, d_cs_ptr, stage_cap, b.n_packs, lb_base};
     }
 

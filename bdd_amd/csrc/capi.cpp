@@ -407,7 +407,7 @@ void bddmma_layout_destroy(bddmma_layout* l) { delete l; }
 // what: 0 n_slots, 1 narrow_slots, 2 n_layers, 3 narrow packs, 4 wide packs, 5 n_hops, 6 n_vars,
 //       7 narrow (pack,hop) records, 8 wide (pack,hop) records, 9 bins, 10 vars per bin, 11 stage groups,
 //       12 narrow layers, 13 stage cap, 14 waves per block, 15 (quad, round) records, 16 pack width,
-//       17 huge packs, 18 huge (pack,hop) records, 19 huge pack width
+//       17 huge packs, 18 huge (pack,hop) records, 19 huge pack width, 20 distinct narrow words stored on the device
 uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
 {
     const HostLayout& L = l->L;
@@ -431,6 +431,7 @@ uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
         case 17: return L.huge.n_packs();
         case 18: return L.huge.hop_node_off.empty() ? 0 : L.huge.hop_node_off.size() - 1;
         case 19: return L.huge_pack_width;
+        case 20: return L.narrow_words_unique.size();
         case 15: return L.ex.cs_ptr.empty() ? 0 : L.ex.cs_ptr.size() - 1;
         default: return 0;
     }
@@ -440,6 +441,7 @@ uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
 //        13 var_ptr(u32) 14 var_layers(u32) 15 bdd_root_slot(u32)
 //        16 bin_ptr(u32) 17 evar(u32) 18 lpos(u32) 19 vpos(u32) 20 pack_group_ptr 21 grp_layer_off 22 grp_hop_end
 //        23 quad_round_ptr 24 cs_ptr 25 cs_entry(u32) 26 cs_slot(u16)   27/28/29/30 huge pack_hop_ptr/hop_node_off/hop_layer_off/pack_steps
+//        31 narrow_words_unique(u32) 32 narrow_word_off(u32, per narrow pack)
 int bddmma_layout_copy(const bddmma_layout* l, int which, void* out)
 {
     const HostLayout& L = l->L;
@@ -479,6 +481,8 @@ int bddmma_layout_copy(const bddmma_layout* l, int which, void* out)
         case 28: return cp(L.huge.hop_node_off);
         case 29: return cp(L.huge.hop_layer_off);
         case 30: return cp(L.huge.pack_steps);
+        case 31: return cp(L.narrow_words_unique);
+        case 32: return cp(L.narrow_word_off);
         default: return BDDMMA_ERR_INVALID_ARGUMENT;
     }
 }

@@ -31,7 +31,8 @@ enum : int { BWD_PLAIN = 0, BWD_SOLVE = 1, BWD_MARGINALS = 2 };
 
 template <typename REAL>
 struct DevPtrs {
-    const uint32_t* nwords;  // narrow node words, indexed by slot
+    const uint32_t* nwords;  // narrow node words: distinct pack sequences, pack p's at PackDev::pack_word_off[p]
+    uint32_t n_nwords;
     const uint64_t* wwords;  // wide node words, indexed by slot - wide_slot_base
     uint32_t wide_slot_base;
     REAL* F;                 // cost from root, per slot
@@ -57,6 +58,7 @@ struct PackDev {
     const uint32_t* hop_node_off;
     const uint32_t* hop_layer_off;
     const uint8_t* pack_steps;
+    const uint32_t* pack_word_off;   // narrow packs: first word of the pack's (shared) word sequence
     const uint32_t* pack_group_ptr;  // narrow packs: stage groups
     const uint32_t* grp_layer_off;
     const uint32_t* grp_hop_end;
@@ -224,7 +226,7 @@ struct NarrowRs {
     rsrc_t words, T, F, lohi, cse, css, dlay, mm;
     __device__ __forceinline__ explicit NarrowRs(const DevPtrs<REAL>& d)
     {
-        words = make_rsrc(d.nwords, d.wide_slot_base);
+        words = make_rsrc(d.nwords, d.n_nwords);
         T = make_rsrc(d.T, d.n_slots);
         F = make_rsrc(d.F, d.n_slots);
         lohi = make_rsrc(d.lohi, 2ull * d.n_layers);
@@ -411,6 +413,8 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDe
     // always readable; offsets beyond q1 are clamped (those hops have no nodes for this pack)
     HopWindow hw{sOffN_[wave], sOffL_[wave], q0, q1};
     auto off = [&](uint32_t q) { return hw.node_off(q); };
+    // word address of slot s of this pack = s + wd (the pack's words live in a sequence shared by all packs of its structure)
+    const uint32_t wd = has_pack ? pk.pack_word_off[p] - pk.hop_node_off[q0] : 0;
     uint32_t nb = 0, ne = 0;
     // pipeline prologue
     uint32_t wa[R], wb[R];
@@ -427,9 +431,9 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDe
             if (MODE == FWD_SOLUTION) sAct[0][j] = (j < ne - nb) ? 1 : 0;
         }
         if (lane < 2) sT[W + lane] = lane == 0 ? REAL(0) : INF;
-        load_words<R>(wa, rs.words, nb, ne - nb, lane);
+        load_words<R>(wa, rs.words, nb + wd, ne - nb, lane);
         const uint32_t ne2 = off(q0 + 2);
-        load_words<R>(wb, rs.words, ne, ne2 - ne, lane);                     // words of hop q0+1 (none if q0+1 == q1)
+        load_words<R>(wb, rs.words, ne + wd, ne2 - ne, lane);                // words of hop q0+1 (none if q0+1 == q1)
         if (NEED_T) load_vals<REAL, R>(ta, rs.T, ne, ne2 - ne, lane);         // T of hop q0+1
         load_layer<REAL, R>(La, wa, hw.layer_off(q0), rs);
     }
@@ -466,7 +470,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDe
             HopLayer<REAL, R> Lb;
             {
                 const uint32_t ne3 = off(q + 3);
-                load_words<R>(wc, rs.words, ne2, ne3 - ne2, lane);
+                load_words<R>(wc, rs.words, ne2 + wd, ne3 - ne2, lane);
                 if (NEED_T) load_vals<REAL, R>(tb, rs.T, ne2, ne3 - ne2, lane);
                 const uint32_t lbase_next = hw.layer_off(q + 1);
                 load_layer<REAL, R>(Lb, wb, lbase_next, rs);  // wb is all padding past the last hop: no loads
@@ -571,6 +575,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDe
     HopWindow hw{sOffN_[wave], sOffL_[wave], q0, q1};
     // node range of hop q; hops below q0 (pipeline run-off) are empty
     auto nb_of = [&](uint32_t q) { return hw.node_off(q); };
+    const uint32_t wd = has_pack ? pk.pack_word_off[p] - pk.hop_node_off[q0] : 0;  // see k_fwd_narrow
     // pipeline prologue: hop q1-1 fully, words of hop q1-2
     uint32_t wa[R], wb[R];
     REAL fa[R], fb[R];
@@ -580,11 +585,11 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDe
         hw.fill(pk, q1 + 1 > q0 + HOP_WIN ? q1 + 1 - HOP_WIN : q0, lane);  // window ends at record q1
         const uint32_t nb = nb_of(q1 - 1);
         const uint32_t n = nb_of(q1) - nb;
-        load_words<R>(wa, rs.words, nb, n, lane);
+        load_words<R>(wa, rs.words, nb + wd, n, lane);
         if (NEED_F) load_vals<REAL, R>(fa, rs.F, nb, n, lane);
         const bool has = (q1 - 1 > q0);
         const uint32_t nb2 = has ? nb_of(q1 - 2) : nb, n2 = has ? nb - nb2 : 0;
-        load_words<R>(wb, rs.words, nb2, n2, lane);
+        load_words<R>(wb, rs.words, nb2 + wd, n2, lane);
         if (NEED_F) load_vals<REAL, R>(fb, rs.F, nb2, n2, lane);
         load_layer<REAL, R>(La, wa, hw.layer_off(q1 - 1), rs);
     }
@@ -621,7 +626,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDe
             {
                 const bool has2 = (q >= q0 + 2);
                 const uint32_t nb3 = has2 ? nb_of(q - 2) : nb, n3 = has2 ? nb_of(q - 1) - nb3 : 0;
-                load_words<R>(wc, rs.words, nb3, n3, lane);
+                load_words<R>(wc, rs.words, nb3 + wd, n3, lane);
                 if (NEED_F) load_vals<REAL, R>(fc, rs.F, nb3, n3, lane);
                 const uint32_t lbase_prev = hw.layer_off(q > q0 ? q - 1 : q);
                 load_layer<REAL, R>(Lb, wb, lbase_prev, rs);  // wb is all padding below the first hop

@@ -2,6 +2,7 @@
 #include "layout.hpp"
 
 #include <algorithm>
+#include <unordered_map>
 #include <cstring>
 #include <limits>
 
@@ -136,6 +137,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     std::vector<uint64_t> lay_first;   // first instruction of every input layer (BDD-major)
     std::vector<uint32_t> bdd_lay_ptr(n_bdds + 1, 0);
     std::vector<uint32_t> bdd_maxw(n_bdds, 0);
+    std::vector<uint64_t> bdd_shape(n_bdds, 0);  // hash of the BDD's structure (arcs and layer boundaries relative to its first entry)
     uint64_t max_var = 0;
     for (uint64_t b = 0; b < n_bdds; ++b) {
         const uint64_t d0 = delims[b], d1 = delims[b + 1];
@@ -200,6 +202,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
                 last_bdd[v] = b;
                 L.num_bdds_per_var[v]++;
                 bdd_maxw[b] = std::max<uint32_t>(bdd_maxw[b], (uint32_t)(e - f));
+                bdd_shape[b] = (bdd_shape[b] ^ (e - f)) * 1099511628211ull + 0x9e3779b97f4a7c15ull;
                 const bool last = (l + 1 == l1);
                 const uint64_t nf = last ? 0 : lay_first[l + 1], ne = last ? 0 : layer_end(b, l + 1);
                 for (uint64_t i = f; i < e; ++i) {
@@ -209,6 +212,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
                             err = "BDD " + std::to_string(b) + ": child index out of range";
                             return BDDMMA_ERR_INVALID_BDD;
                         }
+                        bdd_shape[b] = (bdd_shape[b] ^ (is_term(instr[c]) ? (is_top(instr[c]) ? ~0ull : ~1ull) : c - delims[b])) * 1099511628211ull;
                         if (is_bot(instr[c])) continue;
                         if (is_top(instr[c])) {
                             if (!last) {
@@ -246,6 +250,20 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     }
     HW = (HW + 7u) / 8u * 8u;  // per-pack scratch regions stay 8-byte aligned
     L.huge_pack_width = HW;
+    // Narrow BDDs of the same shape are packed together (stable: input order inside a shape class), so that packs
+    // are structurally identical and share one stored word sequence (layout.hpp: narrow_words_unique).  Classes are
+    // ordered by first appearance.  The result does not depend on the order of the BDDs.
+    if (!(opts && opts->reserved[0] == 1)) {
+        std::unordered_map<uint64_t, uint32_t> cls;
+        std::vector<uint32_t> cls_of(order_n.size());
+        for (size_t k = 0; k < order_n.size(); ++k) cls_of[k] = cls.emplace(bdd_shape[order_n[k]], (uint32_t)cls.size()).first->second;
+        std::vector<uint32_t> idx(order_n.size());
+        for (size_t k = 0; k < idx.size(); ++k) idx[k] = (uint32_t)k;
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cls_of[a] < cls_of[b]; });
+        std::vector<uint32_t> grouped(order_n.size());
+        for (size_t k = 0; k < idx.size(); ++k) grouped[k] = order_n[idx[k]];
+        order_n.swap(grouped);
+    }
     std::vector<uint32_t> lay_pos(Lin);  // slot position of every input layer inside its (pack,hop)
     PackBuilder pn{W, 64}, pw{WW, 0}, ph{std::max(HW, 1u), 0};
     std::vector<uint32_t> widths;
@@ -350,6 +368,37 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     emit(pw, order_w, L.wide, true);
     emit(ph, order_h, L.huge, true);
     L.n_nodes = L.n_input_nodes - 2 * n_bdds;
+    {   // structure templates: store every distinct pack word sequence once
+        const PackSet& N = L.narrow;
+        const uint32_t P = N.n_packs();
+        L.narrow_word_off.assign(P, 0);
+        std::unordered_map<uint64_t, std::vector<uint32_t>> seen;  // hash -> packs already stored with that hash
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint32_t s0 = N.hop_node_off[N.pack_hop_ptr[p]], s1 = N.hop_node_off[N.pack_hop_ptr[p + 1]];
+            uint64_t h = 1469598103934665603ull ^ (s1 - s0);
+            for (uint32_t i = s0; i < s1; ++i) h = (h ^ L.narrow_words[i]) * 1099511628211ull;
+            bool found = false;
+            for (uint32_t o : seen[h]) {
+                const uint32_t o0 = N.hop_node_off[N.pack_hop_ptr[o]], o1 = N.hop_node_off[N.pack_hop_ptr[o + 1]];
+                if (o1 - o0 == s1 - s0 && std::equal(L.narrow_words.begin() + s0, L.narrow_words.begin() + s1, L.narrow_words.begin() + o0)) {
+                    // the hop boundaries must coincide too: the kernels address words by (slot - first slot of the pack)
+                    bool same_hops = N.pack_hop_ptr[p + 1] - N.pack_hop_ptr[p] == N.pack_hop_ptr[o + 1] - N.pack_hop_ptr[o];
+                    for (uint32_t q = 0; same_hops && q <= N.pack_hop_ptr[p + 1] - N.pack_hop_ptr[p]; ++q)
+                        same_hops = N.hop_node_off[N.pack_hop_ptr[p] + q] - s0 == N.hop_node_off[N.pack_hop_ptr[o] + q] - o0;
+                    if (same_hops) {
+                        L.narrow_word_off[p] = L.narrow_word_off[o];
+                        found = true;
+                        break;
+                    }
+                }
+            }
+            if (!found) {
+                L.narrow_word_off[p] = (uint32_t)L.narrow_words_unique.size();
+                L.narrow_words_unique.insert(L.narrow_words_unique.end(), L.narrow_words.begin() + s0, L.narrow_words.begin() + s1);
+                seen[h].push_back(p);
+            }
+        }
+    }
 
     // ---- variable -> layers CSR, sorted by (variable, bdd) (bdd_cuda_base.cu:379-391) ---------
     L.var_ptr.assign(L.n_vars + 1, 0);

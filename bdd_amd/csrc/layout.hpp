@@ -110,6 +110,11 @@ struct HostLayout {
     uint32_t huge_pack_width = 0;  // largest hop of a huge pack (0: none)
     uint32_t narrow_slots = 0;        // slots [0, narrow_slots) belong to narrow packs
     std::vector<uint32_t> narrow_words;  // [narrow_slots]
+    // Packs with the same structure (same BDD shapes at the same slots: every row of one constraint family) have
+    // identical word sequences.  The device holds each distinct sequence once; pack p reads its words at
+    // narrow_word_off[p] + (slot - first slot of the pack), so the copies stay L2-resident instead of streaming from HBM.
+    std::vector<uint32_t> narrow_words_unique;  // concatenated distinct pack word sequences
+    std::vector<uint32_t> narrow_word_off;      // [narrow packs] offset of the pack's sequence in narrow_words_unique
     std::vector<uint64_t> wide_words;    // [n_slots - narrow_slots]: wide packs, then huge packs
 
     // per layer (internal order: pack-major, hop-major, BDD order inside the pack)

@@ -35,6 +35,31 @@ def random_set_cover(n_vars: int, n_rows: int, k: int = 10, seed: int = 12345):
     return col, costs
 
 
+def random_set_cover_mixed(n_vars: int, n_rows: int, k_min: int = 3, k_max: int = 16, seed: int = 12345):
+    """Set cover with row sizes drawn uniformly from [k_min, k_max], rows of all sizes interleaved at random:
+    the structure-heterogeneous counterpart of random_set_cover (BDDs of k_max - k_min + 1 different shapes)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ks = rng.integers(k_min, k_max + 1, size=n_rows)
+    col = BddCollection()
+    covered = np.zeros(n_vars, dtype=bool)
+    for k in range(k_min, k_max + 1):
+        cnt = int((ks == k).sum())
+        if cnt == 0:
+            continue
+        rows = np.sort(rng.integers(0, n_vars, size=(cnt, k), dtype=np.int64), axis=1)
+        while True:
+            dup = (rows[:, 1:] == rows[:, :-1]).any(axis=1)
+            if not dup.any():
+                break
+            rows[dup] = np.sort(rng.integers(0, n_vars, size=(int(dup.sum()), k), dtype=np.int64), axis=1)
+        covered[rows.ravel()] = True
+        col.add_covering(rows.astype(np.uint64))
+    col.permute(rng.permutation(n_rows))
+    costs = rng.uniform(1.0, 10.0, size=n_vars)
+    costs[~covered] = 0.0
+    return col, costs
+
+
 def set_cover_sizes(n_vars: int, n_rows: int, k: int):
     """(N, N', L', V, B, H) of random_set_cover in the notation of SURVEY.md §8."""
     return dict(N=n_rows * (2 * k + 1), N_nt=n_rows * (2 * k - 1), L_nt=n_rows * k, V=n_vars, B=n_rows, H=k)

@@ -284,3 +284,24 @@ def test_roundtrip_long_bdds_many_groups():
     for w in (1, 2, 8):
         check_roundtrip(col, pack_width=64, stage_cap=64, vars_per_bin=64, waves_per_block=w)
 
+
+
+def test_packs_of_equal_structure_share_their_node_words():
+    """Structure templates: the device keeps each distinct pack word sequence once (layout.hpp: narrow_words_unique);
+    reading pack p's words at narrow_word_off[p] reproduces the per-slot words exactly."""
+    from bdd_amd.instances import random_set_cover
+    col, _ = random_set_cover(4000, 3000, 6, seed=2)          # 3000 covering rows of the same size
+    for extra in ([0, 1, 2], [5, 9], [3, 4, 7, 8, 11]):       # and a few rows of other shapes
+        col.add_simplex(extra)
+    lay = Layout(col, pack_width=64)
+    L, h = lay.L, lay.h
+    n_unique = int(L.bddmma_layout_size(h, 20))
+    uniq = np.zeros(max(n_unique, 1), np.uint32)
+    woff = np.zeros(max(lay.np_n, 1), np.uint32)
+    capi.check(L.bddmma_layout_copy(h, 31, uniq.ctypes.data_as(C.c_void_p)), None)
+    capi.check(L.bddmma_layout_copy(h, 32, woff.ctypes.data_as(C.c_void_p)), None)
+    S = lay.sets[0]
+    for p in range(lay.np_n):
+        s0, s1 = int(S["hop_node_off"][S["pack_hop_ptr"][p]]), int(S["hop_node_off"][S["pack_hop_ptr"][p + 1]])
+        np.testing.assert_array_equal(uniq[int(woff[p]):int(woff[p]) + s1 - s0], lay.nwords[s0:s1])
+    assert lay.np_n > 50 and n_unique < lay.narrow_slots // 10   # ~all full packs of 6-variable covering rows share one sequence
