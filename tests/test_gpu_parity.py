@@ -316,11 +316,13 @@ def test_full_size_properties(n_vars, n_rows):
     np.testing.assert_allclose(sd.get_primal_objective_vector_host(), costs, atol=1e-9)
     # per-BDD lower bounds add up to the lower bound (checksum of checksums)
     assert abs(sd.lower_bound_per_bdd().sum() - sd.lower_bound()) <= 1e-9 * abs(sd.lower_bound())
-    if n_rows <= 50_000:
-        o = Oracle(col, costs, "double", threads=os.cpu_count() or 1)
-        for _ in range(10):
-            o.iteration()
-        assert abs(lbs[-1] - o.lower_bound()) <= 1e-9 * abs(o.lower_bound())
+    # and the oracle itself at this size (BASELINE.json: LB within 1e-5 rel. of the CPU parallel mma after equal
+    # iterations; in double the two differ only by the order of the delta sums)
+    o = Oracle(col, costs, "double", threads=min(os.cpu_count() or 1, 32))
+    for _ in range(10):
+        o.iteration()
+    assert abs(lbs[-1] - o.lower_bound()) <= 1e-9 * abs(o.lower_bound())
+    assert abs(lf - o.lower_bound()) <= 1e-5 * abs(o.lower_bound())
 
 
 # ---------------------------------------------------------------- long BDDs: hop-window refills and several stage groups per pack
