@@ -58,7 +58,6 @@ size_t bdd_store::append_local(const std::vector<long>& lo, const std::vector<lo
     const size_t n = var.size(), base = instructions.size();
     const size_t top = base + n + (top_first ? 0 : 1), bot = base + n + (top_first ? 1 : 0);
     auto abs = [&](long c) -> uint64_t { return c == TOP_LOCAL ? top : c == BOT_LOCAL ? bot : base + (size_t)c; };
-    instructions.reserve(base + n + 2);
     for (size_t i = 0; i < n; ++i) instructions.push_back({abs(lo[i]), abs(hi[i]), var[i]});
     const bddmma_instruction t{BDDMMA_TOPSINK, BDDMMA_TOPSINK, BDDMMA_TOPSINK}, f{BDDMMA_BOTSINK, BDDMMA_BOTSINK, BDDMMA_BOTSINK};
     instructions.push_back(top_first ? t : f);
