@@ -461,7 +461,6 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDe
         }
         for (; q < qe; ++q) {
             if (q + 3 >= hw.base + HOP_WIN && hw.base + HOP_WIN <= q1) hw.fill(pk, q, lane);
-            (void)0;
             const uint32_t ne2 = off(q + 2);
             const uint32_t n2 = ne2 - ne;
             // ---- prefetch: layer data of hop q+1 (its words were requested one hop ago), words of hop q+2, T of hop q+2
