@@ -59,6 +59,7 @@ struct SolverT final : SolverBase {
     uint32_t wpb = 1;
     uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0, stage_lds = 0, exch_lds = 0, n_narrow_layers = 0;
     double *d_lb_partial = nullptr, *d_lb = nullptr;
+    double* h_lb = nullptr;  // pinned, device-visible: the reduce kernel writes the bound straight into host memory
     uint32_t* d_counts = nullptr;
     REAL *d_tmp0 = nullptr, *d_tmp1 = nullptr;        // per-layer scratch (min-marginals, sorted outputs)
     char* d_sol = nullptr;
@@ -77,6 +78,7 @@ struct SolverT final : SolverBase {
     {
         if (device >= 0) (void)hipSetDevice(device);
         for (void* p : allocs) (void)hipFree(p);
+        if (h_lb) (void)hipHostFree(h_lb);
         for (auto& e : ev_pool) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
@@ -190,7 +192,8 @@ struct SolverT final : SolverBase {
         if ((rc = dalloc(&d_delta_var, 2 * n_vars))) return rc;
         if ((rc = dalloc(&d_delta_c, 2 * n_vars))) return rc;
         if ((rc = dalloc(&d_lb_partial, nb_.n_packs + wb_.n_packs + hb_.n_packs))) return rc;
-        if ((rc = dalloc(&d_lb, 1))) return rc;
+        HIPCHK(hipHostMalloc((void**)&h_lb, sizeof(double), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void**)&d_lb, h_lb, 0));
         if ((rc = dalloc(&d_counts, 4))) return rc;
         HIPCHK(hipMemsetAsync(d_F, 0, n_slots * sizeof(REAL), stream));
         HIPCHK(hipMemsetAsync(d_T, 0, n_slots * sizeof(REAL), stream));
@@ -362,9 +365,10 @@ struct SolverT final : SolverBase {
     {
         int rc = backward_run();
         if (rc) return rc;
+        // no copy-engine round trip: one block writes the 8 bytes to pinned host memory, the host waits for the stream
         hipLaunchKernelGGL(k_lb_reduce, dim3(1), dim3(1024), 0, stream, d_lb_partial, nb_.n_packs + wb_.n_packs + hb_.n_packs, d_lb);
-        HIPCHK(hipMemcpyAsync(lb, d_lb, sizeof(double), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+        *lb = *(volatile double*)h_lb;
         return BDDMMA_OK;
     }
     int lower_bound_per_bdd(void* out, int on_device) override
