@@ -479,8 +479,10 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         }
         for (uint32_t b = 0; b < X.n_bins; ++b) X.bin_ptr[b + 1] += X.bin_ptr[b];
         // cooperative staging tables
-        // default: 8 packs per workgroup in float, 4 in double (the staging area is 2*sizeof(REAL) per layer)
-        X.waves_per_block = opts && opts->waves_per_block ? opts->waves_per_block : (real_size == 4 ? 8 : 4);
+        // default: 4 packs per workgroup (measured after the node words became shared: 4 beats 8 in float by 5-8 %:
+        // 28 KB of LDS per workgroup instead of 57 KB, i.e. 5 instead of 4 waves per SIMD)
+        (void)real_size;
+        X.waves_per_block = opts && opts->waves_per_block ? opts->waves_per_block : 4;
         // small instances: keep at least ~512 workgroups so that every CU has work
         if (!(opts && opts->waves_per_block))
             while (X.waves_per_block > 1 && Pn / X.waves_per_block < 512) X.waves_per_block /= 2;

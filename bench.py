@@ -34,8 +34,8 @@ def algorithmic_bytes_per_pass(sizes, R):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--precision", default="float", choices=["float", "double"])
     ap.add_argument("--vars", type=int, default=1_000_000)
     ap.add_argument("--rows", type=int, default=500_000)
@@ -129,7 +129,7 @@ def main():
                 "precision": args.precision,
                 "omega": 0.5,
                 "pack_width": args.pack_width or "auto (128; 64 when fewer than 2048 packs)",
-                "waves_per_block": args.wpb or (8 if args.precision == "float" else 4),
+                "waves_per_block": args.wpb or 4,
                 "packs": solver.nr_packs(),
                 "hops": solver.nr_hops(),
                 "delta_exchange": "per-variable gather (deterministic)" if args.deterministic else "binned exchange, LDS accumulators",
