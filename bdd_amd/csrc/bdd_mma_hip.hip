@@ -47,7 +47,8 @@ struct SolverT final : SolverBase {
     REAL* d_hi = nullptr;  // = d_lohi + 1 (stride 2)
     int32_t *d_var = nullptr, *d_bdd = nullptr, *d_nbdds = nullptr;
     uint32_t *d_var_ptr = nullptr, *d_var_layers = nullptr, *d_root_slot = nullptr;
-    REAL* d_delta_var = nullptr;    // 2V: the solver's deferred delta_lo_hi_ (normalised), per variable
+    REAL* d_delta_var = nullptr;    // 2V: the solver's deferred delta_lo_hi_ (normalised), per variable; rebuilt lazily, see delta_var_valid
+    bool delta_var_valid = true;    // false after an exchange that only wrote the broadcast pairs (d_delta_lay)
     REAL* d_delta_lay = nullptr;    // 2L: the same, broadcast to binned entry order (what the sweeps read)
     REAL* d_mm_binned = nullptr;    // L : deferred min-marginal differences in binned entry order
     REAL *d_delta_c = nullptr, *d_delta_lay_c = nullptr;  // scratch for the explicit forward_mm/backward_mm API
@@ -333,9 +334,11 @@ struct SolverT final : SolverBase {
             hipLaunchKernelGGL((k_delta_gather<REAL, true>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr,
                                d_vpos, d_delta_var, (uint32_t)n_vars);
             launch_bcast(d_delta_var, d_delta_lay);
+            delta_var_valid = true;
         } else {
             hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
-                               d_bin_ptr, d_bvar, d_nbdds, d_delta_var, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers);
+                               d_bin_ptr, d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers);
+            delta_var_valid = false;
         }
         prof_end(BDDMMA_K_FINISH_DELTA);
         HIPCHK(hipGetLastError());
@@ -454,12 +457,19 @@ struct SolverT final : SolverBase {
         hipLaunchKernelGGL((k_distribute_delta<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lo, d_hi, d_mm_binned, d_lpos, (uint32_t)n_layers);
         HIPCHK(hipMemsetAsync(d_delta_var, 0, 2 * n_vars * sizeof(REAL), stream));  // bdd_cuda_base.cu:1428
         HIPCHK(hipMemsetAsync(d_delta_lay, 0, 2 * n_layers * sizeof(REAL), stream));
+        delta_var_valid = true;
         fwd_valid = bwd_valid = false;
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
     int get_delta(void* out, int on_device) override
     {
+        HIPCHK(hipSetDevice(device));
+        if (!delta_var_valid) {
+            hipLaunchKernelGGL((k_delta_var_from_lay<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_delta_lay, d_var_ptr, d_vpos,
+                               d_delta_var, (uint32_t)n_vars);
+            delta_var_valid = true;
+        }
         HIPCHK(hipMemcpyAsync(out, d_delta_var, 2 * n_vars * sizeof(REAL), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         return BDDMMA_OK;
@@ -470,6 +480,7 @@ struct SolverT final : SolverBase {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipMemcpyAsync(d_delta_var, in, 2 * n_vars * sizeof(REAL), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
         launch_bcast(d_delta_var, d_delta_lay);
+        delta_var_valid = true;
         HIPCHK(hipStreamSynchronize(stream));
         return BDDMMA_OK;
     }

@@ -1008,7 +1008,9 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
                 x = nb[k] > 0 ? x / REAL(nb[k]) : REAL(0);
                 tile[i] = ACC(x);
             }
-            delta_var[2 * (size_t)v0 + i] = x;
+            // EX_ITER leaves delta_var alone when the solver passes nullptr: the hot loop only needs the broadcast pairs,
+            // and the per-variable copy (8 MB at V = 1 M) is rebuilt on demand by k_delta_var_from_lay
+            if (MODE != EX_ITER || delta_var) delta_var[2 * (size_t)v0 + i] = x;
         }
     }
     if (MODE != EX_ITER) return;
@@ -1103,6 +1105,19 @@ __global__ void k_delta_gather(const REAL* __restrict__ mm_binned, const uint32_
     }
     delta_var[2 * (size_t)v] = lo;
     delta_var[2 * (size_t)v + 1] = hi;
+}
+
+// delta_var[v] = the pair broadcast to the entries of v (any of them; 0 for a variable in no BDD)
+template <typename REAL>
+__global__ void k_delta_var_from_lay(const REAL* __restrict__ delta_lay, const uint32_t* __restrict__ var_ptr,
+                                     const uint32_t* __restrict__ vpos, REAL* __restrict__ delta_var, uint32_t n_vars)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vars) return;
+    const uint32_t k0 = var_ptr[v], k1 = var_ptr[v + 1];
+    const size_t e = k1 > k0 ? vpos[k0] : 0;
+    delta_var[2 * (size_t)v] = k1 > k0 ? delta_lay[2 * e] : REAL(0);
+    delta_var[2 * (size_t)v + 1] = k1 > k0 ? delta_lay[2 * e + 1] : REAL(0);
 }
 
 // binned entry order <-> internal layer order (rare elementwise ops, checkpointing)

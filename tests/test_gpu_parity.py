@@ -231,6 +231,11 @@ def test_deterministic_mode_is_bit_reproducible_and_agrees():
     s = bdd_hip_parallel_mma(col, costs, precision="float")
     s.iterations(10)
     assert abs(s.lower_bound() - runs[0][0]) <= 1e-5 * abs(runs[0][0])
+    # the default exchange keeps only the broadcast pairs; the per-variable delta is rebuilt on demand
+    d = s.get_delta()
+    np.testing.assert_allclose(d, runs[0][1], rtol=1e-4, atol=1e-5)
+    assert np.abs(d).max() > 0
+    np.testing.assert_array_equal(s.get_delta(), d)
 
 
 def test_dual_ops_vs_numpy():
