@@ -166,10 +166,112 @@ class bdd_hip_lbfgs_mma {
     }
     double lower_bound() { return solver_.lower_bound(); }
     bdd_hip_parallel_mma<REAL>& solver() { return solver_; }
+    bddmma_lbfgs* lbfgs_handle() { return l_; }
 
    private:
     bdd_hip_parallel_mma<REAL> solver_;
     bddmma_lbfgs* l_ = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// The two CUDA-free façades the reference ships for embedding the GPU solver in other code
+// (include/bdd_cuda.h:9-31 `bdd_cuda<REAL>`, include/bdd_lbfgs_cuda_mma.h:9-36 `bdd_lbfgs_cuda_mma<REAL>`; their
+// implementations throw "not compiled with CUDA support" without CUDA, src/bdd_cuda.cpp:27,38).  Same public
+// members, same argument meaning; move-only.  min_marginals() returns [variable][bdd] -> {mm0, mm1} as nested vectors
+// (the reference's two_dim_variable_array has the same indexing).
+template <typename REAL>
+class bdd_hip {
+   public:
+    template <typename BDD_COLLECTION>
+    explicit bdd_hip(const BDD_COLLECTION& bdd_col) : s_(bdd_col)
+    {
+    }
+    template <typename BDD_COLLECTION, typename ITERATOR>
+    bdd_hip(const BDD_COLLECTION& bdd_col, ITERATOR cost_begin, ITERATOR cost_end) : s_(bdd_col)
+    {
+        update_costs(cost_begin, cost_begin, cost_begin, cost_end);  // as bdd_cuda.h:36-41
+    }
+    bdd_hip(bdd_hip&&) = default;
+    bdd_hip& operator=(bdd_hip&&) = default;
+
+    template <typename ITERATOR>
+    void update_costs(ITERATOR cost_lo_begin, ITERATOR cost_lo_end, ITERATOR cost_hi_begin, ITERATOR cost_hi_end)
+    {
+        s_.update_costs(std::vector<REAL>(cost_lo_begin, cost_lo_end), std::vector<REAL>(cost_hi_begin, cost_hi_end));
+    }
+    double lower_bound() { return s_.lower_bound(); }
+    size_t nr_variables() const { return s_.nr_variables(); }
+    std::vector<std::vector<std::array<double, 2>>> min_marginals() { return s_.min_marginals(); }
+    void iteration() { s_.iteration(); }
+    void backward_run() { s_.backward_run(); }
+    // incremental_mm_agreement_rounding_cuda (incremental_mm_agreement_rounding_cuda.cu:333-372); empty: no solution found
+    std::vector<char> incremental_mm_agreement_rounding(const double init_delta, const double delta_growth_rate, const int num_itr_lb,
+                                                        const int num_rounds = 500)
+    {
+        return round(s_.handle(), nullptr, init_delta, delta_growth_rate, num_itr_lb, num_rounds);
+    }
+    bdd_hip_parallel_mma<REAL>& solver() { return s_; }
+
+    static std::vector<char> round(bddmma_solver* h, bddmma_lbfgs* l, double init_delta, double growth, int num_itr_lb, int num_rounds)
+    {
+        std::vector<char> sol(bddmma_nr_variables(h), 0);
+        int found = 0;
+        if (bddmma_incremental_mm_agreement_rounding(h, l, init_delta, growth, (uint64_t)num_itr_lb, (uint64_t)num_rounds, 0, 0, sol.data(), &found) != BDDMMA_OK)
+            throw std::runtime_error(std::string("incremental_mm_agreement_rounding: ") + bddmma_last_error(h));
+        if (!found) sol.clear();
+        return sol;
+    }
+
+   private:
+    bdd_hip_parallel_mma<REAL> s_;
+};
+
+template <typename REAL>
+class bdd_lbfgs_hip_mma {
+   public:
+    template <typename BDD_COLLECTION>
+    bdd_lbfgs_hip_mma(const BDD_COLLECTION& bdd_col, const int history_size, const double init_step_size = 1e-6,
+                      const double req_rel_lb_increase = 1e-6, const double step_size_decrease_factor = 0.8,
+                      const double step_size_increase_factor = 1.1)
+        : l_(bdd_hip_parallel_mma<REAL>(bdd_col), params(history_size, init_step_size, req_rel_lb_increase, step_size_decrease_factor, step_size_increase_factor))
+    {
+    }
+    template <typename BDD_COLLECTION, typename ITERATOR>
+    bdd_lbfgs_hip_mma(const BDD_COLLECTION& bdd_col, ITERATOR cost_begin, ITERATOR cost_end, const int history_size,
+                      const double init_step_size = 1e-6, const double req_rel_lb_increase = 1e-6,
+                      const double step_size_decrease_factor = 0.8, const double step_size_increase_factor = 1.1)
+        : bdd_lbfgs_hip_mma(bdd_col, history_size, init_step_size, req_rel_lb_increase, step_size_decrease_factor, step_size_increase_factor)
+    {
+        update_costs(cost_begin, cost_begin, cost_begin, cost_end);  // as bdd_lbfgs_cuda_mma.h:41-52
+    }
+    template <typename ITERATOR>
+    void update_costs(ITERATOR cost_lo_begin, ITERATOR cost_lo_end, ITERATOR cost_hi_begin, ITERATOR cost_hi_end)
+    {
+        const std::vector<REAL> lo(cost_lo_begin, cost_lo_end), hi(cost_hi_begin, cost_hi_end);
+        constexpr int prec = std::is_same<REAL, double>::value ? BDDMMA_F64 : BDDMMA_F32;
+        // lbfgs::update_costs also drops the history (lbfgs_impl.h:343-364)
+        if (bddmma_lbfgs_update_costs(l_.lbfgs_handle(), lo.data(), lo.size(), hi.data(), hi.size(), prec, 0) != BDDMMA_OK)
+            throw std::runtime_error(std::string("bdd_lbfgs_hip_mma: ") + bddmma_last_error(l_.solver().handle()));
+    }
+    double lower_bound() { return l_.lower_bound(); }
+    size_t nr_variables() { return l_.solver().nr_variables(); }
+    std::vector<std::vector<std::array<double, 2>>> min_marginals() { return l_.solver().min_marginals(); }
+    void iteration() { l_.iteration(); }
+    void backward_run() { l_.solver().backward_run(); }
+    std::vector<char> incremental_mm_agreement_rounding(const double init_delta, const double delta_growth_rate, const int num_itr_lb,
+                                                        const int num_rounds = 500)
+    {
+        return bdd_hip<REAL>::round(l_.solver().handle(), l_.lbfgs_handle(), init_delta, delta_growth_rate, num_itr_lb, num_rounds);
+    }
+
+   private:
+    static const bddmma_lbfgs_params* params(int m, double s, double r, double d, double i)
+    {
+        static thread_local bddmma_lbfgs_params p;
+        p = bddmma_lbfgs_params{m, s, r, d, i};
+        return &p;
+    }
+    bdd_hip_lbfgs_mma<REAL> l_;
 };
 
 }  // namespace LPMP

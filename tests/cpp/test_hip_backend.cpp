@@ -134,6 +134,43 @@ static void test_lbfgs_and_move()
     CHECK_NEAR(prev, 1.5, 1e-3);    // test_loose_covering_problem.cpp: LP bound 1.5
 }
 
+// the embedding façades of include/bdd_cuda.h / include/bdd_lbfgs_cuda_mma.h
+template <typename REAL>
+static void test_facades()
+{
+    bdd_store col;
+    for (auto row : std::vector<std::vector<size_t>>{{0, 1, 3}, {0, 2, 4}, {1, 2, 5}}) col.add_covering(row);
+    const std::vector<double> costs(6, 1.0);
+    bdd_hip<REAL> a(col, costs.begin(), costs.end());
+    CHECK(a.nr_variables() == 6);
+    for (int i = 0; i < 300; ++i) a.iteration();
+    CHECK_NEAR(a.lower_bound(), 1.5, 1e-3);
+    CHECK(a.min_marginals().size() == 6);
+    const std::vector<char> sol = a.incremental_mm_agreement_rounding(0.1, 1.1, 50, 100);
+    CHECK(sol.size() == 6);
+    if (sol.size() == 6) {
+        CHECK(col.evaluate(0, sol) && col.evaluate(1, sol) && col.evaluate(2, sol));
+        int ones = 0;
+        for (char x : sol) ones += x;
+        CHECK(ones == 2);   // optimum of the loose covering instance
+    }
+    bdd_hip<REAL> moved(std::move(a));
+    moved.backward_run();
+    bdd_lbfgs_hip_mma<REAL> l(col, costs.begin(), costs.end(), 5);
+    double prev = l.lower_bound();
+    for (int i = 0; i < 60; ++i) {
+        l.iteration();
+        CHECK(l.lower_bound() >= prev - 1e-5);
+        prev = l.lower_bound();
+    }
+    CHECK_NEAR(prev, 1.5, 1e-3);
+    const std::vector<double> zero(6, 0.0), two(6, 2.0);
+    l.update_costs(zero.begin(), zero.begin(), two.begin(), two.end());   // hi += 2: costs 3 per variable, bound 4.5
+    for (int i = 0; i < 300; ++i) l.iteration();
+    CHECK_NEAR(l.lower_bound(), 4.5, 3e-3);
+    CHECK(l.incremental_mm_agreement_rounding(0.1, 1.1, 50, 100).size() == 6);
+}
+
 static void test_checkpoint()
 {
     std::vector<double> c(16, -1.0);
@@ -213,6 +250,8 @@ int main()
         {"explicit forward_mm / backward_mm / distribute_delta <float>", test_explicit_mm_and_distribute<float>},
         {"L-BFGS wrapper, move construction <double>", test_lbfgs_and_move<double>},
         {"L-BFGS wrapper, move construction <float>", test_lbfgs_and_move<float>},
+        {"facades bdd_hip / bdd_lbfgs_hip_mma <double>", test_facades<double>},
+        {"facades bdd_hip / bdd_lbfgs_hip_mma <float>", test_facades<float>},
         {"checkpoint", test_checkpoint},
         {"bdd_solver driver", test_driver},
     };
