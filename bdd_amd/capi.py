@@ -12,7 +12,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbdd_mma_hip.so")
+# BDDMMA_LIB: load another build of the same library (kernel experiments under build/); default: the in-tree build
+LIB_PATH = os.path.abspath(os.environ["BDDMMA_LIB"]) if os.environ.get("BDDMMA_LIB") else os.path.join(_HERE, "csrc", "libbdd_mma_hip.so")
 
 OK = 0
 F32, F64 = 0, 1
