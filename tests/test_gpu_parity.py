@@ -511,3 +511,58 @@ def test_independent_handles_interleaved_and_bad_device():
     assert out == {"a": want_a, "b": want_b}
     with pytest.raises(Exception, match="device"):
         bdd_hip_parallel_mma(col_a, costs_a, device=63)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BDDMMA_FUZZ_SEEDS", "16"))))
+def test_randomised_instances_and_layout_options_vs_oracle(seed):
+    """Differential test: random mixtures of covering / simplex / cardinality / knapsack rows (no row forces a variable, so
+    all min-marginals stay finite and the CPU and GPU update rules coincide) under random layout options — pack widths,
+    packs per workgroup, stage groups, bin sizes, LDS-or-global frontier, BDD order kept or grouped by shape."""
+    from bdd_amd import native
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    V = int(rng.integers(30, 400))
+    rows = []
+    for _ in range(int(rng.integers(20, 300))):
+        kind = rng.integers(0, 5)
+        k = int(rng.integers(2, min(V, 14) + 1))
+        vs = rng.choice(V, size=k, replace=False)
+        if rng.random() < 0.7:
+            vs = np.sort(vs)
+        if kind == 0:
+            rows.append((np.ones(k, int), vs, ">=", 1))
+        elif kind == 1:
+            rows.append((np.ones(k, int), vs, "=", 1))
+        elif kind == 2 and k >= 3:
+            rows.append((np.ones(k, int), vs, "=", int(rng.integers(1, k))))
+        elif kind == 3:
+            co = rng.integers(1, 9, size=k)
+            rows.append((co, vs, "<=", int(rng.integers(co.max(), co.sum()))))          # every variable may still be 1
+        else:
+            co = rng.integers(1, 9, size=k)
+            rows.append((co, vs, ">=", int(rng.integers(1, co.sum() - co.max() + 1))))  # every variable may still be 0
+    col = native.rows_to_bdd_collection(rows)
+    if col.nr_bdds() == 0:
+        pytest.skip("all rows trivial")
+    Vc = col.nr_variables()
+    costs = rng.normal(0, 4, Vc).round(3)
+    pw = int(rng.choice([64, 128, 256]))
+    wpb = int(rng.choice([1, 2, 4, 8]))
+    cap = int(rng.choice([pw, 256, 640])) if wpb < 8 else 256
+    opts = dict(pack_width=pw, waves_per_block=wpb, stage_cap=max(cap, pw), vars_per_bin=int(rng.choice([0, 64, 256])),
+                wide_pack_width=int(rng.choice([0, 64])), keep_bdd_order=bool(rng.integers(0, 2)))
+    s = bdd_hip_parallel_mma(col, costs, precision="double", **opts)
+    o = Oracle(col, costs, "double")
+    assert abs(s.lower_bound() - o.lower_bound()) <= 1e-9 * max(1.0, abs(o.lower_bound())), opts
+    n_it = int(rng.integers(3, 30))
+    for _ in range(n_it):
+        s.iteration(); o.iteration()
+    lb, ref = s.lower_bound(), o.lower_bound()
+    assert np.isfinite(ref) and abs(lb - ref) <= 1e-9 * max(1.0, abs(ref)), (opts, lb, ref)
+    perm = oracle_layer_perm(s, o)
+    _, mm0, mm1 = s.min_marginals_cuda(get_sorted=False)
+    omm = o.min_marginals()
+    np.testing.assert_allclose(mm0[perm], omm[:, 0], rtol=1e-9, atol=1e-8, err_msg=str(opts))
+    np.testing.assert_allclose(mm1[perm], omm[:, 1], rtol=1e-9, atol=1e-8, err_msg=str(opts))
+    f = bdd_hip_parallel_mma(col, costs, precision="float", **opts)
+    f.iterations(n_it)
+    assert abs(f.lower_bound() - ref) <= 2e-5 * max(1.0, abs(ref)), opts
