@@ -280,8 +280,6 @@ class BddCollection:
         Returns (new BDD numbers, next free auxiliary variable).  A cut layer of width 1 — asserted against
         by the reference (:583) — gets one auxiliary variable that has to be 1.
         """
-        if with_implication_bdd:
-            raise NotImplementedError("split_qbdd: the optional implication BDD (bdd_collection.cpp:801-941) is not built")
         assert chunk_size > 0
         d = self.delims
         off = int(d[b])
@@ -356,7 +354,146 @@ class BddCollection:
             hi = np.where(np.asarray(hi) == TOP, _T, np.where(np.asarray(hi) == BOT, _B, np.asarray(hi)))
             new_nrs.append(self._append_local(lo[None, :].astype(np.int64), hi[None, :].astype(np.int64),
                                               np.asarray(var, dtype=np.uint64)[None, :], 1, n, top_first=False))
+        if with_implication_bdd and len(new_nrs) > 2:
+            imp = self._implication_bdd(ins, off, widths, loff, chunk_size, n_chunks, aux, top_local, bot_local)
+            if imp is not None:
+                new_nrs.append(imp)
         return new_nrs, aux[-1] + widths[(n_chunks - 1) * chunk_size]
+
+    def _implication_bdd(self, ins, off, widths, loff, chunk, n_chunks, aux, top_abs, bot_abs):
+        """The optional extra BDD of split_qbdd (bdd_collection.cpp:801-941): over the auxiliary variables only, the
+        conjunction of (a) one simplex per cut ("exactly one node of the cut layer is crossed") and (b) for every node of
+        a cut and every other cut, the clause "this node is crossed => one of the nodes connected to it by a directed path
+        in the original BDD is crossed" (skipped when all nodes of the other cut are connected).  Returns the new BDD
+        number, or None when there is no clause of kind (b) (the reference then drops the simplex BDDs again, :915-919).
+
+        The reference forms the conjunction with bdd_mgr (`bdd_and`, `reorder`, `make_qbdd`); here it is built as the
+        product automaton of the constraints over the variables in ascending order and reduced bottom-up, which gives
+        the same canonical quasi-reduced BDD; the order of the nodes inside a layer (first discovery, hi child first) equals the
+        reference's on most instances but not all — it carries no meaning, and the tests compare up to that order."""
+        n_cuts = n_chunks - 1
+        cut_layer = lambda c: c * chunk                               # cuts are numbered 1 .. n_cuts
+        aux_of = lambda c, i: aux[c - 1] + (widths[cut_layer(c)] - 1 - i)   # node i of cut c <-> auxiliary variable (:836,842)
+        # sources[c][c2][j]: bitmask of the nodes of cut c that reach node j of the later cut c2
+        sources = {}
+        for c in range(1, n_cuts + 1):
+            mask = [1 << i for i in range(widths[cut_layer(c)])]
+            for l in range(cut_layer(c), cut_layer(n_cuts)):
+                nxt = [0] * widths[l + 1]
+                for k, u in enumerate(range(loff[l], loff[l + 1])):
+                    for ch in (int(ins[u, 0]), int(ins[u, 1])):
+                        if ch != top_abs and ch != bot_abs:
+                            nxt[ch - off - loff[l + 1]] |= mask[k]
+                mask = nxt
+                if (l + 1) % chunk == 0:
+                    sources[(c, (l + 1) // chunk)] = mask
+        constraints = []   # ("simplex", vars) | ("clause", negated var, positive vars)
+        for c in range(1, n_cuts + 1):
+            constraints.append(("simplex", [aux_of(c, i) for i in range(widths[cut_layer(c)])]))
+        n_clauses = 0
+        for c in range(1, n_cuts):                                    # forward implications (:826-857)
+            for c2 in range(c + 1, n_cuts + 1):
+                w1, w2 = widths[cut_layer(c)], widths[cut_layer(c2)]
+                for i1 in range(w1):
+                    pos = [aux_of(c2, i2) for i2 in range(w2) if (sources[(c, c2)][i2] >> i1) & 1]
+                    if len(pos) == w2:
+                        continue
+                    constraints.append(("clause", aux_of(c, i1), pos))
+                    n_clauses += 1
+        for c1 in range(2, n_cuts + 1):                               # reverse implications (:861-893)
+            for c2 in range(1, c1):
+                w1, w2 = widths[cut_layer(c1)], widths[cut_layer(c2)]
+                for i1 in range(w1):
+                    pos = [aux_of(c2, i2) for i2 in range(w2) if (sources[(c2, c1)][i1] >> i2) & 1]
+                    if len(pos) == w2:
+                        continue
+                    constraints.append(("clause", aux_of(c1, i1), pos))
+                    n_clauses += 1
+        if n_clauses == 0:
+            return None
+        # ---- product automaton over the auxiliary variables in ascending order
+        v_first, v_last = aux[0], aux[-1] + widths[cut_layer(n_cuts)] - 1
+        by_var = {v: [] for v in range(v_first, v_last + 1)}
+        last_var = []
+        for k, con in enumerate(constraints):
+            vs = con[1] if con[0] == "simplex" else [con[1]] + con[2]
+            last_var.append(max(vs))
+            for v in vs:
+                by_var[v].append(k)
+        DONE = 2                                                        # local state of a finished (accepted) constraint
+        start = tuple(0 for _ in constraints)
+        levels, trans = [{start: 0}], []                                # per level: state -> id ; per level: [(lo, hi)] with ids of the next level or _T / _B
+        for v in range(v_first, v_last + 1):
+            cur, nxt, tr = levels[-1], {}, [None] * len(levels[-1])
+            for st, sid in cur.items():
+                out = []
+                for val in (0, 1):
+                    ns, dead = list(st), False
+                    for k in by_var[v]:
+                        con = constraints[k]
+                        if con[0] == "simplex":
+                            x = ns[k] + val
+                            if x > 1 or (v == last_var[k] and x != 1):
+                                dead = True
+                                break
+                            ns[k] = DONE if v == last_var[k] else x
+                        else:
+                            x = 1 if (ns[k] == 1 or (v == con[1] and val == 0) or (v != con[1] and val == 1)) else 0
+                            if v == last_var[k] and x != 1:
+                                dead = True
+                                break
+                            ns[k] = DONE if v == last_var[k] else x
+                    if dead:
+                        out.append(_B)
+                    elif v == v_last:
+                        out.append(_T)
+                    else:
+                        out.append(nxt.setdefault(tuple(ns), len(nxt)))
+                tr[sid] = tuple(out)
+            trans.append(tr)
+            levels.append(nxt)
+        # ---- bottom-up reduction to the canonical quasi-reduced form
+        n_lev = len(trans)
+        canon = [None] * n_lev           # per level: old id -> canonical id (or _B)
+        tables = [None] * n_lev          # per level: list of (lo, hi) over canonical ids of the next level
+        for l in range(n_lev - 1, -1, -1):
+            uniq, tab, cm = {}, [], []
+            for lo, hi in trans[l]:
+                lo = lo if lo < 0 else canon[l + 1][lo]
+                hi = hi if hi < 0 else canon[l + 1][hi]
+                if lo == _B and hi == _B:
+                    cm.append(_B)
+                    continue
+                key = (lo, hi)
+                if key not in uniq:
+                    uniq[key] = len(tab)
+                    tab.append(key)
+                cm.append(uniq[key])
+            canon[l], tables[l] = cm, tab
+        assert canon[0][0] != _B, "the implication constraints cannot be infeasible"
+        # nodes reachable from the root; inside a layer in order of first discovery when the parents are scanned in
+        # order and the hi child is visited before the lo child (the order make_qbdd leaves, observed on oracle/_ref)
+        order = [[canon[0][0]]] + [[] for _ in range(n_lev - 1)]
+        for l in range(n_lev - 1):
+            seen = set()
+            for k in order[l]:
+                for ch in (tables[l][k][1], tables[l][k][0]):
+                    if ch >= 0 and ch not in seen:
+                        seen.add(ch)
+                        order[l + 1].append(ch)
+        remap, offs, total = [], [], 0
+        for l in range(n_lev):
+            remap.append({k: j for j, k in enumerate(order[l])})
+            offs.append(total)
+            total += len(order[l])
+        lo = np.empty(total, np.int64); hi = np.empty(total, np.int64); var = np.empty(total, np.uint64)
+        for l in range(n_lev):
+            for k, j in remap[l].items():
+                a, b = tables[l][k]
+                lo[offs[l] + j] = a if a < 0 else offs[l + 1] + remap[l + 1][a]
+                hi[offs[l] + j] = b if b < 0 else offs[l + 1] + remap[l + 1][b]
+                var[offs[l] + j] = v_first + l
+        return self._append_local(lo[None, :], hi[None, :], var[None, :], 1, total, top_first=True)
 
     def permute(self, order) -> None:
         """Reorder the BDDs: new BDD i is old BDD order[i] (storage compacted, child indices re-based)."""

@@ -6,7 +6,7 @@ string or dict, `solve()`, `lower_bound()`, `min_marginals()`).  Pipeline, as `b
 read_ILP -> process_ILP -> transform_to_BDDs -> construct_solver -> solve_dual -> perturbation_rounding.
 
 Only the relaxation solvers of the hot path exist here (`cuda parallel mma` and the GPU L-BFGS); the CPU
-solvers, variable re-orderings, the split implication BDD and the exporters other than `.lp` belong to parts of the
+solvers, variable re-orderings and the exporters other than `.lp` belong to parts of the
 reference that SURVEY.md §2 marks out of scope — asking for them raises the same kind of
 `RuntimeError` the reference raises for an unknown option.
 """
@@ -85,14 +85,14 @@ class bdd_solver:
         # conversion and splitting run in the C++ input stage (bdd_amd/csrc/host/, include/bdd_ilp.h);
         # ilp.to_bdd_collection / ilp.split_long_bdds are the same algorithms in Python (tests/test_native_host.py)
         rows = [(c.coefficients, c.variables, c.ineq, c.rhs) for c in ilp.constraints]
-        split_length = None
+        split_length, implication = None, False
         if "split bdds" in self.config:
             sb = self.config["split bdds"] or {}
             # the reference tests contains("implication bdd") and then reads key "implication" (:119); accept both
-            if sb.get("implication bdd", sb.get("implication", False)):
-                raise RuntimeError("split bdds: the implication bdd is not available in this backend")
+            implication = bool(sb.get("implication bdd", sb.get("implication", False)))
             split_length = int(sb.get("split length", 0))       # 0: the occupancy rule of compute_split_length
-        col = native.rows_to_bdd_collection(rows, split_length=split_length, nr_variables=ilp.nr_variables())
+        col = native.rows_to_bdd_collection(rows, split_length=split_length, nr_variables=ilp.nr_variables(),
+                                            with_implication_bdd=implication)
         _log(f"[bdd preprocessor] final #BDDs = {col.nr_bdds()}", self.quiet)
         return col
 

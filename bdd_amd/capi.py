@@ -120,7 +120,7 @@ ILP_SIGNATURES = {
     "bddilp_to_bdds": (_I, [_V, _I, _U64, C.POINTER(_V)]),
     "bddilp_bdds_create": (_I, [C.POINTER(_V)]),
     "bddilp_bdds_add_row": (_I, [_V, _V, _V, _U64, _I, C.c_int64, C.POINTER(_I)]),
-    "bddilp_bdds_split": (_I, [_V, _U64, _U64, _U64P, _U64P]),
+    "bddilp_bdds_split": (_I, [_V, _U64, _U64, _I, _U64P, _U64P]),
     "bddilp_bdds_destroy": (None, [_V]),
     "bddilp_bdds_nr_bdds": (_U64, [_V]),
     "bddilp_bdds_nr_instructions": (_U64, [_V]),

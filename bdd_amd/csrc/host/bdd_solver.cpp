@@ -91,10 +91,9 @@ bdd_store bdd_solver::transform_to_BDDs(const ilp_input& ilp) const
     if (config_.contains("split bdds")) {
         const json& sb = config_["split bdds"];
         // the reference tests contains("implication bdd") and then reads key "implication" (:119); accept both
-        if (sb.bool_or("implication bdd", sb.bool_or("implication", false)))
-            throw std::runtime_error("split bdds: the implication bdd is not available in this backend");
+        const bool implication = sb.bool_or("implication bdd", sb.bool_or("implication", false));
         const size_t len = (size_t)sb.number_or("split length", 0);
-        const auto [n, nv] = col.split_long_bdds(std::max(col.nr_variables(), ilp.nr_variables()), len);
+        const auto [n, nv] = col.split_long_bdds(std::max(col.nr_variables(), ilp.nr_variables()), len, 256 * 2048 / 10, implication);
         (void)nv;
         log("[bdd preprocessor] Split " + std::to_string(n) + " BDDs");
         log("[bdd preprocessor] final #BDDs = " + std::to_string(col.nr_bdds()));

@@ -221,7 +221,7 @@ void bdd_store::remove(std::vector<size_t> bdd_nrs)
     delimiters.swap(nd);
 }
 
-std::pair<std::vector<size_t>, size_t> bdd_store::split_qbdd(size_t b, size_t chunk, size_t aux0)
+std::pair<std::vector<size_t>, size_t> bdd_store::split_qbdd(size_t b, size_t chunk, size_t aux0, bool with_implication_bdd)
 {
     assert(chunk > 0);
     const size_t off = delimiters[b], n_nodes = delimiters[b + 1] - off - 2;
@@ -298,7 +298,174 @@ std::pair<std::vector<size_t>, size_t> bdd_store::split_qbdd(size_t b, size_t ch
         (void)n_tail;
         new_nrs.push_back(append_local(lo, hi, var, false));
     }
+    if (with_implication_bdd && new_nrs.size() > 2 && append_implication_bdd(src, off, top_abs, bot_abs, widths, loff, chunk, n_chunks, aux))
+        new_nrs.push_back(nr_bdds() - 1);
     return {new_nrs, aux.back() + widths[(n_chunks - 1) * chunk]};
+}
+
+// The optional extra BDD of split_qbdd (bdd_collection.cpp:801-941): over the auxiliary variables only, the conjunction of
+// one simplex per cut and, for every node of a cut and every other cut, the clause "this node is crossed => one of the
+// nodes connected to it by a directed path is crossed" (skipped when all nodes of the other cut are connected).  The
+// reference forms the conjunction with bdd_mgr (bdd_and, reorder, make_qbdd); here it is the product automaton of the
+// constraints over the variables in ascending order, reduced bottom-up: the same canonical quasi-reduced BDD, nodes of a
+// layer in make_qbdd's order (first discovery, hi child before lo child).  bdd_amd/bdd_collection.py: _implication_bdd.
+bool bdd_store::append_implication_bdd(const std::vector<bddmma_instruction>& src, size_t off, size_t top_abs, size_t bot_abs,
+                                       const std::vector<size_t>& widths, const std::vector<size_t>& loff, size_t chunk, size_t n_chunks,
+                                       const std::vector<size_t>& aux)
+{
+    const size_t n_cuts = n_chunks - 1;
+    auto cut_layer = [&](size_t c) { return c * chunk; };  // cuts are numbered 1 .. n_cuts
+    auto aux_of = [&](size_t c, size_t i) { return aux[c - 1] + (widths[cut_layer(c)] - 1 - i); };
+    using bits = std::vector<uint64_t>;
+    auto test = [](const bits& m, size_t i) { return (m[i >> 6] >> (i & 63)) & 1u; };
+    // sources[(c, c2)][j]: the nodes of cut c that reach node j of the later cut c2
+    std::map<std::pair<size_t, size_t>, std::vector<bits>> sources;
+    for (size_t c = 1; c <= n_cuts; ++c) {
+        const size_t w = widths[cut_layer(c)], words = (w + 63) / 64;
+        std::vector<bits> mask(w, bits(words, 0));
+        for (size_t i = 0; i < w; ++i) mask[i][i >> 6] |= 1ull << (i & 63);
+        for (size_t l = cut_layer(c); l < cut_layer(n_cuts); ++l) {
+            std::vector<bits> nxt(widths[l + 1], bits(words, 0));
+            for (size_t k = 0; k < widths[l]; ++k) {
+                const bddmma_instruction& u = src[loff[l] + k];
+                for (uint64_t ch : {u.lo, u.hi}) {
+                    if (ch == top_abs || ch == bot_abs) continue;
+                    bits& t = nxt[ch - off - loff[l + 1]];
+                    for (size_t x = 0; x < words; ++x) t[x] |= mask[k][x];
+                }
+            }
+            mask.swap(nxt);
+            if ((l + 1) % chunk == 0) sources[{c, (l + 1) / chunk}] = mask;
+        }
+    }
+    struct con_t { bool simplex; size_t neg; std::vector<size_t> vars; size_t last; };  // clause: neg = the negated variable, vars = the positive ones
+    std::vector<con_t> cons;
+    for (size_t c = 1; c <= n_cuts; ++c) {
+        con_t k{true, 0, {}, 0};
+        for (size_t i = 0; i < widths[cut_layer(c)]; ++i) k.vars.push_back(aux_of(c, i));
+        cons.push_back(k);
+    }
+    size_t n_clauses = 0;
+    auto add_clause = [&](size_t neg, std::vector<size_t> pos, size_t w2) {
+        if (pos.size() == w2) return;
+        cons.push_back(con_t{false, neg, std::move(pos), 0});
+        ++n_clauses;
+    };
+    for (size_t c = 1; c < n_cuts; ++c)  // forward implications (:826-857)
+        for (size_t c2 = c + 1; c2 <= n_cuts; ++c2) {
+            const size_t w1 = widths[cut_layer(c)], w2 = widths[cut_layer(c2)];
+            const auto& sm = sources[{c, c2}];
+            for (size_t i1 = 0; i1 < w1; ++i1) {
+                std::vector<size_t> pos;
+                for (size_t i2 = 0; i2 < w2; ++i2)
+                    if (test(sm[i2], i1)) pos.push_back(aux_of(c2, i2));
+                add_clause(aux_of(c, i1), std::move(pos), w2);
+            }
+        }
+    for (size_t c1 = 2; c1 <= n_cuts; ++c1)  // reverse implications (:861-893)
+        for (size_t c2 = 1; c2 < c1; ++c2) {
+            const size_t w1 = widths[cut_layer(c1)], w2 = widths[cut_layer(c2)];
+            const auto& sm = sources[{c2, c1}];
+            for (size_t i1 = 0; i1 < w1; ++i1) {
+                std::vector<size_t> pos;
+                for (size_t i2 = 0; i2 < w2; ++i2)
+                    if (test(sm[i1], i2)) pos.push_back(aux_of(c2, i2));
+                add_clause(aux_of(c1, i1), std::move(pos), w2);
+            }
+        }
+    if (n_clauses == 0) return false;
+    const size_t v_first = aux[0], v_last = aux.back() + widths[cut_layer(n_cuts)] - 1, n_lev = v_last - v_first + 1;
+    std::vector<std::vector<size_t>> by_var(n_lev);
+    for (size_t k = 0; k < cons.size(); ++k) {
+        std::vector<size_t> vs = cons[k].vars;
+        if (!cons[k].simplex) vs.push_back(cons[k].neg);
+        cons[k].last = *std::max_element(vs.begin(), vs.end());
+        for (size_t v : vs) by_var[v - v_first].push_back(k);
+    }
+    // product automaton: local states 0 / 1 (simplex: ones seen; clause: satisfied), 2 = finished and accepted
+    using state = std::vector<uint8_t>;
+    constexpr long T = TOP_LOCAL, B = BOT_LOCAL;
+    std::vector<std::vector<std::pair<long, long>>> trans(n_lev);
+    std::vector<state> cur{state(cons.size(), 0)};
+    for (size_t l = 0; l < n_lev; ++l) {
+        const size_t v = v_first + l;
+        std::map<state, long> next_id;
+        std::vector<state> nxt;
+        trans[l].resize(cur.size());
+        for (size_t sid = 0; sid < cur.size(); ++sid) {
+            long out[2];
+            for (int val = 0; val < 2; ++val) {
+                state ns = cur[sid];
+                bool dead = false;
+                for (size_t k : by_var[l]) {
+                    const con_t& c = cons[k];
+                    uint8_t x;
+                    if (c.simplex) {
+                        x = (uint8_t)(ns[k] + val);
+                        if (x > 1 || (v == c.last && x != 1)) { dead = true; break; }
+                    } else {
+                        x = (ns[k] == 1 || (v == c.neg && val == 0) || (v != c.neg && val == 1)) ? 1 : 0;
+                        if (v == c.last && x != 1) { dead = true; break; }
+                    }
+                    ns[k] = v == c.last ? 2 : x;
+                }
+                if (dead) out[val] = B;
+                else if (v == v_last) out[val] = T;
+                else {
+                    auto it = next_id.find(ns);
+                    if (it == next_id.end()) {
+                        it = next_id.emplace(ns, (long)nxt.size()).first;
+                        nxt.push_back(ns);
+                    }
+                    out[val] = it->second;
+                }
+            }
+            trans[l][sid] = {out[0], out[1]};
+        }
+        cur.swap(nxt);
+    }
+    // bottom-up reduction to the canonical quasi-reduced form
+    std::vector<std::vector<long>> canon(n_lev);
+    std::vector<std::vector<std::pair<long, long>>> tables(n_lev);
+    for (size_t l = n_lev; l-- > 0;) {
+        std::map<std::pair<long, long>, long> uniq;
+        for (const auto& [lo0, hi0] : trans[l]) {
+            const long lo = lo0 < 0 ? lo0 : canon[l + 1][lo0], hi = hi0 < 0 ? hi0 : canon[l + 1][hi0];
+            if (lo == B && hi == B) { canon[l].push_back(B); continue; }
+            auto it = uniq.find({lo, hi});
+            if (it == uniq.end()) {
+                it = uniq.emplace(std::make_pair(lo, hi), (long)tables[l].size()).first;
+                tables[l].push_back({lo, hi});
+            }
+            canon[l].push_back(it->second);
+        }
+    }
+    assert(canon[0][0] != B);
+    std::vector<std::vector<long>> order(n_lev);
+    order[0].push_back(canon[0][0]);
+    for (size_t l = 0; l + 1 < n_lev; ++l) {
+        std::set<long> seen;
+        for (long k : order[l])
+            for (long ch : {tables[l][k].second, tables[l][k].first})
+                if (ch >= 0 && seen.insert(ch).second) order[l + 1].push_back(ch);
+    }
+    std::vector<std::map<long, size_t>> remap(n_lev);
+    std::vector<size_t> offs(n_lev + 1, 0);
+    for (size_t l = 0; l < n_lev; ++l) {
+        for (size_t j = 0; j < order[l].size(); ++j) remap[l][order[l][j]] = j;
+        offs[l + 1] = offs[l] + order[l].size();
+    }
+    std::vector<long> lo(offs[n_lev]), hi(offs[n_lev]);
+    std::vector<size_t> var(offs[n_lev]);
+    for (size_t l = 0; l < n_lev; ++l)
+        for (const auto& [k, j] : remap[l]) {
+            const auto [a, b2] = tables[l][k];
+            lo[offs[l] + j] = a < 0 ? a : (long)(offs[l + 1] + remap[l + 1].at(a));
+            hi[offs[l] + j] = b2 < 0 ? b2 : (long)(offs[l + 1] + remap[l + 1].at(b2));
+            var[offs[l] + j] = v_first + l;
+        }
+    append_local(lo, hi, var, true);  // make_qbdd leaves the top sink first
+    return true;
 }
 
 size_t bdd_store::compute_split_length(size_t parallelism) const
@@ -325,7 +492,7 @@ size_t bdd_store::compute_split_length(size_t parallelism) const
     return length;
 }
 
-std::pair<size_t, size_t> bdd_store::split_long_bdds(size_t nr_vars, size_t split_length, size_t parallelism)
+std::pair<size_t, size_t> bdd_store::split_long_bdds(size_t nr_vars, size_t split_length, size_t parallelism, bool with_implication_bdd)
 {
     if (split_length == 0) split_length = compute_split_length(parallelism);
     if (split_length == 0) return {0, nr_vars};
@@ -334,7 +501,7 @@ std::pair<size_t, size_t> bdd_store::split_long_bdds(size_t nr_vars, size_t spli
     const size_t nb = nr_bdds();
     for (size_t b = 0; b < nb; ++b) {
         if (layer_widths(b).size() > split_length) {
-            auto [nrs, na] = split_qbdd(b, split_length, next);
+            auto [nrs, na] = split_qbdd(b, split_length, next, with_implication_bdd);
             next = na;
             if (nrs.size() > 1) removed.push_back(b);
         }

@@ -51,16 +51,23 @@ public:
 
     // --- long-BDD splitting (bdd_collection.cpp:507-949, bdd_preprocessor.cpp:372-415)
     // Appends the chunks of BDD b (the original stays); returns the new BDD numbers and the next free aux variable.
-    std::pair<std::vector<size_t>, size_t> split_qbdd(size_t b, size_t chunk_size, size_t aux_var_start);
+    // with_implication_bdd: additionally append the BDD over the auxiliary variables that encodes which nodes of different
+    // cuts are connected (bdd_collection.cpp:801-941) when the split has more than two chunks and such implications exist
+    std::pair<std::vector<size_t>, size_t> split_qbdd(size_t b, size_t chunk_size, size_t aux_var_start, bool with_implication_bdd = false);
     void remove(std::vector<size_t> bdd_nrs);
     // splits every BDD with more than split_length variables (0: compute_split_length); returns {#split, #variables afterwards}
-    std::pair<size_t, size_t> split_long_bdds(size_t nr_variables, size_t split_length, size_t parallelism = 256 * 2048 / 10);
+    std::pair<size_t, size_t> split_long_bdds(size_t nr_variables, size_t split_length, size_t parallelism = 256 * 2048 / 10,
+                                              bool with_implication_bdd = false);
     size_t compute_split_length(size_t parallelism) const;  // bdd_preprocessor.cpp:32-121
 
 private:
     // append one BDD given LOCAL child indices; TOP_LOCAL / BOT_LOCAL mark the sinks
     static constexpr long TOP_LOCAL = -1, BOT_LOCAL = -2;
     size_t append_local(const std::vector<long>& lo, const std::vector<long>& hi, const std::vector<size_t>& var, bool top_first);
+    // returns false when there is no implication between the cuts (nothing appended)
+    bool append_implication_bdd(const std::vector<bddmma_instruction>& src, size_t off, size_t top_abs, size_t bot_abs,
+                                const std::vector<size_t>& widths, const std::vector<size_t>& loff, size_t chunk, size_t n_chunks,
+                                const std::vector<size_t>& aux);
 };
 
 }  // namespace bddmma_host

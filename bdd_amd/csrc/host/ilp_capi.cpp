@@ -75,7 +75,7 @@ int bddilp_to_bdds(const bddilp* ilp, int split, uint64_t split_length, bddilp_b
     if (!ilp || !out) { g_err = "null argument"; return BDDILP_ERR_INVALID_ARGUMENT; }
     return guarded(BDDILP_ERR_INVALID_ARGUMENT, [&] {
         auto* b = new bddilp_bdds{to_bdds(ilp->ilp)};
-        if (split) b->col.split_long_bdds(std::max(b->col.nr_variables(), ilp->ilp.nr_variables()), split_length);
+        if (split) b->col.split_long_bdds(std::max(b->col.nr_variables(), ilp->ilp.nr_variables()), split_length, 256 * 2048 / 10, split == 2);
         *out = b;
         return BDDILP_OK;
     });
@@ -98,10 +98,11 @@ int bddilp_bdds_add_row(bddilp_bdds* b, const int64_t* coeffs, const uint64_t* v
         return BDDILP_OK;
     });
 }
-int bddilp_bdds_split(bddilp_bdds* b, uint64_t nr_variables, uint64_t split_length, uint64_t* nr_split, uint64_t* nr_variables_after)
+int bddilp_bdds_split(bddilp_bdds* b, uint64_t nr_variables, uint64_t split_length, int with_implication_bdd, uint64_t* nr_split,
+                      uint64_t* nr_variables_after)
 {
     return guarded(BDDILP_ERR_INVALID_ARGUMENT, [&] {
-        const auto [n, nv] = b->col.split_long_bdds(nr_variables, split_length);
+        const auto [n, nv] = b->col.split_long_bdds(nr_variables, split_length, 256 * 2048 / 10, with_implication_bdd != 0);
         if (nr_split) *nr_split = n;
         if (nr_variables_after) *nr_variables_after = nv;
         return BDDILP_OK;

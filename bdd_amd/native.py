@@ -64,7 +64,7 @@ def parse_lp(text: str, fmt: str = "lp") -> ILP:
         L.bddilp_destroy(h)
 
 
-def lp_to_bdd_collection(text: str, split: bool = False, split_length: int = 0, normalize: bool = False):
+def lp_to_bdd_collection(text: str, split: bool = False, split_length: int = 0, normalize: bool = False, with_implication_bdd: bool = False):
     """.lp text -> (ILP, BddCollection) entirely in C++ (parse, optional normalisation, conversion, optional splitting)."""
     L = capi.lib()
     h = C.c_void_p()
@@ -73,7 +73,7 @@ def lp_to_bdd_collection(text: str, split: bool = False, split_length: int = 0, 
         if normalize:
             L.bddilp_normalize(h)
         b = C.c_void_p()
-        _check(L.bddilp_to_bdds(h, int(split), int(split_length or 0), C.byref(b)))
+        _check(L.bddilp_to_bdds(h, (2 if with_implication_bdd else 1) if split else 0, int(split_length or 0), C.byref(b)))
         try:
             col = _collection_from_handle(L, b)
         finally:
@@ -83,7 +83,7 @@ def lp_to_bdd_collection(text: str, split: bool = False, split_length: int = 0, 
     return col
 
 
-def rows_to_bdd_collection(rows, split_length: int = None, nr_variables: int = 0) -> BddCollection:
+def rows_to_bdd_collection(rows, split_length: int = None, nr_variables: int = 0, with_implication_bdd: bool = False) -> BddCollection:
     """rows: iterable of (coefficients, variables, ineq, rhs); trivially true rows are skipped, an infeasible one raises."""
     L = capi.lib()
     b = C.c_void_p()
@@ -98,7 +98,8 @@ def rows_to_bdd_collection(rows, split_length: int = None, nr_variables: int = 0
                 raise RuntimeError("problem is infeasible")
         if split_length is not None:
             ns, nv = C.c_uint64(0), C.c_uint64(0)
-            _check(L.bddilp_bdds_split(b, max(int(nr_variables), int(L.bddilp_bdds_nr_variables(b))), int(split_length), C.byref(ns), C.byref(nv)))
+            _check(L.bddilp_bdds_split(b, max(int(nr_variables), int(L.bddilp_bdds_nr_variables(b))), int(split_length),
+                                       int(with_implication_bdd), C.byref(ns), C.byref(nv)))
         return _collection_from_handle(L, b)
     finally:
         L.bddilp_bdds_destroy(b)

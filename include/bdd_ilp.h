@@ -55,13 +55,15 @@ int bddilp_normalize(bddilp* ilp);
 
 /* bdd_preprocessor::add_ilp: one QBDD per row (trivially true rows are skipped, an infeasible row fails with
  * BDDILP_ERR_INFEASIBLE).  split != 0: BDDs longer than split_length variables are cut by split_qbdd
- * (split_length 0: the reference's occupancy rule with MI355X's figures). */
+ * (split_length 0: the reference's occupancy rule with MI355X's figures); split == 2 also adds split_qbdd's
+ * implication BDD over the auxiliary variables (bdd_collection.cpp:801-941, JSON "split bdds": {"implication bdd": true}). */
 int bddilp_to_bdds(const bddilp* ilp, int split, uint64_t split_length, bddilp_bdds** out);
 /* single rows, for tests and front ends that build their own collections */
 int bddilp_bdds_create(bddilp_bdds** out);
 int bddilp_bdds_add_row(bddilp_bdds* b, const int64_t* coeffs, const uint64_t* vars, uint64_t n, int ineq, int64_t rhs,
                         int* status /* 0 added, 1 trivially true (skipped), 2 infeasible */);
-int bddilp_bdds_split(bddilp_bdds* b, uint64_t nr_variables, uint64_t split_length, uint64_t* nr_split, uint64_t* nr_variables_after);
+int bddilp_bdds_split(bddilp_bdds* b, uint64_t nr_variables, uint64_t split_length, int with_implication_bdd, uint64_t* nr_split,
+                      uint64_t* nr_variables_after);
 void bddilp_bdds_destroy(bddilp_bdds* b);
 uint64_t bddilp_bdds_nr_bdds(const bddilp_bdds* b);
 uint64_t bddilp_bdds_nr_instructions(const bddilp_bdds* b);

@@ -63,15 +63,22 @@ def record(name, rc: RefCollection, costs):
     print(name, "V", V, "bdds", rc.nr_bdds(), "lb_init", out["lb_init_f64"], "iter_lb[-1]", out["iter_lb_f64"][-1])
 
 
-def record_split(name, build, chunk, aux0):
-    """bdd_collection::split_qbdd of the reference on BDD 0 (then the original removed): input and output storage"""
+def record_split(name, build, chunk, aux0, implication=False):
+    """bdd_collection::split_qbdd of the reference on BDD 0 (then the original removed): input and output storage.
+    The lo / hi fields of terminal entries carry no information (make_qbdd leaves scratch values there); they are
+    normalised to the sink marker so that the fixtures compare with array equality."""
     rc = RefCollection()
     build(rc)
     before = rc.export()
-    n, next_aux = rc.split_qbdd(0, chunk, aux0)
+    n, next_aux = rc.split_qbdd(0, chunk, aux0, implication)
     after = rc.export()
+    out = after.instr.copy()
+    term = out[:, 2] >= np.uint64(2**64 - 2)
+    out[term, 0] = out[term, 2]
+    out[term, 1] = out[term, 2]
     np.savez_compressed(os.path.join(OUT, name + ".npz"), in_instr=before.instr, in_delims=before.delims,
-                        chunk=chunk, aux0=aux0, n_new=n, next_aux=next_aux, out_instr=after.instr, out_delims=after.delims)
+                        chunk=chunk, aux0=aux0, n_new=n, next_aux=next_aux, implication=implication, out_instr=out,
+                        out_delims=after.delims)
     print(name, "chunks", n, "next aux", next_aux, "nodes", before.nr_bdd_nodes(), "->", after.nr_bdd_nodes())
 
 
@@ -83,6 +90,13 @@ def main():
     record_split("split_equality_12", lambda x: x.add_linear([1, 2, 3, 2, 1, 3, 2, 1, 2, 3, 1, 2], "=", 9, list(range(0, 24, 2))), 5, 30)
     record_split("split_cardinality_11", lambda x: x.add_cardinality(list(range(11)), 4), 2, 11)
     record_split("split_not_needed", lambda x: x.add_covering(list(range(4))), 4, 4)
+    # with the implication BDD over the auxiliary variables (bdd_collection.cpp:801-941)
+    record_split("split_imp_knapsack_12", lambda x: x.add_linear([1, 2, 3, 2, 1, 3, 2, 1, 2, 3, 1, 2], "<=", 11, list(range(12))), 3, 12, True)
+    record_split("split_imp_equality_12", lambda x: x.add_linear([1, 2, 3, 2, 1, 3, 2, 1, 2, 3, 1, 2], "=", 9, list(range(12))), 3, 12, True)
+    record_split("split_imp_cardinality_11", lambda x: x.add_cardinality(list(range(11)), 4), 2, 11, True)
+    record_split("split_imp_covering_10", lambda x: x.add_covering(list(range(10))), 3, 10, True)
+    record_split("split_imp_knapsack_14", lambda x: x.add_linear([3, 1, 4, 1, 5, 2, 6, 5, 3, 5, 2, 3, 2, 3], ">=", 20, list(range(14))), 4, 20, True)
+    record_split("split_imp_two_chunks", lambda x: x.add_covering(list(range(6))), 3, 6, True)    # two chunks: no implication BDD
     ilp = assignment_ilp(3)
     record("matching_3x3_diag", ref_collection_from_ilp(ilp), ilp.objective)
     c = -np.ones((3, 3)); c[:, 0] = -2

@@ -111,3 +111,11 @@ def test_split_bdds_same_parity_and_bound():
     assert abs(o.lower_bound() - split.lower_bound()) <= 1e-7 * max(1.0, abs(o.lower_bound()))
     assert split.lower_bound() <= full.lower_bound() + 1e-6
     assert split.lower_bound() >= full.lower_bound() - 1e-2 * abs(full.lower_bound())
+    # with the implication BDD over the auxiliary variables: one more BDD, still a valid bound, and GPU == oracle
+    imp = bdd_solver(cfg(lp, **{"termination criteria": tc, "split bdds": {"split length": 10, "implication bdd": True}}), quiet=True).solve()
+    assert imp.bdd_col.nr_bdds() == split.bdd_col.nr_bdds() + 1
+    assert imp.lower_bound() <= full.lower_bound() + 1e-6
+    o = Oracle(imp.bdd_col, costs, "double")
+    for _ in range(3000):
+        o.iteration()
+    assert abs(o.lower_bound() - imp.lower_bound()) <= 1e-7 * max(1.0, abs(o.lower_bound()))

@@ -99,6 +99,18 @@ def test_splitting_node_for_node(split_length):
     np.testing.assert_array_equal(got.instr, want.instr)
 
 
+def test_splitting_with_implication_bdd_node_for_node():
+    rows, want = [], BddCollection()
+    for co, rhs in (([1, 2, 3, 2, 1, 3, 2, 1, 2, 3, 1, 2], 11), ([3, 1, 4, 1, 5, 2, 6, 5, 3, 5, 2, 3], 18), ([1] * 12, 5)):
+        rows.append((co, np.arange(12), "<=", rhs))
+        want.add_linear(co, "<=", rhs, np.arange(12))
+    split_long_bdds(want, 12, 3, with_implication_bdd=True)
+    got = native.rows_to_bdd_collection(rows, split_length=3, nr_variables=12, with_implication_bdd=True)
+    assert got.nr_bdds() == 3 * 4 + 3
+    np.testing.assert_array_equal(got.delims, want.delims)
+    np.testing.assert_array_equal(got.instr, want.instr)
+
+
 def test_infeasible_and_trivial_rows_in_lp():
     with pytest.raises(RuntimeError, match="infeasible"):
         native.lp_to_bdd_collection("Minimize\nx + y\nSubject To\nx + y >= 3\nEnd\n")

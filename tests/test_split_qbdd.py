@@ -9,7 +9,7 @@ import pytest
 from bdd_amd import BddCollection
 from bdd_amd.ilp import compute_split_length, split_long_bdds
 from oracle import oracle as O
-from util import GOLDEN_DIR, SPLIT_GOLDEN, collection_from_arrays
+from util import GOLDEN_DIR, SPLIT_GOLDEN, canonical_nodes, collection_from_arrays
 
 needs_ref = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
 
@@ -18,12 +18,46 @@ needs_ref = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not bu
 def test_split_matches_reference_golden(name):
     z = np.load(f"{GOLDEN_DIR}/{name}.npz")
     col = collection_from_arrays(z["in_instr"], z["in_delims"])
-    new_nrs, next_aux = col.split_qbdd(0, int(z["chunk"]), int(z["aux0"]))
+    implication = bool(z["implication"]) if "implication" in z else False
+    new_nrs, next_aux = col.split_qbdd(0, int(z["chunk"]), int(z["aux0"]), implication)
     assert len(new_nrs) == int(z["n_new"]) and next_aux == int(z["next_aux"])
     if len(new_nrs) > 1:
         col.remove([0])
     np.testing.assert_array_equal(col.delims, z["out_delims"])
-    np.testing.assert_array_equal(col.instr, z["out_instr"])
+    if implication and len(new_nrs) == -(-len(collection_from_arrays(z["in_instr"], z["in_delims"]).layer_widths(0)) // int(z["chunk"])) + 1:
+        # the chunks node for node; the implication BDD (last) up to the order of the nodes inside its layers, which
+        # in the reference comes out of bdd_mgr's bdd_and / make_qbdd
+        ref = collection_from_arrays(z["out_instr"], z["out_delims"])
+        last = int(z["out_delims"][-2])
+        np.testing.assert_array_equal(col.instr[:last], z["out_instr"][:last])
+        assert col.layer_widths(col.nr_bdds() - 1) == ref.layer_widths(ref.nr_bdds() - 1)
+        assert canonical_nodes(col, col.nr_bdds() - 1) == canonical_nodes(ref, ref.nr_bdds() - 1)
+    else:
+        np.testing.assert_array_equal(col.instr, z["out_instr"])
+
+
+def test_implication_bdd_semantics():
+    """The implication BDD accepts exactly the auxiliary assignments that some path of the original BDD induces
+    (it is the conjunction of necessary conditions; on these instances it is exact), so adding it does not change the
+    feasible set of the split system."""
+    n = 8
+    col = BddCollection()
+    col.add_linear([2, 1, 3, 1, 2, 1, 2, 3], "<=", 7, list(range(n)))
+    want = {x for x in itertools.product((0, 1), repeat=n) if col.evaluate(0, x)}
+    nsplit, n_all = split_long_bdds(col, n, 2, with_implication_bdd=True)
+    assert nsplit == 1 and col.nr_bdds() == 4 + 1
+    imp = col.nr_bdds() - 1
+    assert set(col.variables(imp)) == set(range(n, n_all))       # over the auxiliary variables only
+    # every feasible x has exactly one auxiliary completion, and the implication BDD accepts it
+    chunks = list(range(col.nr_bdds() - 1))
+    aux_n = n_all - n
+    assert aux_n <= 16
+    for x in list(want)[:12]:
+        sols = [a for a in itertools.product((0, 1), repeat=aux_n) if all(col.evaluate(b, list(x) + list(a)) for b in chunks)]
+        assert len(sols) == 1 and col.evaluate(imp, list(x) + list(sols[0]))
+    # and it rejects one-hot assignments that no path realises (if any exist for this instance)
+    accepted = sum(col.evaluate(imp, [0] * n + list(a)) for a in itertools.product((0, 1), repeat=aux_n))
+    assert 0 < accepted < 2 ** aux_n
 
 
 @needs_ref

@@ -54,3 +54,32 @@ def same_function(col_a, b_a, col_b, b_b, n_vars, max_enum=14):
         if col_a.evaluate(b_a, x) != col_b.evaluate(b_b, x):
             return False
     return True
+
+
+def canonical_nodes(col, b):
+    """BDD b with its nodes renumbered by breadth-first discovery from the root (lo before hi): a list of
+    (variable, lo, hi) with 'T' / 'B' for the sinks.  Two BDDs are isomorphic iff these lists are equal — the order of
+    the nodes inside a layer carries no meaning (and differs between the reference's bdd_mgr-based constructions and
+    the closed-form ones here)."""
+    ins = col.instr
+    root = int(col.delims[b])
+    ids, order = {root: 0}, [root]
+    out = []
+    k = 0
+    while k < len(order):
+        i = order[k]
+        k += 1
+        row = []
+        for c in (int(ins[i, 0]), int(ins[i, 1])):
+            t = int(ins[c, 2])
+            if t == 2**64 - 1:
+                row.append("T")
+            elif t == 2**64 - 2:
+                row.append("B")
+            else:
+                if c not in ids:
+                    ids[c] = len(order)
+                    order.append(c)
+                row.append(ids[c])
+        out.append((int(ins[i, 2]), row[0], row[1]))
+    return out
