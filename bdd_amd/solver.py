@@ -255,11 +255,15 @@ class bdd_hip_lbfgs:
         capi.check(self._L.bddmma_lbfgs_create(C.byref(h), solver._h, C.byref(p)), solver._h)
         self._h = h
 
+    def close(self):
+        """release the history buffers; call before closing the wrapped solver"""
+        if getattr(self, "_h", None):
+            self._L.bddmma_lbfgs_destroy(self._h)
+            self._h = None
+
     def __del__(self):
         try:
-            if self._h:
-                self._L.bddmma_lbfgs_destroy(self._h)
-                self._h = None
+            self.close()
         except Exception:
             pass
 

@@ -566,3 +566,34 @@ def test_randomised_instances_and_layout_options_vs_oracle(seed):
     f = bdd_hip_parallel_mma(col, costs, precision="float", **opts)
     f.iterations(n_it)
     assert abs(f.lower_bound() - ref) <= 2e-5 * max(1.0, abs(ref)), opts
+
+
+def test_handles_do_not_leak_device_memory_and_long_runs_stay_monotone():
+    import torch
+    col, costs = random_set_cover(20_000, 12_000, 7, seed=21)
+    s = bdd_hip_parallel_mma(col, costs, precision="float")   # warm-up: code objects, allocator pools
+    s.iterations(5); s.lower_bound(); s.close()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(60):
+        s = bdd_hip_parallel_mma(col, costs, precision="float" if i % 2 else "double")
+        if i % 3 == 0:
+            l = bdd_hip_lbfgs(s)
+            for _ in range(7):
+                l.iteration()
+            l.close()
+        else:
+            s.iterations(3)
+        s.lower_bound()
+        s.close()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)            # nothing but allocator slack is kept
+    # a long run: the bound never decreases and stays finite (float accumulates 20 000 cost updates per layer)
+    s = bdd_hip_parallel_mma(col, costs, precision="float")
+    prev = s.lower_bound()
+    for _ in range(20):
+        s.iterations(1000)
+        lb = s.lower_bound()
+        assert np.isfinite(lb) and lb >= prev - 1e-4 * abs(prev)
+        prev = lb
+    assert prev <= costs.sum()
