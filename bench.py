@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--deterministic", action="store_true")
-    ap.add_argument("--event-stride", type=int, default=16)
+    ap.add_argument("--event-stride", type=int, default=64)
     args = ap.parse_args()
 
     import torch
