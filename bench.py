@@ -78,7 +78,7 @@ def main():
     R = 4 if args.precision == "float" else 8
     solver.iterations(args.warmup)
     solver.synchronize()
-    # hipEvent pairs around the launches of every 16th iteration, on the solver's own stream (an event pair
+    # hipEvent pairs around the launches of every --event-stride-th (64th) iteration, on the solver's own stream (an event pair
     # per launch costs ~4 us of stream time; at stride 1 the 10.5 M-node iteration is 14 % slower)
     solver.set_profiling(True, stride=args.event_stride)
 
