@@ -967,7 +967,7 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
         lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
     }
     // number of BDDs of the variables this thread normalises (needed only after the accumulation)
-    constexpr int NPT = 16;  // 2 * vars_per_bin <= NPT * EX_THREADS
+    constexpr int NPT = 19;  // 2 * vars_per_bin <= NPT * EX_THREADS
     int nb[NPT];
     if (MODE == EX_ITER) {
 #pragma unroll
@@ -978,24 +978,41 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
     }
     for (uint32_t i = tid; i < 2 * nv; i += EX_THREADS) tile[i] = ACC(0);
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < EX_UNROLL; ++u) {
-        if (m[u] > 0) lds_add(&tile[2 * lv[u] + 1], ACC(m[u]));
-        else if (m[u] < 0) lds_add(&tile[2 * lv[u]], ACC(-m[u]));
-    }
-    for (uint32_t base = e0 + EX_THREADS * EX_UNROLL + tid; base < e1; base += EX_THREADS * EX_UNROLL) {  // bins larger than one chunk
-        REAL m2[EX_UNROLL];
-        uint32_t lv2[EX_UNROLL];
+    // bins larger than one chunk: the loads of chunk c+1 are in flight while chunk c is accumulated
+    constexpr uint32_t CH = EX_THREADS * EX_UNROLL;
+    auto load_chunk = [&](REAL (&mm_)[EX_UNROLL], uint32_t (&lv_)[EX_UNROLL], uint32_t start) {
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
-            const uint32_t e = base + u * EX_THREADS;
-            bload(m2[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
-            lv2[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
+            const uint32_t e = start + tid + u * EX_THREADS;
+            bload(mm_[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
+            lv_[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
         }
+    };
+    auto accumulate = [&](const REAL (&mm_)[EX_UNROLL], const uint32_t (&lv_)[EX_UNROLL]) {
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
-            if (m2[u] > 0) lds_add(&tile[2 * lv2[u] + 1], ACC(m2[u]));
-            else if (m2[u] < 0) lds_add(&tile[2 * lv2[u]], ACC(-m2[u]));
+            if (mm_[u] > 0) lds_add(&tile[2 * lv_[u] + 1], ACC(mm_[u]));
+            else if (mm_[u] < 0) lds_add(&tile[2 * lv_[u]], ACC(-mm_[u]));
+        }
+    };
+    {
+        REAL mc[EX_UNROLL];
+        uint32_t lc[EX_UNROLL];
+        uint32_t cs = e0 + CH;  // start of the next chunk (uniform)
+        bool have = cs < e1;
+        if (have) load_chunk(mc, lc, cs);
+        accumulate(m, lv);
+        while (have) {
+            REAL mn[EX_UNROLL];
+            uint32_t ln[EX_UNROLL];
+            const uint32_t ns = cs + CH;
+            const bool more = ns < e1;
+            if (more) load_chunk(mn, ln, ns);
+            accumulate(mc, lc);
+            if (!more) break;
+#pragma unroll
+            for (int u = 0; u < EX_UNROLL; ++u) { mc[u] = mn[u]; lc[u] = ln[u]; }
+            cs = ns;
         }
     }
     __syncthreads();

@@ -416,13 +416,17 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         Exchange& X = L.ex;
         // default bin: as many variables as a 128 KiB LDS tile holds (2 REAL each), but at least ~256 bins
         // so that the exchange kernel (one workgroup per bin) has enough workgroups to spread over the CUs
-        const uint32_t max_vb = 8192u;  // k_exchange_reduce: 2 * vars_per_bin <= 16 * 1024 threads; 128 KiB of double accumulators
-        uint32_t auto_vb = (uint32_t)(((L.n_vars + 255) / 256 + 255) / 256 * 256);
-        auto_vb = std::min(std::max(auto_vb, 1024u), max_vb);
+        const uint32_t max_vb = 9728u;  // k_exchange_reduce: 2 * vars_per_bin <= 19 * 1024 threads; 152 KiB of double accumulators
+        // ~256 bins (one workgroup per CU), but at least 1024 variables per bin — unless the variables have so many
+        // layers that such a bin would hold several 12 K-entry chunks (long rows: V small, L large): then smaller bins
+        uint32_t auto_vb = (uint32_t)(((L.n_vars + 255) / 256 + 63) / 64 * 64);
+        const uint64_t one_chunk_vars = Lin ? 12288ull * L.n_vars / Lin : 1024;
+        const uint32_t min_vb = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, one_chunk_vars / 64 * 64));
+        auto_vb = std::min(std::max(auto_vb, min_vb), max_vb);
         X.vars_per_bin = opts && opts->vars_per_bin ? opts->vars_per_bin : auto_vb;
         X.stage_cap = opts && opts->stage_cap ? opts->stage_cap : 640;
         if (X.vars_per_bin < 64 || X.vars_per_bin > max_vb) {
-            err = "vars_per_bin must be in [64, 8192]";
+            err = "vars_per_bin must be in [64, 9728]";
             return BDDMMA_ERR_INVALID_ARGUMENT;
         }
         if (X.stage_cap < W || X.stage_cap > 640) {

@@ -70,7 +70,7 @@ typedef struct bddmma_options {
     uint32_t wide_pack_width;  /* max #nodes of one hop inside a workgroup-sized pack whose frontier lives in LDS (default 2048; <= 2048 for
                                   F64, <= 4096 for F32); BDDs with wider layers use the same kernels with the frontier in global memory */
     uint32_t deterministic;    /* 1: delta accumulation by per-variable gather (bit-reproducible) */
-    uint32_t vars_per_bin;     /* variables per exchange bin, <= 8192 (16 B of LDS accumulators each); default: ~V/256 rounded, 1024..8192 */
+    uint32_t vars_per_bin;     /* variables per exchange bin, <= 9728 (16 B of LDS accumulators each); default: ~V/256 rounded, 1024..9728 */
     uint32_t stage_cap;        /* max layers of one stage group of a narrow pack (default 640) */
     uint32_t waves_per_block;  /* narrow packs swept by one workgroup with cooperative staging: 1, 2, 4 or 8 (default 4) */
     uint32_t reserved[2];      /* [0] = 1: keep the input order of the BDDs when forming packs (default: BDDs of equal shape are grouped) */
