@@ -100,7 +100,7 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
     int rc = build_layout_w(instr, delims, n_bdds, opts, L, err, keep_debug_maps, real_size);
     // Few packs (small instance, or few but long BDDs): a sweep is then bound by the latency of one pack's
     // hop chain, so prefer more, narrower packs.  Only when the caller left pack_width open.
-    if (rc == BDDMMA_OK && !(opts && opts->pack_width) && L.narrow.n_packs() < 2048 && L.narrow.n_packs() > 0) {
+    if (rc == BDDMMA_OK && !(opts && opts->pack_width) && L.narrow.n_packs() < 4000 && L.narrow.n_packs() > 0) {
         bddmma_options o = opts ? *opts : bddmma_options{};
         o.pack_width = 64;
         HostLayout L2;

@@ -128,7 +128,7 @@ def main():
                             f"{sizes['N']} BDD nodes (BASELINE.json configs[2]); one independent instance per GPU",
                 "precision": args.precision,
                 "omega": 0.5,
-                "pack_width": args.pack_width or "auto (128; 64 when fewer than 2048 packs)",
+                "pack_width": args.pack_width or "auto (128; 64 when fewer than 4000 packs)",
                 "waves_per_block": args.wpb or 4,
                 "packs": solver.nr_packs(),
                 "hops": solver.nr_hops(),
