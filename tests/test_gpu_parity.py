@@ -540,6 +540,11 @@ def test_randomised_instances_and_layout_options_vs_oracle(seed):
         else:
             co = rng.integers(1, 9, size=k)
             rows.append((co, vs, ">=", int(rng.integers(1, co.sum() - co.max() + 1))))  # every variable may still be 0
+    if seed % 4 == 3:      # a few rows with layers wider than a wavefront: workgroup-per-pack (and, with wide_pack_width 64, huge) packs
+        for _ in range(int(rng.integers(1, 4))):
+            k = int(rng.integers(12, min(V, 20) + 1))
+            co = rng.integers(1, 60, size=k)
+            rows.append((co, np.sort(rng.choice(V, size=k, replace=False)), "<=", int(rng.integers(co.max(), co.sum()))))
     col = native.rows_to_bdd_collection(rows)
     if col.nr_bdds() == 0:
         pytest.skip("all rows trivial")
