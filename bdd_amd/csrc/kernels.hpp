@@ -304,6 +304,7 @@ __device__ __forceinline__ void wave_sync()
 }
 
 constexpr uint32_t HOP_WIN = 64;
+constexpr int HOP_UNROLL = 2;  // hops per trip of the narrow kernels' hop loops (see k_fwd_narrow)
 struct HopWindow {
     uint32_t* node;   // LDS [HOP_WIN]
     uint32_t* layer;  // LDS [HOP_WIN]
@@ -459,7 +460,12 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDe
             }
             if (WPB > 1) __syncthreads(); else wave_sync();
         }
-        for (; q < qe; ++q) {
+        // One hop of the pack.  The loop below executes HOP_UNROLL of them per trip: the compiler drains all outstanding
+        // memory operations at the loop header (s_waitcnt vmcnt(0), which also waits for the stores of the hop just
+        // finished), so the chain "wait, LDS round trips, stores" is paid once per trip; inside a trip the waits are
+        // counted and the pipeline-register rotation is renamed away.  Latency-bound cases gain most: sweeps of
+        // 100-variable rows -10 % (solve) / -22 % (plain), the 1 M-node benchmark -6 %; the saturated 10.5 M one +-1 %.
+        auto hop = [&]() {
             if (q + 3 >= hw.base + HOP_WIN && hw.base + HOP_WIN <= q1) hw.fill(pk, q, lane);
             const uint32_t ne2 = off(q + 2);
             const uint32_t n2 = ne2 - ne;
@@ -539,7 +545,13 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDe
                 if (NEED_T) ta[r] = tb[r];
             }
             La = Lb;
+            ++q;
+        };
+        while (q + HOP_UNROLL <= qe) {
+#pragma unroll
+            for (int u = 0; u < HOP_UNROLL; ++u) hop();
         }
+        while (q < qe) hop();
         if (MODE == FWD_SOLVE) {
             if (WPB > 1) __syncthreads(); else wave_sync();
             stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);  // min-marginal differences of the round -> entry array
@@ -614,7 +626,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDe
             }
             if (WPB > 1) __syncthreads(); else wave_sync();
         }
-        while (q > qs) {
+        auto hop = [&]() {  // see k_fwd_narrow
             --q;
             if (q < hw.base + 2 && hw.base > q0) hw.fill(pk, q + 1 > q0 + HOP_WIN ? q + 1 - HOP_WIN : q0, lane);
             const uint32_t nb = nb_of(q);
@@ -684,7 +696,12 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDe
                 }
             }
             La = Lb;
+        };
+        while (q >= qs + HOP_UNROLL) {
+#pragma unroll
+            for (int u = 0; u < HOP_UNROLL; ++u) hop();
         }
+        while (q > qs) hop();
         if (MODE == BWD_SOLVE) {
             if (WPB > 1) __syncthreads(); else wave_sync();
             stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
