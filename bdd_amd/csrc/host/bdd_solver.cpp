@@ -179,8 +179,12 @@ void bdd_solver::solve()
             std::vector<size_t> per_var(ilp_.nr_variables(), 0);
             for (const auto& c : ilp_.constraints)
                 for (size_t v : std::set<size_t>(c.variables.begin(), c.variables.end())) ++per_var[v];
+            size_t mn = per_var.empty() ? 0 : per_var[0], mx = 0, sum = 0;
+            for (size_t c : per_var) { mn = std::min(mn, c); mx = std::max(mx, c); sum += c; }
             std::cout << "[print_statistics] #variables = " << ilp_.nr_variables() << "\n[print_statistics] #constraints = " << ilp_.constraints.size()
-                      << "\n[print_statistics] #BDDs = " << col_.nr_bdds() << std::endl;
+                      << "\n[print_statistics] #BDDs = " << col_.nr_bdds() << "\n[print_statistics] minimum num. constraints per var = " << mn
+                      << "\n[print_statistics] maximum num. constraints per var = " << mx << "\n[print_statistics] mean num. constraints per var = "
+                      << (per_var.empty() ? 0.0 : (double)sum / (double)per_var.size()) << std::endl;
         }
         for (const char* key : {"export bdd lp", "export bdd graph"})
             if (config_.contains(key)) throw std::runtime_error(std::string("'") + key + "' is not available in this backend");

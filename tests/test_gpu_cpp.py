@@ -48,3 +48,30 @@ def test_cpp_command_line(tmp_path):
     assert lb and abs(float(lb[0].split("=")[1]) - 1.5) <= 1e-3
     obj = [ln for ln in r.stdout.splitlines() if "primal objective" in ln]
     assert obj and abs(float(obj[0].split("=")[1]) - 2.0) <= 1e-9
+
+
+OPB = ("* #variable= 6 #constraint= 3\nmin: +1 x1 +1 x2 +1 x3 +1 x4 +1 x5 +1 x6 ;\n+1 x1 +1 x2 +1 x4 >= 1 ;\n+1 x1 +1 x3 +1 x5 >= 1 ;\n"
+       "+1 x2 +1 x3 +1 x6 >= 1 ;\n")
+
+
+@pytest.mark.gpu
+def test_cpp_command_line_opb_input_statistics_and_split(tmp_path):
+    """OPB file input (by extension), the `print statistics` block and `split bdds` with the implication BDD."""
+    opb = tmp_path / "cover.opb"
+    opb.write_text(OPB)
+    r = subprocess.run([CL_BIN, '{"input": "%s", "print statistics": true, "termination criteria": {"maximum iterations": 300, '
+                                '"improvement slope": 0.0, "minimum improvement": 0.0}}' % opb], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "#variables = 6" in r.stdout and "#BDDs = 3" in r.stdout and "maximum num. constraints per var = 2" in r.stdout
+    lb = [ln for ln in r.stdout.splitlines() if "final lower bound" in ln]
+    assert lb and abs(float(lb[0].split("=")[1]) - 1.5) <= 1e-3
+    rows = " + ".join(f"y{i}" for i in range(30))
+    lp = tmp_path / "long.lp"
+    lp.write_text("Minimize\n" + " + ".join(f"{1 + (7 * i) % 11} y{i}" for i in range(30)) + f"\nSubject To\n{rows} >= 3\nEnd\n")
+    r = subprocess.run([CL_BIN, '{"input": "%s", "split bdds": {"split length": 6, "implication bdd": true}, "termination criteria": '
+                                '{"maximum iterations": 3000, "improvement slope": 0.0, "minimum improvement": 0.0}}' % lp],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "final #BDDs = 6" in r.stdout                     # 5 chunks + the implication BDD
+    lb = [ln for ln in r.stdout.splitlines() if "final lower bound" in ln]
+    assert lb and float(lb[0].split("=")[1]) <= 1 + 1 + 1 + 1e-6 and float(lb[0].split("=")[1]) >= 2.9   # costs 1 at i = 0, 11, 22
