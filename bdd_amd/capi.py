@@ -31,6 +31,12 @@ class LbfgsParams(C.Structure):
                 ("step_size_decrease_factor", C.c_double), ("step_size_increase_factor", C.c_double)]
 
 
+class LbfgsState(C.Structure):
+    _fields_ = [("step_size", C.c_double), ("last_applied_step", C.c_double), ("mma_iterations", C.c_uint64),
+                ("lbfgs_iterations", C.c_uint64), ("history_entries", C.c_int32), ("num_unsuccessful_updates", C.c_int32),
+                ("last_kind", C.c_int32), ("last_trials", C.c_int32)]
+
+
 class RunResult(C.Structure):
     _fields_ = [("iterations", C.c_uint64), ("lb_initial", C.c_double), ("lb_final", C.c_double),
                 ("seconds", C.c_double), ("stop_reason", C.c_int32)]
@@ -85,6 +91,9 @@ SIGNATURES = {
     "bddmma_lbfgs_destroy": (None, [_V]),
     "bddmma_lbfgs_iteration": (_I, [_V]),
     "bddmma_lbfgs_update_costs": (_I, [_V, _V, _U64, _V, _U64, _I, _I]),
+    "bddmma_lbfgs_flush": (_I, [_V]),
+    "bddmma_lbfgs_get_state": (_I, [_V, C.POINTER(LbfgsState)]),
+    "bddmma_perturb_primal_costs": (_I, [_V, _V, _D, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), _V, _V, _V]),
     "bddmma_run_solver": (_I, [_V, _V, _U64, _D, _D, _D, _I, C.POINTER(RunResult)]),
     "bddmma_incremental_mm_agreement_rounding": (_I, [_V, _V, _D, _D, _U64, _U64, C.c_uint32, _I, _V, C.POINTER(_I)]),
     "bddmma_save": (_I, [_V, C.c_char_p]),

@@ -673,10 +673,18 @@ struct SolverT final : SolverBase {
         return BDDMMA_OK;
     }
     void* stream_handle() override { return (void*)stream; }
-    int rounding_round(double delta, uint32_t round, uint32_t seed, uint32_t counts[4], char* sol_host) override
+    int rounding_scratch(void** c0_dev, void** c1_dev) override
+    {
+        *c0_dev = d_delta_c;
+        *c1_dev = d_delta_c + n_vars;
+        return BDDMMA_OK;
+    }
+    int rounding_round(double delta, uint32_t round, uint32_t seed, uint32_t counts[4], char* sol_host, void* c0_host, void* c1_host,
+                       bool apply_update, int* applied) override
     {
         HIPCHK(hipSetDevice(device));
         int rc;
+        *applied = 0;
         if ((rc = distribute_delta())) return rc;                 // :265
         if ((rc = forward_run())) return rc;                      // min_marginals_cuda(), :266
         if ((rc = launch_bwd<BWD_MARGINALS>(nullptr, REAL(0), BDDMMA_K_OTHER))) return rc;
@@ -687,12 +695,16 @@ struct SolverT final : SolverBase {
         hipLaunchKernelGGL((k_round_perturb<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_tmp0, d_tmp1, d_var_ptr, d_var_layers,
                            c0, c1, d_sol, d_counts, (uint32_t)n_vars, delta, round, seed);
         HIPCHK(hipMemcpyAsync(counts, d_counts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (c0_host) HIPCHK(hipMemcpyAsync(c0_host, c0, n_vars * sizeof(REAL), hipMemcpyDeviceToHost, stream));
+        if (c1_host) HIPCHK(hipMemcpyAsync(c1_host, c1, n_vars * sizeof(REAL), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         if ((uint64_t)counts[0] + counts[1] == n_vars) {          // all min-marginals agree: read off the solution, :295-305
             HIPCHK(hipMemcpyAsync(sol_host, d_sol, n_vars, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
             return BDDMMA_OK;
         }
+        *applied = 1;
+        if (!apply_update) return BDDMMA_OK;                        // the caller applies it (through the L-BFGS wrapper)
         return update_costs(c0, n_vars, c1, n_vars, precision, 1);  // :327
     }
     // STREAM triad / copy over temporary BDDMMA_TRIAD_BYTES arrays (n4 is a multiple of 4 * grid * 256)

@@ -17,6 +17,8 @@ using namespace bddmma;
 
 struct bddmma_lbfgs;
 extern "C" int bddmma_lbfgs_iteration(bddmma_lbfgs* l);
+extern "C" int bddmma_lbfgs_update_costs(bddmma_lbfgs* l, const void* lo, uint64_t n_lo, const void* hi, uint64_t n_hi, int elem_precision,
+                                         int on_device);
 
 namespace {
 thread_local std::string g_err;
@@ -259,6 +261,28 @@ int bddmma_run_solver(bddmma_solver* s, bddmma_lbfgs* lbfgs, uint64_t max_iter, 
     });
 }
 
+// perturb_primal_costs (incremental_mm_agreement_rounding_cuda.cu:262-331).  The cost update goes through the solver type the
+// caller holds: with an L-BFGS wrapper that is lbfgs::update_costs, which drops the (s, y) history first (lbfgs_impl.h:343-364).
+static int perturb_round(SolverBase* b, bddmma_lbfgs* lbfgs, double cur_delta, uint32_t round, uint32_t seed, uint32_t counts[4], char* sol,
+                         void* c0_host, void* c1_host, int* applied)
+{
+    int rc = b->rounding_round(cur_delta, round, seed, counts, sol, c0_host, c1_host, lbfgs == nullptr, applied);
+    if (rc || !*applied || !lbfgs) return rc;
+    void *c0 = nullptr, *c1 = nullptr;
+    if ((rc = b->rounding_scratch(&c0, &c1))) return rc;
+    return bddmma_lbfgs_update_costs(lbfgs, c0, b->n_vars, c1, b->n_vars, b->precision, 1);
+}
+
+int bddmma_perturb_primal_costs(bddmma_solver* s, bddmma_lbfgs* lbfgs, double cur_delta, uint32_t round_index, uint32_t seed,
+                                uint32_t counts[4], char* sol, void* cost_delta_0, void* cost_delta_1)
+{
+    if (!sol || !counts) return BDDMMA_ERR_INVALID_ARGUMENT;
+    return guarded(s, [&](SolverBase* b) {
+        int applied = 0;
+        return perturb_round(b, lbfgs, cur_delta, round_index, seed, counts, sol, cost_delta_0, cost_delta_1, &applied);
+    });
+}
+
 // incremental_mm_agreement_rounding_cuda (incremental_mm_agreement_rounding_cuda.cu:333-372)
 int bddmma_incremental_mm_agreement_rounding(bddmma_solver* s, bddmma_lbfgs* lbfgs, double init_delta, double delta_growth_rate,
                                              uint64_t num_itr_lb, uint64_t num_rounds, uint32_t seed, int verbose, char* sol, int* found)
@@ -279,11 +303,12 @@ int bddmma_incremental_mm_agreement_rounding(bddmma_solver* s, bddmma_lbfgs* lbf
         for (uint64_t round = 0; round < num_rounds; ++round) {
             cur_delta = std::min(cur_delta * delta_growth_rate, 1e6);
             uint32_t counts[4];
-            if ((rc = b->rounding_round(cur_delta, (uint32_t)round, seed, counts, sol))) return rc;
+            int applied = 0;
+            if ((rc = perturb_round(b, lbfgs, cur_delta, (uint32_t)round, seed, counts, sol, nullptr, nullptr, &applied))) return rc;
             if (verbose)
                 std::printf("[incremental primal rounding] round %llu, cost delta %g: #ones %u, #zeros %u, #equal %u, #inconsistent %u\n",
                             (unsigned long long)round, cur_delta, counts[0], counts[1], counts[2], counts[3]);
-            if ((uint64_t)counts[0] + counts[1] == b->n_vars) {
+            if (!applied) {
                 *found = 1;
                 return BDDMMA_OK;
             }

@@ -1168,8 +1168,8 @@ __global__ void k_layers_to_entries(const REAL* __restrict__ in, const uint32_t*
     if (l < n) binned[lpos[l]] = in[l];
 }
 
-// set_vars_costs_func (bdd_cuda_base.cu:457-474).  The quotient is formed in double and rounded
-// once to REAL, as the reference CPU solver does (bdd_parallel_mma_base.cpp:640,651).
+// set_vars_costs_func (bdd_cuda_base.cu:457-474).  Quotient and sum are formed in double and rounded
+// once to REAL, as the reference CPU solver does (bdd_parallel_mma_base.cpp:640,651,674-677).
 template <typename REAL, typename TIN>
 __global__ void k_update_costs(REAL* __restrict__ cost, const int32_t* __restrict__ var, const int32_t* __restrict__ nbdds,
                                const TIN* __restrict__ c, uint64_t n_c, uint32_t n_layers)
@@ -1181,7 +1181,7 @@ __global__ void k_update_costs(REAL* __restrict__ cost, const int32_t* __restric
         cost[2 * (size_t)l] = REAL(0);  // :465-469
         return;
     }
-    cost[2 * (size_t)l] += REAL((double)c[v] / (double)nbdds[v]);
+    cost[2 * (size_t)l] = REAL((double)cost[2 * (size_t)l] + (double)c[v] / (double)nbdds[v]);
 }
 
 template <typename REAL>
@@ -1312,7 +1312,8 @@ __global__ void k_round_perturb(const REAL* __restrict__ mm0, const REAL* __rest
     REAL s0 = 0, s1 = 0;
     for (uint32_t k = var_ptr[v]; k < var_ptr[v + 1]; ++k) {
         const REAL a = mm0[var_layers[k]], b = mm1[var_layers[k]];
-        const int dir = (a + REAL(1e-6) <= b) ? -1 : ((b + REAL(1e-6) <= a) ? 1 : 0);
+        // mm_diff_direction_func (:29-41): `mm_0 + 1e-6 <= mm_1` with a double literal, i.e. compared in double
+        const int dir = ((double)a + 1e-6 <= (double)b) ? -1 : (((double)b + 1e-6 <= (double)a) ? 1 : 0);
         dmin = min(dmin, dir);
         dmax = max(dmax, dir);
         s0 += a;

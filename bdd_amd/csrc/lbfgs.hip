@@ -29,6 +29,7 @@ struct bddmma_lbfgs {
     virtual ~bddmma_lbfgs() {}
     virtual int iteration() = 0;
     virtual void flush() = 0;
+    virtual void get_state(bddmma_lbfgs_state* out) const = 0;
 };
 
 namespace {
@@ -106,12 +107,17 @@ struct Lbfgs final : bddmma_lbfgs {
     double step_size = 0;
     int unsuccessful = 0;
     bool prev_stored = false;
+    // diagnostics (bddmma_lbfgs_get_state): what the last iteration() did
+    int last_kind = 0, last_trials = 0;
+    double last_applied_step = 0;
+    uint64_t mma_iterations = 0, lbfgs_iterations = 0;
     uint32_t n = 0;
     hipStream_t st = nullptr;
 
+    int device = 0;  // cached: the wrapped solver may already be gone when the wrapper is destroyed
     ~Lbfgs() override
     {
-        (void)hipSetDevice(s->impl->device);
+        (void)hipSetDevice(device);
         for (void* q : allocs) (void)hipFree(q);
     }
     template <typename T>
@@ -124,7 +130,8 @@ struct Lbfgs final : bddmma_lbfgs {
     int init()
     {
         SolverBase* b = s->impl;
-        LHIP(hipSetDevice(b->device));
+        device = b->device;
+        LHIP(hipSetDevice(device));
         n = (uint32_t)b->n_layers;
         st = (hipStream_t)b->stream_handle();
         step_size = p.init_step_size;
@@ -139,6 +146,17 @@ struct Lbfgs final : bddmma_lbfgs {
             free_slots.push_back(h);
         }
         return 0;
+    }
+    void get_state(bddmma_lbfgs_state* out) const override
+    {
+        out->step_size = step_size;
+        out->history_entries = (int32_t)history.size();
+        out->num_unsuccessful_updates = unsuccessful;
+        out->last_kind = last_kind;
+        out->last_trials = last_trials;
+        out->last_applied_step = last_applied_step;
+        out->mma_iterations = mma_iterations;
+        out->lbfgs_iterations = lbfgs_iterations;
     }
     void flush() override  // flush_lbfgs_states, lbfgs_impl.h:318-326
     {
@@ -248,10 +266,13 @@ struct Lbfgs final : bddmma_lbfgs {
             if (net != 0.0) {
                 int r = b->gradient_step(dir, net, 1);
                 if (r) { err = b->err; return r; }
+                ++last_trials;
             }
             prev_step = new_step;
+            last_applied_step = new_step;
             return 0;
         };
+        last_trials = 0;
         size_t num_updates = 0;
         double cur = 0.0, best_step = 0.0, best_impr = 0.0;
         do {
@@ -289,10 +310,17 @@ struct Lbfgs final : bddmma_lbfgs {
         }
         if ((rc = b->bdds_solution(0, cur_g, 1))) { err = b->err; return rc; }
         if ((rc = store_iterate())) return rc;
-        if (update_possible() && (int)lb_history.size() >= p.history_size) {
+        if (update_possible() && (int)lb_history.size() >= p.history_size) {  // choose_solver, :409-417
             if ((rc = compute_direction())) return rc;
             if ((rc = b->make_dual_feasible(dir, 1))) { err = b->err; return rc; }
             if ((rc = search_step_size_and_apply())) return rc;
+            last_kind = 1;
+            ++lbfgs_iterations;
+        } else {
+            last_kind = 0;
+            last_trials = 0;
+            last_applied_step = 0.0;
+            ++mma_iterations;
         }
         if ((rc = b->iteration(0.5))) { err = b->err; return rc; }
         if ((rc = lower_bound(&lb))) return rc;
@@ -359,6 +387,20 @@ int bddmma_lbfgs_iteration(bddmma_lbfgs* l)
     int rc = l->iteration();
     if (rc) l->s->impl->err = l->err;
     return rc;
+}
+
+int bddmma_lbfgs_flush(bddmma_lbfgs* l)
+{
+    if (!l) return BDDMMA_ERR_INVALID_ARGUMENT;
+    l->flush();
+    return BDDMMA_OK;
+}
+
+int bddmma_lbfgs_get_state(const bddmma_lbfgs* l, bddmma_lbfgs_state* out)
+{
+    if (!l || !out) return BDDMMA_ERR_INVALID_ARGUMENT;
+    l->get_state(out);
+    return BDDMMA_OK;
 }
 
 int bddmma_lbfgs_update_costs(bddmma_lbfgs* l, const void* lo, uint64_t n_lo, const void* hi, uint64_t n_hi,

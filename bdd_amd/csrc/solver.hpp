@@ -65,7 +65,11 @@ struct SolverBase {
     virtual void* stream_handle() = 0;
     virtual int time_kernel(int kind, uint64_t reps, double* ms) = 0;
     // one round of perturb_primal_costs (incremental_mm_agreement_rounding_cuda.cu:262-331); counts = #one,#zero,#equal,#inconsistent
-    virtual int rounding_round(double delta, uint32_t round, uint32_t seed, uint32_t counts[4], char* sol_host) = 0;
+    // `applied` = 0 when the solution was read off (all variables one / zero) and the costs were left alone; c0_host / c1_host
+    // (REAL[n_vars], may be null) receive the perturbation.  With apply_update = false the perturbation is computed but not applied.
+    virtual int rounding_round(double delta, uint32_t round, uint32_t seed, uint32_t counts[4], char* sol_host, void* c0_host, void* c1_host,
+                               bool apply_update, int* applied) = 0;
+    virtual int rounding_scratch(void** c0_dev, void** c1_dev) = 0;  // device vectors holding the last perturbation (REAL[n_vars] each)
 
     int synchronize();
     void prof_begin(int kclass);

@@ -20,6 +20,19 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+def _is_dev(x):
+    """a device buffer: anything with data_ptr() living on a GPU (torch CUDA tensors) — the thrust::device_vector
+    overloads of the reference.  Passed through the C-ABI as a raw pointer with on_device = 1."""
+    return hasattr(x, "data_ptr") and bool(getattr(x, "is_cuda", False))
+
+
+def _dev_ptr(x, n, dtype):
+    """raw pointer of a contiguous device buffer holding >= n elements of `dtype`"""
+    assert x.is_contiguous() and x.numel() >= n, "device buffer too small or not contiguous"
+    assert x.element_size() == np.dtype(dtype).itemsize, "device buffer has the wrong element type"
+    return C.c_void_p(x.data_ptr())
+
+
 class bdd_hip_parallel_mma:
     """Drop-in for bdd_cuda_parallel_mma<REAL> (value_type = float | double)."""
 
@@ -103,6 +116,12 @@ class bdd_hip_parallel_mma:
 
     # ---- costs
     def update_costs(self, cost_delta_0, cost_delta_1):
+        if _is_dev(cost_delta_0) or _is_dev(cost_delta_1):   # update_costs(device_vector<REAL>, device_vector<REAL>), bdd_cuda_base.cu:476-500
+            n0 = cost_delta_0.numel() if cost_delta_0 is not None else 0
+            n1 = cost_delta_1.numel() if cost_delta_1 is not None else 0
+            self._ck(self._L.bddmma_update_costs(self._h, _dev_ptr(cost_delta_0, n0, self.value_type) if n0 else None, n0,
+                                                 _dev_ptr(cost_delta_1, n1, self.value_type) if n1 else None, n1, self._prec, 1))
+            return
         lo = np.ascontiguousarray(cost_delta_0, dtype=np.float64)
         hi = np.ascontiguousarray(cost_delta_1, dtype=np.float64)
         self._ck(self._L.bddmma_update_costs(self._h, _ptr(lo), lo.size, _ptr(hi), hi.size, capi.F64, 0))
@@ -110,15 +129,27 @@ class bdd_hip_parallel_mma:
     def set_cost(self, c, var):
         self._ck(self._L.bddmma_set_cost(self._h, float(c), int(var)))
 
-    def get_solver_costs(self):
+    def get_solver_costs(self, out=None):
         n = self.nr_layers()
+        if out is not None:   # three device buffers
+            self._ck(self._L.bddmma_get_solver_costs(self._h, *(_dev_ptr(x, n, self.value_type) for x in out), 1))
+            return out
         lo, hi, mm = (np.zeros(n, self.value_type) for _ in range(3))
         self._ck(self._L.bddmma_get_solver_costs(self._h, _ptr(lo), _ptr(hi), _ptr(mm), 0))
         return lo, hi, mm
 
     def set_solver_costs(self, lo, hi, mm):
+        if _is_dev(lo):
+            n = self.nr_layers()
+            self._ck(self._L.bddmma_set_solver_costs(self._h, *(_dev_ptr(x, n, self.value_type) for x in (lo, hi, mm)), 1))
+            return
         lo, hi, mm = (np.ascontiguousarray(x, dtype=self.value_type) for x in (lo, hi, mm))
         self._ck(self._L.bddmma_set_solver_costs(self._h, _ptr(lo), _ptr(hi), _ptr(mm), 0))
+
+    def get_primal_objective_vector(self, out):
+        """compute_primal_objective_vec into a device buffer (bdd_cuda_base.cu:1352-1362)"""
+        self._ck(self._L.bddmma_primal_objective_vec(self._h, _dev_ptr(out, self.nr_variables(), self.value_type), 1))
+        return out
 
     def get_primal_objective_vector_host(self):
         out = np.zeros(self.nr_variables(), self.value_type)
@@ -134,7 +165,10 @@ class bdd_hip_parallel_mma:
         self._ck(self._L.bddmma_lower_bound(self._h, C.byref(lb)))
         return lb.value
 
-    def lower_bound_per_bdd(self):
+    def lower_bound_per_bdd(self, out=None):
+        if out is not None:
+            self._ck(self._L.bddmma_lower_bound_per_bdd(self._h, _dev_ptr(out, self.nr_bdds(), self.value_type), 1))
+            return out
         out = np.zeros(self.nr_bdds(), self.value_type)
         self._ck(self._L.bddmma_lower_bound_per_bdd(self._h, _ptr(out), 0))
         return out
@@ -147,27 +181,51 @@ class bdd_hip_parallel_mma:
         self._ck(self._L.bddmma_iterations(self._h, float(omega), int(n)))
 
     def forward_mm(self, omega, delta_lo_hi):
+        if _is_dev(delta_lo_hi):   # forward_mm(omega, device_vector<REAL>&), bdd_cuda_parallel_mma.cu:207-257
+            self._ck(self._L.bddmma_forward_mm(self._h, float(omega), _dev_ptr(delta_lo_hi, 2 * self.nr_variables(), self.value_type), 1))
+            return
         assert delta_lo_hi.dtype == self.value_type and delta_lo_hi.size == 2 * self.nr_variables()
         self._ck(self._L.bddmma_forward_mm(self._h, float(omega), _ptr(delta_lo_hi), 0))
 
     def backward_mm(self, omega, delta_lo_hi):
+        if _is_dev(delta_lo_hi):
+            self._ck(self._L.bddmma_backward_mm(self._h, float(omega), _dev_ptr(delta_lo_hi, 2 * self.nr_variables(), self.value_type), 1))
+            return
         assert delta_lo_hi.dtype == self.value_type and delta_lo_hi.size == 2 * self.nr_variables()
         self._ck(self._L.bddmma_backward_mm(self._h, float(omega), _ptr(delta_lo_hi), 0))
 
     def normalize_delta(self, delta_lo_hi):
+        if _is_dev(delta_lo_hi):
+            self._ck(self._L.bddmma_normalize_delta(self._h, _dev_ptr(delta_lo_hi, 2 * self.nr_variables(), self.value_type), 1))
+            return
         self._ck(self._L.bddmma_normalize_delta(self._h, _ptr(delta_lo_hi), 0))
 
     def distribute_delta(self):
         self._ck(self._L.bddmma_distribute_delta(self._h))
 
-    def get_delta(self):
+    def set_delta(self, delta_lo_hi):
+        if _is_dev(delta_lo_hi):
+            self._ck(self._L.bddmma_set_delta(self._h, _dev_ptr(delta_lo_hi, 2 * self.nr_variables(), self.value_type), 1))
+            return
+        d = np.ascontiguousarray(delta_lo_hi, dtype=self.value_type)
+        self._ck(self._L.bddmma_set_delta(self._h, _ptr(d), 0))
+
+    def get_delta(self, out=None):
+        if out is not None:
+            self._ck(self._L.bddmma_get_delta(self._h, _dev_ptr(out, 2 * self.nr_variables(), self.value_type), 1))
+            return out
         out = np.zeros(2 * self.nr_variables(), self.value_type)
         self._ck(self._L.bddmma_get_delta(self._h, _ptr(out), 0))
         return out
 
     # ---- min-marginals / solutions
-    def min_marginals_cuda(self, get_sorted=True):
+    def min_marginals_cuda(self, get_sorted=True, out=None):
         n = self.nr_layers()
+        if out is not None:   # (int32 var, REAL mm0, REAL mm1) device buffers, as min_marginals_cuda returns them (bdd_cuda_base.cu:716-749)
+            v, m0, m1 = out
+            self._ck(self._L.bddmma_min_marginals(self._h, 1 if get_sorted else 0, _dev_ptr(v, n, np.int32), _dev_ptr(m0, n, self.value_type),
+                                                  _dev_ptr(m1, n, self.value_type), 1))
+            return out
         var = np.zeros(n, np.int32)
         mm0, mm1 = np.zeros(n, self.value_type), np.zeros(n, self.value_type)
         self._ck(self._L.bddmma_min_marginals(self._h, 1 if get_sorted else 0, _ptr(var), _ptr(mm0), _ptr(mm1), 0))
@@ -181,7 +239,10 @@ class bdd_hip_parallel_mma:
         return [np.stack([mm0[ptr[v]:ptr[v + 1]], mm1[ptr[v]:ptr[v + 1]]], axis=1).astype(np.float64)
                 for v in range(self.nr_variables())]
 
-    def bdds_solution_vec(self):
+    def bdds_solution_vec(self, out=None):
+        if out is not None:   # device_vector<char> (bdd_cuda_base.cu:1138-1145)
+            self._ck(self._L.bddmma_bdds_solution(self._h, 0, _dev_ptr(out, self.nr_layers(), np.int8), 1))
+            return out
         out = np.zeros(self.nr_layers(), np.int8)
         self._ck(self._L.bddmma_bdds_solution(self._h, 0, _ptr(out), 0))
         return out
@@ -194,18 +255,39 @@ class bdd_hip_parallel_mma:
         return [out[ptr[v]:ptr[v + 1]].astype(np.float64) for v in range(self.nr_variables())]
 
     # ---- L-BFGS support
-    def net_solver_costs(self):
+    def net_solver_costs(self, out=None):
+        if out is not None:
+            self._ck(self._L.bddmma_net_solver_costs(self._h, _dev_ptr(out, self.nr_layers(), self.value_type), 1))
+            return out
         out = np.zeros(self.nr_layers(), self.value_type)
         self._ck(self._L.bddmma_net_solver_costs(self._h, _ptr(out), 0))
         return out
 
     def make_dual_feasible(self, d):
+        if _is_dev(d):
+            self._ck(self._L.bddmma_make_dual_feasible(self._h, _dev_ptr(d, self.nr_layers(), self.value_type), 1))
+            return
         assert d.dtype == self.value_type and d.size == self.nr_layers()
         self._ck(self._L.bddmma_make_dual_feasible(self._h, _ptr(d), 0))
 
     def gradient_step(self, g, step_size):
+        if _is_dev(g):
+            self._ck(self._L.bddmma_gradient_step(self._h, _dev_ptr(g, self.nr_layers(), self.value_type), float(step_size), 1))
+            return
         g = np.ascontiguousarray(g, dtype=self.value_type)
         self._ck(self._L.bddmma_gradient_step(self._h, _ptr(g), float(step_size), 0))
+
+    # ---- primal rounding
+    def perturb_primal_costs(self, cur_delta, round_index=0, seed=0, lbfgs=None):
+        """one round of perturb_primal_costs (incremental_mm_agreement_rounding_cuda.cu:262-331)
+        -> dict(counts = (#one, #zero, #equal, #inconsistent), sol, cost_delta_0, cost_delta_1)"""
+        n = self.nr_variables()
+        counts = (C.c_uint32 * 4)()
+        sol = np.zeros(n, np.int8)
+        c0, c1 = np.zeros(n, self.value_type), np.zeros(n, self.value_type)
+        self._ck(self._L.bddmma_perturb_primal_costs(self._h, lbfgs._h if lbfgs is not None else None, float(cur_delta), int(round_index),
+                                                     int(seed), counts, _ptr(sol), _ptr(c0), _ptr(c1)))
+        return dict(counts=tuple(int(c) for c in counts), sol=sol, cost_delta_0=c0, cost_delta_1=c1)
 
     # ---- checkpoint (bdd_cuda_base.cu:1486-1550; pickle in bdd_cuda_parallel_mma_py.cu:15-38)
     def save(self, path: str):
@@ -272,6 +354,14 @@ class bdd_hip_lbfgs:
 
     def lower_bound(self):
         return self.solver.lower_bound()
+
+    def flush(self):
+        capi.check(self._L.bddmma_lbfgs_flush(self._h), self.solver._h)
+
+    def state(self):
+        st = capi.LbfgsState()
+        capi.check(self._L.bddmma_lbfgs_get_state(self._h, C.byref(st)), self.solver._h)
+        return {k: getattr(st, k) for k, _ in capi.LbfgsState._fields_}
 
     def update_costs(self, lo, hi):
         lo = np.ascontiguousarray(lo, dtype=np.float64)

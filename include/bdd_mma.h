@@ -180,6 +180,20 @@ void bddmma_lbfgs_destroy(bddmma_lbfgs* l);
 int bddmma_lbfgs_iteration(bddmma_lbfgs* l);       /* lbfgs::iteration(), lbfgs_impl.h:137-157 */
 int bddmma_lbfgs_update_costs(bddmma_lbfgs* l, const void* lo, uint64_t n_lo, const void* hi, uint64_t n_hi,
                               int elem_precision, int on_device);  /* lbfgs_impl.h:353-364: also drops history */
+int bddmma_lbfgs_flush(bddmma_lbfgs* l);           /* flush_lbfgs_states(), lbfgs_impl.h:318-326 */
+/* What the state machine did in the last bddmma_lbfgs_iteration (the reference only logs these; exposed so that the
+ * parity tests can compare the decision sequence with the CPU restatement oracle/lbfgs_oracle.py). */
+typedef struct bddmma_lbfgs_state {
+    double step_size;                 /* lbfgs::step_size after the last iteration */
+    double last_applied_step;         /* step left applied by search_step_size_and_apply (0: none / rolled back) */
+    uint64_t mma_iterations;          /* lbfgs::mma_iterations */
+    uint64_t lbfgs_iterations;        /* lbfgs::lbfgs_iterations */
+    int32_t history_entries;          /* history.size() */
+    int32_t num_unsuccessful_updates; /* num_unsuccessful_lbfgs_updates_ */
+    int32_t last_kind;                /* choose_solver() of the last iteration: 0 mma, 1 lbfgs */
+    int32_t last_trials;              /* gradient steps taken by the last step-size search */
+} bddmma_lbfgs_state;
+int bddmma_lbfgs_get_state(const bddmma_lbfgs* l, bddmma_lbfgs_state* out);
 
 /* ---- run_solver (include/run_solver_util.h:10-77) ------------------------- */
 typedef struct bddmma_run_result {
@@ -200,6 +214,16 @@ int bddmma_run_solver(bddmma_solver* s, bddmma_lbfgs* lbfgs_or_null, uint64_t ma
 int bddmma_incremental_mm_agreement_rounding(bddmma_solver* s, bddmma_lbfgs* lbfgs_or_null, double init_delta,
                                              double delta_growth_rate, uint64_t num_itr_lb, uint64_t num_rounds,
                                              uint32_t seed, int verbose, char* sol, int* found);
+
+/* One round of perturb_primal_costs (incremental_mm_agreement_rounding_cuda.cu:262-331): distribute_delta, min-marginals,
+ * per-variable sign agreement (:29-65,76-108), sums (:110-134) and the perturbation {delta,0} / {0,delta} / random
+ * (:136-205), then update_costs — through the L-BFGS wrapper (which drops its history, lbfgs_impl.h:343-364) when
+ * `lbfgs_or_null` is given.  counts = #one, #zero, #equal, #inconsistent.  When all variables are `one` or `zero` the
+ * solution is written to sol (char[nr_variables]) and the costs are left alone.  cost_delta_0 / cost_delta_1 (REAL[nr_variables],
+ * host, may be NULL) receive the perturbation that was applied.  The random draws of the `equal` / `inconsistent` types
+ * come from a counter-based hash of (variable, round, seed) instead of thrust::default_random_engine. */
+int bddmma_perturb_primal_costs(bddmma_solver* s, bddmma_lbfgs* lbfgs_or_null, double cur_delta, uint32_t round_index, uint32_t seed,
+                                uint32_t counts[4], char* sol, void* cost_delta_0, void* cost_delta_1);
 
 /* ---- checkpoint (bdd_cuda_base.cu:1486-1550) ------------------------------ */
 int bddmma_save(const bddmma_solver* s, const char* path);

@@ -35,6 +35,7 @@ typedef struct ORACLE {
     size_t* nr_bdds_per_var; /* n_vars */
     REAL* delta_in;          /* 2*n_vars, {lo,hi} interleaved; empty until first iteration() */
     REAL* delta_out;
+    REAL* mm_last;           /* n_layers: what the layer itself gave up in its last mm pass (the GPU solver's deffered_mm_diff_) */
     int have_delta_in, have_delta_out;
     int mp_state;            /* message_passing_state: 0 none, 1 after_forward, 2 after_backward */
     int lb_valid;
@@ -96,7 +97,7 @@ void FN(oracle_destroy)(ORACLE* o)
 {
     if (!o) return;
     free(o->nodes); free(o->bdd_layer_ptr); free(o->layer_node_ptr); free(o->layer_var);
-    free(o->nr_bdds_per_var); free(o->delta_in); free(o->delta_out); free(o);
+    free(o->nr_bdds_per_var); free(o->delta_in); free(o->delta_out); free(o->mm_last); free(o);
 }
 
 /* add_bdds, bdd_parallel_mma_base.cpp:75-170.  instr = flat bdd_collection storage. */
@@ -122,6 +123,7 @@ ORACLE* FN(oracle_create)(const uint64_t* instr /* [n][3] = lo,hi,index */, cons
     o->layer_node_ptr = (size_t*)calloc(total_layers + 1, sizeof(size_t));
     o->layer_var = (size_t*)calloc(total_layers ? total_layers : 1, sizeof(size_t));
     o->nr_bdds_per_var = (size_t*)calloc(max_v ? max_v : 1, sizeof(size_t));
+    o->mm_last = (REAL*)calloc(total_layers ? total_layers : 1, sizeof(REAL));
     size_t nn = 0, nl = 0;
     for (size_t b = 0; b < n_bdds; ++b) {
         o->bdd_layer_ptr[b] = nl;
@@ -194,8 +196,9 @@ void FN(oracle_update_costs)(ORACLE* o, const double* lo, uint64_t n_lo, const d
             if (var < n_hi) hi_cost = hi[var] / (double)o->nr_bdds_per_var[var];
         }
         for (size_t i = o->layer_node_ptr[l]; i < o->layer_node_ptr[l + 1]; ++i) {
-            if (o->nodes[i].offset_low != TERM0) o->nodes[i].low_cost += (REAL)lo_cost;
-            if (o->nodes[i].offset_high != TERM0) o->nodes[i].high_cost += (REAL)hi_cost;
+            /* `low_cost += lo_cost` with a double right-hand side (:674-677): the sum is formed in double and rounded once */
+            if (o->nodes[i].offset_low != TERM0) o->nodes[i].low_cost = (REAL)((double)o->nodes[i].low_cost + lo_cost);
+            if (o->nodes[i].offset_high != TERM0) o->nodes[i].high_cost = (REAL)((double)o->nodes[i].high_cost + hi_cost);
         }
     }
 }
@@ -289,7 +292,7 @@ static inline void FN(atomic_store)(REAL* f, REAL d)
 }
 
 /* layer update shared by forward_mm(bdd) :832-872 and backward_mm(bdd) :904-941 */
-static inline void FN(mm_layer_update)(ORACLE* o, size_t first, size_t last, size_t var, REAL omega, REAL* delta_out,
+static inline void FN(mm_layer_update)(ORACLE* o, size_t layer, size_t first, size_t last, size_t var, REAL omega, REAL* delta_out,
                                       int reverse)
 {
     REAL cur_mm[2] = {RINF, RINF};
@@ -309,6 +312,9 @@ static inline void FN(mm_layer_update)(ORACLE* o, size_t first, size_t last, siz
         }
     }
     const int f0 = isfinite(cur_mm[0]), f1 = isfinite(cur_mm[1]);
+    /* the GPU solver keeps this amount per layer (mm_diff_out, bdd_cuda_parallel_mma.cu:36-39,131-137): omega * (m1 - m0),
+     * 0 if either is non-finite; the CPU solver only accumulates it into delta_out.  Same value, same rounding. */
+    o->mm_last[layer] = (f0 && f1) ? (cur_mm[0] < cur_mm[1] ? omega * (cur_mm[1] - cur_mm[0]) : -(omega * (cur_mm[0] - cur_mm[1]))) : (REAL)0;
     if (!f0) FN(atomic_store)(&delta_out[2 * var + 0], RINF);
     if (!f1) FN(atomic_store)(&delta_out[2 * var + 1], RINF);
     if (f0 && f1) {
@@ -337,7 +343,7 @@ static void FN(forward_mm_bdd)(ORACLE* o, size_t b, REAL omega, REAL* delta_out,
     for (size_t l = o->bdd_layer_ptr[b]; l < o->bdd_layer_ptr[b + 1]; ++l) {
         const size_t first = o->layer_node_ptr[l], last = o->layer_node_ptr[l + 1];
         const size_t var = o->layer_var[l];
-        FN(mm_layer_update)(o, first, last, var, omega, delta_out, 0);
+        FN(mm_layer_update)(o, l, first, last, var, omega, delta_out, 0);
         if (l + 1 < o->bdd_layer_ptr[b + 1])
             for (size_t i = o->layer_node_ptr[l + 1]; i < o->layer_node_ptr[l + 2]; ++i) o->nodes[i].m = RINF;
         for (size_t i = first; i < last; ++i) {
@@ -354,7 +360,7 @@ static REAL FN(backward_mm_bdd)(ORACLE* o, size_t b, REAL omega, REAL* delta_out
     for (ptrdiff_t l = (ptrdiff_t)o->bdd_layer_ptr[b + 1] - 1; l >= (ptrdiff_t)o->bdd_layer_ptr[b]; --l) {
         const size_t first = o->layer_node_ptr[l], last = o->layer_node_ptr[l + 1];
         const size_t var = o->layer_var[l];
-        FN(mm_layer_update)(o, first, last, var, omega, delta_out, 1);
+        FN(mm_layer_update)(o, (size_t)l, first, last, var, omega, delta_out, 1);
         for (ptrdiff_t i = (ptrdiff_t)last - 1; i >= (ptrdiff_t)first; --i) {
             o->nodes[i].low_cost += delta_in[2 * var + 0];
             o->nodes[i].high_cost += delta_in[2 * var + 1];
@@ -534,6 +540,23 @@ void FN(oracle_gradient_step)(ORACLE* o, const REAL* duals, double step_size)
         for (size_t i = o->layer_node_ptr[l]; i < o->layer_node_ptr[l + 1]; ++i)
             if (o->nodes[i].offset_high != TERM0) o->nodes[i].high_cost += step_size * duals[l];
 }
+
+/* net_solver_costs of the GPU solver (compute_net_costs_func, bdd_cuda_parallel_mma.cu:432-463): hi - lo + the layer's own
+ * deferred min-marginal difference.  (The CPU solver's net_solver_costs, bdd_parallel_mma_base.cpp:1284-1326, spreads the
+ * deferred amount evenly over the BDDs of the variable instead; the L-BFGS oracle follows the GPU definition, which is the
+ * path under test.)  Layer costs are read as oracle_get_costs does. */
+void FN(oracle_net_solver_costs)(const ORACLE* o, REAL* out)
+{
+    for (size_t l = 0; l < o->n_layers; ++l) {
+        REAL lo = 0, hi = 0;
+        for (size_t i = o->layer_node_ptr[l]; i < o->layer_node_ptr[l + 1]; ++i) {
+            if (o->nodes[i].offset_low != TERM0) lo = o->nodes[i].low_cost;
+            if (o->nodes[i].offset_high != TERM0) hi = o->nodes[i].high_cost;
+        }
+        out[l] = hi - lo + o->mm_last[l];
+    }
+}
+void FN(oracle_get_mm_last)(const ORACLE* o, REAL* out) { memcpy(out, o->mm_last, o->n_layers * sizeof(REAL)); }
 
 #undef CAT_
 #undef CAT

@@ -155,6 +155,17 @@ class Oracle:
         self._f("oracle_bdds_solution_vec")(self.h, _p(out))
         return out
 
+    def net_solver_costs(self):
+        """hi - lo + the layer's own deferred min-marginal difference (GPU definition, bdd_cuda_parallel_mma.cu:432-463)."""
+        out = np.zeros(self.nr_layers(), self.dtype)
+        self._f("oracle_net_solver_costs")(self.h, _p(out))
+        return out
+
+    def mm_last(self):
+        out = np.zeros(self.nr_layers(), self.dtype)
+        self._f("oracle_get_mm_last")(self.h, _p(out))
+        return out
+
     def make_dual_feasible(self, d):
         assert d.dtype == self.dtype
         self._f("oracle_make_dual_feasible")(self.h, _p(d))
