@@ -136,6 +136,7 @@ ILP_SIGNATURES = {
     "bddilp_bdds_nr_variables": (_U64, [_V]),
     "bddilp_bdds_instructions": (_V, [_V]),
     "bddilp_bdds_delimiters": (_V, [_V]),
+    "bddilp_random_set_cover": (_I, [_U64, _U64, _U64, _U64, _V, _V]),
 }
 
 _lib = None

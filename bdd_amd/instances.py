@@ -35,6 +35,21 @@ def random_set_cover(n_vars: int, n_rows: int, k: int = 10, seed: int = 12345):
     return col, costs
 
 
+def random_set_cover_mt(n_vars: int, n_rows: int, k: int = 10, seed: int = 12345):
+    """The benchmark instance: random set cover drawn from std::mt19937_64(seed) by the host library
+    (bddilp_random_set_cover, bdd_amd/csrc/host/instances.cpp — the draw order is documented there), so that the C++
+    command line and Python produce the same rows.  Same shape as random_set_cover."""
+    from . import capi
+    rows = np.zeros((n_rows, k), np.uint64)
+    costs = np.zeros(n_vars, np.float64)
+    rc = capi.lib().bddilp_random_set_cover(n_vars, n_rows, k, seed, rows.ctypes.data, costs.ctypes.data)
+    if rc != 0:
+        raise ValueError("bddilp_random_set_cover: invalid arguments")
+    col = BddCollection()
+    col.add_covering(rows)
+    return col, costs
+
+
 def random_set_cover_mixed(n_vars: int, n_rows: int, k_min: int = 3, k_max: int = 16, seed: int = 12345):
     """Set cover with row sizes drawn uniformly from [k_min, k_max], rows of all sizes interleaved at random:
     the structure-heterogeneous counterpart of random_set_cover (BDDs of k_max - k_min + 1 different shapes)."""

@@ -5,13 +5,17 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
 A "step" is one iteration() of the solver = forward_mm + normalize + backward_mm + normalize over
-the whole instance (reference: bdd_cuda_parallel_mma.cu:142-153).  Workload: random set cover,
+the whole instance (reference: bdd_cuda_parallel_mma.cu:142-153).  Default workload: random set cover,
 row size 10, V = 1e6, B = 5e5 -> 10.5 M BDD nodes (BASELINE.json configs[2], the configuration the
-metric is quoted on).  Multi-GPU: independent instances, one per GPU, no collective on the data
-path ("replicas only"); `value` = iterations of all ranks / max-over-ranks time.
-Inputs are resident in HBM before the timed region starts.
+metric is quoted on), rows and costs from std::mt19937_64(12345 + rank) (bdd_amd/csrc/host/instances.cpp).
+`value` is the float run; the double run of the same instance ("double vs float") is timed in the same
+invocation and reported as `value_f64` / `roofline_f64`.
+Multi-GPU: independent instances, one per GPU, no collective on the data path ("replicas only",
+SURVEY.md §8e); the timing barrier and the max-over-ranks go over gloo (CPU), RCCL is never initialised;
+`value` = iterations of all ranks / max-over-ranks time.  Inputs are resident in HBM before the timed region.
 """
 import argparse
+import hashlib
 import json
 import os
 import re
@@ -24,11 +28,42 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "HBM3E peak BW")
+KERNEL_SOURCES = ("bdd_amd/csrc/kernels.hpp", "bdd_amd/csrc/bdd_mma_hip.hip", "bdd_amd/csrc/layout.cpp")
 
 
-def algorithmic_bytes_per_pass(sizes, R):
-    """12 N' + 2R N + (5R+4) L' + (8R+4) V  (one forward_mm or backward_mm sweep)."""
-    return 12 * sizes["N_nt"] + 2 * R * sizes["N"] + (5 * R + 4) * sizes["L_nt"] + (8 * R + 4) * sizes["V"]
+def sweep_bytes(sizes, R):
+    """Algorithmic bytes ONE sweep launch (k_fwd_narrow / k_bwd_narrow) processes — SURVEY.md §8d's per-pass figure without
+    the per-variable term, which the exchange launch moves: 12 N' + 2R N + (5R+4) L'."""
+    return 12 * sizes["N_nt"] + 2 * R * sizes["N"] + (5 * R + 4) * sizes["L_nt"]
+
+
+def exchange_bytes(sizes, R):
+    """The per-variable term of SURVEY.md §8d, processed by one k_exchange_reduce launch: (8R+4) V."""
+    return (8 * R + 4) * sizes["V"]
+
+
+def iteration_bytes(sizes, R):
+    """B_iter of SURVEY.md §8d = 2 [12 N' + 2R N + (5R+4) L' + (8R+4) V]."""
+    return 2 * (sweep_bytes(sizes, R) + exchange_bytes(sizes, R))
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def workload_name(sizes, args):
+    n = sizes["N"]
+    cfg = {1_050_000: "configs[1]", 10_500_000: "configs[2]"}.get(n) if args.k == 10 else None
+    label = f"BASELINE.json {cfg}" if cfg else "not a BASELINE.json configuration"
+    return (f"random set cover (std::mt19937_64 seed 12345 + rank), row size {args.k}, V={args.vars}, B={args.rows}: "
+            f"{n} BDD nodes ({label}); one independent instance per GPU")
+
+
+def nodes_label(n):
+    return f"{n / 1e6:.3g}M".replace(".0M", "M")
 
 
 def main():
@@ -36,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--precision", default="float", choices=["float", "double"])
+    ap.add_argument("--precision", default="float", choices=["float", "double"], help="precision of `value` (the other one is value_f64 / value_f32)")
     ap.add_argument("--vars", type=int, default=1_000_000)
     ap.add_argument("--rows", type=int, default=500_000)
     ap.add_argument("--k", type=int, default=10)
@@ -45,9 +80,10 @@ def main():
     ap.add_argument("--stage-cap", type=int, default=0)
     ap.add_argument("--wpb", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-second-precision", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--deterministic", action="store_true")
-    ap.add_argument("--event-stride", type=int, default=64)
+    ap.add_argument("--event-stride", type=int, default=0, help="hipEvent pairs around every n-th iteration's launches (0: steps // 16)")
     args = ap.parse_args()
 
     import torch
@@ -61,38 +97,42 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")   # replicas only: the barrier and the max are host-side, no RCCL communicator is created
 
-    def barrier():
-        if dist is not None:
-            dist.barrier(device_ids=[local_rank])
-
-    from bdd_amd.instances import random_set_cover, set_cover_sizes
+    from bdd_amd.instances import random_set_cover_mt, set_cover_sizes
     from bdd_amd.solver import bdd_hip_parallel_mma
 
     sizes = set_cover_sizes(args.vars, args.rows, args.k)
-    col, costs = random_set_cover(args.vars, args.rows, args.k, seed=12345 + rank)
-    solver = bdd_hip_parallel_mma(col, costs, precision=args.precision, device=local_rank,
-                                  pack_width=args.pack_width, deterministic=args.deterministic,
-                                  vars_per_bin=args.vars_per_bin, stage_cap=args.stage_cap, waves_per_block=args.wpb)
-    R = 4 if args.precision == "float" else 8
-    solver.iterations(args.warmup)
-    solver.synchronize()
-    # hipEvent pairs around the launches of every --event-stride-th (64th) iteration, on the solver's own stream (an event pair
-    # per launch costs ~4 us of stream time; at stride 1 the 10.5 M-node iteration is 14 % slower)
-    solver.set_profiling(True, stride=args.event_stride)
+    col, costs = random_set_cover_mt(args.vars, args.rows, args.k, seed=12345 + rank)
+    stride = args.event_stride or max(1, args.steps // 16)
 
-    dt = timed_region(lambda: solver.iterations(args.steps),
-                      lambda: (solver.synchronize(), torch.cuda.synchronize()), dist, local_rank)
-    prof = solver.get_profile()
-    solver.set_profiling(False)
-    lb = solver.lower_bound()
+    def run(precision):
+        """warm-up, the timed K steps (barrier + device sync on both sides), hipEvent profile, lower bound"""
+        solver = bdd_hip_parallel_mma(col, costs, precision=precision, device=local_rank,
+                                      pack_width=args.pack_width, deterministic=args.deterministic,
+                                      vars_per_bin=args.vars_per_bin, stage_cap=args.stage_cap, waves_per_block=args.wpb)
+        solver.iterations(args.warmup)
+        solver.synchronize()
+        dt = timed_region(lambda: solver.iterations(args.steps),
+                          lambda: (solver.synchronize(), torch.cuda.synchronize()), dist)
+        # Kernel durations: the same K steps once more with hipEvent pairs on the solver's own stream around the launches of every
+        # `stride`-th iteration (>= 16 samples per kernel class for any K >= 16).  An event pair per launch costs ~4 us of stream
+        # time (-14 % it/s at stride 1), so the instrumented pass is kept out of `value`; its own rate is reported next to it.
+        solver.set_profiling(True, stride=stride)
+        dt_ev = timed_region(lambda: solver.iterations(args.steps),
+                             lambda: (solver.synchronize(), torch.cuda.synchronize()), dist)
+        prof = solver.get_profile()
+        prof["ms_per_step_instrumented"] = dt_ev / args.steps * 1e3
+        solver.set_profiling(False)
+        return solver, dt, prof, solver.lower_bound()
+
+    other = "double" if args.precision == "float" else "float"
+    solver, dt, prof, lb = run(args.precision)
 
     triad_gbs = copy_gbs = lb_rate = None
     if rank == 0:
-        # outside the timed region: (1) the same loop with the lower bound fetched every iteration, as
-        # run_solver does (one extra plain backward sweep + reduce + 8-byte D2H per iteration); (2) the
-        # STREAM-triad bandwidth of this box (3 x 1 GiB per launch), the measured ceiling next to the 8 TB/s spec
+        # outside the timed region: (1) the same loop with the lower bound fetched every iteration, as run_solver does
+        # (one extra plain backward sweep + reduce + 8-byte D2H per iteration); (2) STREAM triad / copy of this box
         n_lb = min(args.steps, 100)
         solver.synchronize()
         t0 = time.perf_counter()
@@ -102,16 +142,21 @@ def main():
         lb_rate = n_lb / (time.perf_counter() - t0)
         triad_gbs = 3 * (1 << 30) / (solver.time_kernel(6, 20) * 1e-3) / 1e9
         copy_gbs = 2 * (1 << 30) / (solver.time_kernel(7, 20) * 1e-3) / 1e9
+    packs, hops, resident = solver.nr_packs(), solver.nr_hops(), solver.device_bytes()
+    solver.close()
+
+    second = None
+    if not args.no_second_precision:
+        s2, dt2, prof2, lb2 = run(other)
+        second = (dt2, prof2, lb2)
+        s2.close()
 
     if rank == 0:
         its = aggregate_rate(world, args.steps, dt)
-        names = ["forward_mm", "backward_mm", "finish_delta", "other"]
-        avg_ms = [prof["total_ms"][i] / max(prof["launches"][i], 1) for i in range(4)]
-        dom = 0 if avg_ms[0] >= avg_ms[1] else 1
-        bytes_pass = algorithmic_bytes_per_pass(sizes, R)
-        achieved = bytes_pass / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
+        R = 4 if args.precision == "float" else 8
+        sfx = "f32" if args.precision == "float" else "f64"
         out = {
-            "metric": "parallel-MMA iterations/sec, 10M BDD nodes, 1 GPU (+ achieved HBM GB/s in roofline)",
+            "metric": f"parallel-MMA iterations/sec, {nodes_label(sizes['N'])} BDD nodes, {world} GPU (+ achieved HBM GB/s in roofline)",
             "value": its,
             "unit": "iterations/s",
             "n_gpus": world,
@@ -121,58 +166,84 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "float" else "f64",
+            "dtype": sfx,
             "data": "synthetic",
             "config": {
-                "workload": f"random set cover, row size {args.k}, V={args.vars}, B={args.rows}: "
-                            f"{sizes['N']} BDD nodes (BASELINE.json configs[2]); one independent instance per GPU",
+                "workload": workload_name(sizes, args),
                 "precision": args.precision,
                 "omega": 0.5,
                 "pack_width": args.pack_width or "auto (128; 64 when fewer than 4000 packs)",
-                "waves_per_block": args.wpb or 4,
-                "packs": solver.nr_packs(),
-                "hops": solver.nr_hops(),
+                "waves_per_block": args.wpb or "auto",
+                "packs": packs,
+                "hops": hops,
                 "delta_exchange": "per-variable gather (deterministic)" if args.deterministic else "binned exchange, LDS accumulators",
-                "hbm_resident_bytes": solver.device_bytes(),
+                "hbm_resident_bytes": resident,
+                "event_stride": stride,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": names[dom],
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(names[dom], args),
-                "algorithmic_bytes_per_launch": bytes_pass,
-                "avg_launch_ms": {names[i]: avg_ms[i] for i in range(3)},
-                "timed_launches": {names[i]: prof["launches"][i] for i in range(3)},
-                "whole_iteration_GBs": 2 * bytes_pass * its / world / 1e9,
-                "stream_triad_GBs": triad_gbs,
-                "stream_copy_GBs": copy_gbs,
-                "frac_of_stream_triad": achieved / triad_gbs if triad_gbs else None,
-            },
+            "roofline": roofline(prof, sizes, R, its / world, args, sfx, triad_gbs, copy_gbs),
             "value_with_lower_bound_every_iteration": lb_rate,
-            "lower_bound_after": {"iterations": args.warmup + args.steps, "value": lb},
+            "lower_bound_after": {"iterations": args.warmup + 2 * args.steps, "value": lb},
         }
+        if second is not None:
+            dt2, prof2, lb2 = second
+            R2, sfx2 = (8, "f64") if other == "double" else (4, "f32")
+            its2 = aggregate_rate(world, args.steps, dt2)
+            out["value_" + sfx2] = its2
+            out["ms_per_step_" + sfx2] = dt2 / args.steps * 1e3
+            out["roofline_" + sfx2] = roofline(prof2, sizes, R2, its2 / world, args, sfx2, triad_gbs, copy_gbs)
+            out["lower_bound_after_" + sfx2] = {"iterations": args.warmup + 2 * args.steps, "value": lb2,
+                                               "rel_diff_to_" + sfx: abs(lb2 - lb) / max(abs(lb), 1e-300)}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(col, costs, args, sizes)
         print(json.dumps(out), flush=True)
-    barrier()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
-def timed_region(run_steps, device_sync, dist, local_rank, backend_device=True):
+def roofline(prof, sizes, R, its_per_gpu, args, sfx, triad_gbs, copy_gbs):
+    """`achieved` = algorithmic bytes the named (slower) sweep launch processes / its average duration, from hipEvent pairs recorded on
+    the solver's stream inside the timed region; `frac_whole_iteration` prices the whole iteration (4 launches + gaps) on the
+    driver's clock against B_iter; `traffic` = counter-measured HBM bytes per launch of the same kernel (committed rocprofv3 PMC
+    passes; null when the kernel sources changed since they were taken)."""
+    names = ["forward_mm", "backward_mm", "finish_delta", "other"]
+    avg_ms = [prof["total_ms"][i] / max(prof["launches"][i], 1) for i in range(4)]
+    dom = 0 if avg_ms[0] >= avg_ms[1] else 1
+    b_sweep, b_exch, b_iter = sweep_bytes(sizes, R), exchange_bytes(sizes, R), iteration_bytes(sizes, R)
+    achieved = b_sweep / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
+    traffic = measured_traffic(names[dom], args, sfx)
+    whole = b_iter * its_per_gpu / 1e9
+    return {
+        "bound": "hbm",
+        "kernel": names[dom],
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "frac_counter_bytes": (traffic / (avg_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms[dom] > 0 else None,
+        "algorithmic_bytes_per_launch": b_sweep,
+        "algorithmic_bytes_exchange_launch": b_exch,
+        "algorithmic_bytes_per_iteration": b_iter,
+        "frac_exchange_launch": (b_exch / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_ms[2] > 0 else None,
+        "whole_iteration_GBs": whole,
+        "frac_whole_iteration": whole / HBM_PEAK_GBS,
+        "avg_launch_ms": {names[i]: avg_ms[i] for i in range(3)},
+        "ms_per_step_instrumented_pass": prof.get("ms_per_step_instrumented"),
+        "timed_launches": {names[i]: prof["launches"][i] for i in range(3)},
+        "stream_triad_GBs": triad_gbs,
+        "stream_copy_GBs": copy_gbs,
+    }
+
+
+def timed_region(run_steps, device_sync, dist):
     """barrier + device sync, EXACTLY the K steps, device sync + barrier; returns the MAX over ranks of the
-    wall time (the driver's contract).  `dist` is torch.distributed or None (single process)."""
+    wall time (the driver's contract).  `dist` is torch.distributed (gloo) or None (single process)."""
     import torch
 
     def barrier():
         if dist is not None:
-            if backend_device:
-                dist.barrier(device_ids=[local_rank])
-            else:
-                dist.barrier()
+            dist.barrier()
 
     barrier()
     device_sync()
@@ -182,7 +253,7 @@ def timed_region(run_steps, device_sync, dist, local_rank, backend_device=True):
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend_device else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -193,21 +264,26 @@ def aggregate_rate(world, steps, dt):
     return world * steps / dt
 
 
-def measured_traffic(kernel, args):
+def measured_traffic(kernel, args, sfx):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/<tag>/traffic.json, produced by tools/profile.sh + tools/collect_profiles.py: separate --pmc runs,
-    bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md §HBM).  None when no profile matches."""
-    if (args.vars, args.rows, args.k) != (1_000_000, 500_000, 10) or args.deterministic:
+    bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md §HBM).  The file is stamped with the hash of the
+    kernel sources it was measured on; None when no profile matches the workload or the sources changed since."""
+    tag = {(1_000_000, 500_000, 10): "10m", (100_000, 50_000, 10): "1m"}.get((args.vars, args.rows, args.k))
+    if tag is None or args.deterministic or args.pack_width or args.wpb or args.vars_per_bin or args.stage_cap:
         return None
-    tag = "r01_f32" if args.precision == "float" else "r01_f64"
-    path = os.path.join(ROOT, "profiles", tag, "traffic.json")
-    if not os.path.exists(path):
-        return None
-    want = "k_fwd_narrow" if kernel == "forward_mm" else "k_bwd_narrow"
-    for name, v in json.load(open(path)).items():
-        m = re.search(want + r"<\w+, \d+, (\d+), \d+>", name)   # <REAL, R, MODE, waves per block>; MODE 1 = solve
-        if m and m.group(1) == "1":
-            return v["hbm_bytes"]
+    for rnd in ("r02",):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_{sfx}", "traffic.json")
+        if not os.path.exists(path):
+            continue
+        d = json.load(open(path))
+        if d.get("_source_hash") != source_hash():
+            return None
+        want = "k_fwd_narrow" if kernel == "forward_mm" else "k_bwd_narrow"
+        for name, v in d.items():
+            m = re.search(want + r"<\w+, \d+, (\d+), \d+>", name)   # <REAL, R, MODE, waves per block>; MODE 1 = solve
+            if m and m.group(1) == "1":
+                return v["hbm_bytes"]
     return None
 
 

@@ -71,6 +71,12 @@ uint64_t bddilp_bdds_nr_variables(const bddilp_bdds* b);
 const bddmma_instruction* bddilp_bdds_instructions(const bddilp_bdds* b); /* [nr_instructions] */
 const uint64_t* bddilp_bdds_delimiters(const bddilp_bdds* b);             /* [nr_bdds + 1] */
 
+
+/* The benchmark's synthetic instance: random set cover, n_rows rows of k distinct variables, costs U(1,10)
+ * (0 for variables in no row), all drawn from one std::mt19937_64(seed) — draw order in bdd_amd/csrc/host/instances.cpp.
+ * rows: uint64[n_rows * k] (each row sorted), costs: double[n_vars]. */
+int bddilp_random_set_cover(uint64_t n_vars, uint64_t n_rows, uint64_t k, uint64_t seed, uint64_t* rows, double* costs);
+
 #ifdef __cplusplus
 }
 #endif

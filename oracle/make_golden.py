@@ -82,8 +82,45 @@ def record_split(name, build, chunk, aux0, implication=False):
     print(name, "chunks", n, "next aux", next_aux, "nodes", before.nr_bdd_nodes(), "->", after.nr_bdd_nodes())
 
 
+def record_fullsize():
+    """BASELINE.json's full-size instances (configs[1], configs[2]) through the reference-compiled code: rows from
+    bdd_amd.instances.random_set_cover_mt (std::mt19937_64(12345), draw order in bdd_amd/csrc/host/instances.cpp), BDDs built
+    by the reference's not_all_false_constraint -> make_qbdd -> rebase, iteration() over the reference's node arithmetic.
+    Only the lower bounds are stored (the instance is regenerated from the seed): lb after update_costs and after every
+    iteration, double and float."""
+    import time
+    from bdd_amd import capi
+    out = {}
+    for tag, V, B, k, iters in (("1m", 100_000, 50_000, 10, 20), ("10m", 1_000_000, 500_000, 10, 10)):
+        rows = np.zeros((B, k), np.uint64)
+        costs = np.zeros(V)
+        assert capi.lib().bddilp_random_set_cover(V, B, k, 12345, rows.ctypes.data, costs.ctypes.data) == 0
+        t0 = time.time()
+        rc = RefCollection()
+        for r in rows:
+            rc.add_covering(r)
+        print(tag, "reference collection built in", round(time.time() - t0, 1), "s")
+        out[f"{tag}_params"] = np.array([V, B, k, 12345, iters], np.int64)
+        out[f"{tag}_rows_checksum"] = np.array([int(rows.sum() % (2**61 - 1))], np.int64)
+        out[f"{tag}_costs_sum"] = np.array([costs.sum()])
+        for prec in ("f64", "f32"):
+            m = RefMma(rc, "double" if prec == "f64" else "float")
+            m.update_costs([], costs)
+            lbs = [m.lower_bound()]
+            for _ in range(iters):
+                lbs.append(m.iteration())
+            out[f"{tag}_lb_{prec}"] = np.array(lbs)
+            print(tag, prec, "lb after", iters, "iterations:", repr(lbs[-1]), "time", round(time.time() - t0, 1), "s")
+            del m
+        del rc
+    np.savez_compressed(os.path.join(OUT, "fullsize_set_cover_mt.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--fullsize" in sys.argv:
+        record_fullsize()
+        return
     record_split("split_covering_10", lambda x: x.add_covering(list(range(10))), 3, 10)
     record_split("split_simplex_9", lambda x: x.add_simplex(list(range(9))), 4, 20)
     record_split("split_knapsack_12", lambda x: x.add_linear([1, 2, 3, 2, 1, 3, 2, 1, 2, 3, 1, 2], "<=", 11, list(range(12))), 4, 12)

@@ -19,7 +19,7 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     steps = 5
     per_step = 0.02 * (rank + 1)  # rank 1 is twice as slow: the reported time must be ITS time
-    dt = bench.timed_region(lambda: time.sleep(steps * per_step), lambda: None, dist, 0, backend_device=False)
+    dt = bench.timed_region(lambda: time.sleep(steps * per_step), lambda: None, dist)   # exactly what bench.py does at N > 1: gloo
     out[rank] = (dt, bench.aggregate_rate(world, steps, dt))
     dist.destroy_process_group()
 
@@ -43,5 +43,30 @@ def test_algorithmic_bytes_formula():
     from bdd_amd.instances import set_cover_sizes
     sz = set_cover_sizes(1_000_000, 500_000, 10)
     assert sz["N"] == 10_500_000
-    assert bench.algorithmic_bytes_per_pass(sz, 4) == 354_000_000   # B_iter = 708 MB (float)
-    assert bench.algorithmic_bytes_per_pass(sz, 8) == 570_000_000   # 1140 MB (double)
+    assert bench.iteration_bytes(sz, 4) == 708_000_000     # B_iter = 708 MB (float)
+    assert bench.iteration_bytes(sz, 8) == 1_140_000_000   # 1140 MB (double)
+    assert bench.sweep_bytes(sz, 4) == 318_000_000 and bench.exchange_bytes(sz, 4) == 36_000_000   # what each launch processes
+    assert bench.sweep_bytes(sz, 8) == 502_000_000 and bench.exchange_bytes(sz, 8) == 68_000_000
+
+
+def test_labels_follow_the_sizes_and_traffic_is_stamped():
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+    from bdd_amd.instances import set_cover_sizes
+    a = argparse.Namespace(vars=100_000, rows=50_000, k=10, deterministic=False, pack_width=0, wpb=0, vars_per_bin=0, stage_cap=0)
+    assert "configs[1]" in bench.workload_name(set_cover_sizes(100_000, 50_000, 10), a)
+    a10 = argparse.Namespace(**{**vars(a), "vars": 1_000_000, "rows": 500_000})
+    assert "configs[2]" in bench.workload_name(set_cover_sizes(1_000_000, 500_000, 10), a10)
+    odd = argparse.Namespace(**{**vars(a), "vars": 3000, "rows": 2000})
+    assert "not a BASELINE.json configuration" in bench.workload_name(set_cover_sizes(3000, 2000, 10), odd)
+    assert bench.nodes_label(10_500_000) == "10.5M" and bench.nodes_label(1_050_000) == "1.05M"
+    # committed PMC traffic is only quoted while the kernel sources it was measured on are unchanged
+    t = bench.measured_traffic("forward_mm", a10, "f32")
+    import json
+    path = os.path.join(ROOT, "profiles", "r02_10m_f32", "traffic.json")
+    if os.path.exists(path):
+        stamped = json.load(open(path)).get("_source_hash")
+        assert (t is not None) == (stamped == bench.source_hash())
+    else:
+        assert t is None

@@ -12,11 +12,11 @@ import numpy as np
 import pytest
 
 from bdd_amd import BddCollection, parse_lp, to_bdd_collection
-from bdd_amd.instances import GRID_3X3, LONG_CHAIN, SHORT_CHAIN, assignment_ilp, brute_force_optimum, mrf_ilp, random_set_cover
+from bdd_amd.instances import GRID_3X3, LONG_CHAIN, SHORT_CHAIN, assignment_ilp, brute_force_optimum, mrf_ilp, random_set_cover, random_set_cover_mt
 from bdd_amd.solver import bdd_hip_lbfgs, bdd_hip_parallel_mma, run_solver
 from oracle.oracle import Oracle
 from test_oracle_kat import SIMPLEX_KATS
-from util import GOLDEN, load_golden, pad_costs, suffix
+from util import FULLSIZE, GOLDEN, load_golden, pad_costs, suffix
 
 pytestmark = pytest.mark.gpu
 
@@ -302,16 +302,28 @@ def test_run_solver_and_lbfgs():
 
 
 # ---------------------------------------------------------------- BASELINE.json full size, size-independent properties
-@pytest.mark.parametrize("n_vars,n_rows", [(100_000, 50_000), (1_000_000, 500_000)])
-def test_full_size_properties(n_vars, n_rows):
-    col, costs = random_set_cover(n_vars, n_rows, 10, seed=12345)
+@pytest.mark.parametrize("tag", ["1m", "10m"])
+def test_full_size_properties(tag):
+    """BASELINE.json configs[1] / configs[2]: the mt19937_64(12345) instance the benchmark runs, against the lower-bound
+    trajectory the reference-compiled code produced on it (tests/golden/fullsize_set_cover_mt.npz, oracle/make_golden.py
+    --fullsize: reference bdd_collection + bdd_branch_instruction node arithmetic), plus size-independent properties and the
+    restated oracle run here."""
+    z = np.load(FULLSIZE)
+    n_vars, n_rows, k, seed, iters = (int(x) for x in z[f"{tag}_params"])
+    col, costs = random_set_cover_mt(n_vars, n_rows, k, seed)
     assert col.nr_bdd_nodes() == n_rows * 21
+    assert abs(costs.sum() - float(z[f"{tag}_costs_sum"][0])) <= 1e-9 * costs.sum()      # same instance as the fixture's
+    ref64, ref32 = z[f"{tag}_lb_f64"], z[f"{tag}_lb_f32"]
     sf = bdd_hip_parallel_mma(col, costs, precision="float")
     sd = bdd_hip_parallel_mma(col, costs, precision="double")
+    assert abs(sd.lower_bound() - ref64[0]) <= 1e-9 * abs(ref64[0])
+    assert abs(sf.lower_bound() - ref32[0]) <= 1e-5 * abs(ref32[0])
     lbs = []
-    for _ in range(10):
+    for it in range(iters):
         sf.iteration(); sd.iteration()
         lf, ld = sf.lower_bound(), sd.lower_bound()
+        assert abs(ld - ref64[it + 1]) <= 1e-9 * abs(ref64[it + 1]), (it, ld, ref64[it + 1])   # reference node arithmetic, double
+        assert abs(lf - ref32[it + 1]) <= 1e-5 * abs(ref32[it + 1]), (it, lf, ref32[it + 1])   # BASELINE.json: 1e-5 rel.
         assert abs(lf - ld) <= 1e-5 * abs(ld)            # float vs double agree (BASELINE.md: ~1e-11 on CPU)
         lbs.append(ld)
     assert all(b >= a - 1e-9 * abs(a) for a, b in zip(lbs, lbs[1:]))  # MMA is monotone
@@ -321,10 +333,9 @@ def test_full_size_properties(n_vars, n_rows):
     np.testing.assert_allclose(sd.get_primal_objective_vector_host(), costs, atol=1e-9)
     # per-BDD lower bounds add up to the lower bound (checksum of checksums)
     assert abs(sd.lower_bound_per_bdd().sum() - sd.lower_bound()) <= 1e-9 * abs(sd.lower_bound())
-    # and the oracle itself at this size (BASELINE.json: LB within 1e-5 rel. of the CPU parallel mma after equal
-    # iterations; in double the two differ only by the order of the delta sums)
+    # and the restated oracle itself at this size, same iteration count
     o = Oracle(col, costs, "double", threads=min(os.cpu_count() or 1, 32))
-    for _ in range(10):
+    for _ in range(iters):
         o.iteration()
     assert abs(lbs[-1] - o.lower_bound()) <= 1e-9 * abs(o.lower_bound())
     assert abs(lf - o.lower_bound()) <= 1e-5 * abs(o.lower_bound())

@@ -166,3 +166,22 @@ def test_bdds_solution_and_dual_ops():
     s = np.zeros(6)
     np.add.at(s, var, g)
     assert np.allclose(s[nb > 0], 0)
+
+
+@pytest.mark.parametrize("precision", ["double", "float"])
+def test_oracle_full_size_vs_reference_compiled_trajectory(precision):
+    """BASELINE.json configs[1] (1.05 M nodes): the restated oracle reproduces the lower-bound trajectory that the
+    reference-compiled code (oracle/_ref: reference bdd_collection + bdd_branch_instruction arithmetic) produced on the
+    mt19937_64(12345) benchmark instance — tests/golden/fullsize_set_cover_mt.npz, oracle/make_golden.py --fullsize."""
+    from bdd_amd.instances import random_set_cover_mt
+    from util import FULLSIZE
+    z = np.load(FULLSIZE)
+    n_vars, n_rows, k, seed, iters = (int(x) for x in z["1m_params"])
+    col, costs = random_set_cover_mt(n_vars, n_rows, k, seed)
+    ref = z["1m_lb_f64" if precision == "double" else "1m_lb_f32"]
+    o = Oracle(col, costs, precision, threads=4)
+    rel = 1e-11 if precision == "double" else 1e-6   # only the order of the delta sums (and of the bound's summation) differs
+    assert abs(o.lower_bound() - ref[0]) <= rel * abs(ref[0])
+    for it in range(iters):
+        o.iteration()
+        assert abs(o.lower_bound() - ref[it + 1]) <= rel * abs(ref[it + 1]), (it, o.lower_bound(), ref[it + 1])

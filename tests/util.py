@@ -8,7 +8,8 @@ from bdd_amd.bdd_collection import BddCollection
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _ALL = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-GOLDEN = [n for n in _ALL if not n.startswith("split_")]        # MMA traces (oracle/make_golden.py: record)
+GOLDEN = [n for n in _ALL if not n.startswith(("split_", "fullsize_"))]   # MMA traces (oracle/make_golden.py: record)
+FULLSIZE = os.path.join(GOLDEN_DIR, "fullsize_set_cover_mt.npz")  # lower-bound trajectories of the reference-compiled code at BASELINE.json's full sizes
 SPLIT_GOLDEN = [n for n in _ALL if n.startswith("split_")]      # split_qbdd input/output pairs (record_split)
 
 

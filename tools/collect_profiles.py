@@ -27,7 +27,12 @@ for k, d in agg.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         f, w = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]), sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
         traffic[k] = {"fetch_kib_reported": f, "write_kib_reported": w, "hbm_bytes": (2 * f + w) * 1024}
+# stamp: bench.py quotes these bytes only while the kernel sources are the ones they were measured on
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+traffic["_source_hash"] = bench.source_hash()
 json.dump(traffic, open(f"{dst}/traffic.json", "w"), indent=1)
+del traffic["_source_hash"]
 for k, v in traffic.items():
     if "narrow" in k or "exchange" in k:
         print(k, round(v["hbm_bytes"] / 1e6, 1), "MB")
