@@ -69,7 +69,11 @@ struct SolverT final : SolverBase {
         uint8_t* pack_steps = nullptr;
         uint32_t n_packs = 0;
     } nb_, wb_, hb_;  // narrow, wide, huge packs
-    uint32_t wide_lds = 0;
+    uint32_t wide_lds = 0, wide_threads = 256, wide_npt = 1;
+    // resident sweeps of the narrow packs (kernels.hpp: k_fwd_res / k_bwd_res)
+    uint32_t *d_pack_hdr = nullptr, *d_quad_hdr = nullptr;
+    bool use_res = false;
+    uint32_t res_ns = 0, res_nl = 0, res_lds = 0;
     uint32_t huge_pack_width = 0;
     unsigned char* d_huge_scratch = nullptr;  // frontier arrays of the huge packs (global memory instead of LDS)
 
@@ -92,7 +96,8 @@ struct SolverT final : SolverBase {
     template <typename T>
     int dalloc(T** p, uint64_t n)
     {
-        const uint64_t bytes = std::max<uint64_t>(n, 1) * sizeof(T);
+        // + 1 KiB: the resident sweeps copy in whole 1 KiB pieces and may read up to 1008 bytes past a pack's range (kernels.hpp: wave_copy_to_lds)
+        const uint64_t bytes = std::max<uint64_t>(n, 1) * sizeof(T) + 1024;
         HIPCHK(hipMalloc((void**)p, bytes));
         allocs.push_back(*p);
         dev_bytes += bytes;
@@ -206,19 +211,54 @@ struct SolverT final : SolverBase {
         SET_DYN((k_exchange_reduce<REAL, double, EX_ITER>), exch_lds);
         SET_DYN((k_exchange_reduce<REAL, double, EX_RAW>), exch_lds);
 #undef SET_DYN
+        // resident sweeps: chosen when every narrow pack fits its wave's LDS slice and the instance is small enough that the streaming
+        // kernels are latency-bound (few waves per SIMD); reserved[1] = 1 turns them off, = 2 forces them on
+        if (nb_.n_packs && L.res.ok) {
+            if ((rc = upload(&d_pack_hdr, L.res.pack_hdr))) return rc;
+            if ((rc = upload(&d_quad_hdr, L.res.quad_hdr))) return rc;
+            res_ns = (L.res.max_slots + 255) / 256 * 256;
+            res_nl = (L.res.max_layers + 127) / 128 * 128;
+            res_lds = wpb * stage_cap * 2 * (uint32_t)sizeof(REAL) + wpb * res_wave_bytes(sizeof(REAL), res_ns, res_nl);
+            const uint32_t static_lds = wpb * (2 * (pack_width + 2) * (uint32_t)sizeof(REAL) + 512);
+            const uint32_t mode = opts ? opts->reserved[1] : 0;
+            const bool fits = res_lds + static_lds <= 160 * 1024 - 512;
+            // automatic choice: resident when all workgroups of a sweep can be in flight at once with their LDS slices (small and medium
+            // instances, which are latency-bound); larger instances keep the streaming kernels, whose small LDS footprint lets 5 waves per
+            // SIMD hide the latency (measured at 10.5 M nodes: streaming 50 us, resident 108 us per sweep; at 1 M nodes 12.5 vs 11 us)
+            const uint64_t wgs_per_cu = fits ? (160 * 1024) / (res_lds + static_lds) : 0;
+            const bool all_in_flight = (uint64_t)cdiv(nb_.n_packs, wpb) <= 256ull * std::min<uint64_t>(wgs_per_cu, 2048 / (64 * wpb));
+            use_res = fits && mode != 1 && (mode == 2 || all_in_flight);
+            if (use_res) {
+#define SET_RES(R_, W_) \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_res<REAL, R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds)); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_res<REAL, R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds));
+#define SET_RES_W(R_) \
+    switch (wpb) { case 1: SET_RES(R_, 1) break; case 2: SET_RES(R_, 2) break; case 4: SET_RES(R_, 4) break; default: SET_RES(R_, 8) break; }
+                switch (pack_width) {
+                    case 64: SET_RES_W(1) break;
+                    case 128: SET_RES_W(2) break;
+                    default: SET_RES_W(4) break;
+                }
+#undef SET_RES_W
+#undef SET_RES
+            }
+        }
         if (wb_.n_packs) {
-            wide_lds = (uint32_t)wide_lds_bytes(sizeof(REAL), wide_pack_width, true);
-            if (wide_lds > 160 * 1024) {
-                err = "wide_pack_width needs " + std::to_string(wide_lds) + " B of LDS (> 160 KiB)";
+            // one workgroup per wide pack, thread t owns the nodes t + i * wide_threads of a hop (kernels.hpp: k_fwd_wide2)
+            wide_threads = std::min<uint32_t>(1024, (wide_pack_width + 63) / 64 * 64);
+            wide_npt = (wide_pack_width + wide_threads - 1) / wide_threads;
+            wide_npt = wide_npt <= 1 ? 1 : (wide_npt <= 2 ? 2 : 4);
+            wide_lds = (uint32_t)wide2_lds_bytes(sizeof(REAL), wide_pack_width, true);
+            if (wide_lds > 160 * 1024 || wide_pack_width > 4096) {
+                err = "wide_pack_width " + std::to_string(wide_pack_width) + " needs " + std::to_string(wide_lds) + " B of LDS (> 160 KiB)";
                 return BDDMMA_ERR_UNSUPPORTED;
             }
 #define SET_LDS(K) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds))
-            SET_LDS((k_fwd_wide<REAL, FWD_PLAIN>));
-            SET_LDS((k_fwd_wide<REAL, FWD_SOLVE>));
-            SET_LDS((k_fwd_wide<REAL, FWD_SOLUTION>));
-            SET_LDS((k_bwd_wide<REAL, BWD_PLAIN>));
-            SET_LDS((k_bwd_wide<REAL, BWD_SOLVE>));
-            SET_LDS((k_bwd_wide<REAL, BWD_MARGINALS>));
+#define SET_LDS_N(N_) \
+    SET_LDS((k_fwd_wide2<REAL, FWD_PLAIN, N_>)); SET_LDS((k_fwd_wide2<REAL, FWD_SOLVE, N_>)); SET_LDS((k_fwd_wide2<REAL, FWD_SOLUTION, N_>)); \
+    SET_LDS((k_bwd_wide2<REAL, BWD_PLAIN, N_>)); SET_LDS((k_bwd_wide2<REAL, BWD_SOLVE, N_>)); SET_LDS((k_bwd_wide2<REAL, BWD_MARGINALS, N_>));
+            if (wide_npt == 1) { SET_LDS_N(1) } else if (wide_npt == 2) { SET_LDS_N(2) } else { SET_LDS_N(4) }
+#undef SET_LDS_N
 #undef SET_LDS
         }
         HIPCHK(hipStreamSynchronize(stream));
@@ -254,7 +294,11 @@ struct SolverT final : SolverBase {
             // SOLVE sweeps: `wpb` packs per workgroup with cooperative staging; the other modes stage nothing
             const uint32_t w = (MODE == FWD_SOLVE) ? wpb : 1;
             const dim3 grid(8 * cdiv(cdiv(nb_.n_packs, w), 8)), block(64 * w);
-#define LAUNCH_N(R_, W_) hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
+            const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
+            const bool res = use_res && MODE == FWD_SOLVE;
+#define LAUNCH_N(R_, W_)                                                                                                      \
+    if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, res_lds, stream, d, pk, rd, omega);                       \
+    else hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
     switch (w) { case 1: LAUNCH_N(R_, 1); break; case 2: LAUNCH_N(R_, 2); break; case 4: LAUNCH_N(R_, 4); break; default: LAUNCH_N(R_, 8); break; }
             switch (pack_width) {
@@ -267,7 +311,12 @@ struct SolverT final : SolverBase {
         }
         if (wb_.n_packs) {
             const PackDev pk = pdev(wb_, nb_.n_packs);
-            hipLaunchKernelGGL((k_fwd_wide<REAL, MODE>), dim3(wb_.n_packs), dim3(WIDE_THREADS), wide_lds, stream, d, pk, omega, wide_pack_width, (unsigned char*)nullptr);
+            const dim3 g(wb_.n_packs), b(wide_threads);
+            switch (wide_npt) {
+                case 1: hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 1>), g, b, wide_lds, stream, d, pk, omega, wide_pack_width); break;
+                case 2: hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 2>), g, b, wide_lds, stream, d, pk, omega, wide_pack_width); break;
+                default: hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 4>), g, b, wide_lds, stream, d, pk, omega, wide_pack_width); break;
+            }
         }
         if (hb_.n_packs) {
             const PackDev pk = pdev(hb_, nb_.n_packs + wb_.n_packs);
@@ -288,7 +337,11 @@ struct SolverT final : SolverBase {
             // SOLVE sweeps: `wpb` packs per workgroup with cooperative staging; the other modes stage nothing
             const uint32_t w = (MODE == BWD_SOLVE) ? wpb : 1;
             const dim3 grid(8 * cdiv(cdiv(nb_.n_packs, w), 8)), block(64 * w);
-#define LAUNCH_N(R_, W_) hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
+            const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
+            const bool res = use_res && MODE == BWD_SOLVE;
+#define LAUNCH_N(R_, W_)                                                                                                      \
+    if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, res_lds, stream, d, pk, rd, omega);                       \
+    else hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
     switch (w) { case 1: LAUNCH_N(R_, 1); break; case 2: LAUNCH_N(R_, 2); break; case 4: LAUNCH_N(R_, 4); break; default: LAUNCH_N(R_, 8); break; }
             switch (pack_width) {
@@ -301,7 +354,12 @@ struct SolverT final : SolverBase {
         }
         if (wb_.n_packs) {
             const PackDev pk = pdev(wb_, nb_.n_packs);
-            hipLaunchKernelGGL((k_bwd_wide<REAL, MODE>), dim3(wb_.n_packs), dim3(WIDE_THREADS), wide_lds, stream, d, pk, omega, wide_pack_width, (unsigned char*)nullptr);
+            const dim3 g(wb_.n_packs), b(wide_threads);
+            switch (wide_npt) {
+                case 1: hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 1>), g, b, wide_lds, stream, d, pk, omega, wide_pack_width); break;
+                case 2: hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 2>), g, b, wide_lds, stream, d, pk, omega, wide_pack_width); break;
+                default: hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 4>), g, b, wide_lds, stream, d, pk, omega, wide_pack_width); break;
+            }
         }
         if (hb_.n_packs) {
             const PackDev pk = pdev(hb_, nb_.n_packs + wb_.n_packs);

@@ -722,6 +722,252 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDe
 }
 
 // =============================================================================================
+// narrow packs, resident sweeps: the whole pack is copied to LDS in one round trip, then swept out of LDS
+// =============================================================================================
+// The streaming kernels above walk a pack with a software pipeline that is two hops deep: enough when 5 waves per SIMD hide the
+// rest of the memory latency (the 10 M-node benchmark), but a small or medium instance has ~1 wave per SIMD, and then every hop
+// waits for memory it asked for two hops ago, after a start-up chain of 7-8 dependent round trips (pack tables, hop offsets, words,
+// layer costs, staging tables, delta pairs).  Packs are short — tens of hops — so here a wave fetches EVERYTHING its pack needs at
+// once: the pack's node words, opposite-direction potentials and arc costs are contiguous in memory, so they arrive as a few 1 KiB
+// direct-to-LDS copies (global_load_lds_dwordx4, no staging registers) issued back to back from one 32-byte header; the hop loop
+// then runs out of LDS with no loads at all.  Three dependent round trips per sweep (header; bulk copies + staging tables; delta
+// pairs) instead of ~8 + one per two hops.  Same arithmetic, same order, same results as k_fwd_narrow / k_bwd_narrow.
+struct ResDev {
+    const uint32_t* pack_hdr;  // layout.hpp: struct Resident
+    const uint32_t* quad_hdr;
+    uint32_t ns;               // node slots reserved per wave in LDS (multiple of 256: whole 1 KiB pieces)
+    uint32_t nl;               // layers reserved per wave in LDS (multiple of 128)
+};
+typedef __attribute__((address_space(3))) void* lds_vptr_t;
+typedef __attribute__((address_space(1))) const void* glb_vptr_t;
+
+// One wave copies `bytes` (rounded up to whole 1 KiB pieces) from global memory to LDS: lane l of piece k moves the 16 bytes at
+// src + 1024 k + 16 l to dst + 1024 k + 16 l.  dst is wave-uniform and 16-byte aligned; the source only needs 4-byte alignment.
+// Reads up to 1008 bytes past the range: device allocations are padded by 1 KiB (SolverT::dalloc).
+__device__ __forceinline__ void wave_copy_to_lds(const void* src, void* dst, uint32_t bytes, int lane)
+{
+    const unsigned char* g = reinterpret_cast<const unsigned char*>(src) + lane * 16;
+    unsigned char* l = reinterpret_cast<unsigned char*>(dst);
+    for (uint32_t o = 0; o < bytes; o += 1024)
+        __builtin_amdgcn_global_load_lds((glb_vptr_t)(g + o), (lds_vptr_t)(l + o), 16, 0, 0);
+}
+__host__ __device__ inline uint32_t res_wave_bytes(uint32_t real_size, uint32_t ns, uint32_t nl)
+{
+    return ns * 4u + (ns + 4u) * real_size + nl * 2u * real_size;  // words | potentials + 2 sink entries (+2 pad) | {lo, hi}
+}
+
+template <typename REAL, int R, int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev pk, ResDev rd, REAL omega)
+{
+    constexpr int W = 64 * R;
+    using P2 = typename Pair<REAL>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    __shared__ REAL sF_[WPB][2][W + 2];  // frontier: cost from root of the current / next hop; [W], [W + 1]: dummy push targets of sink children
+    __shared__ uint32_t sOffN_[WPB][64], sOffL_[WPB][64];
+    const uint32_t tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int lane = tid & 63;
+    auto& sF = sF_[wave];
+    uint32_t* sOffN = sOffN_[wave];
+    uint32_t* sOffL = sOffL_[wave];
+    const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
+    const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
+    if (quad >= n_quads) return;
+    const uint32_t p = quad * WPB + wave;
+    const bool has_pack = p < pk.n_packs;
+    // dynamic LDS: [staged {delta_lo, delta_hi} / mm: WPB * stage_cap pairs][per wave: words | T of every slot | {lo, hi} of every layer]
+    P2* sD = reinterpret_cast<P2*>(dyn_lds);
+    P2* sDw = sD + (size_t)wave * pk.stage_cap;
+    const uint32_t wave_off = WPB * pk.stage_cap * (uint32_t)sizeof(P2) + (uint32_t)wave * res_wave_bytes(sizeof(REAL), rd.ns, rd.nl);
+    uint32_t* sW = reinterpret_cast<uint32_t*>(dyn_lds + wave_off);
+    REAL* sTa = reinterpret_cast<REAL*>(dyn_lds + wave_off + rd.ns * 4u);
+    P2* sC = reinterpret_cast<P2*>(dyn_lds + wave_off + rd.ns * 4u + (rd.ns + 4u) * (uint32_t)sizeof(REAL));
+    // ---- round trip 1: the headers
+    const uint32_t* hp = rd.pack_hdr + 8 * (size_t)(has_pack ? p : 0);
+    const uint32_t slot0 = hp[0], layer0 = hp[2], q0 = hp[4], woff = hp[6];
+    const uint32_t nslots = has_pack ? hp[1] : 0, nlayers = has_pack ? hp[3] : 0, nh = has_pack ? (hp[5] & 0xFFFFu) : 0;
+    const int steps = (int)(hp[5] >> 16);
+    const uint32_t c0 = rd.quad_hdr[4 * (size_t)quad], cnt = rd.quad_hdr[4 * (size_t)quad + 1];
+    const REAL INF = inf_v<REAL>();
+    const NarrowRs<REAL> rs(d);
+    // ---- round trip 2: the whole pack -> LDS, hop offsets, staging tables; round trip 3 (inside stage_load): the delta pairs
+    wave_copy_to_lds(d.nwords + woff, sW, nslots * 4u, lane);
+    wave_copy_to_lds(d.T + slot0, sTa, nslots * (uint32_t)sizeof(REAL), lane);
+    wave_copy_to_lds(d.lohi + 2 * (size_t)layer0, sC, nlayers * (uint32_t)sizeof(P2), lane);
+    {
+        const uint32_t q = q0 + min((uint32_t)lane, nh);
+        const uint32_t on = pk.hop_node_off[q], ol = pk.hop_layer_off[q];
+        sOffN[lane] = on - slot0;
+        sOffL[lane] = ol - layer0;
+    }
+    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
+    stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the direct-to-LDS copies have landed
+    if (lane < 2) sTa[rd.ns + lane] = lane == 0 ? REAL(0) : INF;  // sink entries: cost to terminal 0 (top) / +inf (bot)
+    wave_sync();
+    uint32_t nb = 0, ne = __builtin_amdgcn_readfirstlane(sOffN[1]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t j = lane + 64 * r;
+        sF[0][j] = (j < ne) ? REAL(0) : INF;  // every slot of hop 0 is a root (flush_costs_from_root)
+    }
+    if (WPB > 1) __syncthreads(); else wave_sync();
+    int cur = 0;
+    for (uint32_t h = 0; h < nh; ++h) {
+        const uint32_t ne2 = __builtin_amdgcn_readfirstlane(sOffN[min(h + 2, nh)]);
+        const uint32_t n = ne - nb;
+        uint32_t lb = __builtin_amdgcn_readfirstlane(sOffL[h]);
+        REAL f[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t j = lane + 64 * r;
+            sF[cur ^ 1][j] = INF;
+            f[r] = sF[cur][j];
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t j = lane + 64 * r;
+            constexpr uint32_t PADW = nw_pad_word(W);
+            const uint32_t w = j < n ? sW[nb + j] : PADW;
+            const bool act = !(w & NW_PAD);
+            const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
+            // layer index inside the pack = layers of the hops before + layer heads in the lanes below
+            const unsigned long long heads = __ballot(nw_head(w));
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(heads >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)heads, 0u));
+            const uint32_t ll = act ? lb + below - (nw_pos(w) != 0 ? 1u : 0u) : 0u;
+            lb += (uint32_t)__popcll(heads);
+            const P2 c = sC[ll];
+            const REAL tl = sTa[lo_i < (uint32_t)W ? ne + lo_i : rd.ns + (lo_i - W)];
+            const REAL th = sTa[hi_i < (uint32_t)W ? ne + hi_i : rd.ns + (hi_i - W)];
+            const P2 dd = sDw[ll];
+            REAL m0 = act ? (f[r] + c.x) + tl : INF;
+            REAL m1 = act ? (f[r] + c.y) + th : INF;
+            seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps);
+            const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
+            const REAL nlo = (c.x + rmin(mm, REAL(0))) + dd.x;
+            const REAL nhi = (c.y + rmin(-mm, REAL(0))) + dd.y;
+            const bool head = nw_head(w);
+            P2 nc;
+            nc.x = nlo;
+            nc.y = nhi;
+            bstore(nc, rs.lohi, head ? (layer0 + ll) * (uint32_t)sizeof(P2) : OOB);
+            if (head) sDw[ll].x = mm;  // every lane of the layer has read its pair above (same wave, in order)
+            lds_min(&sF[cur ^ 1][lo_i], f[r] + nlo);  // sink children and padding lanes push into the dummies
+            lds_min(&sF[cur ^ 1][hi_i], f[r] + nhi);
+            bstore(f[r], rs.F, act ? (slot0 + nb + j) * (uint32_t)sizeof(REAL) : OOB);
+        }
+        wave_sync();
+        cur ^= 1;
+        nb = ne;
+        ne = ne2;
+    }
+    if (WPB > 1) __syncthreads(); else wave_sync();
+    stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);  // min-marginal differences -> entry array
+}
+
+template <typename REAL, int R, int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev pk, ResDev rd, REAL omega)
+{
+    constexpr int W = 64 * R;
+    using P2 = typename Pair<REAL>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    __shared__ REAL sT_[WPB][2][W + 2];  // cost to terminal of the hop above / of this hop; [W] = 0 (top sink), [W + 1] = +inf (bot sink)
+    __shared__ uint32_t sOffN_[WPB][64], sOffL_[WPB][64];
+    const uint32_t tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int lane = tid & 63;
+    auto& sT = sT_[wave];
+    uint32_t* sOffN = sOffN_[wave];
+    uint32_t* sOffL = sOffL_[wave];
+    const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
+    const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
+    if (quad >= n_quads) return;
+    const uint32_t p = quad * WPB + wave;
+    const bool has_pack = p < pk.n_packs;
+    P2* sD = reinterpret_cast<P2*>(dyn_lds);
+    P2* sDw = sD + (size_t)wave * pk.stage_cap;
+    const uint32_t wave_off = WPB * pk.stage_cap * (uint32_t)sizeof(P2) + (uint32_t)wave * res_wave_bytes(sizeof(REAL), rd.ns, rd.nl);
+    uint32_t* sW = reinterpret_cast<uint32_t*>(dyn_lds + wave_off);
+    REAL* sFa = reinterpret_cast<REAL*>(dyn_lds + wave_off + rd.ns * 4u);  // cost from root of every slot (forward sweep)
+    P2* sC = reinterpret_cast<P2*>(dyn_lds + wave_off + rd.ns * 4u + (rd.ns + 4u) * (uint32_t)sizeof(REAL));
+    const uint32_t* hp = rd.pack_hdr + 8 * (size_t)(has_pack ? p : 0);
+    const uint32_t slot0 = hp[0], layer0 = hp[2], q0 = hp[4], woff = hp[6];
+    const uint32_t nslots = has_pack ? hp[1] : 0, nlayers = has_pack ? hp[3] : 0, nh = has_pack ? (hp[5] & 0xFFFFu) : 0;
+    const int steps = (int)(hp[5] >> 16);
+    const uint32_t c0 = rd.quad_hdr[4 * (size_t)quad], cnt = rd.quad_hdr[4 * (size_t)quad + 1];
+    const REAL INF = inf_v<REAL>();
+    const NarrowRs<REAL> rs(d);
+    wave_copy_to_lds(d.nwords + woff, sW, nslots * 4u, lane);
+    wave_copy_to_lds(d.F + slot0, sFa, nslots * (uint32_t)sizeof(REAL), lane);
+    wave_copy_to_lds(d.lohi + 2 * (size_t)layer0, sC, nlayers * (uint32_t)sizeof(P2), lane);
+    {
+        const uint32_t q = q0 + min((uint32_t)lane, nh);
+        const uint32_t on = pk.hop_node_off[q], ol = pk.hop_layer_off[q];
+        sOffN[lane] = on - slot0;
+        sOffL[lane] = ol - layer0;
+    }
+    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
+    stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane < 4) sT[lane >> 1][W + (lane & 1)] = (lane & 1) ? INF : REAL(0);
+    if (WPB > 1) __syncthreads(); else wave_sync();
+    int cur = 0;
+    for (uint32_t h = nh; h-- > 0;) {
+        const uint32_t nb = __builtin_amdgcn_readfirstlane(sOffN[h]), ne = __builtin_amdgcn_readfirstlane(sOffN[h + 1]);
+        const uint32_t n = ne - nb;
+        uint32_t lb = __builtin_amdgcn_readfirstlane(sOffL[h]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t j = lane + 64 * r;
+            constexpr uint32_t PADW = nw_pad_word(W);
+            const uint32_t w = j < n ? sW[nb + j] : PADW;
+            const bool act = !(w & NW_PAD);
+            const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
+            const unsigned long long heads = __ballot(nw_head(w));
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(heads >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)heads, 0u));
+            const uint32_t ll = act ? lb + below - (nw_pos(w) != 0 ? 1u : 0u) : 0u;
+            lb += (uint32_t)__popcll(heads);
+            const P2 c = sC[ll];
+            const REAL fa = sFa[act ? nb + j : 0];
+            const REAL tl = sT[cur][lo_i];  // sinks: [W] = 0, [W + 1] = +inf
+            const REAL th = sT[cur][hi_i];
+            const P2 dd = sDw[ll];
+            REAL m0 = act ? (fa + c.x) + tl : INF;
+            REAL m1 = act ? (fa + c.y) + th : INF;
+            seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps);
+            const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
+            const REAL nlo = (c.x + rmin(mm, REAL(0))) + dd.x;
+            const REAL nhi = (c.y + rmin(-mm, REAL(0))) + dd.y;
+            const REAL t = rmin(nhi + th, nlo + tl);
+            const bool head = nw_head(w);
+            P2 nc;
+            nc.x = nlo;
+            nc.y = nhi;
+            bstore(nc, rs.lohi, head ? (layer0 + ll) * (uint32_t)sizeof(P2) : OOB);
+            if (head) sDw[ll].x = mm;
+            if (act) sT[cur ^ 1][j] = t;
+            bstore(t, rs.T, act ? (slot0 + nb + j) * (uint32_t)sizeof(REAL) : OOB);
+        }
+        wave_sync();
+        cur ^= 1;
+    }
+    if (WPB > 1) __syncthreads(); else wave_sync();
+    stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
+    if (!has_pack) return;
+    // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251)
+    const uint32_t n0 = __builtin_amdgcn_readfirstlane(sOffN[1]);
+    double sum = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t j = lane + 64 * r;
+        if (j < n0) sum += (double)sT[cur][j];
+    }
+    for (int off2 = 32; off2 > 0; off2 >>= 1) sum += __shfl_down(sum, off2);
+    if (lane == 0) d.lb_partial[pk.lb_base + p] = sum;
+}
+
+// =============================================================================================
 // wide packs: one workgroup per pack; layers may span waves, so the layer min goes through LDS
 // =============================================================================================
 constexpr int WIDE_THREADS = 256;
@@ -932,6 +1178,415 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
     if (tid == 0) {
         double t = 0.0;
         for (int i = 0; i < WIDE_THREADS / 64; ++i) t += red[i];
+        d.lb_partial[pk.lb_base + p] = t;
+    }
+}
+
+// =============================================================================================
+// wide packs, LDS frontier: register-resident rewrite of the workgroup-per-pack sweeps
+// =============================================================================================
+// One workgroup of T = blockDim.x threads (a multiple of 64, <= 1024) sweeps one wide pack; thread `tid` owns the nodes
+// tid + i * T, i < NPT, of every hop (NPT = 1 for packs up to 1024 nodes per hop), so everything a node needs between the
+// min-marginal phase and the update phase stays in registers and the node words are read once per hop.
+//   * global loads are branch-free raw buffer ops issued three hops ahead (words, potentials), two hops ahead (the layer's
+//     entry index, which needs the word) and one hop ahead (arc costs, delta pair), so a hop never waits for memory it asked
+//     for in the same hop;
+//   * the per-layer minimum goes through LDS (ds_min per node into the layer's slot: layers may span wavefronts);
+//   * two workgroup barriers per hop in the solve / marginal modes (after the minima, after the pushes), one in the plain and
+//     solution modes (three rotating frontier buffers make the second one unnecessary);
+//   * sink children are ordinary LDS indices (ww = cost-to-terminal 0 / dummy push target, ww + 1 = +inf), as in the narrow kernels.
+// The old k_*_wide kernels above remain for huge packs (frontier in global memory).
+__host__ __device__ inline size_t wide2_lds_bytes(size_t real_size, uint32_t ww, bool solution)
+{
+    return 8 * real_size * (size_t)(ww + 2) + (solution ? 3 * (size_t)(ww + 2) : 0);
+}
+constexpr uint64_t WW_PAD_WORD = WW_BOT | (WW_BOT << WW_CHILD_BITS);  // inactive lane: children = bot sink, layer 0, not a head
+
+template <typename REAL>
+struct WideRs {
+    rsrc_t words, T, F, lohi, lpos, dlay, mm;
+    __device__ __forceinline__ explicit WideRs(const DevPtrs<REAL>& d)
+    {
+        words = make_rsrc(d.wwords, (uint64_t)d.n_slots - d.wide_slot_base);
+        T = make_rsrc(d.T, d.n_slots);
+        F = make_rsrc(d.F, d.n_slots);
+        lohi = make_rsrc(d.lohi, 2ull * d.n_layers);
+        lpos = make_rsrc(d.lpos, d.n_layers);
+        dlay = make_rsrc(d.delta_lay, 2ull * d.n_layers);
+        mm = make_rsrc(d.mm_binned, d.n_layers);
+    }
+};
+__device__ __forceinline__ uint64_t bload_u64(rsrc_t r, uint32_t off)
+{
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    return ((uint64_t)v[1] << 32) | (uint64_t)v[0];
+}
+__device__ __forceinline__ uint32_t ww_child(uint32_t c, uint32_t ww) { return c >= (uint32_t)WW_TOP ? ww + (c - (uint32_t)WW_TOP) : c; }
+__device__ __forceinline__ uint32_t ww_lo(uint64_t w, uint32_t ww) { return ww_child((uint32_t)(w & WW_CHILD_MASK), ww); }
+__device__ __forceinline__ uint32_t ww_hi(uint64_t w, uint32_t ww) { return ww_child((uint32_t)((w >> WW_CHILD_BITS) & WW_CHILD_MASK), ww); }
+__device__ __forceinline__ uint32_t ww_layer(uint64_t w) { return (uint32_t)((w >> (2 * WW_CHILD_BITS)) & WW_CHILD_MASK); }
+
+template <int NPT>
+__device__ __forceinline__ void wide_load_words(uint64_t (&w)[NPT], rsrc_t words, uint32_t wb, uint32_t n, uint32_t tid, uint32_t T)
+{
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const uint32_t j = tid + i * T;
+        const uint64_t x = bload_u64(words, j < n ? (wb + j) * 8u : OOB);
+        w[i] = j < n ? x : WW_PAD_WORD;
+    }
+}
+template <typename REAL, int NPT>
+__device__ __forceinline__ void wide_load_vals(REAL (&v)[NPT], rsrc_t src, uint32_t nb, uint32_t n, uint32_t tid, uint32_t T)
+{
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const uint32_t j = tid + i * T;
+        bload(v[i], src, j < n ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
+    }
+}
+
+template <typename REAL, int MODE, int NPT>
+__global__ void __launch_bounds__(1024) k_fwd_wide2(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
+{
+    using P2 = typename Pair<REAL>::type;
+    constexpr bool NEED_T = (MODE != FWD_PLAIN);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, T = blockDim.x;
+    const uint32_t p = blockIdx.x;
+    if (p >= pk.n_packs) return;
+    const uint32_t S = ww + 2;
+    // All LDS arrays are addressed as lds[offset + index] with integer offsets that rotate from hop to hop: with rotating POINTERS the
+    // compiler loses the address space and emits flat loads / a flat compare-and-swap loop for the float minimum (seen in the ISA).
+    REAL* const lds = reinterpret_cast<REAL*>(smem);           // 8 arrays of S values: F x3, T, minima x4
+    unsigned char* const ldsA = smem + 8 * sizeof(REAL) * S;   // 3 arrays of S flags (solution mode)
+    // T of the next hop.  Solve mode: one buffer, rewritten in phase B (its readers are behind the phase-A barrier).  Solution mode has
+    // no such barrier, so it alternates between two buffers (the second one is the space of the minima, unused there).
+    const uint32_t oT0 = 3 * S, oT1 = MODE == FWD_SOLUTION ? 4 * S : 3 * S;
+    const uint32_t oM0 = 4 * S, oM1 = 6 * S;  // minima of lo / hi: [oM0 + cur * S + l], [oM1 + cur * S + l]
+    const REAL INF = inf_v<REAL>();
+    const WideRs<REAL> rs(d);
+    const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
+    auto noff = [&](uint32_t q) { return pk.hop_node_off[min(q, q1)]; };
+    auto loff = [&](uint32_t q) { return pk.hop_layer_off[min(q, q1)]; };
+    const uint32_t wsb = d.wide_slot_base;
+    // node / layer offsets of hops q .. q+4 / q .. q+3
+    uint32_t nv[5], lv[4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) nv[i] = noff(q0 + i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lv[i] = loff(q0 + i);
+    // ---- prologue: three dependent round trips, once per pack
+    uint64_t W0[NPT], W1[NPT], W2[NPT];
+    wide_load_words<NPT>(W0, rs.words, nv[0] - wsb, nv[1] - nv[0], tid, T);
+    wide_load_words<NPT>(W1, rs.words, nv[1] - wsb, nv[2] - nv[1], tid, T);
+    wide_load_words<NPT>(W2, rs.words, nv[2] - wsb, nv[3] - nv[2], tid, T);
+    REAL T1[NPT], T2[NPT];
+    if (NEED_T) {
+        wide_load_vals<REAL, NPT>(T1, rs.T, nv[1], nv[2] - nv[1], tid, T);
+        wide_load_vals<REAL, NPT>(T2, rs.T, nv[2], nv[3] - nv[2], tid, T);
+    }
+    uint32_t E0[NPT], E1[NPT];
+    P2 C0[NPT], D0[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const uint32_t j = tid + i * T;
+        const bool a0 = j < nv[1] - nv[0], a1 = j < nv[2] - nv[1];
+        bload(C0[i], rs.lohi, a0 ? (lv[0] + ww_layer(W0[i])) * (uint32_t)sizeof(P2) : OOB);
+        E0[i] = E1[i] = 0;
+        if (MODE == FWD_SOLVE) {
+            E0[i] = bload_u32(rs.lpos, a0 ? (lv[0] + ww_layer(W0[i])) * 4u : OOB);
+            E1[i] = bload_u32(rs.lpos, a1 ? (lv[1] + ww_layer(W1[i])) * 4u : OOB);
+        }
+    }
+    if (MODE == FWD_SOLVE) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) bload(D0[i], rs.dlay, (tid + i * T) < nv[1] - nv[0] ? E0[i] * (uint32_t)sizeof(P2) : OOB);
+    }
+    // LDS: roots, empty next frontiers, T of hop q0+1, empty minima
+    for (uint32_t j = tid; j < S; j += T) {
+        lds[j] = j < nv[1] - nv[0] ? REAL(0) : INF;  // every node of hop 0 is a root (flush_costs_from_root)
+        lds[S + j] = INF;
+        lds[2 * S + j] = INF;
+        if (MODE == FWD_SOLVE) { lds[oM0 + j] = INF; lds[oM0 + S + j] = INF; lds[oM1 + j] = INF; lds[oM1 + S + j] = INF; }
+        if (MODE == FWD_SOLUTION) { ldsA[j] = j < nv[1] - nv[0] ? 1 : 0; ldsA[S + j] = 0; ldsA[2 * S + j] = 0; }
+    }
+    if (NEED_T) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const uint32_t j = tid + i * T;
+            if (j < nv[2] - nv[1]) lds[oT0 + j] = T1[i];
+        }
+        if (tid < 4) lds[((tid >> 1) ? oT1 : oT0) + ww + (tid & 1)] = (tid & 1) ? INF : REAL(0);
+    }
+    __syncthreads();
+    uint32_t fc = 0, cur = 0;  // frontier buffer fc: current, (fc+1)%3: next, (fc+2)%3: being cleared for the hop after
+    for (uint32_t q = q0; q < q1; ++q) {
+        const uint32_t n = nv[1] - nv[0];
+        const uint32_t oFc = fc * S, oFn = (fc == 2 ? 0 : fc + 1) * S, oFx = (fc == 0 ? 2 : fc - 1) * S;
+        const uint32_t oT = cur ? oT1 : oT0, oTn = cur ? oT0 : oT1;
+        const uint32_t oMa = oM0 + cur * S, oMb = oM1 + cur * S, oMa_n = oM0 + (cur ^ 1) * S, oMb_n = oM1 + (cur ^ 1) * S;
+        // ---- prefetch (consumed in later hops): words / T of hop q+3, entry indices of hop q+2, arc costs and delta pairs of hop q+1
+        uint64_t W3[NPT];
+        REAL T3[NPT];
+        uint32_t E2[NPT];
+        P2 C1[NPT], D1[NPT];
+        const uint32_t nv5 = noff(q + 5), lv4 = loff(q + 4);
+        wide_load_words<NPT>(W3, rs.words, nv[3] - wsb, nv[4] - nv[3], tid, T);
+        if (NEED_T) wide_load_vals<REAL, NPT>(T3, rs.T, nv[3], nv[4] - nv[3], tid, T);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const uint32_t j = tid + i * T;
+            const bool a1 = j < nv[2] - nv[1], a2 = j < nv[3] - nv[2];
+            bload(C1[i], rs.lohi, a1 ? (lv[1] + ww_layer(W1[i])) * (uint32_t)sizeof(P2) : OOB);
+            E2[i] = 0;
+            if (MODE == FWD_SOLVE) {
+                E2[i] = bload_u32(rs.lpos, a2 ? (lv[2] + ww_layer(W2[i])) * 4u : OOB);
+                bload(D1[i], rs.dlay, a1 ? E1[i] * (uint32_t)sizeof(P2) : OOB);
+            }
+        }
+        // ---- phase A: per-layer minima of the two min-marginals
+        REAL f[NPT], tl[NPT], th[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const uint32_t j = tid + i * T;
+            const bool act = j < n;
+            f[i] = act ? lds[oFc + j] : INF;
+            if (NEED_T) {
+                tl[i] = lds[oT + ww_lo(W0[i], ww)];
+                th[i] = lds[oT + ww_hi(W0[i], ww)];
+            }
+            if (MODE == FWD_SOLVE) {
+                const uint32_t l = ww_layer(W0[i]);
+                lds_min(&lds[oMa + l], act ? (f[i] + C0[i].x) + tl[i] : INF);
+                lds_min(&lds[oMb + l], act ? (f[i] + C0[i].y) + th[i] : INF);
+            }
+        }
+        if (MODE == FWD_SOLVE) __syncthreads();
+        // ---- phase B: cost update, pushes into the next frontier
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const uint32_t j = tid + i * T;
+            const bool act = j < n;
+            const uint64_t w = W0[i];
+            const uint32_t l = ww_layer(w), lo_i = ww_lo(w, ww), hi_i = ww_hi(w, ww);
+            REAL nlo = C0[i].x, nhi = C0[i].y;
+            if (MODE == FWD_SOLVE) {
+                const REAL m0 = lds[oMa + l], m1 = lds[oMb + l];
+                const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
+                nlo = (nlo + rmin(mm, REAL(0))) + D0[i].x;
+                nhi = (nhi + rmin(-mm, REAL(0))) + D0[i].y;
+                const bool head = act && (w & WW_HEAD);
+                P2 nc;
+                nc.x = nlo;
+                nc.y = nhi;
+                bstore(nc, rs.lohi, head ? (lv[0] + l) * (uint32_t)sizeof(P2) : OOB);
+                bstore(mm, rs.mm, head ? E0[i] * (uint32_t)sizeof(REAL) : OOB);
+            } else if (MODE == FWD_SOLUTION) {
+                if (act && ldsA[oFc + j]) {
+                    const REAL hi_path = f[i] + (th[i] + nhi);  // backward_step_with_path_costs, bdd_cuda_base.cu:633-640
+                    const REAL lo_path = f[i] + (tl[i] + nlo);
+                    const bool take_lo = (hi_path - lo_path) > 0;
+                    d.sol_out[lv[0] + l] = take_lo ? 0 : 1;
+                    ldsA[oFn + (take_lo ? lo_i : hi_i)] = 1;  // sink entries are dummies
+                }
+            }
+            lds_min(&lds[oFn + lo_i], f[i] + nlo);  // inactive lanes push +inf into the bot-sink dummy
+            lds_min(&lds[oFn + hi_i], f[i] + nhi);
+            bstore(f[i], rs.F, act ? (nv[0] + j) * (uint32_t)sizeof(REAL) : OOB);
+        }
+        // set-up of later hops: the frontier after next is cleared, T of hop q+2 goes to LDS (phase A of the next hop reads it),
+        // the minima of hop q+1 are reset
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const uint32_t j = tid + i * T;
+            if (j < nv[3] - nv[2]) {
+                lds[oFx + j] = INF;
+                if (MODE == FWD_SOLUTION) ldsA[oFx + j] = 0;
+                if (NEED_T) lds[oTn + j] = T2[i];
+            }
+        }
+        if (MODE == FWD_SOLVE) {
+            const uint32_t nl1 = lv[2] - lv[1];
+            for (uint32_t l = tid; l < nl1; l += T) { lds[oMa_n + l] = INF; lds[oMb_n + l] = INF; }
+        }
+        __syncthreads();
+        // rotate
+        fc = fc == 2 ? 0 : fc + 1;
+        cur ^= 1;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            W0[i] = W1[i]; W1[i] = W2[i]; W2[i] = W3[i];
+            E0[i] = E1[i]; E1[i] = E2[i];
+            C0[i] = C1[i];
+            if (MODE == FWD_SOLVE) D0[i] = D1[i];
+            if (NEED_T) T2[i] = T3[i];
+        }
+        nv[0] = nv[1]; nv[1] = nv[2]; nv[2] = nv[3]; nv[3] = nv[4]; nv[4] = nv5;
+        lv[0] = lv[1]; lv[1] = lv[2]; lv[2] = lv[3]; lv[3] = lv4;
+    }
+}
+
+template <typename REAL, int MODE, int NPT>
+__global__ void __launch_bounds__(1024) k_bwd_wide2(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
+{
+    using P2 = typename Pair<REAL>::type;
+    constexpr bool NEED_F = (MODE != BWD_PLAIN);
+    constexpr bool NEED_M = (MODE != BWD_PLAIN);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double red[16];
+    const uint32_t tid = threadIdx.x, T = blockDim.x;
+    const uint32_t p = blockIdx.x;
+    if (p >= pk.n_packs) return;
+    const uint32_t S = ww + 2;
+    REAL* const lds = reinterpret_cast<REAL*>(smem);  // integer offsets instead of rotating pointers, see k_fwd_wide2
+    const uint32_t oM0 = 4 * S, oM1 = 6 * S;
+    const REAL INF = inf_v<REAL>();
+    const WideRs<REAL> rs(d);
+    const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
+    const uint32_t wsb = d.wide_slot_base;
+    // hop h below the current one: node range [nb(h), nb(h+1)), empty below q0
+    auto nb_of = [&](int64_t h) { return pk.hop_node_off[h < (int64_t)q0 ? q0 : (uint32_t)h]; };
+    auto cnt_of = [&](int64_t h) { return h < (int64_t)q0 ? 0u : pk.hop_node_off[h + 1] - pk.hop_node_off[h]; };
+    auto lb_of = [&](int64_t h) { return pk.hop_layer_off[h < (int64_t)q0 ? q0 : (uint32_t)h]; };
+    auto nl_of = [&](int64_t h) { return h < (int64_t)q0 ? 0u : pk.hop_layer_off[h + 1] - pk.hop_layer_off[h]; };
+    int64_t q = (int64_t)q1 - 1;
+    // ---- prologue
+    uint64_t W0[NPT], W1[NPT], W2[NPT];
+    REAL F0[NPT], F1[NPT], F2[NPT];
+    wide_load_words<NPT>(W0, rs.words, nb_of(q) - wsb, cnt_of(q), tid, T);
+    wide_load_words<NPT>(W1, rs.words, nb_of(q - 1) - wsb, cnt_of(q - 1), tid, T);
+    wide_load_words<NPT>(W2, rs.words, nb_of(q - 2) - wsb, cnt_of(q - 2), tid, T);
+    if (NEED_F) {
+        wide_load_vals<REAL, NPT>(F0, rs.F, nb_of(q), cnt_of(q), tid, T);
+        wide_load_vals<REAL, NPT>(F1, rs.F, nb_of(q - 1), cnt_of(q - 1), tid, T);
+        wide_load_vals<REAL, NPT>(F2, rs.F, nb_of(q - 2), cnt_of(q - 2), tid, T);
+    }
+    uint32_t E0[NPT], E1[NPT];
+    P2 C0[NPT], D0[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const uint32_t j = tid + i * T;
+        const bool a0 = j < cnt_of(q), a1 = j < cnt_of(q - 1);
+        bload(C0[i], rs.lohi, a0 ? (lb_of(q) + ww_layer(W0[i])) * (uint32_t)sizeof(P2) : OOB);
+        E0[i] = E1[i] = 0;
+        if (MODE == BWD_SOLVE) {
+            E0[i] = bload_u32(rs.lpos, a0 ? (lb_of(q) + ww_layer(W0[i])) * 4u : OOB);
+            E1[i] = bload_u32(rs.lpos, a1 ? (lb_of(q - 1) + ww_layer(W1[i])) * 4u : OOB);
+        }
+    }
+    if (MODE == BWD_SOLVE) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) bload(D0[i], rs.dlay, (tid + i * T) < cnt_of(q) ? E0[i] * (uint32_t)sizeof(P2) : OOB);
+    }
+    for (uint32_t j = tid; j < S; j += T) {
+        if (NEED_M) { lds[oM0 + j] = INF; lds[oM0 + S + j] = INF; lds[oM1 + j] = INF; lds[oM1 + S + j] = INF; }
+    }
+    if (tid < 4) lds[(tid >> 1) * S + ww + (tid & 1)] = (tid & 1) ? INF : REAL(0);
+    __syncthreads();
+    uint32_t tc = 0, cur = 0;  // T buffer tc: hop q+1 (children), tc^1: hop q (being written)
+    for (; q >= (int64_t)q0; --q) {
+        const uint32_t n = cnt_of(q), nb = nb_of(q), lb = lb_of(q);
+        const uint32_t oTc = tc * S, oTn = (tc ^ 1) * S;
+        const uint32_t oMa = oM0 + cur * S, oMb = oM1 + cur * S, oMa_n = oM0 + (cur ^ 1) * S, oMb_n = oM1 + (cur ^ 1) * S;
+        // ---- prefetch: words / F of hop q-3, entry indices of hop q-2, arc costs and delta pairs of hop q-1
+        uint64_t W3[NPT];
+        REAL F3[NPT];
+        uint32_t E2[NPT];
+        P2 C1[NPT], D1[NPT];
+        const uint32_t c1 = cnt_of(q - 1), c2 = cnt_of(q - 2), c3 = cnt_of(q - 3);
+        const uint32_t lb1 = lb_of(q - 1), lb2 = lb_of(q - 2);
+        wide_load_words<NPT>(W3, rs.words, nb_of(q - 3) - wsb, c3, tid, T);
+        if (NEED_F) wide_load_vals<REAL, NPT>(F3, rs.F, nb_of(q - 3), c3, tid, T);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const uint32_t j = tid + i * T;
+            bload(C1[i], rs.lohi, j < c1 ? (lb1 + ww_layer(W1[i])) * (uint32_t)sizeof(P2) : OOB);
+            E2[i] = 0;
+            if (MODE == BWD_SOLVE) {
+                E2[i] = bload_u32(rs.lpos, j < c2 ? (lb2 + ww_layer(W2[i])) * 4u : OOB);
+                bload(D1[i], rs.dlay, j < c1 ? E1[i] * (uint32_t)sizeof(P2) : OOB);
+            }
+        }
+        // ---- phase A
+        REAL tl[NPT], th[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const uint32_t j = tid + i * T;
+            const bool act = j < n;
+            tl[i] = lds[oTc + ww_lo(W0[i], ww)];
+            th[i] = lds[oTc + ww_hi(W0[i], ww)];
+            if (NEED_M) {
+                const uint32_t l = ww_layer(W0[i]);
+                REAL a, b;
+                if (MODE == BWD_SOLVE) {
+                    a = (F0[i] + C0[i].x) + tl[i];
+                    b = (F0[i] + C0[i].y) + th[i];
+                } else {  // backward_step_with_path_costs, bdd_cuda_base.cu:633-641
+                    a = F0[i] + (tl[i] + C0[i].x);
+                    b = F0[i] + (th[i] + C0[i].y);
+                }
+                lds_min(&lds[oMa + l], act ? a : INF);
+                lds_min(&lds[oMb + l], act ? b : INF);
+            }
+        }
+        if (NEED_M) __syncthreads();
+        // ---- phase B
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const uint32_t j = tid + i * T;
+            const bool act = j < n;
+            const uint64_t w = W0[i];
+            const uint32_t l = ww_layer(w);
+            const bool head = act && (w & WW_HEAD);
+            REAL t;
+            if (MODE == BWD_SOLVE) {
+                const REAL m0 = lds[oMa + l], m1 = lds[oMb + l];
+                const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
+                const REAL nlo = (C0[i].x + rmin(mm, REAL(0))) + D0[i].x;
+                const REAL nhi = (C0[i].y + rmin(-mm, REAL(0))) + D0[i].y;
+                t = rmin(nhi + th[i], nlo + tl[i]);
+                P2 nc;
+                nc.x = nlo;
+                nc.y = nhi;
+                bstore(nc, rs.lohi, head ? (lb + l) * (uint32_t)sizeof(P2) : OOB);
+                bstore(mm, rs.mm, head ? E0[i] * (uint32_t)sizeof(REAL) : OOB);
+            } else {
+                t = rmin(th[i] + C0[i].y, tl[i] + C0[i].x);  // backward_step, bdd_cuda_base.cu:646-667
+                if (MODE == BWD_MARGINALS && head) {
+                    d.mm0_out[lb + l] = lds[oMa + l];
+                    d.mm1_out[lb + l] = lds[oMb + l];
+                }
+            }
+            if (act) lds[oTn + j] = t;
+            bstore(t, rs.T, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
+        }
+        if (NEED_M) {
+            const uint32_t nl1 = nl_of(q - 1);
+            for (uint32_t l = tid; l < nl1; l += T) { lds[oMa_n + l] = INF; lds[oMb_n + l] = INF; }
+        }
+        __syncthreads();
+        tc ^= 1;
+        cur ^= 1;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            W0[i] = W1[i]; W1[i] = W2[i]; W2[i] = W3[i];
+            if (NEED_F) { F0[i] = F1[i]; F1[i] = F2[i]; F2[i] = F3[i]; }
+            E0[i] = E1[i]; E1[i] = E2[i];
+            C0[i] = C1[i];
+            if (MODE == BWD_SOLVE) D0[i] = D1[i];
+        }
+    }
+    // lower bound contribution of this pack (bdd_cuda_base.cu:1243-1251)
+    const uint32_t n0 = pk.hop_node_off[q0 + 1] - pk.hop_node_off[q0];
+    double acc = 0.0;
+    for (uint32_t j = tid; j < n0; j += T) acc += (double)lds[tc * S + j];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (uint32_t i = 0; i < T / 64; ++i) t += red[i];
         d.lb_partial[pk.lb_base + p] = t;
     }
 }

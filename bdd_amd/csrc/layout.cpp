@@ -265,7 +265,23 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         order_n.swap(grouped);
     }
     std::vector<uint32_t> lay_pos(Lin);  // slot position of every input layer inside its (pack,hop)
-    PackBuilder pn{W, 64}, pw{WW, 0}, ph{std::max(HW, 1u), 0};
+    // Wide packs are swept by one workgroup each, two barriers per hop whatever the width, so for a given amount of wide BDDs
+    // narrower packs mean more workgroups in flight.  The pack width adapts: aim at >= 1024 packs (4 workgroups per CU), but a
+    // pack must hold the widest of these BDDs; wide_pack_width (the option) stays the upper limit.
+    uint32_t WWe = WW;
+    if (!order_w.empty()) {
+        uint64_t sum_w = 0;
+        uint32_t max_w = 0;
+        for (uint32_t b : order_w) {
+            sum_w += bdd_maxw[b];
+            max_w = std::max(max_w, bdd_maxw[b]);
+        }
+        const uint64_t want = std::max<uint64_t>(max_w, (sum_w + 1023) / 1024);
+        WWe = (uint32_t)std::min<uint64_t>(WW, (want + 63) / 64 * 64);
+        WWe = std::max(WWe, (max_w + 0u));  // WW itself need not be a multiple of 64
+    }
+    L.wide_pack_width = WWe;
+    PackBuilder pn{W, 64}, pw{WWe, 0}, ph{std::max(HW, 1u), 0};
     std::vector<uint32_t> widths;
     auto form = [&](PackBuilder& pb, const std::vector<uint32_t>& order) {
         for (uint32_t k = 0; k < order.size(); ++k) {
@@ -424,7 +440,13 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         const uint32_t min_vb = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, one_chunk_vars / 64 * 64));
         auto_vb = std::min(std::max(auto_vb, min_vb), max_vb);
         X.vars_per_bin = opts && opts->vars_per_bin ? opts->vars_per_bin : auto_vb;
-        X.stage_cap = opts && opts->stage_cap ? opts->stage_cap : 640;
+        // stage groups hold <= stage_cap layers of one pack; the default is the largest pack's layer count (one group per pack) up to
+        // 640, so that small packs do not reserve LDS staging space they never use
+        uint32_t auto_cap = W;
+        for (uint32_t p = 0; p < L.narrow.n_packs(); ++p)
+            auto_cap = std::max(auto_cap, L.narrow.hop_layer_off[L.narrow.pack_hop_ptr[p + 1]] - L.narrow.hop_layer_off[L.narrow.pack_hop_ptr[p]]);
+        auto_cap = std::min<uint32_t>(640, (auto_cap + 63) / 64 * 64);
+        X.stage_cap = opts && opts->stage_cap ? opts->stage_cap : auto_cap;
         if (X.vars_per_bin < 64 || X.vars_per_bin > max_vb) {
             err = "vars_per_bin must be in [64, 9728]";
             return BDDMMA_ERR_INVALID_ARGUMENT;
@@ -534,6 +556,35 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         }
         X.vpos.assign(Lin, 0);
         for (uint32_t k = 0; k < Lin; ++k) X.vpos[k] = X.lpos[L.var_layers[k]];
+        // headers of the resident sweeps (layout.hpp: struct Resident)
+        {
+            Resident& Rz = L.res;
+            const uint32_t WPB = X.waves_per_block;
+            const uint32_t n_quads = (Pn + WPB - 1) / WPB;
+            Rz.ok = Pn > 0;
+            Rz.pack_hdr.assign((size_t)Pn * 8, 0);
+            Rz.quad_hdr.assign((size_t)n_quads * 4, 0);
+            for (uint32_t p = 0; p < Pn; ++p) {
+                const uint32_t q0 = N.pack_hop_ptr[p], q1 = N.pack_hop_ptr[p + 1];
+                const uint32_t s0 = N.hop_node_off[q0], s1 = N.hop_node_off[q1];
+                const uint32_t l0 = N.hop_layer_off[q0], l1 = N.hop_layer_off[q1];
+                uint32_t* h = &Rz.pack_hdr[(size_t)p * 8];
+                h[0] = s0; h[1] = s1 - s0; h[2] = l0; h[3] = l1 - l0; h[4] = q0;
+                h[5] = (q1 - q0) | ((uint32_t)N.pack_steps[p] << 16);
+                h[6] = L.narrow_word_off[p];
+                Rz.max_slots = std::max(Rz.max_slots, s1 - s0);
+                Rz.max_layers = std::max(Rz.max_layers, l1 - l0);
+                if (q1 - q0 > 63 || X.pack_group_ptr[p + 1] - X.pack_group_ptr[p] != 1) Rz.ok = false;
+            }
+            for (uint32_t Q = 0; Q < n_quads; ++Q) {
+                const uint32_t r0 = X.quad_round_ptr[Q], r1 = X.quad_round_ptr[Q + 1];
+                uint32_t* h = &Rz.quad_hdr[(size_t)Q * 4];
+                h[0] = r1 > r0 ? X.cs_ptr[r0] : 0;
+                h[1] = r1 > r0 ? X.cs_ptr[r0 + 1] - X.cs_ptr[r0] : 0;
+                h[2] = r1 - r0;
+                if (r1 - r0 != 1) Rz.ok = false;
+            }
+        }
     }
     return BDDMMA_OK;
 }

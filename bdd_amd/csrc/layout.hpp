@@ -98,6 +98,18 @@ struct Exchange {
     std::vector<uint16_t> cs_slot;         // [narrow layers] staged item -> LDS slot = wave * stage_cap + (layer - group's first layer)
 };
 
+// Resident sweeps (kernels.hpp: k_fwd_res / k_bwd_res): a narrow pack whose node words, opposite-direction potentials and arc
+// costs fit in its wave's LDS slice is loaded with a handful of 1 KiB direct-to-LDS copies in ONE memory round trip and swept out
+// of LDS; the streaming kernels pay a dependent round trip per table and a latency-bound software pipeline per hop, which is
+// what bounds small and medium instances.  Everything a wave needs to start is in one 32-byte header.
+struct Resident {
+    bool ok = false;                 // every narrow pack has <= 63 hops and a single stage group
+    uint32_t max_slots = 0;          // largest pack, in node slots / layers
+    uint32_t max_layers = 0;
+    std::vector<uint32_t> pack_hdr;  // [8 per narrow pack] first slot, #slots, first layer, #layers, first hop record, #hops | steps << 16, word offset, 0
+    std::vector<uint32_t> quad_hdr;  // [4 per quad] first staged item, #staged items, #rounds, 0
+};
+
 struct HostLayout {
     uint64_t n_bdds = 0, n_vars = 0, n_hops = 0;
     uint64_t n_input_nodes = 0;   // incl. terminals (reference nr_bdd_nodes())
@@ -129,6 +141,7 @@ struct HostLayout {
     // per hop statistics (over all packs)
     std::vector<uint64_t> nodes_per_hop, layers_per_hop;
     Exchange ex;
+    Resident res;
     // slot -> input instruction index (debug / round-trip tests), UINT64_MAX for padding
     std::vector<uint64_t> slot_to_instr;
 };
