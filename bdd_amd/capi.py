@@ -23,7 +23,8 @@ K_FORWARD_MM, K_BACKWARD_MM, K_FINISH_DELTA, K_OTHER, K_COUNT = 0, 1, 2, 3, 4
 class Options(C.Structure):
     _fields_ = [("pack_width", C.c_uint32), ("wide_pack_width", C.c_uint32), ("deterministic", C.c_uint32),
                 ("vars_per_bin", C.c_uint32), ("stage_cap", C.c_uint32), ("waves_per_block", C.c_uint32),
-                ("reserved", C.c_uint32 * 2)]
+                ("keep_bdd_order", C.c_uint32), ("resident_sweeps", C.c_uint32), ("exchange_by_variable", C.c_uint32),
+                ("reserved", C.c_uint32 * 3)]
 
 
 class LbfgsParams(C.Structure):

@@ -58,6 +58,8 @@ struct SolverT final : SolverBase {
     uint32_t *d_quad_round_ptr = nullptr, *d_cs_ptr = nullptr, *d_cs_entry = nullptr;
     uint16_t* d_cs_slot = nullptr;
     uint32_t wpb = 1;
+    bool entry_by_var = false;  // entries ordered by (variable, bdd): exchange = k_exchange_byvar
+    bool exch_small = false;
     uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0, stage_lds = 0, exch_lds = 0, n_narrow_layers = 0;
     double *d_lb_partial = nullptr, *d_lb = nullptr;
     double* h_lb = nullptr;  // pinned, device-visible: the reduce kernel writes the bound straight into host memory
@@ -70,6 +72,8 @@ struct SolverT final : SolverBase {
         uint32_t n_packs = 0;
     } nb_, wb_, hb_;  // narrow, wide, huge packs
     uint32_t wide_lds = 0, wide_threads = 256, wide_npt = 1;
+    // (Running the wide launch on a second stream next to the narrow one was measured and dropped: the event fork / join costs ~10 us
+    // per pass on this platform, more than the overlap returns — knapsack benchmark 8 990 -> 8 261 it/s.)
     // resident sweeps of the narrow packs (kernels.hpp: k_fwd_res / k_bwd_res)
     uint32_t *d_pack_hdr = nullptr, *d_quad_hdr = nullptr;
     bool use_res = false;
@@ -180,6 +184,7 @@ struct SolverT final : SolverBase {
         if ((rc = upload(&d_cs_entry, L.ex.cs_entry))) return rc;
         if ((rc = upload(&d_cs_slot, L.ex.cs_slot))) return rc;
         wpb = L.ex.waves_per_block;
+        entry_by_var = L.ex.entry_by_var;
         vars_per_bin = L.ex.vars_per_bin; n_bins = L.ex.n_bins; stage_cap = L.ex.stage_cap;
         n_narrow_layers = L.ex.grp_layer_off.empty() ? 0 : L.ex.grp_layer_off.back();
         if (2 * n_layers * sizeof(REAL) >= 0xFFFFFFFFull || n_slots * sizeof(REAL) >= 0xFFFFFFFFull) {
@@ -210,9 +215,10 @@ struct SolverT final : SolverBase {
 #define SET_DYN(K, BYTES) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
         SET_DYN((k_exchange_reduce<REAL, double, EX_ITER>), exch_lds);
         SET_DYN((k_exchange_reduce<REAL, double, EX_RAW>), exch_lds);
+        exch_small = vars_per_bin <= EXS_MAX_VARS_PER_BIN;  // 256-thread workgroups (kernels.hpp: EXS_*)
 #undef SET_DYN
         // resident sweeps: chosen when every narrow pack fits its wave's LDS slice and the instance is small enough that the streaming
-        // kernels are latency-bound (few waves per SIMD); reserved[1] = 1 turns them off, = 2 forces them on
+        // kernels are latency-bound (few waves per SIMD); resident_sweeps = 1 turns them off, = 2 forces them on
         if (nb_.n_packs && L.res.ok) {
             if ((rc = upload(&d_pack_hdr, L.res.pack_hdr))) return rc;
             if ((rc = upload(&d_quad_hdr, L.res.quad_hdr))) return rc;
@@ -220,13 +226,14 @@ struct SolverT final : SolverBase {
             res_nl = (L.res.max_layers + 127) / 128 * 128;
             res_lds = wpb * stage_cap * 2 * (uint32_t)sizeof(REAL) + wpb * res_wave_bytes(sizeof(REAL), res_ns, res_nl);
             const uint32_t static_lds = wpb * (2 * (pack_width + 2) * (uint32_t)sizeof(REAL) + 512);
-            const uint32_t mode = opts ? opts->reserved[1] : 0;
+            const uint32_t mode = opts ? opts->resident_sweeps : 0;
             const bool fits = res_lds + static_lds <= 160 * 1024 - 512;
-            // automatic choice: resident when all workgroups of a sweep can be in flight at once with their LDS slices (small and medium
-            // instances, which are latency-bound); larger instances keep the streaming kernels, whose small LDS footprint lets 5 waves per
-            // SIMD hide the latency (measured at 10.5 M nodes: streaming 50 us, resident 108 us per sweep; at 1 M nodes 12.5 vs 11 us)
+            // automatic choice: small instances only — at most 2 waves per SIMD (2048 packs), all workgroups in flight at once with their
+            // LDS slices.  Measured (float, sweep fwd / bwd in us, streaming vs resident): 1 M nodes (1563 packs) 12.1 / 12.2 vs 11.4 / 10.5;
+            // 2 M 18.5 / 19.1 vs 20.5 / 19.7; 4 M 27.3 / 25.5 vs 41.8 / 39.0; 10.5 M 50 / 45 vs 108 / 98 — with more waves per SIMD the
+            // streaming kernels hide their latency and the resident ones only lose occupancy to their LDS footprint.
             const uint64_t wgs_per_cu = fits ? (160 * 1024) / (res_lds + static_lds) : 0;
-            const bool all_in_flight = (uint64_t)cdiv(nb_.n_packs, wpb) <= 256ull * std::min<uint64_t>(wgs_per_cu, 2048 / (64 * wpb));
+            const bool all_in_flight = nb_.n_packs <= 2048 && (uint64_t)cdiv(nb_.n_packs, wpb) <= 256ull * std::min<uint64_t>(wgs_per_cu, 2048 / (64 * wpb));
             use_res = fits && mode != 1 && (mode == 2 || all_in_flight);
             if (use_res) {
 #define SET_RES(R_, W_) \
@@ -289,6 +296,16 @@ struct SolverT final : SolverBase {
         DevPtrs<REAL> d = ptrs(delta_lay);
         const uint32_t dyn = (MODE == FWD_SOLVE) ? stage_lds : 0;
         prof_begin(kclass);
+        hipStream_t sw = stream;
+        if (wb_.n_packs) {
+            const PackDev pk = pdev(wb_, nb_.n_packs);
+            const dim3 g(wb_.n_packs), b(wide_threads);
+            switch (wide_npt) {
+                case 1: hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 1>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
+                case 2: hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 2>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
+                default: hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 4>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
+            }
+        }
         if (nb_.n_packs) {
             const PackDev pk = pdev(nb_, 0);
             // SOLVE sweeps: `wpb` packs per workgroup with cooperative staging; the other modes stage nothing
@@ -309,15 +326,6 @@ struct SolverT final : SolverBase {
 #undef LAUNCH_W
 #undef LAUNCH_N
         }
-        if (wb_.n_packs) {
-            const PackDev pk = pdev(wb_, nb_.n_packs);
-            const dim3 g(wb_.n_packs), b(wide_threads);
-            switch (wide_npt) {
-                case 1: hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 1>), g, b, wide_lds, stream, d, pk, omega, wide_pack_width); break;
-                case 2: hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 2>), g, b, wide_lds, stream, d, pk, omega, wide_pack_width); break;
-                default: hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 4>), g, b, wide_lds, stream, d, pk, omega, wide_pack_width); break;
-            }
-        }
         if (hb_.n_packs) {
             const PackDev pk = pdev(hb_, nb_.n_packs + wb_.n_packs);
             hipLaunchKernelGGL((k_fwd_wide<REAL, MODE, true>), dim3(hb_.n_packs), dim3(WIDE_THREADS), 0, stream, d, pk, omega, huge_pack_width, d_huge_scratch);
@@ -332,6 +340,16 @@ struct SolverT final : SolverBase {
         DevPtrs<REAL> d = ptrs(delta_lay);
         const uint32_t dyn = (MODE == BWD_SOLVE) ? stage_lds : 0;
         prof_begin(kclass);
+        hipStream_t sw = stream;
+        if (wb_.n_packs) {
+            const PackDev pk = pdev(wb_, nb_.n_packs);
+            const dim3 g(wb_.n_packs), b(wide_threads);
+            switch (wide_npt) {
+                case 1: hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 1>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
+                case 2: hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 2>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
+                default: hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 4>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
+            }
+        }
         if (nb_.n_packs) {
             const PackDev pk = pdev(nb_, 0);
             // SOLVE sweeps: `wpb` packs per workgroup with cooperative staging; the other modes stage nothing
@@ -351,15 +369,6 @@ struct SolverT final : SolverBase {
             }
 #undef LAUNCH_W
 #undef LAUNCH_N
-        }
-        if (wb_.n_packs) {
-            const PackDev pk = pdev(wb_, nb_.n_packs);
-            const dim3 g(wb_.n_packs), b(wide_threads);
-            switch (wide_npt) {
-                case 1: hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 1>), g, b, wide_lds, stream, d, pk, omega, wide_pack_width); break;
-                case 2: hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 2>), g, b, wide_lds, stream, d, pk, omega, wide_pack_width); break;
-                default: hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 4>), g, b, wide_lds, stream, d, pk, omega, wide_pack_width); break;
-            }
         }
         if (hb_.n_packs) {
             const PackDev pk = pdev(hb_, nb_.n_packs + wb_.n_packs);
@@ -388,14 +397,24 @@ struct SolverT final : SolverBase {
     int exchange()
     {
         prof_begin(BDDMMA_K_FINISH_DELTA);
-        if (deterministic) {
+        if (entry_by_var) {
+            // entries of a variable are consecutive: one thread per variable reduces, normalises and broadcasts (deterministic order)
+            hipLaunchKernelGGL((k_exchange_byvar<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr, d_delta_lay,
+                               (uint32_t)n_vars, (uint32_t)n_layers);
+            delta_var_valid = false;
+        } else if (deterministic) {
             hipLaunchKernelGGL((k_delta_gather<REAL, true>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr,
                                d_vpos, d_delta_var, (uint32_t)n_vars);
             launch_bcast(d_delta_var, d_delta_lay);
             delta_var_valid = true;
         } else {
-            hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
-                               d_bin_ptr, d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers);
+            if (exch_small)
+                hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, EXS_THREADS, EXS_UNROLL, EXS_NPT>), dim3(n_bins), dim3(EXS_THREADS), exch_lds,
+                                   stream, d_mm_binned, d_bin_ptr, d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars,
+                                   (uint32_t)n_layers);
+            else
+                hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
+                                   d_bin_ptr, d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers);
             delta_var_valid = false;
         }
         prof_end(BDDMMA_K_FINISH_DELTA);

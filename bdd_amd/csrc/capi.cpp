@@ -324,7 +324,7 @@ int bddmma_incremental_mm_agreement_rounding(bddmma_solver* s, bddmma_lbfgs* lbf
 // ---- checkpoint: the layout is a pure function of (collection, options), so the file holds the
 // collection + options + the mutable state (costs, deferred mm, deferred delta).  Mirrors what the
 // reference archives (bdd_cuda_base.cu:1486-1550; cost_from_root/terminal are not saved there either).
-static const char kMagic[8] = {'B', 'D', 'D', 'M', 'M', 'A', '0', '1'};
+static const char kMagic[8] = {'B', 'D', 'D', 'M', 'M', 'A', '0', '2'};
 
 int bddmma_save(const bddmma_solver* s, const char* path)
 {
@@ -432,7 +432,8 @@ void bddmma_layout_destroy(bddmma_layout* l) { delete l; }
 // what: 0 n_slots, 1 narrow_slots, 2 n_layers, 3 narrow packs, 4 wide packs, 5 n_hops, 6 n_vars,
 //       7 narrow (pack,hop) records, 8 wide (pack,hop) records, 9 bins, 10 vars per bin, 11 stage groups,
 //       12 narrow layers, 13 stage cap, 14 waves per block, 15 (quad, round) records, 16 pack width,
-//       17 huge packs, 18 huge (pack,hop) records, 19 huge pack width, 20 distinct narrow words stored on the device
+//       17 huge packs, 18 huge (pack,hop) records, 19 huge pack width, 20 distinct narrow words stored on the device,
+//       21 entries ordered by (variable, bdd), 22 resident sweeps possible, 23 / 24 largest narrow pack in slots / layers
 uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
 {
     const HostLayout& L = l->L;
@@ -458,6 +459,10 @@ uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
         case 19: return L.huge_pack_width;
         case 20: return L.narrow_words_unique.size();
         case 15: return L.ex.cs_ptr.empty() ? 0 : L.ex.cs_ptr.size() - 1;
+        case 21: return L.ex.entry_by_var ? 1 : 0;
+        case 22: return L.res.ok ? 1 : 0;
+        case 23: return L.res.max_slots;
+        case 24: return L.res.max_layers;
         default: return 0;
     }
 }
@@ -467,6 +472,7 @@ uint64_t bddmma_layout_size(const bddmma_layout* l, int what)
 //        16 bin_ptr(u32) 17 evar(u32) 18 lpos(u32) 19 vpos(u32) 20 pack_group_ptr 21 grp_layer_off 22 grp_hop_end
 //        23 quad_round_ptr 24 cs_ptr 25 cs_entry(u32) 26 cs_slot(u16)   27/28/29/30 huge pack_hop_ptr/hop_node_off/hop_layer_off/pack_steps
 //        31 narrow_words_unique(u32) 32 narrow_word_off(u32, per narrow pack)
+//        35 pack_hdr(u32 x 8 per narrow pack) 36 quad_hdr(u32 x 4 per quad)
 int bddmma_layout_copy(const bddmma_layout* l, int which, void* out)
 {
     const HostLayout& L = l->L;
@@ -508,6 +514,8 @@ int bddmma_layout_copy(const bddmma_layout* l, int which, void* out)
         case 30: return cp(L.huge.pack_steps);
         case 31: return cp(L.narrow_words_unique);
         case 32: return cp(L.narrow_word_off);
+        case 35: return cp(L.res.pack_hdr);
+        case 36: return cp(L.res.quad_hdr);
         default: return BDDMMA_ERR_INVALID_ARGUMENT;
     }
 }

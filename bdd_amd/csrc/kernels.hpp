@@ -1612,8 +1612,15 @@ __device__ __forceinline__ void lds_add(REAL* p, REAL v)
 enum : int { EX_ITER = 0, EX_RAW = 1 };
 constexpr int EX_THREADS = 1024;
 constexpr int EX_UNROLL = 12;  // entries per thread and chunk: a bin of <= 12288 entries is one chunk, all loads in flight at once
+constexpr int EX_NPT = 19;     // 2 * vars_per_bin <= EX_NPT * EX_THREADS
+// Small instances (few hundred bins of 1024 threads would leave most CUs idle and pay 16-wave barriers for a handful of entries per
+// thread): the same kernel with 256-thread workgroups over bins of <= 1024 variables.
+constexpr int EXS_THREADS = 256;
+constexpr int EXS_UNROLL = 12;
+constexpr int EXS_NPT = 8;
+constexpr uint32_t EXS_MAX_VARS_PER_BIN = EXS_THREADS * EXS_NPT / 2;
 
-template <typename REAL, typename ACC, int MODE>
+template <typename REAL, typename ACC, int MODE, int EX_THREADS = bddmma::EX_THREADS, int EX_UNROLL = bddmma::EX_UNROLL, int NPT = bddmma::EX_NPT>
 __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
                                                                   const uint16_t* __restrict__ bvar, const int32_t* __restrict__ nbdds,
                                                                   REAL* __restrict__ delta_var, REAL* __restrict__ delta_lay,
@@ -1639,7 +1646,6 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
         lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
     }
     // number of BDDs of the variables this thread normalises (needed only after the accumulation)
-    constexpr int NPT = 19;  // 2 * vars_per_bin <= NPT * EX_THREADS
     int nb[NPT];
     if (MODE == EX_ITER) {
 #pragma unroll
@@ -1730,6 +1736,46 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
             bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
         }
     }
+}
+
+// Exchange for entry arrays ordered by (variable, bdd) (layout.hpp: Exchange::entry_by_var): the entries of variable v are
+// var_ptr[v] .. var_ptr[v + 1], so compute_delta (bdd_cuda_parallel_mma.cu:358-393), normalize_delta (:410-430) and the broadcast of
+// the pair to the variable's layers are one thread per variable over a contiguous run — neighbouring threads read and write
+// neighbouring addresses, there are no LDS accumulators and no barriers, and the sum has the fixed order of the reduce_by_key variant
+// the reference keeps commented out (:395-407).  One dependent round trip (var_ptr) before the values instead of the binned kernel's
+// chain of loads, LDS atomics and three workgroup barriers: 3.5 us instead of 9.7 us at 1 M nodes.
+template <typename REAL>
+__global__ void __launch_bounds__(256) k_exchange_byvar(const REAL* __restrict__ mm, const uint32_t* __restrict__ var_ptr,
+                                                          REAL* __restrict__ delta_lay, uint32_t n_vars, uint32_t n_entries)
+{
+    using P2 = typename Pair<REAL>::type;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    const rsrc_t rvp = make_rsrc(var_ptr, (uint64_t)n_vars + 1), rmm = make_rsrc(mm, n_entries), rdl = make_rsrc(delta_lay, 2ull * n_entries);
+    const uint32_t k0 = bload_u32(rvp, v < n_vars ? v * 4u : OOB), k1 = bload_u32(rvp, v < n_vars ? (v + 1) * 4u : OOB);
+    const uint32_t n = k1 - k0;  // 0 for threads past the last variable and for variables in no BDD
+    constexpr int J = 8;         // values requested together; variables in more BDDs continue one by one
+    REAL m[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) bload(m[j], rmm, (uint32_t)j < n ? (k0 + j) * (uint32_t)sizeof(REAL) : OOB);  // dropped: 0
+    REAL lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if (m[j] > 0) hi += m[j];
+        else if (m[j] < 0) lo += -m[j];
+    }
+    for (uint32_t j = J; j < n; ++j) {
+        REAL x;
+        bload(x, rmm, (k0 + j) * (uint32_t)sizeof(REAL));
+        if (x > 0) hi += x;
+        else if (x < 0) lo += -x;
+    }
+    if (n == 0) return;
+    P2 pr;
+    pr.x = lo / REAL(n);
+    pr.y = hi / REAL(n);
+#pragma unroll
+    for (int j = 0; j < J; ++j) bstore(pr, rdl, (uint32_t)j < n ? (k0 + j) * (uint32_t)sizeof(P2) : OOB);
+    for (uint32_t j = J; j < n; ++j) bstore(pr, rdl, (k0 + j) * (uint32_t)sizeof(P2));
 }
 
 // Exchange, step B: broadcast the per-variable pairs to every entry (what the next sweep adds to the

@@ -253,7 +253,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     // Narrow BDDs of the same shape are packed together (stable: input order inside a shape class), so that packs
     // are structurally identical and share one stored word sequence (layout.hpp: narrow_words_unique).  Classes are
     // ordered by first appearance.  The result does not depend on the order of the BDDs.
-    if (!(opts && opts->reserved[0] == 1)) {
+    if (!(opts && opts->keep_bdd_order == 1)) {
         std::unordered_map<uint64_t, uint32_t> cls;
         std::vector<uint32_t> cls_of(order_n.size());
         for (size_t k = 0; k < order_n.size(); ++k) cls_of[k] = cls.emplace(bdd_shape[order_n[k]], (uint32_t)cls.size()).first->second;
@@ -433,11 +433,13 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         // default bin: as many variables as a 128 KiB LDS tile holds (2 REAL each), but at least ~256 bins
         // so that the exchange kernel (one workgroup per bin) has enough workgroups to spread over the CUs
         const uint32_t max_vb = 9728u;  // k_exchange_reduce: 2 * vars_per_bin <= 19 * 1024 threads; 152 KiB of double accumulators
-        // ~256 bins (one workgroup per CU), but at least 1024 variables per bin — unless the variables have so many
+        // ~256 bins (one workgroup per CU), but at least 512 variables per bin — unless the variables have so many
         // layers that such a bin would hold several 12 K-entry chunks (long rows: V small, L large): then smaller bins
         uint32_t auto_vb = (uint32_t)(((L.n_vars + 255) / 256 + 63) / 64 * 64);
         const uint64_t one_chunk_vars = Lin ? 12288ull * L.n_vars / Lin : 1024;
-        const uint32_t min_vb = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, one_chunk_vars / 64 * 64));
+        // (512: measured at V = 100 k — exchange 5.2 / 4.6 / 7.1 us with 256 / 512 / 1024 variables per bin, while the sweeps, whose runs
+        // in the entry arrays shrink with the bins, take 23.8 / 22.9 / 22.1 us)
+        const uint32_t min_vb = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(64, one_chunk_vars / 64 * 64));
         auto_vb = std::min(std::max(auto_vb, min_vb), max_vb);
         X.vars_per_bin = opts && opts->vars_per_bin ? opts->vars_per_bin : auto_vb;
         // stage groups hold <= stage_cap layers of one pack; the default is the largest pack's layer count (one group per pack) up to
@@ -489,9 +491,21 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
             if (X.grp_layer_off[g + 1] < X.grp_layer_off[g]) X.grp_layer_off[g + 1] = X.grp_layer_off[g];
         struct Key { uint32_t bin, group, layer; };
         std::vector<Key> keys(Lin);
-        for (uint32_t l = 0; l < Lin; ++l) keys[l] = Key{(uint32_t)L.layer_var[l] / X.vars_per_bin, layer_group[l], l};
-        // layers are already sorted by (group, layer); a stable sort by bin yields (bin, group, layer)
-        std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.bin < b.bin; });
+        // entries by (variable, bdd) (layout.hpp): only on request.  Measured at 1 / 2 / 4 M nodes: the exchange launch drops from 9.7 to
+        // 5.3 us, but every sweep gains 6 / 14 / 35 us because its gathers and scatters in the entry arrays lose their runs — even
+        // with the arrays in L2, a sweep's staging time follows the number of cache lines it touches.
+        X.entry_by_var = opts && opts->exchange_by_variable == 2;
+        if (X.entry_by_var) {
+            // (variable, bdd) order = the order of var_layers; bins are ranges of variables, so they stay contiguous
+            for (uint32_t k = 0; k < Lin; ++k) {
+                const uint32_t l = L.var_layers[k];
+                keys[k] = Key{(uint32_t)L.layer_var[l] / X.vars_per_bin, layer_group[l], l};
+            }
+        } else {
+            for (uint32_t l = 0; l < Lin; ++l) keys[l] = Key{(uint32_t)L.layer_var[l] / X.vars_per_bin, layer_group[l], l};
+            // layers are already sorted by (group, layer); a stable sort by bin yields (bin, group, layer)
+            std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.bin < b.bin; });
+        }
         X.bin_ptr.assign(X.n_bins + 1, 0);
         X.evar.assign(Lin, 0);
         X.bvar.assign(Lin, 0);
@@ -556,6 +570,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         }
         X.vpos.assign(Lin, 0);
         for (uint32_t k = 0; k < Lin; ++k) X.vpos[k] = X.lpos[L.var_layers[k]];
+
         // headers of the resident sweeps (layout.hpp: struct Resident)
         {
             Resident& Rz = L.res;

@@ -96,6 +96,12 @@ struct Exchange {
     std::vector<uint32_t> cs_ptr;          // [rounds+1] first staged item of each (quad, round)
     std::vector<uint32_t> cs_entry;        // [narrow layers] staged item -> entry (ascending inside a round)
     std::vector<uint16_t> cs_slot;         // [narrow layers] staged item -> LDS slot = wave * stage_cap + (layer - group's first layer)
+    // entry_by_var: entries ordered by (variable, bdd) instead of (bin, group, layer).  The entries of one variable are then
+    // consecutive, and compute_delta + normalize_delta + the broadcast become one thread per variable over a contiguous run
+    // (kernels.hpp: k_exchange_byvar): no LDS accumulators, no barriers, a third of the binned kernel's latency chain.  The price is
+    // that the sweeps' accesses to the entry arrays lose their (bin, quad) runs, which only matters when those arrays do not stay in
+    // cache — so this order is for small and medium instances.
+    bool entry_by_var = false;
 };
 
 // Resident sweeps (kernels.hpp: k_fwd_res / k_bwd_res): a narrow pack whose node words, opposite-direction potentials and arc

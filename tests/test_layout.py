@@ -17,12 +17,13 @@ BOT = np.uint64(2**64 - 2)
 
 
 class Layout:
-    def __init__(self, col, pack_width=0, wide_pack_width=0, vars_per_bin=0, stage_cap=0, waves_per_block=0):
+    def __init__(self, col, pack_width=0, wide_pack_width=0, vars_per_bin=0, stage_cap=0, waves_per_block=0, exchange_by_variable=0):
         L = capi.lib()
         instr = np.ascontiguousarray(col.instr, dtype=np.uint64)
         delims = np.ascontiguousarray(col.delims, dtype=np.uint64)
         h = C.c_void_p()
         opts = capi.Options(pack_width, wide_pack_width, 0, vars_per_bin, stage_cap, waves_per_block)
+        opts.exchange_by_variable = exchange_by_variable
         rc = L.bddmma_layout_create(C.byref(h), instr.ctypes.data_as(C.c_void_p), delims.ctypes.data_as(C.c_void_p),
                                     col.nr_bdds(), C.byref(opts))
         capi.check(rc, None)
@@ -66,6 +67,9 @@ class Layout:
         self.cs_ptr = get(24, n_rounds + 1, np.uint32)
         self.cs_entry = get(25, self.narrow_layers, np.uint32)
         self.cs_slot = get(26, self.narrow_layers, np.uint16)
+        self.entry_by_var, self.res_ok, self.res_max_slots, self.res_max_layers = bool(sz(21)), bool(sz(22)), sz(23), sz(24)
+        self.pack_hdr = get(35, 8 * self.np_n, np.uint32).reshape(-1, 8)
+        self.quad_hdr = get(36, 4 * n_quads, np.uint32).reshape(-1, 4)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -130,12 +134,12 @@ def check_exchange(lay):
             l0, l1 = int(S["hop_layer_off"][q]), int(S["hop_layer_off"][qe])
             assert (int(lay.grp_layer_off[g]), int(lay.grp_layer_off[g + 1])) == (l0, l1)
             assert 0 < l1 - l0 <= lay.stage_cap
-            # inside one bin the group's entries are consecutive and ordered by layer
+            # push exchange: inside one bin the group's entries are consecutive and ordered by layer
             e = lay.lpos[l0:l1].astype(np.int64)
             b = ebin[e]
             for bb in np.unique(b):
                 ee = e[b == bb]
-                assert np.all(np.diff(ee) == 1)
+                assert lay.entry_by_var or np.all(np.diff(ee) == 1)
             q = qe
         assert q == int(S["pack_hop_ptr"][p + 1])
     assert int(lay.grp_layer_off[-1]) == lay.narrow_layers
@@ -157,9 +161,35 @@ def check_exchange(lay):
                 assert not seen[e_layer]
                 seen[e_layer] = True
     assert seen.all()
+    if lay.entry_by_var:
+        # entries are the (variable, bdd)-sorted layers, so a variable's entries are var_ptr[v] .. var_ptr[v + 1]
+        np.testing.assert_array_equal(lay.lpos[lay.var_layers], np.arange(L))
+        np.testing.assert_array_equal(lay.vpos, np.arange(L))
+    # headers of the resident sweeps
+    S = lay.sets[0]
+    for p in range(lay.np_n):
+        q0, q1 = int(S["pack_hop_ptr"][p]), int(S["pack_hop_ptr"][p + 1])
+        h = lay.pack_hdr[p]
+        assert (int(h[0]), int(h[0] + h[1])) == (int(S["hop_node_off"][q0]), int(S["hop_node_off"][q1]))
+        assert (int(h[2]), int(h[2] + h[3])) == (int(S["hop_layer_off"][q0]), int(S["hop_layer_off"][q1]))
+        assert int(h[4]) == q0 and int(h[5]) & 0xFFFF == q1 - q0 and int(h[5]) >> 16 == int(S["steps"][p])
+        assert int(h[1]) <= lay.res_max_slots and int(h[3]) <= lay.res_max_layers
+    for Q in range(len(lay.quad_round_ptr) - 1):
+        r0, r1 = int(lay.quad_round_ptr[Q]), int(lay.quad_round_ptr[Q + 1])
+        assert int(lay.quad_hdr[Q][2]) == r1 - r0
+        if r1 > r0:
+            assert (int(lay.quad_hdr[Q][0]), int(lay.quad_hdr[Q][1])) == (int(lay.cs_ptr[r0]), int(lay.cs_ptr[r0 + 1] - lay.cs_ptr[r0]))
+    one_group = all(int(lay.pack_group_ptr[p + 1] - lay.pack_group_ptr[p]) == 1 for p in range(lay.np_n))
+    short = all(int(lay.pack_hdr[p][5]) & 0xFFFF <= 63 for p in range(lay.np_n))
+    assert lay.res_ok == (lay.np_n > 0 and one_group and short)
 
 
 def check_roundtrip(col, **kw):
+    if "exchange_by_variable" not in kw:   # both entry orders: (bin, group, layer) and (variable, bdd)
+        off = Layout(col, **kw)
+        assert not off.entry_by_var
+        check_exchange(off)
+        kw = dict(kw, exchange_by_variable=2)
     lay = Layout(col, **kw)
     check_exchange(lay)
     dec = lay.decode()
