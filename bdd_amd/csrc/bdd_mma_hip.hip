@@ -107,22 +107,43 @@ struct SolverT final : SolverBase {
         dev_bytes += bytes;
         return BDDMMA_OK;
     }
+    struct DevField { const void* ptr = nullptr; uint64_t count = 0; };
+    DevField dev_fields[LAYOUT_ARRAY_IDS];  // layout array id (layout.hpp: visit_layout_arrays) -> where it lives on the device
     template <typename T>
-    int upload(T** p, const std::vector<T>& h)
+    int upload(T** p, const std::vector<T>& h, int id = 0)
     {
         int rc = dalloc(p, h.size());
         if (rc) return rc;
         if (!h.empty()) HIPCHK(hipMemcpyAsync(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+        if (id) dev_fields[id] = DevField{*p, h.size()};
         return BDDMMA_OK;
     }
-    int upload_packs(PackBufs& b, const PackSet& ps)
+    int download_layout(HostLayout& H) override
+    {
+        HIPCHK(hipSetDevice(device));
+        H = HostLayout();
+        set_layout_scalars(H, lay_scalars);
+        hipError_t e = hipSuccess;
+        visit_layout_arrays(H, [&](int id, auto& vec) {
+            using T = typename std::remove_reference_t<decltype(vec)>::value_type;
+            if (id == 36) { vec.assign(nodes_per_hop.begin(), nodes_per_hop.end()); return; }
+            if (id == 37) { vec.assign(layers_per_hop.begin(), layers_per_hop.end()); return; }
+            const DevField& f = dev_fields[id];
+            vec.resize(f.count);
+            if (f.count && e == hipSuccess) e = hipMemcpyAsync(vec.data(), f.ptr, f.count * sizeof(T), hipMemcpyDeviceToHost, stream);
+        });
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        HIPCHK(e);
+        return BDDMMA_OK;
+    }
+    int upload_packs(PackBufs& b, const PackSet& ps, int id0)
     {
         b.n_packs = ps.n_packs();
         int rc;
-        if ((rc = upload(&b.pack_hop_ptr, ps.pack_hop_ptr))) return rc;
-        if ((rc = upload(&b.hop_node_off, ps.hop_node_off))) return rc;
-        if ((rc = upload(&b.hop_layer_off, ps.hop_layer_off))) return rc;
-        if ((rc = upload(&b.pack_steps, ps.pack_steps))) return rc;
+        if ((rc = upload(&b.pack_hop_ptr, ps.pack_hop_ptr, id0))) return rc;
+        if ((rc = upload(&b.hop_node_off, ps.hop_node_off, id0 + 1))) return rc;
+        if ((rc = upload(&b.hop_layer_off, ps.hop_layer_off, id0 + 2))) return rc;
+        if ((rc = upload(&b.pack_steps, ps.pack_steps, id0 + 3))) return rc;
         return BDDMMA_OK;
     }
 
@@ -138,6 +159,8 @@ struct SolverT final : SolverBase {
         nodes_per_hop = L.nodes_per_hop; layers_per_hop = L.layers_per_hop;
         h_nbdds = L.num_bdds_per_var; h_var_ptr = L.var_ptr;
         h_layer_var = L.layer_var; h_layer_bdd = L.layer_bdd;
+        lay_scalars = layout_scalars(L);
+        if (opts) saved_opts = *opts;
         deterministic = opts && opts->deterministic;
         // the kernels address every array through a buffer descriptor with 32-bit byte offsets (kernels.hpp: make_rsrc);
         // an access past 4 GiB would be dropped silently, so refuse such instances up front
@@ -147,19 +170,19 @@ struct SolverT final : SolverBase {
             return BDDMMA_ERR_UNSUPPORTED;
         }
         int rc;
-        if ((rc = upload(&d_nwords, L.narrow_words_unique))) return rc;
+        if ((rc = upload(&d_nwords, L.narrow_words_unique, 1))) return rc;
         n_nwords = (uint32_t)L.narrow_words_unique.size();
-        if ((rc = upload(&d_pack_word_off, L.narrow_word_off))) return rc;
-        if ((rc = upload(&d_wwords, L.wide_words))) return rc;
-        if ((rc = upload(&d_var, L.layer_var))) return rc;
-        if ((rc = upload(&d_bdd, L.layer_bdd))) return rc;
-        if ((rc = upload(&d_nbdds, L.num_bdds_per_var))) return rc;
-        if ((rc = upload(&d_var_ptr, L.var_ptr))) return rc;
-        if ((rc = upload(&d_var_layers, L.var_layers))) return rc;
-        if ((rc = upload(&d_root_slot, L.bdd_root_slot))) return rc;
-        if ((rc = upload_packs(nb_, L.narrow))) return rc;
-        if ((rc = upload_packs(wb_, L.wide))) return rc;
-        if ((rc = upload_packs(hb_, L.huge))) return rc;
+        if ((rc = upload(&d_pack_word_off, L.narrow_word_off, 2))) return rc;
+        if ((rc = upload(&d_wwords, L.wide_words, 3))) return rc;
+        if ((rc = upload(&d_var, L.layer_var, 4))) return rc;
+        if ((rc = upload(&d_bdd, L.layer_bdd, 5))) return rc;
+        if ((rc = upload(&d_nbdds, L.num_bdds_per_var, 6))) return rc;
+        if ((rc = upload(&d_var_ptr, L.var_ptr, 7))) return rc;
+        if ((rc = upload(&d_var_layers, L.var_layers, 8))) return rc;
+        if ((rc = upload(&d_root_slot, L.bdd_root_slot, 9))) return rc;
+        if ((rc = upload_packs(nb_, L.narrow, 10))) return rc;
+        if ((rc = upload_packs(wb_, L.wide, 14))) return rc;
+        if ((rc = upload_packs(hb_, L.huge, 18))) return rc;
         huge_pack_width = L.huge_pack_width;
         if (hb_.n_packs && (rc = dalloc(&d_huge_scratch, (size_t)hb_.n_packs * wide_lds_bytes(sizeof(REAL), huge_pack_width, true)))) return rc;
         wide_slot_base = L.narrow_slots;
@@ -171,18 +194,18 @@ struct SolverT final : SolverBase {
         if ((rc = dalloc(&d_mm_binned, n_layers))) return rc;
         if ((rc = dalloc(&d_delta_lay, 2 * n_layers))) return rc;
         if ((rc = dalloc(&d_delta_lay_c, 2 * n_layers))) return rc;
-        if ((rc = upload(&d_evar, L.ex.evar))) return rc;
-        if ((rc = upload(&d_bvar, L.ex.bvar))) return rc;
-        if ((rc = upload(&d_lpos, L.ex.lpos))) return rc;
-        if ((rc = upload(&d_vpos, L.ex.vpos))) return rc;
-        if ((rc = upload(&d_bin_ptr, L.ex.bin_ptr))) return rc;
-        if ((rc = upload(&d_pack_group_ptr, L.ex.pack_group_ptr))) return rc;
-        if ((rc = upload(&d_grp_layer_off, L.ex.grp_layer_off))) return rc;
-        if ((rc = upload(&d_grp_hop_end, L.ex.grp_hop_end))) return rc;
-        if ((rc = upload(&d_quad_round_ptr, L.ex.quad_round_ptr))) return rc;
-        if ((rc = upload(&d_cs_ptr, L.ex.cs_ptr))) return rc;
-        if ((rc = upload(&d_cs_entry, L.ex.cs_entry))) return rc;
-        if ((rc = upload(&d_cs_slot, L.ex.cs_slot))) return rc;
+        if ((rc = upload(&d_evar, L.ex.evar, 22))) return rc;
+        if ((rc = upload(&d_bvar, L.ex.bvar, 23))) return rc;
+        if ((rc = upload(&d_lpos, L.ex.lpos, 24))) return rc;
+        if ((rc = upload(&d_vpos, L.ex.vpos, 25))) return rc;
+        if ((rc = upload(&d_bin_ptr, L.ex.bin_ptr, 26))) return rc;
+        if ((rc = upload(&d_pack_group_ptr, L.ex.pack_group_ptr, 27))) return rc;
+        if ((rc = upload(&d_grp_layer_off, L.ex.grp_layer_off, 28))) return rc;
+        if ((rc = upload(&d_grp_hop_end, L.ex.grp_hop_end, 29))) return rc;
+        if ((rc = upload(&d_quad_round_ptr, L.ex.quad_round_ptr, 30))) return rc;
+        if ((rc = upload(&d_cs_ptr, L.ex.cs_ptr, 31))) return rc;
+        if ((rc = upload(&d_cs_entry, L.ex.cs_entry, 32))) return rc;
+        if ((rc = upload(&d_cs_slot, L.ex.cs_slot, 33))) return rc;
         wpb = L.ex.waves_per_block;
         entry_by_var = L.ex.entry_by_var;
         vars_per_bin = L.ex.vars_per_bin; n_bins = L.ex.n_bins; stage_cap = L.ex.stage_cap;
@@ -219,9 +242,9 @@ struct SolverT final : SolverBase {
 #undef SET_DYN
         // resident sweeps: chosen when every narrow pack fits its wave's LDS slice and the instance is small enough that the streaming
         // kernels are latency-bound (few waves per SIMD); resident_sweeps = 1 turns them off, = 2 forces them on
+        if ((rc = upload(&d_pack_hdr, L.res.pack_hdr, 34))) return rc;
+        if ((rc = upload(&d_quad_hdr, L.res.quad_hdr, 35))) return rc;
         if (nb_.n_packs && L.res.ok) {
-            if ((rc = upload(&d_pack_hdr, L.res.pack_hdr))) return rc;
-            if ((rc = upload(&d_quad_hdr, L.res.quad_hdr))) return rc;
             res_ns = (L.res.max_slots + 255) / 256 * 256;
             res_nl = (L.res.max_layers + 127) / 128 * 128;
             res_lds = wpb * stage_cap * 2 * (uint32_t)sizeof(REAL) + wpb * res_wave_bytes(sizeof(REAL), res_ns, res_nl);

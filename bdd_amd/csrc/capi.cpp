@@ -3,6 +3,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -58,17 +59,24 @@ int bddmma_create(bddmma_solver** out, int precision, int device, const bddmma_i
     if (!out) return BDDMMA_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     try {
+        static const bool timing = std::getenv("BDDMMA_LAYOUT_TIMING") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!timing) return;
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[create] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+            t_last = now;
+        };
         HostLayout L;
         int rc = build_layout(instr, bdd_delims, n_bdds, opts, L, g_err, false, precision == BDDMMA_F64 ? 8 : 4);
         if (rc) return rc;
+        lap("host layout");
         SolverBase* impl = nullptr;
         rc = create_solver(&impl, precision, device, L, opts, g_err);
         if (rc) return rc;
+        lap("device buffers + upload");
         impl->n_packs_narrow = L.narrow.n_packs();
         impl->n_packs_wide = L.wide.n_packs() + L.huge.n_packs();
-        impl->saved_instr.assign(instr, instr + bdd_delims[n_bdds]);
-        impl->saved_delims.assign(bdd_delims, bdd_delims + n_bdds + 1);
-        if (opts) impl->saved_opts = *opts;
         if (costs_hi && n_costs) {
             rc = impl->update_costs(nullptr, 0, costs_hi, n_costs, BDDMMA_F64, 0);
             if (rc) {
@@ -77,6 +85,7 @@ int bddmma_create(bddmma_solver** out, int precision, int device, const bddmma_i
                 return rc;
             }
         }
+        lap("update_costs");
         *out = new bddmma_solver{impl};
         return BDDMMA_OK;
     } catch (const std::exception& e) {
@@ -321,29 +330,93 @@ int bddmma_incremental_mm_agreement_rounding(bddmma_solver* s, bddmma_lbfgs* lbf
     });
 }
 
-// ---- checkpoint: the layout is a pure function of (collection, options), so the file holds the
-// collection + options + the mutable state (costs, deferred mm, deferred delta).  Mirrors what the
-// reference archives (bdd_cuda_base.cu:1486-1550; cost_from_root/terminal are not saved there either).
-static const char kMagic[8] = {'B', 'D', 'D', 'M', 'M', 'A', '0', '2'};
+// ---- checkpoint (bdd_cuda_base.cu:1486-1550: every index array of the layout + the costs are archived) -------------------------
+// File: magic, header {precision, #arrays, sizeof(LayoutScalars), sizeof(bddmma_options)}, LayoutScalars, options, the layout arrays
+// as {id, element size, count, data} records (layout.hpp: visit_layout_arrays), then lo / hi / deferred mm / delta.  Loading
+// uploads the arrays as they are: build_layout does not run again.
+static const char kMagic[8] = {'B', 'D', 'D', 'M', 'M', 'A', '0', '3'};
+
+namespace {
+struct FileCloser {
+    FILE* f;
+    ~FileCloser() { if (f) std::fclose(f); }
+};
+// Consistency of a layout read from a file: the offsets every kernel trusts must be monotone and end where the sizes say.
+bool layout_plausible(const HostLayout& L, std::string& why)
+{
+    auto mono_to = [&](const auto& v, uint64_t first, uint64_t last, const char* name) {
+        if (v.empty()) { why = std::string(name) + " is empty"; return false; }
+        if (v.front() != first || v.back() != last) { why = std::string(name) + " does not span its range"; return false; }
+        for (size_t i = 1; i < v.size(); ++i)
+            if (v[i] < v[i - 1]) { why = std::string(name) + " is not monotone"; return false; }
+        return true;
+    };
+    if (L.n_layers == 0 || L.n_vars == 0 || L.n_bdds == 0) { why = "empty layout"; return false; }
+    if (L.layer_var.size() != L.n_layers || L.layer_bdd.size() != L.n_layers || L.var_layers.size() != L.n_layers ||
+        L.ex.lpos.size() != L.n_layers || L.ex.evar.size() != L.n_layers || L.ex.bvar.size() != L.n_layers || L.ex.vpos.size() != L.n_layers ||
+        L.num_bdds_per_var.size() != L.n_vars || L.var_ptr.size() != L.n_vars + 1 || L.bdd_root_slot.size() != L.n_bdds ||
+        L.ex.bin_ptr.size() != (size_t)L.ex.n_bins + 1) { why = "array sizes do not match the header"; return false; }
+    if (!mono_to(L.var_ptr, 0, L.n_layers, "var_ptr") || !mono_to(L.ex.bin_ptr, 0, L.n_layers, "bin_ptr")) return false;
+    uint64_t slots = 0, layers = 0;
+    for (const PackSet* ps : {&L.narrow, &L.wide, &L.huge}) {
+        const uint32_t P = ps->n_packs();
+        if (P == 0) continue;
+        if (ps->pack_steps.size() != P) { why = "pack_steps size"; return false; }
+        if (!mono_to(ps->pack_hop_ptr, 0, ps->hop_node_off.size() - 1, "pack_hop_ptr")) return false;
+        if (ps->hop_layer_off.size() != ps->hop_node_off.size()) { why = "hop offset sizes"; return false; }
+        if (!mono_to(ps->hop_node_off, slots, ps->hop_node_off.back(), "hop_node_off") ||
+            !mono_to(ps->hop_layer_off, layers, ps->hop_layer_off.back(), "hop_layer_off")) return false;
+        slots = ps->hop_node_off.back();
+        layers = ps->hop_layer_off.back();
+    }
+    if (slots != L.n_slots || layers != L.n_layers) { why = "pack offsets do not cover the slots / layers"; return false; }
+    for (uint32_t e : L.ex.lpos) if (e >= L.n_layers) { why = "lpos out of range"; return false; }
+    for (int32_t v : L.layer_var) if (v < 0 || (uint64_t)v >= L.n_vars) { why = "layer variable out of range"; return false; }
+    const uint32_t Pn = L.narrow.n_packs();
+    if (Pn) {
+        if (L.narrow_word_off.size() != Pn || L.ex.pack_group_ptr.size() != (size_t)Pn + 1 || L.res.pack_hdr.size() != (size_t)Pn * 8) { why = "narrow pack tables"; return false; }
+        const uint32_t nl = L.narrow.hop_layer_off.back();
+        if (L.ex.cs_entry.size() != nl || L.ex.cs_slot.size() != nl) { why = "staging tables"; return false; }
+        if (!mono_to(L.ex.cs_ptr, 0, nl, "cs_ptr") || !mono_to(L.ex.quad_round_ptr, 0, L.ex.cs_ptr.size() - 1, "quad_round_ptr")) return false;
+        for (uint32_t e : L.ex.cs_entry) if (e >= L.n_layers) { why = "cs_entry out of range"; return false; }
+        for (uint32_t p = 0; p < Pn; ++p) {
+            const uint32_t s0 = L.narrow.hop_node_off[L.narrow.pack_hop_ptr[p]], s1 = L.narrow.hop_node_off[L.narrow.pack_hop_ptr[p + 1]];
+            if ((uint64_t)L.narrow_word_off[p] + (s1 - s0) > L.narrow_words_unique.size()) { why = "word offsets out of range"; return false; }
+        }
+    }
+    if (L.wide_words.size() != L.n_slots - L.narrow_slots) { why = "wide words"; return false; }
+    return true;
+}
+}  // namespace
 
 int bddmma_save(const bddmma_solver* s, const char* path)
 {
     return guarded(s, [&](SolverBase* b) {
         if (!path) return BDDMMA_ERR_INVALID_ARGUMENT;
         const size_t R = b->precision == BDDMMA_F64 ? 8 : 4;
-        std::vector<char> lo(b->n_layers * R), hi(b->n_layers * R), mm(b->n_layers * R), delta(2 * b->n_vars * R);
-        int rc = b->get_solver_costs(lo.data(), hi.data(), mm.data(), 0);
+        HostLayout H;
+        int rc = b->download_layout(H);
         if (rc) return rc;
+        std::vector<char> lo(b->n_layers * R), hi(b->n_layers * R), mm(b->n_layers * R), delta(2 * b->n_vars * R);
+        if ((rc = b->get_solver_costs(lo.data(), hi.data(), mm.data(), 0))) return rc;
         if ((rc = b->get_delta(delta.data(), 0))) return rc;
-        FILE* f = std::fopen(path, "wb");
+        FileCloser fc{std::fopen(path, "wb")};
+        FILE* f = fc.f;
         if (!f) { b->err = std::string("cannot open ") + path; return BDDMMA_ERR_IO; }
         bool ok = true;
         auto w = [&](const void* p, size_t n) { ok = ok && (n == 0 || std::fwrite(p, 1, n, f) == n); };
-        const uint64_t hdr[4] = {(uint64_t)b->precision, b->n_bdds, (uint64_t)b->saved_instr.size(), b->n_layers};
-        w(kMagic, 8); w(hdr, sizeof(hdr)); w(&b->saved_opts, sizeof(bddmma_options));
-        w(b->saved_delims.data(), b->saved_delims.size() * 8);
-        w(b->saved_instr.data(), b->saved_instr.size() * sizeof(bddmma_instruction));
+        uint64_t n_arrays = 0;
+        visit_layout_arrays(H, [&](int, auto&) { ++n_arrays; });
+        const uint64_t hdr[4] = {(uint64_t)b->precision, n_arrays, sizeof(LayoutScalars), sizeof(bddmma_options)};
+        const LayoutScalars sc = layout_scalars(H);
+        w(kMagic, 8); w(hdr, sizeof(hdr)); w(&sc, sizeof(sc)); w(&b->saved_opts, sizeof(bddmma_options));
+        visit_layout_arrays(H, [&](int id, auto& vec) {
+            const uint64_t rec[3] = {(uint64_t)id, sizeof(vec[0]), vec.size()};
+            w(rec, sizeof(rec));
+            w(vec.data(), vec.size() * sizeof(vec[0]));
+        });
         w(lo.data(), lo.size()); w(hi.data(), hi.size()); w(mm.data(), mm.size()); w(delta.data(), delta.size());
+        fc.f = nullptr;
         ok = (std::fclose(f) == 0) && ok;
         if (!ok) { b->err = std::string("write failed: ") + path; return BDDMMA_ERR_IO; }
         return BDDMMA_OK;
@@ -354,40 +427,66 @@ int bddmma_load(bddmma_solver** out, int device, const char* path)
 {
     if (!out || !path) return BDDMMA_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    FILE* f = std::fopen(path, "rb");
+    FileCloser fc{std::fopen(path, "rb")};
+    FILE* f = fc.f;
     if (!f) { g_err = std::string("cannot open ") + path; return BDDMMA_ERR_IO; }
-    bool ok = true;
-    auto r = [&](void* p, size_t n) { ok = ok && (n == 0 || std::fread(p, 1, n, f) == n); };
-    char magic[8];
-    uint64_t hdr[4] = {0, 0, 0, 0};
-    bddmma_options opts{};
-    r(magic, 8); r(hdr, sizeof(hdr)); r(&opts, sizeof(opts));
-    if (!ok || std::memcmp(magic, kMagic, 8) != 0 || hdr[1] == 0 || hdr[1] > (1ull << 40) || hdr[2] > (1ull << 40)) {
-        std::fclose(f);
-        g_err = std::string("not a bdd_mma checkpoint: ") + path;
-        return BDDMMA_ERR_IO;
-    }
-    int rc = BDDMMA_OK;
+    SolverBase* impl = nullptr;
     try {
-        std::vector<uint64_t> delims(hdr[1] + 1);
-        std::vector<bddmma_instruction> instr(hdr[2]);
-        r(delims.data(), delims.size() * 8);
-        r(instr.data(), instr.size() * sizeof(bddmma_instruction));
-        if (!ok) { std::fclose(f); g_err = "truncated checkpoint"; return BDDMMA_ERR_IO; }
-        rc = bddmma_create(out, (int)hdr[0], device, instr.data(), delims.data(), hdr[1], nullptr, 0, &opts);
-        if (rc) { std::fclose(f); return rc; }
-        SolverBase* b = (*out)->impl;
-        const size_t R = b->precision == BDDMMA_F64 ? 8 : 4;
-        if (b->n_layers != hdr[3]) ok = false;
-        std::vector<char> lo(b->n_layers * R), hi(b->n_layers * R), mm(b->n_layers * R), delta(2 * b->n_vars * R);
+        bool ok = true;
+        auto r = [&](void* p, size_t n) { ok = ok && (n == 0 || std::fread(p, 1, n, f) == n); };
+        if (std::fseek(f, 0, SEEK_END) != 0) { g_err = "cannot seek"; return BDDMMA_ERR_IO; }
+        const uint64_t file_size = (uint64_t)std::ftell(f);
+        std::rewind(f);
+        char magic[8];
+        uint64_t hdr[4] = {0, 0, 0, 0};
+        r(magic, 8); r(hdr, sizeof(hdr));
+        if (!ok || std::memcmp(magic, kMagic, 8) != 0 || hdr[0] > 1 || hdr[2] != sizeof(LayoutScalars) || hdr[3] != sizeof(bddmma_options) ||
+            hdr[1] > 1000) {
+            g_err = std::string("not a bdd_mma checkpoint (or one of another version): ") + path;
+            return BDDMMA_ERR_IO;
+        }
+        LayoutScalars sc{};
+        bddmma_options opts{};
+        r(&sc, sizeof(sc)); r(&opts, sizeof(opts));
+        HostLayout H;
+        set_layout_scalars(H, sc);
+        bool bad = false;
+        for (uint64_t a = 0; a < hdr[1] && ok && !bad; ++a) {
+            uint64_t rec[3] = {0, 0, 0};
+            r(rec, sizeof(rec));
+            if (!ok) break;
+            // a count the rest of the file cannot hold means a truncated or corrupt record: refuse before allocating
+            if (rec[1] == 0 || rec[1] > 8 || rec[2] > (file_size - (uint64_t)std::ftell(f)) / rec[1]) { bad = true; break; }
+            bool found = false;
+            visit_layout_arrays(H, [&](int id, auto& vec) {
+                if ((uint64_t)id != rec[0] || found) return;
+                found = true;
+                if (sizeof(vec[0]) != rec[1]) { bad = true; return; }
+                vec.resize(rec[2]);
+                r(vec.data(), rec[2] * rec[1]);
+            });
+            if (!found) bad = true;
+        }
+        std::string why;
+        if (!ok || bad || !layout_plausible(H, why)) {
+            g_err = "corrupt or truncated checkpoint" + (why.empty() ? std::string() : " (" + why + ")");
+            return BDDMMA_ERR_IO;
+        }
+        int rc = create_solver(&impl, (int)hdr[0], device, H, &opts, g_err);
+        if (rc) return rc;
+        impl->n_packs_narrow = H.narrow.n_packs();
+        impl->n_packs_wide = H.wide.n_packs() + H.huge.n_packs();
+        const size_t R = impl->precision == BDDMMA_F64 ? 8 : 4;
+        std::vector<char> lo(impl->n_layers * R), hi(impl->n_layers * R), mm(impl->n_layers * R), delta(2 * impl->n_vars * R);
         r(lo.data(), lo.size()); r(hi.data(), hi.size()); r(mm.data(), mm.size()); r(delta.data(), delta.size());
-        std::fclose(f);
-        if (!ok) { g_err = "truncated checkpoint"; bddmma_destroy(*out); *out = nullptr; return BDDMMA_ERR_IO; }
-        rc = b->set_solver_costs(lo.data(), hi.data(), mm.data(), 0);
-        if (rc == BDDMMA_OK) rc = b->set_delta(delta.data(), 0);
-        if (rc) { g_err = b->err; bddmma_destroy(*out); *out = nullptr; }
-        return rc;
+        if (!ok) { g_err = "truncated checkpoint"; delete impl; return BDDMMA_ERR_IO; }
+        rc = impl->set_solver_costs(lo.data(), hi.data(), mm.data(), 0);
+        if (rc == BDDMMA_OK) rc = impl->set_delta(delta.data(), 0);
+        if (rc) { g_err = impl->err; delete impl; return rc; }
+        *out = new bddmma_solver{impl};
+        return BDDMMA_OK;
     } catch (const std::exception& e) {
+        delete impl;
         g_err = e.what();
         return BDDMMA_ERR_IO;
     }

@@ -2,6 +2,11 @@
 #include "layout.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <cstring>
 #include <limits>
@@ -9,6 +14,47 @@
 namespace bddmma {
 
 namespace {
+
+// Host threads for the layout build (std::thread: no OpenMP runtime to link).  The reference builds its layout with ~10 device
+// sorts (bdd_cuda_base.cu:146-391); here it is host work, spread over the cores: f(begin, end, thread) over contiguous chunks.
+struct Par {
+    unsigned nt = 1;
+    Par()
+    {
+        const char* e = std::getenv("BDDMMA_THREADS");
+        const unsigned hw = std::thread::hardware_concurrency();
+        nt = e ? (unsigned)std::atoi(e) : std::min(hw ? hw : 1u, 32u);
+        if (nt < 1) nt = 1;
+    }
+    template <typename F>
+    void run(uint64_t n, F&& f, uint64_t min_parallel = 2048) const
+    {
+        if (nt == 1 || n < min_parallel) {
+            if (n) f((uint64_t)0, n, 0u);
+            return;
+        }
+        const uint64_t chunk = (n + nt - 1) / nt;
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) {
+            const uint64_t b = t * chunk, e = std::min(n, b + chunk);
+            if (b >= e) break;
+            th.emplace_back([&f, b, e, t] { f(b, e, t); });
+        }
+        for (auto& x : th) x.join();
+    }
+};
+// first error (lowest item index) found by any thread
+struct FirstError {
+    std::mutex m;
+    uint64_t at = std::numeric_limits<uint64_t>::max();
+    int code = 0;
+    std::string msg;
+    void set(uint64_t item, int c, std::string text)
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (item < at) { at = item; code = c; msg = std::move(text); }
+    }
+};
 
 inline bool is_top(const bddmma_instruction& i) { return i.index == BDDMMA_TOPSINK; }
 inline bool is_bot(const bddmma_instruction& i) { return i.index == BDDMMA_BOTSINK; }
@@ -114,6 +160,15 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
                           const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps, uint32_t real_size)
 {
     L = HostLayout();
+    // BDDMMA_LAYOUT_TIMING=1: phase times on stderr
+    static const bool timing = std::getenv("BDDMMA_LAYOUT_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[layout] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if (!instr || !delims || n_bdds == 0) {
         err = "empty BDD collection";
         return BDDMMA_ERR_INVALID_ARGUMENT;
@@ -134,44 +189,63 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     L.n_input_nodes = delims[n_bdds] - delims[0];
 
     // ---- pass 1: parse + validate every BDD (bdd_cuda_base.cu:86-144) ------------------------
+    const Par par;
     std::vector<uint64_t> lay_first;   // first instruction of every input layer (BDD-major)
     std::vector<uint32_t> bdd_lay_ptr(n_bdds + 1, 0);
     std::vector<uint32_t> bdd_maxw(n_bdds, 0);
     std::vector<uint64_t> bdd_shape(n_bdds, 0);  // hash of the BDD's structure (arcs and layer boundaries relative to its first entry)
     uint64_t max_var = 0;
-    for (uint64_t b = 0; b < n_bdds; ++b) {
-        const uint64_t d0 = delims[b], d1 = delims[b + 1];
-        bdd_lay_ptr[b] = (uint32_t)lay_first.size();
-        if (d1 < d0 + 3) {
-            err = "BDD " + std::to_string(b) + " has fewer than 3 entries";
-            return BDDMMA_ERR_INVALID_BDD;
-        }
-        const bddmma_instruction& t0 = instr[d1 - 2];
-        const bddmma_instruction& t1 = instr[d1 - 1];
-        if (!((is_top(t0) && is_bot(t1)) || (is_bot(t0) && is_top(t1)))) {
-            err = "BDD " + std::to_string(b) + ": the last two entries must be the top and bot sinks";
-            return BDDMMA_ERR_INVALID_BDD;
-        }
-        uint64_t prev = BDDMMA_BOTSINK - 7;
-        for (uint64_t i = d0; i < d1 - 2; ++i) {
-            if (is_term(instr[i])) {
-                err = "BDD " + std::to_string(b) + ": terminal entry before the end";
-                return BDDMMA_ERR_INVALID_BDD;
+    {
+        // 1a: terminals where they belong, layers per BDD, largest variable
+        FirstError fe;
+        std::vector<uint64_t> tmax(par.nt, 0);
+        par.run(n_bdds, [&](uint64_t b0, uint64_t b1, unsigned t) {
+            uint64_t mv = 0;
+            for (uint64_t b = b0; b < b1; ++b) {
+                const uint64_t d0 = delims[b], d1 = delims[b + 1];
+                if (d1 < d0 + 3) { fe.set(b, BDDMMA_ERR_INVALID_BDD, "BDD " + std::to_string(b) + " has fewer than 3 entries"); return; }
+                const bddmma_instruction& t0 = instr[d1 - 2];
+                const bddmma_instruction& t1 = instr[d1 - 1];
+                if (!((is_top(t0) && is_bot(t1)) || (is_bot(t0) && is_top(t1)))) {
+                    fe.set(b, BDDMMA_ERR_INVALID_BDD, "BDD " + std::to_string(b) + ": the last two entries must be the top and bot sinks");
+                    return;
+                }
+                uint64_t prev = BDDMMA_BOTSINK - 7;
+                uint32_t nl = 0;
+                for (uint64_t i = d0; i < d1 - 2; ++i) {
+                    if (is_term(instr[i])) { fe.set(b, BDDMMA_ERR_INVALID_BDD, "BDD " + std::to_string(b) + ": terminal entry before the end"); return; }
+                    if (instr[i].index != prev) {
+                        ++nl;
+                        prev = instr[i].index;
+                        mv = std::max(mv, prev);
+                    }
+                }
+                bdd_lay_ptr[b + 1] = nl;
             }
-            if (instr[i].index != prev) {
-                lay_first.push_back(i);
-                prev = instr[i].index;
-                max_var = std::max(max_var, prev);
-            }
-        }
-        if (lay_first.size() > std::numeric_limits<uint32_t>::max() - 2) {
-            err = "too many layers";
-            return BDDMMA_ERR_UNSUPPORTED;
+            tmax[t] = mv;
+        });
+        if (fe.code) { err = fe.msg; return fe.code; }
+        for (uint64_t v : tmax) max_var = std::max(max_var, v);
+        uint64_t total = 0;
+        for (uint64_t b = 0; b < n_bdds; ++b) {
+            total += bdd_lay_ptr[b + 1];
+            if (total > std::numeric_limits<uint32_t>::max() - 2) { err = "too many layers"; return BDDMMA_ERR_UNSUPPORTED; }
+            bdd_lay_ptr[b + 1] = (uint32_t)total;
         }
     }
-    bdd_lay_ptr[n_bdds] = (uint32_t)lay_first.size();
-    const uint32_t Lin = (uint32_t)lay_first.size();
-    lay_first.push_back(0);  // sentinel slot, patched per BDD below
+    const uint32_t Lin = bdd_lay_ptr[n_bdds];
+    lay_first.assign((size_t)Lin + 1, 0);  // + sentinel slot
+    par.run(n_bdds, [&](uint64_t b0, uint64_t b1, unsigned) {
+        for (uint64_t b = b0; b < b1; ++b) {
+            uint64_t prev = BDDMMA_BOTSINK - 7;
+            uint32_t l = bdd_lay_ptr[b];
+            for (uint64_t i = delims[b]; i < delims[b + 1] - 2; ++i)
+                if (instr[i].index != prev) {
+                    lay_first[l++] = i;
+                    prev = instr[i].index;
+                }
+        }
+    });
     if (max_var >= (uint64_t)std::numeric_limits<int32_t>::max()) {
         err = "variable index too large";
         return BDDMMA_ERR_UNSUPPORTED;
@@ -184,54 +258,72 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         return (l + 1 < bdd_lay_ptr[b + 1]) ? lay_first[l + 1] : delims[b + 1] - 2;
     };
     {
-        std::vector<uint64_t> last_bdd(L.n_vars, std::numeric_limits<uint64_t>::max());
-        for (uint64_t b = 0; b < n_bdds; ++b) {
-            const uint64_t d1 = delims[b + 1];
-            const uint32_t l0 = bdd_lay_ptr[b], l1 = bdd_lay_ptr[b + 1];
-            if (layer_end(b, l0) - lay_first[l0] != 1) {
-                err = "BDD " + std::to_string(b) + " does not have exactly one root node";
-                return BDDMMA_ERR_INVALID_BDD;
-            }
-            for (uint32_t l = l0; l < l1; ++l) {
-                const uint64_t f = lay_first[l], e = layer_end(b, l);
-                const uint64_t v = instr[f].index;
-                if (last_bdd[v] == b) {
-                    err = "BDD " + std::to_string(b) + " is not reordered: variable " + std::to_string(v) + " appears in two layers";
-                    return BDDMMA_ERR_INVALID_BDD;
+        // 1b: one root, every variable in one layer, arcs go to the next layer (QBDD), widths, shape hash, BDDs per variable
+        FirstError fe;
+        std::vector<uint64_t> thops(par.nt, 0);
+        par.run(n_bdds, [&](uint64_t b0, uint64_t b1, unsigned t) {
+            std::vector<uint64_t> vars;
+            uint64_t hops = 0;
+            for (uint64_t b = b0; b < b1; ++b) {
+                const uint64_t d1 = delims[b + 1];
+                const uint32_t l0 = bdd_lay_ptr[b], l1 = bdd_lay_ptr[b + 1];
+                if (layer_end(b, l0) - lay_first[l0] != 1) {
+                    fe.set(b, BDDMMA_ERR_INVALID_BDD, "BDD " + std::to_string(b) + " does not have exactly one root node");
+                    return;
                 }
-                last_bdd[v] = b;
-                L.num_bdds_per_var[v]++;
-                bdd_maxw[b] = std::max<uint32_t>(bdd_maxw[b], (uint32_t)(e - f));
-                bdd_shape[b] = (bdd_shape[b] ^ (e - f)) * 1099511628211ull + 0x9e3779b97f4a7c15ull;
-                const bool last = (l + 1 == l1);
-                const uint64_t nf = last ? 0 : lay_first[l + 1], ne = last ? 0 : layer_end(b, l + 1);
-                for (uint64_t i = f; i < e; ++i) {
-                    for (int side = 0; side < 2; ++side) {
-                        const uint64_t c = side ? instr[i].hi : instr[i].lo;
-                        if (c >= d1 || c < delims[b]) {
-                            err = "BDD " + std::to_string(b) + ": child index out of range";
-                            return BDDMMA_ERR_INVALID_BDD;
-                        }
-                        bdd_shape[b] = (bdd_shape[b] ^ (is_term(instr[c]) ? (is_top(instr[c]) ? ~0ull : ~1ull) : c - delims[b])) * 1099511628211ull;
-                        if (is_bot(instr[c])) continue;
-                        if (is_top(instr[c])) {
-                            if (!last) {
-                                err = "BDD " + std::to_string(b) + " is not a QBDD: arc to the top sink skips variables";
-                                return BDDMMA_ERR_INVALID_BDD;
+                vars.clear();
+                uint32_t maxw = 0;
+                uint64_t shape = 0;
+                for (uint32_t l = l0; l < l1; ++l) {
+                    const uint64_t f = lay_first[l], e = layer_end(b, l);
+                    const uint64_t v = instr[f].index;
+                    vars.push_back(v);
+                    __atomic_fetch_add(&L.num_bdds_per_var[v], 1, __ATOMIC_RELAXED);
+                    maxw = std::max<uint32_t>(maxw, (uint32_t)(e - f));
+                    shape = (shape ^ (e - f)) * 1099511628211ull + 0x9e3779b97f4a7c15ull;
+                    const bool last = (l + 1 == l1);
+                    const uint64_t nf = last ? 0 : lay_first[l + 1], ne = last ? 0 : layer_end(b, l + 1);
+                    for (uint64_t i = f; i < e; ++i) {
+                        for (int side = 0; side < 2; ++side) {
+                            const uint64_t c = side ? instr[i].hi : instr[i].lo;
+                            if (c >= d1 || c < delims[b]) {
+                                fe.set(b, BDDMMA_ERR_INVALID_BDD, "BDD " + std::to_string(b) + ": child index out of range");
+                                return;
                             }
-                            continue;
-                        }
-                        if (last || c < nf || c >= ne) {
-                            err = "BDD " + std::to_string(b) + " is not a QBDD: arc does not go to the next variable's layer";
-                            return BDDMMA_ERR_INVALID_BDD;
+                            shape = (shape ^ (is_term(instr[c]) ? (is_top(instr[c]) ? ~0ull : ~1ull) : c - delims[b])) * 1099511628211ull;
+                            if (is_bot(instr[c])) continue;
+                            if (is_top(instr[c])) {
+                                if (!last) {
+                                    fe.set(b, BDDMMA_ERR_INVALID_BDD, "BDD " + std::to_string(b) + " is not a QBDD: arc to the top sink skips variables");
+                                    return;
+                                }
+                                continue;
+                            }
+                            if (last || c < nf || c >= ne) {
+                                fe.set(b, BDDMMA_ERR_INVALID_BDD, "BDD " + std::to_string(b) + " is not a QBDD: arc does not go to the next variable's layer");
+                                return;
+                            }
                         }
                     }
                 }
+                // is_reordered (bdd_cuda_base.cu:98-99): no variable in two layers of one BDD
+                std::sort(vars.begin(), vars.end());
+                const auto dup = std::adjacent_find(vars.begin(), vars.end());
+                if (dup != vars.end()) {
+                    fe.set(b, BDDMMA_ERR_INVALID_BDD, "BDD " + std::to_string(b) + " is not reordered: variable " + std::to_string(*dup) + " appears in two layers");
+                    return;
+                }
+                bdd_maxw[b] = maxw;
+                bdd_shape[b] = shape;
+                hops = std::max<uint64_t>(hops, l1 - l0);
             }
-            L.n_hops = std::max<uint64_t>(L.n_hops, l1 - l0);
-        }
+            thops[t] = std::max(thops[t], hops);
+        });
+        if (fe.code) { err = fe.msg; return fe.code; }
+        for (uint64_t h : thops) L.n_hops = std::max(L.n_hops, h);
     }
 
+    lap("parse + validate");
     // ---- pass 2: narrow / wide classification and greedy pack formation ----------------------
     const uint32_t narrow_limit = std::min<uint32_t>(NARROW_MAX_LAYER_WIDTH, W);
     std::vector<uint32_t> order_n, order_w, order_h;
@@ -253,6 +345,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     // Narrow BDDs of the same shape are packed together (stable: input order inside a shape class), so that packs
     // are structurally identical and share one stored word sequence (layout.hpp: narrow_words_unique).  Classes are
     // ordered by first appearance.  The result does not depend on the order of the BDDs.
+    std::vector<uint32_t> order_cls;  // shape class of order_n[k] (empty when the input order is kept)
     if (!(opts && opts->keep_bdd_order == 1)) {
         std::unordered_map<uint64_t, uint32_t> cls;
         std::vector<uint32_t> cls_of(order_n.size());
@@ -261,7 +354,11 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         for (size_t k = 0; k < idx.size(); ++k) idx[k] = (uint32_t)k;
         std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cls_of[a] < cls_of[b]; });
         std::vector<uint32_t> grouped(order_n.size());
-        for (size_t k = 0; k < idx.size(); ++k) grouped[k] = order_n[idx[k]];
+        order_cls.resize(order_n.size());
+        for (size_t k = 0; k < idx.size(); ++k) {
+            grouped[k] = order_n[idx[k]];
+            order_cls[k] = cls_of[idx[k]];
+        }
         order_n.swap(grouped);
     }
     std::vector<uint32_t> lay_pos(Lin);  // slot position of every input layer inside its (pack,hop)
@@ -293,10 +390,94 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         }
         pb.finish((uint32_t)order.size());
     };
-    form(pn, order_n);
+    // Narrow BDDs arrive grouped by shape.  A long run of one shape (every row of a constraint family) is packed in closed form:
+    // first-fit of identical BDDs repeats the same pack, so one pack is simulated and stamped out; the per-BDD work (checking
+    // that the widths really are the representative's, writing the slot positions) is spread over the host threads.
+    auto form_narrow = [&]() {
+        if (order_cls.empty()) { form(pn, order_n); return; }
+        PackBuilder& pb = pn;
+        const uint32_t n_order = (uint32_t)order_n.size();
+        std::vector<uint32_t> rep_w;
+        std::vector<std::vector<uint32_t>> pos;  // pos[j][h]: slot position of layer h of the j-th BDD of a pack
+        uint32_t k = 0;
+        while (k < n_order) {
+            uint32_t k1 = k;
+            while (k1 < n_order && order_cls[k1] == order_cls[k]) ++k1;
+            const uint32_t m = k1 - k;
+            const uint64_t b_rep = order_n[k];
+            const uint32_t l_rep = bdd_lay_ptr[b_rep], n = bdd_lay_ptr[b_rep + 1] - l_rep;
+            bool uniform = m >= 256;
+            if (uniform) {
+                rep_w.resize(n);
+                for (uint32_t h = 0; h < n; ++h) rep_w[h] = (uint32_t)(layer_end(b_rep, l_rep + h) - lay_first[l_rep + h]);
+                // the class id comes from a hash: make sure the widths really agree
+                std::vector<char> bad(par.nt, 0);
+                par.run(m, [&](uint64_t i0, uint64_t i1, unsigned t) {
+                    for (uint64_t i = i0; i < i1 && !bad[t]; ++i) {
+                        const uint64_t b = order_n[k + i];
+                        const uint32_t l0 = bdd_lay_ptr[b];
+                        if (bdd_lay_ptr[b + 1] - l0 != n) { bad[t] = 1; break; }
+                        for (uint32_t h = 0; h < n; ++h)
+                            if ((uint32_t)(layer_end(b, l0 + h) - lay_first[l0 + h]) != rep_w[h]) { bad[t] = 1; break; }
+                    }
+                });
+                for (char c : bad) uniform = uniform && !c;
+            }
+            if (!uniform) {
+                for (uint32_t kk = k; kk < k1; ++kk) {
+                    const uint64_t b = order_n[kk];
+                    const uint32_t l0 = bdd_lay_ptr[b], nn = bdd_lay_ptr[b + 1] - l0;
+                    widths.resize(nn);
+                    for (uint32_t h = 0; h < nn; ++h) widths[h] = (uint32_t)(layer_end(b, l0 + h) - lay_first[l0 + h]);
+                    pb.add(kk, widths.data(), nn, &lay_pos[l0]);
+                }
+                k = k1;
+                continue;
+            }
+            pb.close();  // a uniform run starts with an empty pack
+            // simulate one pack
+            pos.clear();
+            std::vector<uint32_t> used(n, 0);
+            uint32_t maxw = 0;
+            for (uint32_t h = 0; h < n; ++h) maxw = std::max(maxw, rep_w[h]);
+            for (;;) {
+                bool fits = true;
+                for (uint32_t h = 0; h < n && fits; ++h)
+                    if (pb.place(used[h], rep_w[h]) + rep_w[h] > pb.width) fits = false;
+                if (!fits) break;
+                pos.emplace_back(n);
+                for (uint32_t h = 0; h < n; ++h) {
+                    pos.back()[h] = pb.place(used[h], rep_w[h]);
+                    used[h] = pos.back()[h] + rep_w[h];
+                }
+            }
+            const uint32_t c = (uint32_t)pos.size();  // >= 1: a narrow BDD always fits an empty pack
+            for (uint32_t first = 0; first < m; first += c) {
+                const uint32_t cnt = std::min(c, m - first);
+                pb.pack_first_bdd.push_back(k + first);
+                pb.pack_hop_ptr.push_back((uint32_t)pb.flat_used.size());
+                for (uint32_t h = 0; h < n; ++h) {
+                    pb.flat_used.push_back(pos[cnt - 1][h] + rep_w[h]);
+                    pb.flat_nlayers.push_back(cnt);
+                }
+                pb.pack_steps.push_back(PackBuilder::steps_for(maxw));
+            }
+            par.run(m, [&](uint64_t i0, uint64_t i1, unsigned) {
+                for (uint64_t i = i0; i < i1; ++i) {
+                    const uint32_t l0 = bdd_lay_ptr[order_n[k + i]];
+                    const std::vector<uint32_t>& pj = pos[i % c];
+                    for (uint32_t h = 0; h < n; ++h) lay_pos[l0 + h] = pj[h];
+                }
+            });
+            k = k1;
+        }
+        pb.finish(n_order);
+    };
+    form_narrow();
     form(pw, order_w);
     form(ph, order_h);
 
+    lap("classify + pack formation");
     // ---- pass 3: emit ----------------------------------------------------------------------
     uint64_t total_slots = 0;
     for (uint32_t u : pn.flat_used) total_slots += u;
@@ -320,70 +501,82 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     std::vector<uint32_t> in_layer_to_internal(Lin);
 
     uint32_t slot_cursor = 0, layer_cursor = 0;
+    std::vector<std::vector<uint64_t>> t_nodes(par.nt, std::vector<uint64_t>(L.n_hops, 0)), t_layers(par.nt, std::vector<uint64_t>(L.n_hops, 0));
     auto emit = [&](PackBuilder& pb, const std::vector<uint32_t>& order, PackSet& ps, bool wide) {
         const uint32_t P = pb.n_packs();
         ps.pack_hop_ptr.resize(P + 1);
         ps.pack_steps = pb.pack_steps;
-        std::vector<uint32_t> lcount;
-        for (uint32_t p = 0; p < P; ++p) {
-            const uint32_t q0 = pb.pack_hop_ptr[p], q1 = pb.pack_hop_ptr[p + 1];
-            ps.pack_hop_ptr[p] = (uint32_t)ps.hop_node_off.size();
-            const uint32_t H = q1 - q0;
-            const uint32_t base_q = (uint32_t)ps.hop_node_off.size();
-            for (uint32_t h = 0; h < H; ++h) {
-                ps.hop_node_off.push_back(slot_cursor);
-                ps.hop_layer_off.push_back(layer_cursor);
-                slot_cursor += pb.flat_used[q0 + h];
-                layer_cursor += pb.flat_nlayers[q0 + h];
-            }
-            lcount.assign(H, 0);
-            for (uint32_t k = pb.pack_first_bdd[p]; k < pb.pack_first_bdd[p + 1]; ++k) {
-                const uint64_t b = order[k];
-                const uint32_t l0 = bdd_lay_ptr[b], n = bdd_lay_ptr[b + 1] - l0;
-                for (uint32_t h = 0; h < n; ++h) {
-                    const uint32_t l = l0 + h;
-                    const uint64_t f = lay_first[l], e = layer_end(b, l);
-                    const uint32_t lloc = lcount[h]++;
-                    const uint32_t lg = ps.hop_layer_off[base_q + h] + lloc;
-                    in_layer_to_internal[l] = lg;
-                    L.layer_var[lg] = (int32_t)instr[f].index;
-                    L.layer_bdd[lg] = (int32_t)b;
-                    L.nodes_per_hop[h] += e - f;
-                    L.layers_per_hop[h] += 1;
-                    const bool last = (h + 1 == n);
-                    const uint64_t nf = last ? 0 : lay_first[l + 1];
-                    const uint32_t npos = last ? 0 : lay_pos[l + 1];
-                    for (uint64_t i = f; i < e; ++i) {
-                        const uint32_t j = lay_pos[l] + (uint32_t)(i - f);
-                        const uint32_t slot = ps.hop_node_off[base_q + h] + j;
-                        if (h == 0) L.bdd_root_slot[b] = slot;
-                        if (keep_debug_maps) L.slot_to_instr[slot] = i;
-                        uint64_t ch[2];
-                        for (int side = 0; side < 2; ++side) {
-                            const uint64_t c = side ? instr[i].hi : instr[i].lo;
-                            if (is_bot(instr[c])) ch[side] = wide ? WW_BOT : nw_bot(W);
-                            else if (is_top(instr[c])) ch[side] = wide ? WW_TOP : nw_top(W);
-                            else ch[side] = npos + (c - nf);
-                        }
-                        if (wide) {
-                            L.wide_words[slot - narrow_slots] =
-                                ch[0] | (ch[1] << WW_CHILD_BITS) | ((uint64_t)lloc << (2 * WW_CHILD_BITS)) | (i == f ? WW_HEAD : 0);
-                        } else {
-                            L.narrow_words[slot] = (uint32_t)ch[0] | ((uint32_t)ch[1] << NW_CHILD_BITS) |
-                                                   ((uint32_t)(i - f) << NW_POS_SHIFT) | ((uint32_t)(e - f - 1) << NW_LEN_SHIFT);
+        // offsets of every (pack, hop) record first (a running sum), then the packs are emitted independently
+        const uint32_t n_rec = P ? pb.pack_hop_ptr[P] : 0;
+        ps.hop_node_off.resize((size_t)n_rec + 1);
+        ps.hop_layer_off.resize((size_t)n_rec + 1);
+        for (uint32_t p = 0; p < P; ++p) ps.pack_hop_ptr[p] = pb.pack_hop_ptr[p];
+        ps.pack_hop_ptr[P] = n_rec;
+        for (uint32_t r = 0; r < n_rec; ++r) {
+            ps.hop_node_off[r] = slot_cursor;
+            ps.hop_layer_off[r] = layer_cursor;
+            slot_cursor += pb.flat_used[r];
+            layer_cursor += pb.flat_nlayers[r];
+        }
+        ps.hop_node_off[n_rec] = slot_cursor;
+        ps.hop_layer_off[n_rec] = layer_cursor;
+        par.run(P, [&](uint64_t p0, uint64_t p1, unsigned t) {  // min_parallel below: a pack is hundreds of nodes
+            std::vector<uint32_t> lcount;
+            for (uint32_t p = (uint32_t)p0; p < (uint32_t)p1; ++p) {
+                const uint32_t base_q = pb.pack_hop_ptr[p];
+                const uint32_t H = pb.pack_hop_ptr[p + 1] - base_q;
+                lcount.assign(H, 0);
+                for (uint32_t k = pb.pack_first_bdd[p]; k < pb.pack_first_bdd[p + 1]; ++k) {
+                    const uint64_t b = order[k];
+                    const uint32_t l0 = bdd_lay_ptr[b], n = bdd_lay_ptr[b + 1] - l0;
+                    for (uint32_t h = 0; h < n; ++h) {
+                        const uint32_t l = l0 + h;
+                        const uint64_t f = lay_first[l], e = layer_end(b, l);
+                        const uint32_t lloc = lcount[h]++;
+                        const uint32_t lg = ps.hop_layer_off[base_q + h] + lloc;
+                        in_layer_to_internal[l] = lg;
+                        L.layer_var[lg] = (int32_t)instr[f].index;
+                        L.layer_bdd[lg] = (int32_t)b;
+                        t_nodes[t][h] += e - f;
+                        t_layers[t][h] += 1;
+                        const bool last = (h + 1 == n);
+                        const uint64_t nf = last ? 0 : lay_first[l + 1];
+                        const uint32_t npos = last ? 0 : lay_pos[l + 1];
+                        for (uint64_t i = f; i < e; ++i) {
+                            const uint32_t j = lay_pos[l] + (uint32_t)(i - f);
+                            const uint32_t slot = ps.hop_node_off[base_q + h] + j;
+                            if (h == 0) L.bdd_root_slot[b] = slot;
+                            if (keep_debug_maps) L.slot_to_instr[slot] = i;
+                            uint64_t ch[2];
+                            for (int side = 0; side < 2; ++side) {
+                                const uint64_t c = side ? instr[i].hi : instr[i].lo;
+                                if (is_bot(instr[c])) ch[side] = wide ? WW_BOT : nw_bot(W);
+                                else if (is_top(instr[c])) ch[side] = wide ? WW_TOP : nw_top(W);
+                                else ch[side] = npos + (c - nf);
+                            }
+                            if (wide) {
+                                L.wide_words[slot - narrow_slots] =
+                                    ch[0] | (ch[1] << WW_CHILD_BITS) | ((uint64_t)lloc << (2 * WW_CHILD_BITS)) | (i == f ? WW_HEAD : 0);
+                            } else {
+                                L.narrow_words[slot] = (uint32_t)ch[0] | ((uint32_t)ch[1] << NW_CHILD_BITS) |
+                                                       ((uint32_t)(i - f) << NW_POS_SHIFT) | ((uint32_t)(e - f - 1) << NW_LEN_SHIFT);
+                            }
                         }
                     }
                 }
             }
-        }
-        ps.pack_hop_ptr[P] = (uint32_t)ps.hop_node_off.size();
-        ps.hop_node_off.push_back(slot_cursor);
-        ps.hop_layer_off.push_back(layer_cursor);
+        }, 64);
     };
     emit(pn, order_n, L.narrow, false);
     emit(pw, order_w, L.wide, true);
     emit(ph, order_h, L.huge, true);
+    for (unsigned t = 0; t < par.nt; ++t)
+        for (uint64_t h = 0; h < L.n_hops; ++h) {
+            L.nodes_per_hop[h] += t_nodes[t][h];
+            L.layers_per_hop[h] += t_layers[t][h];
+        }
     L.n_nodes = L.n_input_nodes - 2 * n_bdds;
+    lap("emit words");
     {   // structure templates: store every distinct pack word sequence once
         const PackSet& N = L.narrow;
         const uint32_t P = N.n_packs();
@@ -416,6 +609,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         }
     }
 
+    lap("structure templates");
     // ---- variable -> layers CSR, sorted by (variable, bdd) (bdd_cuda_base.cu:379-391) ---------
     L.var_ptr.assign(L.n_vars + 1, 0);
     for (uint64_t v = 0; v < L.n_vars; ++v) L.var_ptr[v + 1] = L.var_ptr[v] + (uint32_t)L.num_bdds_per_var[v];
@@ -427,6 +621,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
             L.var_layers[cursor[L.layer_var[lg]]++] = lg;
         }
     }
+    lap("variable CSR");
     // ---- variable <-> layer exchange tables (see layout.hpp, struct Exchange) --------------------
     {
         Exchange& X = L.ex;
@@ -489,35 +684,48 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         for (uint32_t l = 0; l < narrow_layers; ++l) X.grp_layer_off[layer_group[l] + 1] = l + 1;
         for (uint32_t g = 0; g < G; ++g)
             if (X.grp_layer_off[g + 1] < X.grp_layer_off[g]) X.grp_layer_off[g + 1] = X.grp_layer_off[g];
-        struct Key { uint32_t bin, group, layer; };
-        std::vector<Key> keys(Lin);
         // entries by (variable, bdd) (layout.hpp): only on request.  Measured at 1 / 2 / 4 M nodes: the exchange launch drops from 9.7 to
         // 5.3 us, but every sweep gains 6 / 14 / 35 us because its gathers and scatters in the entry arrays lose their runs — even
         // with the arrays in L2, a sweep's staging time follows the number of cache lines it touches.
         X.entry_by_var = opts && opts->exchange_by_variable == 2;
-        if (X.entry_by_var) {
-            // (variable, bdd) order = the order of var_layers; bins are ranges of variables, so they stay contiguous
-            for (uint32_t k = 0; k < Lin; ++k) {
-                const uint32_t l = L.var_layers[k];
-                keys[k] = Key{(uint32_t)L.layer_var[l] / X.vars_per_bin, layer_group[l], l};
-            }
-        } else {
-            for (uint32_t l = 0; l < Lin; ++l) keys[l] = Key{(uint32_t)L.layer_var[l] / X.vars_per_bin, layer_group[l], l};
-            // layers are already sorted by (group, layer); a stable sort by bin yields (bin, group, layer)
-            std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.bin < b.bin; });
-        }
+        // Entry order (bin, group, layer): the layers are already in (group, layer) order (narrow packs first, wide layers form the
+        // last pseudo group), so this is a stable counting sort by bin — chunks of the sequence are counted and scattered by the host
+        // threads independently.  With entry_by_var the sequence is var_layers ((variable, bdd) order; bins are ranges of variables).
+        (void)layer_group;
         X.bin_ptr.assign(X.n_bins + 1, 0);
         X.evar.assign(Lin, 0);
         X.bvar.assign(Lin, 0);
         X.lpos.assign(Lin, 0);
-        for (uint32_t e = 0; e < Lin; ++e) {
-            const Key& k = keys[e];
-            X.bin_ptr[k.bin + 1]++;
-            X.evar[e] = (uint32_t)L.layer_var[k.layer];
-            X.bvar[e] = (uint16_t)((uint32_t)L.layer_var[k.layer] - k.bin * X.vars_per_bin);
-            X.lpos[k.layer] = e;
+        {
+            const uint32_t VB = X.vars_per_bin, NB = X.n_bins;
+            auto layer_at = [&](uint64_t k) -> uint32_t { return X.entry_by_var ? L.var_layers[k] : (uint32_t)k; };
+            std::vector<std::vector<uint32_t>> hist(par.nt, std::vector<uint32_t>(NB, 0));
+            std::vector<uint64_t> chunk_begin(par.nt + 1, Lin);
+            par.run(Lin, [&](uint64_t k0, uint64_t k1, unsigned t) {
+                chunk_begin[t] = k0;
+                for (uint64_t k = k0; k < k1; ++k) hist[t][(uint32_t)L.layer_var[layer_at(k)] / VB]++;
+            });
+            for (uint32_t bb = 0; bb < NB; ++bb) {
+                uint32_t run = X.bin_ptr[bb];
+                for (unsigned t = 0; t < par.nt; ++t) {
+                    const uint32_t c = hist[t][bb];
+                    hist[t][bb] = run;  // first entry of (chunk t, bin bb)
+                    run += c;
+                }
+                X.bin_ptr[bb + 1] = run;
+            }
+            par.run(Lin, [&](uint64_t k0, uint64_t k1, unsigned t) {
+                for (uint64_t k = k0; k < k1; ++k) {
+                    const uint32_t l = layer_at(k);
+                    const uint32_t v = (uint32_t)L.layer_var[l], bb = v / VB;
+                    const uint32_t e = hist[t][bb]++;
+                    X.evar[e] = v;
+                    X.bvar[e] = (uint16_t)(v - bb * VB);
+                    X.lpos[l] = e;
+                }
+            });
         }
-        for (uint32_t b = 0; b < X.n_bins; ++b) X.bin_ptr[b + 1] += X.bin_ptr[b];
+        lap("entry tables");
         // cooperative staging tables
         // default: 4 packs per workgroup (measured after the node words became shared: 4 beats 8 in float by 5-8 %:
         // 28 KB of LDS per workgroup instead of 57 KB, i.e. 5 instead of 4 waves per SIMD)
@@ -537,39 +745,59 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         {
             const uint32_t WPB = X.waves_per_block;
             const uint32_t n_quads = (Pn + WPB - 1) / WPB;
+            // record offsets first (rounds per quad, items per round), then the quads fill their ranges independently
             X.quad_round_ptr.assign(n_quads + 1, 0);
-            X.cs_ptr.assign(1, 0);
-            X.cs_entry.reserve(narrow_layers);
-            X.cs_slot.reserve(narrow_layers);
-            std::vector<std::pair<uint32_t, uint16_t>> items;
             for (uint32_t Q = 0; Q < n_quads; ++Q) {
-                X.quad_round_ptr[Q] = (uint32_t)X.cs_ptr.size() - 1;
                 uint32_t rounds = 0;
                 for (uint32_t w = 0; w < WPB && Q * WPB + w < Pn; ++w) {
                     const uint32_t p = Q * WPB + w;
                     rounds = std::max(rounds, X.pack_group_ptr[p + 1] - X.pack_group_ptr[p]);
                 }
-                for (uint32_t k = 0; k < rounds; ++k) {
-                    items.clear();
+                X.quad_round_ptr[Q + 1] = X.quad_round_ptr[Q] + rounds;
+            }
+            const uint32_t n_rounds = X.quad_round_ptr[n_quads];
+            X.cs_ptr.assign((size_t)n_rounds + 1, 0);
+            for (uint32_t Q = 0; Q < n_quads; ++Q)
+                for (uint32_t r = X.quad_round_ptr[Q]; r < X.quad_round_ptr[Q + 1]; ++r) {
+                    const uint32_t k = r - X.quad_round_ptr[Q];
+                    uint32_t items = 0;
                     for (uint32_t w = 0; w < WPB && Q * WPB + w < Pn; ++w) {
                         const uint32_t p = Q * WPB + w;
                         const uint32_t g = X.pack_group_ptr[p] + k;
-                        if (g >= X.pack_group_ptr[p + 1]) continue;
-                        for (uint32_t l = X.grp_layer_off[g]; l < X.grp_layer_off[g + 1]; ++l)
-                            items.push_back({X.lpos[l], (uint16_t)(w * X.stage_cap + (l - X.grp_layer_off[g]))});
+                        if (g < X.pack_group_ptr[p + 1]) items += X.grp_layer_off[g + 1] - X.grp_layer_off[g];
                     }
-                    std::sort(items.begin(), items.end());
-                    for (const auto& it : items) {
-                        X.cs_entry.push_back(it.first);
-                        X.cs_slot.push_back(it.second);
-                    }
-                    X.cs_ptr.push_back((uint32_t)X.cs_entry.size());
+                    X.cs_ptr[r + 1] = X.cs_ptr[r] + items;
                 }
-            }
-            X.quad_round_ptr[n_quads] = (uint32_t)X.cs_ptr.size() - 1;
+            X.cs_entry.assign(narrow_layers, 0);
+            X.cs_slot.assign(narrow_layers, 0);
+            par.run(n_quads, [&](uint64_t Q0, uint64_t Q1, unsigned) {  // (a quad is ~2 500 items to gather and sort)
+                std::vector<std::pair<uint32_t, uint16_t>> items;
+                for (uint32_t Q = (uint32_t)Q0; Q < (uint32_t)Q1; ++Q)
+                    for (uint32_t r = X.quad_round_ptr[Q]; r < X.quad_round_ptr[Q + 1]; ++r) {
+                        const uint32_t k = r - X.quad_round_ptr[Q];
+                        items.clear();
+                        for (uint32_t w = 0; w < WPB && Q * WPB + w < Pn; ++w) {
+                            const uint32_t p = Q * WPB + w;
+                            const uint32_t g = X.pack_group_ptr[p] + k;
+                            if (g >= X.pack_group_ptr[p + 1]) continue;
+                            for (uint32_t l = X.grp_layer_off[g]; l < X.grp_layer_off[g + 1]; ++l)
+                                items.push_back({X.lpos[l], (uint16_t)(w * X.stage_cap + (l - X.grp_layer_off[g]))});
+                        }
+                        std::sort(items.begin(), items.end());
+                        uint32_t o = X.cs_ptr[r];
+                        for (const auto& it : items) {
+                            X.cs_entry[o] = it.first;
+                            X.cs_slot[o] = it.second;
+                            ++o;
+                        }
+                    }
+            }, 16);
         }
+        lap("cooperative staging tables");
         X.vpos.assign(Lin, 0);
-        for (uint32_t k = 0; k < Lin; ++k) X.vpos[k] = X.lpos[L.var_layers[k]];
+        par.run(Lin, [&](uint64_t k0, uint64_t k1, unsigned) {
+            for (uint64_t k = k0; k < k1; ++k) X.vpos[k] = X.lpos[L.var_layers[k]];
+        });
 
         // headers of the resident sweeps (layout.hpp: struct Resident)
         {
@@ -601,6 +829,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
             }
         }
     }
+    lap("vpos + resident headers");
     return BDDMMA_OK;
 }
 

@@ -152,6 +152,54 @@ struct HostLayout {
     std::vector<uint64_t> slot_to_instr;
 };
 
+// ---- checkpointing the layout ------------------------------------------------------------------
+// The reference archives every index array of the device layout (bdd_cuda_base.cu:1486-1550) so that a solver can be restored
+// without redoing the construction.  Same here: the scalars below + every array visit_layout_arrays names are what the device
+// solver is built from (create_solver), so writing them and reading them back skips build_layout entirely.
+struct LayoutScalars {
+    uint64_t n_bdds, n_vars, n_hops, n_input_nodes, n_slots, n_nodes, n_layers;
+    uint32_t pack_width, wide_pack_width, huge_pack_width, narrow_slots;
+    uint32_t vars_per_bin, n_bins, stage_cap, waves_per_block, entry_by_var;
+    uint32_t res_ok, res_max_slots, res_max_layers;
+    uint32_t reserved[4];
+};
+inline LayoutScalars layout_scalars(const HostLayout& L)
+{
+    LayoutScalars s{};
+    s.n_bdds = L.n_bdds; s.n_vars = L.n_vars; s.n_hops = L.n_hops; s.n_input_nodes = L.n_input_nodes; s.n_slots = L.n_slots;
+    s.n_nodes = L.n_nodes; s.n_layers = L.n_layers;
+    s.pack_width = L.pack_width; s.wide_pack_width = L.wide_pack_width; s.huge_pack_width = L.huge_pack_width; s.narrow_slots = L.narrow_slots;
+    s.vars_per_bin = L.ex.vars_per_bin; s.n_bins = L.ex.n_bins; s.stage_cap = L.ex.stage_cap; s.waves_per_block = L.ex.waves_per_block;
+    s.entry_by_var = L.ex.entry_by_var ? 1 : 0;
+    s.res_ok = L.res.ok ? 1 : 0; s.res_max_slots = L.res.max_slots; s.res_max_layers = L.res.max_layers;
+    return s;
+}
+inline void set_layout_scalars(HostLayout& L, const LayoutScalars& s)
+{
+    L.n_bdds = s.n_bdds; L.n_vars = s.n_vars; L.n_hops = s.n_hops; L.n_input_nodes = s.n_input_nodes; L.n_slots = s.n_slots;
+    L.n_nodes = s.n_nodes; L.n_layers = s.n_layers;
+    L.pack_width = s.pack_width; L.wide_pack_width = s.wide_pack_width; L.huge_pack_width = s.huge_pack_width; L.narrow_slots = s.narrow_slots;
+    L.ex.vars_per_bin = s.vars_per_bin; L.ex.n_bins = s.n_bins; L.ex.stage_cap = s.stage_cap; L.ex.waves_per_block = s.waves_per_block;
+    L.ex.entry_by_var = s.entry_by_var != 0;
+    L.res.ok = s.res_ok != 0; L.res.max_slots = s.res_max_slots; L.res.max_layers = s.res_max_layers;
+}
+// every array create_solver consumes, with a stable id (the checkpoint format); v(id, vector&)
+template <typename LAYOUT, typename V>
+void visit_layout_arrays(LAYOUT& L, V&& v)
+{
+    v(1, L.narrow_words_unique); v(2, L.narrow_word_off); v(3, L.wide_words);
+    v(4, L.layer_var); v(5, L.layer_bdd); v(6, L.num_bdds_per_var); v(7, L.var_ptr); v(8, L.var_layers); v(9, L.bdd_root_slot);
+    v(10, L.narrow.pack_hop_ptr); v(11, L.narrow.hop_node_off); v(12, L.narrow.hop_layer_off); v(13, L.narrow.pack_steps);
+    v(14, L.wide.pack_hop_ptr); v(15, L.wide.hop_node_off); v(16, L.wide.hop_layer_off); v(17, L.wide.pack_steps);
+    v(18, L.huge.pack_hop_ptr); v(19, L.huge.hop_node_off); v(20, L.huge.hop_layer_off); v(21, L.huge.pack_steps);
+    v(22, L.ex.evar); v(23, L.ex.bvar); v(24, L.ex.lpos); v(25, L.ex.vpos); v(26, L.ex.bin_ptr);
+    v(27, L.ex.pack_group_ptr); v(28, L.ex.grp_layer_off); v(29, L.ex.grp_hop_end);
+    v(30, L.ex.quad_round_ptr); v(31, L.ex.cs_ptr); v(32, L.ex.cs_entry); v(33, L.ex.cs_slot);
+    v(34, L.res.pack_hdr); v(35, L.res.quad_hdr);
+    v(36, L.nodes_per_hop); v(37, L.layers_per_hop);
+}
+constexpr int LAYOUT_ARRAY_IDS = 38;
+
 // Returns BDDMMA_OK or an error code; `err` receives the message.
 int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
                  const bddmma_options* opts, HostLayout& out, std::string& err, bool keep_debug_maps,

