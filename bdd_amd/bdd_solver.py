@@ -109,8 +109,15 @@ class bdd_solver:
             raise RuntimeError(f"relaxation solver {name} unknown")
         # NB: the reference constructs the <float> GPU solver for "double" and vice versa (:167-174); here
         # "precision" means what it says.
-        c = np.zeros(max(bdd_col.nr_variables(), len(costs)))
-        c[: len(costs)] = costs
+        # The solver's variables are those of the BDDs.  A variable that occurs in the objective only is free: its better value
+        # contributes min(0, c) to the bound and is fixed in the primal (the reference only asserts on such costs,
+        # bdd_parallel_mma_base.cpp:685-695).
+        nv = bdd_col.nr_variables()
+        costs = np.asarray(costs, float)
+        c = np.zeros(nv)
+        c[: min(nv, len(costs))] = costs[:nv]
+        self.free_ones = (costs[nv:] < 0).astype(np.int8)
+        self.free_constant = float(costs[nv:][costs[nv:] < 0].sum())
         s = bdd_hip_parallel_mma(bdd_col, c, precision="double" if precision == "double" else "float",
                                  device=int(self.config.get("device", 0)))
         lb = None
@@ -153,7 +160,12 @@ class bdd_solver:
         if not found.value:
             _log("[incremental primal rounding] No solution found", self.quiet)
             return []
-        self.solution = sol[: self.ilp.nr_variables()].astype(int).tolist()
+        full = np.zeros(max(V, self.ilp.nr_variables()), np.int8)
+        full[:V] = sol
+        n_free = min(len(self.free_ones), len(full) - V) if len(full) > V else 0
+        if n_free:
+            full[V:V + n_free] = self.free_ones[:n_free]   # variables of the objective only: their better value
+        self.solution = full[: self.ilp.nr_variables()].astype(int).tolist()
         obj = self.ilp.evaluate(self.solution) if self.ilp.feasible(self.solution) else float("inf")
         _log(f"[incremental primal rounding] solution objective = {obj}", self.quiet)
         return self.solution
@@ -177,7 +189,7 @@ class bdd_solver:
         return self
 
     def lower_bound(self) -> float:
-        return self.solver.lower_bound() + self.ilp.constant
+        return self.solver.lower_bound() + self.ilp.constant + getattr(self, "free_constant", 0.0)
 
     def min_marginals(self):
         """[var][bdd] -> (mm0, mm1).  (The reference throws for GPU solvers, :497-514; the backend has them.)"""

@@ -52,6 +52,7 @@ _V, _U64, _I, _D = C.c_void_p, C.c_uint64, C.c_int, C.c_double
 SIGNATURES = {
     "bddmma_create": (_I, [C.POINTER(_V), _I, _I, _V, _V, _U64, _V, _U64, C.POINTER(Options)]),
     "bddmma_destroy": (None, [_V]),
+    "bddmma_device_count": (_I, []),
     "bddmma_last_error": (C.c_char_p, [_V]),
     "bddmma_nr_variables": (_U64, [_V]),
     "bddmma_nr_bdds": (_U64, [_V]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "bddmma_get_delta": (_I, [_V, _V, _I]),
     "bddmma_set_delta": (_I, [_V, _V, _I]),
     "bddmma_min_marginals": (_I, [_V, _I, _V, _V, _V, _I]),
+    "bddmma_min_marginal_diff": (_I, [_V, _V, _I]),
     "bddmma_bdds_solution": (_I, [_V, _I, _V, _I]),
     "bddmma_net_solver_costs": (_I, [_V, _V, _I]),
     "bddmma_make_dual_feasible": (_I, [_V, _V, _I]),

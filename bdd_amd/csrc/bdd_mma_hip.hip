@@ -720,6 +720,19 @@ struct SolverT final : SolverBase {
         HIPCHK(e);
         return BDDMMA_OK;
     }
+    int min_marginal_diff(void* out, int on_device) override
+    {
+        HIPCHK(hipSetDevice(device));
+        int rc;
+        if ((rc = forward_run())) return rc;
+        if ((rc = launch_bwd<BWD_MARGINALS>(nullptr, REAL(0), BDDMMA_K_OTHER))) return rc;
+        bwd_valid = true;
+        REAL* dst = on_device ? (REAL*)out : d_tmp0;  // in place over mm0 when the result goes to the host
+        hipLaunchKernelGGL((k_diff<REAL, REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, dst, (const REAL*)d_tmp1, (const REAL*)d_tmp0, (uint32_t)n_layers);
+        if (!on_device) return copy_out(out, dst, n_layers * sizeof(REAL), 0);
+        HIPCHK(hipStreamSynchronize(stream));
+        return BDDMMA_OK;
+    }
     int bdds_solution(int sorted, char* sol, int on_device) override
     {
         HIPCHK(hipSetDevice(device));
@@ -930,6 +943,12 @@ int SolverBase::time_iterations(double omega, uint64_t n, double* ms)
     HIPCHK(hipEventElapsedTime(&f, ev_t0, ev_t1));
     *ms = f;
     return BDDMMA_OK;
+}
+
+int device_count()
+{
+    int count = 0;
+    return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
 }
 
 int create_solver(SolverBase** out, int precision, int device, const HostLayout& L, const bddmma_options* opts, std::string& err)

@@ -94,6 +94,8 @@ int bddmma_create(bddmma_solver** out, int precision, int device, const bddmma_i
     }
 }
 
+int bddmma_device_count(void) { return device_count(); }
+
 void bddmma_destroy(bddmma_solver* s)
 {
     if (!s) return;
@@ -209,6 +211,10 @@ int bddmma_set_delta(bddmma_solver* s, const void* in, int on_device)
 int bddmma_min_marginals(bddmma_solver* s, int sorted, int32_t* var, void* mm0, void* mm1, int on_device)
 {
     return guarded(s, [&](SolverBase* b) { return b->min_marginals(sorted, var, mm0, mm1, on_device); });
+}
+int bddmma_min_marginal_diff(bddmma_solver* s, void* out, int on_device)
+{
+    return guarded(s, [&](SolverBase* b) { return out ? b->min_marginal_diff(out, on_device) : BDDMMA_ERR_INVALID_ARGUMENT; });
 }
 int bddmma_bdds_solution(bddmma_solver* s, int sorted, char* sol, int on_device)
 {

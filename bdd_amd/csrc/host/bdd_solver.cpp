@@ -1,6 +1,13 @@
 // bdd_solver.cpp — see bdd_solver.hpp.
 #include "bdd_solver.hpp"
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+#include "../../../include/bdd_ilp.h"
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -38,7 +45,7 @@ std::string extension(const std::string& p)
 }
 }  // namespace
 
-bdd_solver::bdd_solver(const std::string& config, bool quiet) : quiet_(quiet)
+bdd_solver::bdd_solver(const std::string& config, bool quiet, int device) : quiet_(quiet), device_(device)
 {
     config_ = json::parse(file_exists(config) ? slurp(config) : config);
     if (!config_.is_object()) throw std::runtime_error("configuration must be a JSON object");
@@ -111,9 +118,21 @@ void bdd_solver::construct_solver(const bdd_store& col, const std::vector<double
     if (!GPU_MMA.count(name) && !GPU_LBFGS.count(name)) throw std::runtime_error("relaxation solver " + name + " unknown");
     // NB: the reference constructs the <float> GPU solver for "double" and vice versa (:167-174); here
     // "precision" means what it says.
-    std::vector<double> c(std::max(col.nr_variables(), costs.size()), 0.0);
-    std::copy(costs.begin(), costs.end(), c.begin());
-    const int rc = bddmma_create(&solver_, precision == "double" ? BDDMMA_F64 : BDDMMA_F32, (int)config_.number_or("device", 0),
+    // The solver's variables are those of the BDDs.  A variable that occurs in the objective only (in no constraint, with an index
+    // past the last constrained one) is free: its better value contributes min(0, c) to the bound and is fixed in the primal.
+    // (The reference only asserts on such costs, bdd_parallel_mma_base.cpp:685-695; release builds drop them.)
+    const size_t nv = col.nr_variables();
+    std::vector<double> c(nv, 0.0);
+    std::copy(costs.begin(), costs.begin() + (long)std::min(nv, costs.size()), c.begin());
+    free_constant_ = 0;
+    free_ones_.assign(costs.size() > nv ? costs.size() - nv : 0, 0);
+    for (size_t v = nv; v < costs.size(); ++v)
+        if (costs[v] < 0) {
+            free_constant_ += costs[v];
+            free_ones_[v - nv] = 1;
+        }
+    const int device = device_ >= 0 ? device_ : (int)config_.number_or("device", 0);
+    const int rc = bddmma_create(&solver_, precision == "double" ? BDDMMA_F64 : BDDMMA_F32, device,
                                  col.instructions.data(), col.delimiters.data(), col.nr_bdds(), c.data(), c.size(), nullptr);
     if (rc != BDDMMA_OK) throw std::runtime_error(bddmma_last_error(nullptr));
     if (GPU_LBFGS.count(name)) {
@@ -136,6 +155,7 @@ bddmma_run_result bdd_solver::solve_dual()
     check(bddmma_run_solver(solver_, lbfgs_, (uint64_t)tc.number_or("maximum iterations", 1000), tc.number_or("minimum improvement", 1e-6),
                             tc.number_or("improvement slope", 1e-9), tc.number_or("time limit", 3600), quiet_ ? 0 : 1, &res));
     log("[bdd solver] Terminated dual optimization");
+    result_ = res;
     return res;
 }
 
@@ -152,6 +172,11 @@ std::vector<char> bdd_solver::perturbation_rounding()
     if (!found) {
         log("[incremental primal rounding] No solution found");
         return {};
+    }
+    if (sol.size() < ilp_.nr_variables()) {  // variables of the objective only: their better value (construct_solver)
+        const size_t nv = sol.size();
+        sol.resize(ilp_.nr_variables(), 0);
+        for (size_t v = nv; v < sol.size() && v - nv < free_ones_.size(); ++v) sol[v] = free_ones_[v - nv];
     }
     sol.resize(ilp_.nr_variables());  // auxiliary split variables are not part of the answer
     solution_ = sol;
@@ -201,7 +226,7 @@ double bdd_solver::lower_bound()
 {
     double lb = 0;
     check(bddmma_lower_bound(solver_, &lb));
-    return lb + ilp_.constant;
+    return lb + ilp_.constant + free_constant_;
 }
 
 std::vector<std::vector<std::array<double, 2>>> bdd_solver::min_marginals()
@@ -215,6 +240,108 @@ std::vector<std::vector<std::array<double, 2>>> bdd_solver::min_marginals()
     std::vector<std::vector<std::array<double, 2>>> out(V);
     for (size_t l = 0; l < L; ++l) out[var[l]].push_back({f64 ? m0d[l] : (double)m0f[l], f64 ? m1d[l] : (double)m1f[l]});
     out.resize(ilp_.nr_variables() ? std::min(V, ilp_.nr_variables()) : V);
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------- batch farm
+std::vector<batch_result> solve_batch(const std::vector<std::string>& configs, const std::vector<int>& devices, bool quiet)
+{
+    std::vector<batch_result> out(configs.size());
+    if (devices.empty()) throw std::runtime_error("solve_batch: no devices");
+    std::atomic<size_t> next{0};
+    auto worker = [&](int device) {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= configs.size()) return;
+            batch_result& r = out[i];
+            r.config = configs[i];
+            r.device = device;
+            const auto t0 = std::chrono::steady_clock::now();
+            try {
+                bdd_solver s(configs[i], quiet, device);
+                s.solve();
+                r.lower_bound = s.lower_bound();
+                r.iterations = s.result().iterations;
+                r.has_primal = !s.solution().empty();
+                r.primal = s.solution_objective();
+                r.ok = true;
+            } catch (const std::exception& e) {
+                r.error = e.what();
+            }
+            r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int d : devices) th.emplace_back(worker, d);
+    for (auto& t : th) t.join();
+    return out;
+}
+
+std::vector<bench_result> bench_set_cover(uint64_t n_vars, uint64_t n_rows, uint64_t k, const std::vector<uint64_t>& seeds, const std::vector<int>& devices,
+                                          const std::string& precision, uint64_t warmup, uint64_t iterations, double* aggregate)
+{
+    if (devices.empty() || seeds.empty()) throw std::runtime_error("bench_set_cover: no devices / seeds");
+    std::vector<bench_result> out(seeds.size());
+    std::vector<double> ms(seeds.size(), 0.0);
+    // every instance is built first; the timed loops start together (a barrier over the threads) and run concurrently
+    std::mutex m;
+    std::condition_variable cv;
+    size_t ready = 0;
+    auto worker = [&](size_t i) {
+        bench_result& r = out[i];
+        r.device = devices[i % devices.size()];
+        r.seed = seeds[i];
+        bddmma_solver* s = nullptr;
+        try {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<uint64_t> rows(n_rows * k);
+            std::vector<double> costs(n_vars);
+            if (bddilp_random_set_cover(n_vars, n_rows, k, seeds[i], rows.data(), costs.data()) != BDDILP_OK) throw std::runtime_error("invalid instance sizes");
+            bdd_store col;
+            std::vector<size_t> row(k);
+            for (uint64_t b = 0; b < n_rows; ++b) {
+                for (uint64_t j = 0; j < k; ++j) row[j] = (size_t)rows[b * k + j];
+                col.add_covering(row);
+            }
+            costs.resize(col.nr_variables());
+            const int rc = bddmma_create(&s, (precision == "float" || precision == "single") ? BDDMMA_F32 : BDDMMA_F64, r.device, col.instructions.data(),
+                                         col.delimiters.data(), col.nr_bdds(), costs.data(), costs.size(), nullptr);
+            if (rc != BDDMMA_OK) throw std::runtime_error(bddmma_last_error(nullptr));
+            if (bddmma_iterations(s, 0.5, warmup) != BDDMMA_OK || bddmma_synchronize(s) != BDDMMA_OK) throw std::runtime_error(bddmma_last_error(s));
+            r.construct_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            r.ok = true;
+        } catch (const std::exception& e) {
+            r.error = e.what();
+        }
+        {
+            std::unique_lock<std::mutex> l(m);
+            if (++ready == seeds.size()) cv.notify_all();
+            else cv.wait(l, [&] { return ready == seeds.size(); });
+        }
+        if (r.ok) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (bddmma_iterations(s, 0.5, iterations) != BDDMMA_OK || bddmma_synchronize(s) != BDDMMA_OK) {
+                r.ok = false;
+                r.error = bddmma_last_error(s);
+            }
+            ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (r.ok) {
+                r.iterations_per_second = iterations / (ms[i] * 1e-3);
+                bddmma_lower_bound(s, &r.lower_bound);
+            }
+        }
+        if (s) bddmma_destroy(s);
+    };
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < seeds.size(); ++i) th.emplace_back(worker, i);
+    for (auto& t : th) t.join();
+    if (aggregate) {
+        double worst = 0;
+        size_t n_ok = 0;
+        for (size_t i = 0; i < seeds.size(); ++i)
+            if (out[i].ok) { worst = std::max(worst, ms[i]); ++n_ok; }
+        *aggregate = worst > 0 ? n_ok * iterations / (worst * 1e-3) : 0;
+    }
     return out;
 }
 

@@ -5,7 +5,8 @@
 // perturbation_rounding (bdd_solver::solve, :477-495).  Only the relaxation solvers of the hot path exist
 // ("cuda parallel mma" and the GPU L-BFGS names); asking for a CPU solver, an ILP re-ordering or an exporter
 // other than .lp throws std::runtime_error like the reference does for an unknown option.
-// bdd_amd/bdd_solver.py is the same driver in Python (the pybind module's role, bdd_solver_py.cpp:9-20).
+// bdd_solver_py.cpp binds this class for Python (the reference's pybind module, src/bdd_solver/bdd_solver_py.cpp:9-20);
+// bdd_amd/bdd_solver.py is the same driver written in Python, kept as the readable specification.
 #pragma once
 #include <array>
 #include <string>
@@ -20,7 +21,8 @@ namespace bddmma_host {
 class bdd_solver {
 public:
     // config: JSON text or the path of a JSON file (bdd_solver.cpp:468-475)
-    explicit bdd_solver(const std::string& config, bool quiet = false);
+    // device >= 0 overrides the config's "device" (the batch farm places one solver per GPU)
+    explicit bdd_solver(const std::string& config, bool quiet = false, int device = -1);
     ~bdd_solver();
     bdd_solver(const bdd_solver&) = delete;
     bdd_solver& operator=(const bdd_solver&) = delete;
@@ -40,6 +42,7 @@ public:
     const bdd_store& bdds() const { return col_; }
     const std::vector<char>& solution() const { return solution_; }
     double solution_objective() const { return solution_objective_; }
+    const bddmma_run_result& result() const { return result_; }  // of the last solve_dual()
     bddmma_solver* handle() { return solver_; }
 
 private:
@@ -47,13 +50,44 @@ private:
     void check(int rc) const;
     json config_;
     bool quiet_;
+    int device_ = -1;
     bool constructed_ = false;
+    // variables that occur in the objective only (in no constraint): fixed to their better value, min(0, c) goes to the bound
+    double free_constant_ = 0;
+    std::vector<char> free_ones_;
     ilp_input ilp_;
     bdd_store col_;
     bddmma_solver* solver_ = nullptr;
     bddmma_lbfgs* lbfgs_ = nullptr;
     std::vector<char> solution_;
     double solution_objective_ = 0;
+    bddmma_run_result result_{};
 };
+
+// ---- batch farm: independent instances over the GPUs of one node, one host thread per device, no collective
+// (BASELINE.json north_star / configs[4]; the reference hard-codes device 0, include/cuda_utils.h:111-114).
+struct batch_result {
+    std::string config;
+    int device = -1;
+    bool ok = false;
+    std::string error;
+    double lower_bound = 0, primal = 0, seconds = 0;
+    bool has_primal = false;
+    uint64_t iterations = 0;
+};
+// configs are handed to the device threads dynamically (a thread takes the next one when its GPU is free); devices may repeat
+std::vector<batch_result> solve_batch(const std::vector<std::string>& configs, const std::vector<int>& devices, bool quiet);
+
+struct bench_result {
+    int device = -1;
+    uint64_t seed = 0;
+    bool ok = false;
+    std::string error;
+    double construct_seconds = 0, iterations_per_second = 0, lower_bound = 0;
+};
+// random set cover (bddilp_random_set_cover) with seeds[i] on devices[i % devices.size()], all started together; *aggregate =
+// iterations of all instances / the slowest one's time (the weak-scaling figure of the benchmark)
+std::vector<bench_result> bench_set_cover(uint64_t n_vars, uint64_t n_rows, uint64_t k, const std::vector<uint64_t>& seeds, const std::vector<int>& devices,
+                                          const std::string& precision, uint64_t warmup, uint64_t iterations, double* aggregate);
 
 }  // namespace bddmma_host

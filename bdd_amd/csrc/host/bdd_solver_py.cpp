@@ -1,0 +1,175 @@
+// bdd_solver_py.cpp — pybind11 module `bdd_solver_py`: the Python face of the C++ driver and of the GPU solver.
+//
+// Mirrors the reference's two pybind modules for this path:
+//   bdd_solver_py.bdd_solver            src/bdd_solver/bdd_solver_py.cpp:9-20   (ctor from a config string / dict, solve,
+//                                       lower_bound, min_marginals, min_marginals_with_variable_names)
+//   bdd_cuda_parallel_mma_py.bdd_cuda_parallel_mma   src/bdd_solver/bdd_cuda_parallel_mma_py.cu:15-80  (ctor from an ILP, pickle
+//                                       through the solver's own serialisation, sizes, lower_bound,
+//                                       compute_and_set_min_marginal_diff on a device pointer)
+// Everything computes through the C-ABI of include/bdd_mma.h / include/bdd_ilp.h; nothing here touches HIP.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iterator>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unistd.h>
+#include <vector>
+
+#include "../../../include/bdd_ilp.h"
+#include "../../../include/bdd_mma.h"
+#include "bdd_solver.hpp"
+
+namespace py = pybind11;
+
+namespace {
+
+std::string config_text(const py::object& cfg)
+{
+    if (py::isinstance<py::str>(cfg)) return cfg.cast<std::string>();
+    return py::module_::import("json").attr("dumps")(cfg).cast<std::string>();  // a dict, as pybind11_json would take it
+}
+
+void ck(int rc, const bddmma_solver* s)
+{
+    if (rc != BDDMMA_OK) throw std::runtime_error(std::string("bdd_mma error ") + std::to_string(rc) + ": " + bddmma_last_error(s));
+}
+
+// LPMP::bdd_cuda_parallel_mma<REAL> as the Python module exposes it
+struct hip_solver {
+    bddmma_solver* h = nullptr;
+    hip_solver() = default;
+    hip_solver(const hip_solver&) = delete;
+    hip_solver& operator=(const hip_solver&) = delete;
+    ~hip_solver() { bddmma_destroy(h); }
+
+    // ctor from an ILP (bdd_cuda_parallel_mma_py.cu:38-43): .lp / OPB text -> one QBDD per row -> solver, objective as costs
+    static std::unique_ptr<hip_solver> from_ilp(const std::string& text, const std::string& precision, int device)
+    {
+        bddilp* ilp = nullptr;
+        if (bddilp_parse(text.c_str(), &ilp) != BDDILP_OK) throw std::runtime_error(std::string("cannot parse the ILP: ") + bddilp_last_error());
+        bddilp_bdds* col = nullptr;
+        if (bddilp_to_bdds(ilp, 0, 0, &col) != BDDILP_OK) {
+            const std::string msg = bddilp_last_error();
+            bddilp_destroy(ilp);
+            throw std::runtime_error(msg);
+        }
+        std::vector<double> obj(bddilp_nr_variables(ilp));
+        double constant = 0;
+        bddilp_objective(ilp, obj.data(), &constant);
+        obj.resize(std::min<size_t>(obj.size(), bddilp_bdds_nr_variables(col)));
+        auto s = std::make_unique<hip_solver>();
+        const int prec = (precision == "float" || precision == "single") ? BDDMMA_F32 : BDDMMA_F64;
+        const int rc = bddmma_create(&s->h, prec, device, bddilp_bdds_instructions(col), bddilp_bdds_delimiters(col), bddilp_bdds_nr_bdds(col),
+                                     obj.data(), obj.size(), nullptr);
+        bddilp_bdds_destroy(col);
+        bddilp_destroy(ilp);
+        ck(rc, nullptr);
+        return s;
+    }
+    // pickle (bdd_cuda_parallel_mma_py.cu:15-37): the solver's own archive (bddmma_save / bddmma_load) as bytes
+    py::bytes dumps() const
+    {
+        char path[] = "/dev/shm/bddmma_pickle_XXXXXX";
+        const int fd = mkstemp(path);
+        if (fd < 0) throw std::runtime_error("cannot create a temporary file for pickling");
+        close(fd);
+        const int rc = bddmma_save(h, path);
+        std::string blob;
+        if (rc == BDDMMA_OK) {
+            std::ifstream f(path, std::ios::binary);
+            blob.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        }
+        std::remove(path);
+        ck(rc, h);
+        return py::bytes(blob);
+    }
+    static std::unique_ptr<hip_solver> loads(const py::bytes& b, int device)
+    {
+        const std::string blob = b;
+        char path[] = "/dev/shm/bddmma_pickle_XXXXXX";
+        const int fd = mkstemp(path);
+        if (fd < 0) throw std::runtime_error("cannot create a temporary file for unpickling");
+        close(fd);
+        { std::ofstream f(path, std::ios::binary); f.write(blob.data(), (std::streamsize)blob.size()); }
+        auto s = std::make_unique<hip_solver>();
+        const int rc = bddmma_load(&s->h, device, path);
+        std::remove(path);
+        ck(rc, nullptr);
+        return s;
+    }
+};
+
+}  // namespace
+
+PYBIND11_MODULE(bdd_solver_py, m)
+{
+    m.doc() = "Bindings for the BDD solver with the MI355X parallel-MMA backend.";
+    using bddmma_host::bdd_solver;
+    py::class_<bdd_solver>(m, "bdd_solver")
+        .def(py::init([](const py::object& cfg, bool quiet) { return std::make_unique<bdd_solver>(config_text(cfg), quiet); }), py::arg("config"),
+             py::arg("quiet") = false)
+        .def("solve", [](py::object self) { self.cast<bdd_solver&>().solve(); return self; })
+        .def("lower_bound", &bdd_solver::lower_bound)
+        .def("min_marginals", &bdd_solver::min_marginals)   // [var][bdd] -> [mm0, mm1]
+        .def("min_marginals_with_variable_names",           // bdd_solver.cpp:516-527: (names, mm0 per variable, mm1 per variable)
+             [](bdd_solver& s) {
+                 const auto mm = s.min_marginals();
+                 std::vector<std::vector<double>> m0(mm.size()), m1(mm.size());
+                 for (size_t v = 0; v < mm.size(); ++v)
+                     for (const auto& p : mm[v]) { m0[v].push_back(p[0]); m1[v].push_back(p[1]); }
+                 std::vector<std::string> names(s.ilp().var_names.begin(), s.ilp().var_names.begin() + (long)mm.size());
+                 return py::make_tuple(names, m0, m1);
+             })
+        .def_property_readonly("solution",
+                               [](const bdd_solver& s) -> py::object {
+                                   if (s.solution().empty()) return py::none();
+                                   py::list l;
+                                   for (char c : s.solution()) l.append((int)c);
+                                   return l;
+                               })
+        .def_property_readonly("solution_objective", &bdd_solver::solution_objective)
+        .def_property_readonly("result", [](const bdd_solver& s) {
+            const bddmma_run_result& r = s.result();
+            py::dict d;
+            d["iterations"] = r.iterations; d["lb_initial"] = r.lb_initial; d["lb_final"] = r.lb_final; d["seconds"] = r.seconds;
+            d["stop_reason"] = r.stop_reason;
+            return d;
+        });
+
+    py::class_<hip_solver>(m, "bdd_hip_parallel_mma")
+        .def(py::init([](const std::string& ilp_text, const std::string& precision, int device) { return hip_solver::from_ilp(ilp_text, precision, device); }),
+             py::arg("ilp"), py::arg("precision") = "double", py::arg("device") = 0)
+        .def(py::pickle([](const hip_solver& s) { return s.dumps(); }, [](const py::bytes& b) { return hip_solver::loads(b, 0); }))
+        .def("__repr__", [](const hip_solver& s) {
+            return "<bdd_hip_parallel_mma>: nr_variables: " + std::to_string(bddmma_nr_variables(s.h)) + ", nr_bdds: " + std::to_string(bddmma_nr_bdds(s.h)) +
+                   ", nr_layers: " + std::to_string(bddmma_nr_layers(s.h));
+        })
+        .def("nr_primal_variables", [](const hip_solver& s) { return bddmma_nr_variables(s.h); })
+        .def("nr_layers", [](const hip_solver& s) { return bddmma_nr_layers(s.h); })
+        .def("nr_hops", [](const hip_solver& s) { return bddmma_nr_hops(s.h); })
+        .def("nr_bdds", [](const hip_solver& s) { return bddmma_nr_bdds(s.h); })
+        .def("iteration", [](hip_solver& s, double omega) { ck(bddmma_iteration(s.h, omega), s.h); }, py::arg("omega") = 0.5)
+        .def("iterations", [](hip_solver& s, uint64_t n, double omega) { ck(bddmma_iterations(s.h, omega, n), s.h); }, py::arg("n"), py::arg("omega") = 0.5)
+        .def("lower_bound", [](hip_solver& s) { double lb = 0; ck(bddmma_lower_bound(s.h, &lb), s.h); return lb; })
+        // bdd_cuda_parallel_mma_py.cu:56-72: hi - lo min-marginal of every layer into a caller-owned DEVICE buffer (REAL[nr_layers])
+        .def("compute_and_set_min_marginal_diff",
+             [](hip_solver& s, uint64_t mm_diff_out_ptr) { ck(bddmma_min_marginal_diff(s.h, reinterpret_cast<void*>(mm_diff_out_ptr), 1), s.h); })
+        // the same into a new host list (no counterpart in the reference; convenient without a device buffer)
+        .def("min_marginal_diff", [](hip_solver& s) {
+            const size_t L = bddmma_nr_layers(s.h);
+            std::vector<double> out(L);
+            if (bddmma_precision(s.h) == BDDMMA_F64) {
+                ck(bddmma_min_marginal_diff(s.h, out.data(), 0), s.h);
+            } else {
+                std::vector<float> f(L);
+                ck(bddmma_min_marginal_diff(s.h, f.data(), 0), s.h);
+                out.assign(f.begin(), f.end());
+            }
+            return out;
+        });
+}

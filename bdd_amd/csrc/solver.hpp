@@ -58,6 +58,7 @@ struct SolverBase {
     virtual int set_solver_costs(const void* lo, const void* hi, const void* mm, int on_device) = 0;
     virtual int primal_objective_vec(void* out, int on_device) = 0;
     virtual int min_marginals(int sorted, int32_t* var, void* mm0, void* mm1, int on_device) = 0;
+    virtual int min_marginal_diff(void* out, int on_device) = 0;
     virtual int bdds_solution(int sorted, char* sol, int on_device) = 0;
     virtual int net_solver_costs(void* out, int on_device) = 0;
     virtual int make_dual_feasible(void* g, int on_device) = 0;
@@ -79,6 +80,7 @@ struct SolverBase {
     int time_iterations(double omega, uint64_t n, double* ms);
 };
 
+int device_count();
 int create_solver(SolverBase** out, int precision, int device, const HostLayout& L, const bddmma_options* opts, std::string& err);
 
 }  // namespace bddmma

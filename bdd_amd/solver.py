@@ -241,6 +241,15 @@ class bdd_hip_parallel_mma:
         return [np.stack([mm0[ptr[v]:ptr[v + 1]], mm1[ptr[v]:ptr[v + 1]]], axis=1).astype(np.float64)
                 for v in range(self.nr_variables())]
 
+    def min_marginal_diff(self, out=None):
+        """mm1 - mm0 per layer (compute_and_set_min_marginal_diff, bdd_cuda_parallel_mma_py.cu:56-72); `out`: device buffer"""
+        if out is not None:
+            self._ck(self._L.bddmma_min_marginal_diff(self._h, _dev_ptr(out, self.nr_layers(), self.value_type), 1))
+            return out
+        res = np.zeros(self.nr_layers(), self.value_type)
+        self._ck(self._L.bddmma_min_marginal_diff(self._h, _ptr(res), 0))
+        return res
+
     def bdds_solution_vec(self, out=None):
         if out is not None:   # device_vector<char> (bdd_cuda_base.cu:1138-1145)
             self._ck(self._L.bddmma_bdds_solution(self._h, 0, _dev_ptr(out, self.nr_layers(), np.int8), 1))

@@ -96,6 +96,9 @@ int bddmma_create(bddmma_solver** out, int precision, int device,
                   const double* costs_hi, uint64_t n_costs, const bddmma_options* opts);
 void bddmma_destroy(bddmma_solver* s);
 
+/* Number of HIP devices visible to the process (0 when there is none / no driver).  One host thread per device, each with its own
+ * handles, is the multi-GPU model: independent instances, no collective (reference: device 0 hard-coded, include/cuda_utils.h:111-114). */
+int bddmma_device_count(void);
 /* Error text of the last failed call on `s`; with s == NULL the last failed bddmma_create. */
 const char* bddmma_last_error(const bddmma_solver* s);
 
@@ -161,6 +164,9 @@ int bddmma_set_delta(bddmma_solver* s, const void* in, int on_device);
 /* min_marginals_cuda(get_sorted) (bdd_cuda_base.cu:716-749): var int32[nr_layers], mm0/mm1 REAL[nr_layers].
  * sorted != 0: ordered by (variable, bdd) as primal_variable_sorting_order_ (bdd_cuda_base.cu:379-391). */
 int bddmma_min_marginals(bddmma_solver* s, int sorted, int32_t* var, void* mm0, void* mm1, int on_device);
+/* mm1 - mm0 per layer, internal layer order, REAL[nr_layers] (compute_and_set_min_marginal_diff of the reference's Python module,
+ * src/bdd_solver/bdd_cuda_parallel_mma_py.cu:56-72: min_marginals_cuda(false) followed by thrust::minus into the caller's buffer). */
+int bddmma_min_marginal_diff(bddmma_solver* s, void* out, int on_device);
 /* bdds_solution_vec() (bdd_cuda_base.cu:1139-1202): char[nr_layers] argmin path per BDD, internal
  * layer order (sorted = 0) or (variable,bdd) order (sorted = 1, as bdds_solution(), :1204-1233). */
 int bddmma_bdds_solution(bddmma_solver* s, int sorted, char* sol, int on_device);

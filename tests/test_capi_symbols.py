@@ -49,3 +49,13 @@ def test_load_rejects_files_that_are_not_checkpoints(tmp_path):
         p.write_bytes(blob)
         assert L.bddmma_load(C.byref(h), 0, str(p).encode()) == -6 and not h.value      # BDDMMA_ERR_IO, before any device work
     assert L.bddmma_load(C.byref(h), 0, str(tmp_path / "missing.bin").encode()) == -6
+
+
+def test_pybind_module_is_built_and_reports_errors_without_a_gpu():
+    from bdd_amd import bdd_solver_py
+    assert {"bdd_solver", "bdd_hip_parallel_mma"} <= set(dir(bdd_solver_py))
+    import pytest
+    with pytest.raises(RuntimeError):
+        bdd_solver_py.bdd_solver("{ this is not json", True)
+    with pytest.raises(RuntimeError):
+        bdd_solver_py.bdd_solver({"relaxation solver": "cuda parallel mma"}, True).solve()   # no input specified

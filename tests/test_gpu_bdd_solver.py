@@ -119,3 +119,53 @@ def test_split_bdds_same_parity_and_bound():
     for _ in range(3000):
         o.iteration()
     assert abs(o.lower_bound() - imp.lower_bound()) <= 1e-7 * max(1.0, abs(o.lower_bound()))
+
+
+@pytest.mark.parametrize("front_end", ["python", "pybind"])
+def test_variables_that_occur_in_the_objective_only(front_end):
+    """an ILP whose last variables appear in no constraint used to fail in bddmma_create (cost vector longer than the
+    BDDs' variables).  They are free: min(0, c) goes to the bound, the primal takes their better value."""
+    lp = ("Minimize\n2 x1 + 3 x2 + x3 - 4 y1 + 5 y2\nSubject To\nx1 + x2 + x3 >= 1\nx1 + x2 <= 1\nBounds\nBinaries\nx1\nx2\nx3\ny1\ny2\nEnd\n")
+    c = cfg(lp, **{"perturbation rounding": {"inner iterations": 20, "outer iterations": 30}})
+    if front_end == "python":
+        s = bdd_solver(c, quiet=True).solve()
+    else:
+        from bdd_amd import bdd_solver_py
+        s = bdd_solver_py.bdd_solver(c, quiet=True).solve()
+    assert abs(s.lower_bound() - (1.0 - 4.0)) <= 1e-6          # x3 = 1 covers the row; y1 = 1 is free money
+    assert s.solution is not None and list(s.solution) == [0, 0, 1, 1, 0]
+
+
+def test_batch_farm_command_line(tmp_path):
+    """bdd_solver_cl --batch / --bench-set-cover: independent instances, one host thread per device slot (here two slots on GPU 0)."""
+    import os
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bdd_amd", "csrc", "bdd_solver_cl")
+    cfgs = []
+    for i, (ilp, lb) in enumerate([(assignment_ilp(3), -6.0), (mrf_ilp(**LONG_CHAIN), -9.0), (assignment_ilp(8), -16.0), (mrf_ilp(**GRID_3X3), -8.0)]):
+        p = tmp_path / f"c{i}.json"
+        p.write_text(json.dumps(cfg(ilp.write_lp())))
+        cfgs.append((str(p), lb))
+    out = subprocess.run([exe, "--batch", *[c for c, _ in cfgs], "--devices", "0,0", "--quiet"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 4 and all(r["ok"] and r["device"] == 0 for r in rows)
+    for r, (path, lb) in zip(rows, cfgs):
+        assert r["config"] == path and abs(r["lower_bound"] - lb) <= 1e-6
+    # a failing config is reported, the others still run
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps(cfg("Minimize\nx\nSubject To\nx >= 2\nBounds\nBinaries\nx\nEnd\n")))
+    out = subprocess.run([exe, "--batch", cfgs[0][0], str(bad), "--devices", "0", "--quiet"], capture_output=True, text=True, timeout=300)
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 1 and rows[0]["ok"] and not rows[1]["ok"] and "error" in rows[1]
+    # the benchmark instance of bench.py, two replicas on one GPU, same bound as the Python path
+    out = subprocess.run([exe, "--bench-set-cover", "3000", "2500", "8", "--iterations", "40", "--warmup", "10", "--seeds", "12345-12346", "--devices", "0,0",
+                          "--precision", "double"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 3 and rows[2]["instances"] == 2 and rows[2]["aggregate_iterations_per_second"] > 0
+    from bdd_amd.instances import random_set_cover_mt
+    from bdd_amd.solver import bdd_hip_parallel_mma
+    col, costs = random_set_cover_mt(3000, 2500, 8, seed=12346)
+    ref = bdd_hip_parallel_mma(col, costs, precision="double")
+    ref.iterations(50)
+    assert abs(rows[1]["lower_bound"] - ref.lower_bound()) <= 1e-9 * abs(ref.lower_bound())
