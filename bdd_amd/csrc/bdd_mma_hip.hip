@@ -216,9 +216,28 @@ struct SolverT final : SolverBase {
         }
         stage_lds = L.ex.waves_per_block * stage_cap * 2 * (uint32_t)sizeof(REAL);
         exch_lds = vars_per_bin * 2 * (uint32_t)sizeof(double);  // accumulators are double for both precisions
-        if (exch_lds > 160 * 1024 - 1024 || stage_lds > 60 * 1024) {
-            err = "vars_per_bin / stage_cap need more LDS than a CU has";
+        // LDS of a narrow solve workgroup: the dynamic staging area + the kernel's static arrays (frontier F x2 and T per wave, the hop
+        // offset windows) — k_fwd_narrow is the larger of the two.  Above the 64 KiB a launch gets by default the kernels need the
+        // attribute (pack_width 256, double, 4 waves per block is ~67 KiB); above what a CU has the options are refused here,
+        // not at the first sweep.
+        const uint32_t narrow_static = L.ex.waves_per_block * (3 * (pack_width + 2) * (uint32_t)sizeof(REAL) + 2 * 64 * 4 + 2);
+        if (exch_lds > 160 * 1024 - 1024 || stage_lds + narrow_static > 160 * 1024 - 1024) {
+            err = "vars_per_bin / stage_cap / waves_per_block need more LDS than a CU has (" + std::to_string(stage_lds + narrow_static) + " B per sweep workgroup)";
             return BDDMMA_ERR_INVALID_ARGUMENT;
+        }
+        if (stage_lds + narrow_static > 64 * 1024) {
+#define SET_N1(K_) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
+#define SET_N(R_, W_) SET_N1((k_fwd_narrow<REAL, R_, FWD_SOLVE, W_>)) SET_N1((k_bwd_narrow<REAL, R_, BWD_SOLVE, W_>))
+#define SET_N_W(R_) \
+    switch (L.ex.waves_per_block) { case 1: SET_N(R_, 1) break; case 2: SET_N(R_, 2) break; case 4: SET_N(R_, 4) break; default: SET_N(R_, 8) break; }
+            switch (pack_width) {
+                case 64: SET_N_W(1) break;
+                case 128: SET_N_W(2) break;
+                default: SET_N_W(4) break;
+            }
+#undef SET_N_W
+#undef SET_N
+#undef SET_N1
         }
         if ((rc = dalloc(&d_tmp0, n_layers))) return rc;
         if ((rc = dalloc(&d_tmp1, n_layers))) return rc;

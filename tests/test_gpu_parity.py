@@ -379,7 +379,8 @@ def test_full_size_properties(tag):
 
 # ---------------------------------------------------------------- long BDDs: hop-window refills and several stage groups per pack
 @pytest.mark.parametrize("precision", ["double", "float"])
-@pytest.mark.parametrize("pack_width,stage_cap,wpb", [(64, 64, 4), (128, 640, 1), (256, 256, 2), (64, 128, 8)])
+@pytest.mark.parametrize("pack_width,stage_cap,wpb", [(64, 64, 4), (128, 640, 1), (256, 256, 2), (64, 128, 8),
+                                                      (256, 640, 4)])   # last: > 64 KiB of LDS per workgroup in double
 def test_long_bdds_vs_oracle(precision, pack_width, stage_cap, wpb):
     rng = np.random.Generator(np.random.PCG64(33))
     V = 700
