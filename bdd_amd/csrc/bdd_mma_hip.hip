@@ -60,6 +60,7 @@ struct SolverT final : SolverBase {
     uint32_t wpb = 1;
     bool entry_by_var = false;  // entries ordered by (variable, bdd): exchange = k_exchange_byvar
     bool exch_small = false;
+    bool narrow_seg = false;  // some narrow pack has layers wider than two nodes: seg_min2 goes through LDS and needs scratch
     uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0, stage_lds = 0, exch_lds = 0, n_narrow_layers = 0;
     double *d_lb_partial = nullptr, *d_lb = nullptr;
     double* h_lb = nullptr;  // pinned, device-visible: the reduce kernel writes the bound straight into host memory
@@ -208,6 +209,7 @@ struct SolverT final : SolverBase {
         if ((rc = upload(&d_cs_slot, L.ex.cs_slot, 33))) return rc;
         wpb = L.ex.waves_per_block;
         entry_by_var = L.ex.entry_by_var;
+        for (uint8_t st : L.narrow.pack_steps) narrow_seg = narrow_seg || st >= 2;
         vars_per_bin = L.ex.vars_per_bin; n_bins = L.ex.n_bins; stage_cap = L.ex.stage_cap;
         n_narrow_layers = L.ex.grp_layer_off.empty() ? 0 : L.ex.grp_layer_off.back();
         if (2 * n_layers * sizeof(REAL) >= 0xFFFFFFFFull || n_slots * sizeof(REAL) >= 0xFFFFFFFFull) {
@@ -220,13 +222,13 @@ struct SolverT final : SolverBase {
         // offset windows) — k_fwd_narrow is the larger of the two.  Above the 64 KiB a launch gets by default the kernels need the
         // attribute (pack_width 256, double, 4 waves per block is ~67 KiB); above what a CU has the options are refused here,
         // not at the first sweep.
-        const uint32_t narrow_static = L.ex.waves_per_block * (3 * (pack_width + 2) * (uint32_t)sizeof(REAL) + 2 * 64 * 4 + 2);
+        const uint32_t narrow_static = L.ex.waves_per_block * (3 * (pack_width + 2) * (uint32_t)sizeof(REAL) + 2 * 64 * 4 + 2) + seg_bytes(L.ex.waves_per_block);
         if (exch_lds > 160 * 1024 - 1024 || stage_lds + narrow_static > 160 * 1024 - 1024) {
             err = "vars_per_bin / stage_cap / waves_per_block need more LDS than a CU has (" + std::to_string(stage_lds + narrow_static) + " B per sweep workgroup)";
             return BDDMMA_ERR_INVALID_ARGUMENT;
         }
         if (stage_lds + narrow_static > 64 * 1024) {
-#define SET_N1(K_) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
+#define SET_N1(K_) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(stage_lds + seg_bytes(L.ex.waves_per_block))));
 #define SET_N(R_, W_) SET_N1((k_fwd_narrow<REAL, R_, FWD_SOLVE, W_>)) SET_N1((k_bwd_narrow<REAL, R_, BWD_SOLVE, W_>))
 #define SET_N_W(R_) \
     switch (L.ex.waves_per_block) { case 1: SET_N(R_, 1) break; case 2: SET_N(R_, 2) break; case 4: SET_N(R_, 4) break; default: SET_N(R_, 8) break; }
@@ -267,7 +269,7 @@ struct SolverT final : SolverBase {
             res_ns = (L.res.max_slots + 255) / 256 * 256;
             res_nl = (L.res.max_layers + 127) / 128 * 128;
             res_lds = wpb * stage_cap * 2 * (uint32_t)sizeof(REAL) + wpb * res_wave_bytes(sizeof(REAL), res_ns, res_nl);
-            const uint32_t static_lds = wpb * (2 * (pack_width + 2) * (uint32_t)sizeof(REAL) + 512);
+            const uint32_t static_lds = wpb * (2 * (pack_width + 2) * (uint32_t)sizeof(REAL) + 512) + seg_bytes(wpb);
             const uint32_t mode = opts ? opts->resident_sweeps : 0;
             const bool fits = res_lds + static_lds <= 160 * 1024 - 512;
             // automatic choice: small instances only — at most 2 waves per SIMD (2048 packs), all workgroups in flight at once with their
@@ -279,8 +281,8 @@ struct SolverT final : SolverBase {
             use_res = fits && mode != 1 && (mode == 2 || all_in_flight);
             if (use_res) {
 #define SET_RES(R_, W_) \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_res<REAL, R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds)); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_res<REAL, R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_res<REAL, R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(res_lds + seg_bytes(wpb)))); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_res<REAL, R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(res_lds + seg_bytes(wpb))));
 #define SET_RES_W(R_) \
     switch (wpb) { case 1: SET_RES(R_, 1) break; case 2: SET_RES(R_, 2) break; case 4: SET_RES(R_, 4) break; default: SET_RES(R_, 8) break; }
                 switch (pack_width) {
@@ -326,17 +328,19 @@ struct SolverT final : SolverBase {
         d.mm0_out = d_tmp0; d.mm1_out = d_tmp1; d.sol_out = d_sol;
         return d;
     }
-    PackDev pdev(const PackBufs& b, uint32_t lb_base) const
+    PackDev pdev(const PackBufs& b, uint32_t lb_base, uint32_t seg_off = 0) const
     {
         return PackDev{b.pack_hop_ptr, b.hop_node_off, b.hop_layer_off, b.pack_steps, d_pack_word_off,
-                       d_pack_group_ptr, d_grp_layer_off, d_grp_hop_end, d_quad_round_ptr, d_cs_ptr, stage_cap, b.n_packs, lb_base};
+                       d_pack_group_ptr, d_grp_layer_off, d_grp_hop_end, d_quad_round_ptr, d_cs_ptr, stage_cap, seg_off, b.n_packs, lb_base};
     }
+    // dynamic LDS of a narrow launch with `w` waves per workgroup: `base` bytes of the kernel's own use, then (only when some pack has
+    // layers wider than two nodes) the seg_min2 scratch, 128 REALs per wave
+    uint32_t seg_bytes(uint32_t w) const { return narrow_seg ? w * 128 * (uint32_t)sizeof(REAL) : 0; }
 
     template <int MODE>
     int launch_fwd(const REAL* delta_lay, REAL omega, int kclass)
     {
         DevPtrs<REAL> d = ptrs(delta_lay);
-        const uint32_t dyn = (MODE == FWD_SOLVE) ? stage_lds : 0;
         prof_begin(kclass);
         hipStream_t sw = stream;
         if (wb_.n_packs) {
@@ -349,14 +353,16 @@ struct SolverT final : SolverBase {
             }
         }
         if (nb_.n_packs) {
-            const PackDev pk = pdev(nb_, 0);
             // SOLVE sweeps: `wpb` packs per workgroup with cooperative staging; the other modes stage nothing
             const uint32_t w = (MODE == FWD_SOLVE) ? wpb : 1;
+            const bool res = use_res && MODE == FWD_SOLVE;
+            const uint32_t base_lds = res ? res_lds : ((MODE == FWD_SOLVE) ? stage_lds : 0);
+            const uint32_t dyn = base_lds + seg_bytes(w);
+            const PackDev pk = pdev(nb_, 0, base_lds);
             const dim3 grid(8 * cdiv(cdiv(nb_.n_packs, w), 8)), block(64 * w);
             const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
-            const bool res = use_res && MODE == FWD_SOLVE;
 #define LAUNCH_N(R_, W_)                                                                                                      \
-    if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, res_lds, stream, d, pk, rd, omega);                       \
+    if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, d, pk, rd, omega);                           \
     else hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
     switch (w) { case 1: LAUNCH_N(R_, 1); break; case 2: LAUNCH_N(R_, 2); break; case 4: LAUNCH_N(R_, 4); break; default: LAUNCH_N(R_, 8); break; }
@@ -380,7 +386,6 @@ struct SolverT final : SolverBase {
     int launch_bwd(const REAL* delta_lay, REAL omega, int kclass)
     {
         DevPtrs<REAL> d = ptrs(delta_lay);
-        const uint32_t dyn = (MODE == BWD_SOLVE) ? stage_lds : 0;
         prof_begin(kclass);
         hipStream_t sw = stream;
         if (wb_.n_packs) {
@@ -393,14 +398,16 @@ struct SolverT final : SolverBase {
             }
         }
         if (nb_.n_packs) {
-            const PackDev pk = pdev(nb_, 0);
             // SOLVE sweeps: `wpb` packs per workgroup with cooperative staging; the other modes stage nothing
             const uint32_t w = (MODE == BWD_SOLVE) ? wpb : 1;
+            const bool res = use_res && MODE == BWD_SOLVE;
+            const uint32_t base_lds = res ? res_lds : ((MODE == BWD_SOLVE) ? stage_lds : 0);
+            const uint32_t dyn = base_lds + seg_bytes(w);
+            const PackDev pk = pdev(nb_, 0, base_lds);
             const dim3 grid(8 * cdiv(cdiv(nb_.n_packs, w), 8)), block(64 * w);
             const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
-            const bool res = use_res && MODE == BWD_SOLVE;
 #define LAUNCH_N(R_, W_)                                                                                                      \
-    if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, res_lds, stream, d, pk, rd, omega);                       \
+    if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, d, pk, rd, omega);                           \
     else hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
     switch (w) { case 1: LAUNCH_N(R_, 1); break; case 2: LAUNCH_N(R_, 2); break; case 4: LAUNCH_N(R_, 4); break; default: LAUNCH_N(R_, 8); break; }

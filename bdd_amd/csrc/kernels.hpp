@@ -65,6 +65,7 @@ struct PackDev {
     const uint32_t* quad_round_ptr;  // cooperative staging rounds of each quad of packs
     const uint32_t* cs_ptr;          // first staged item of each (quad, round)
     uint32_t stage_cap;
+    uint32_t seg_off;  // byte offset of the seg_min2 scratch (128 REALs per wave) inside the dynamic LDS
     uint32_t n_packs;
     uint32_t lb_base;  // index of this set's first pack in lb_partial
 };
@@ -144,8 +145,20 @@ __device__ __forceinline__ double dpp_from_prev(double v)
     return __builtin_bit_cast(double, ((unsigned long long)h2 << 32) | l2);
 }
 
+// Wider layers: every lane folds its two values into the layer's LDS slots with ds_min (slot = lane of the layer's head, unique inside
+// the 64-lane group) and reads the result back — 6 LDS instructions and 3 dependent LDS round trips whatever the width.  The first
+// version did ceil(log2(width)) __shfl_down halving steps + a __shfl broadcast per value: 14 ds_bpermute in 7 dependent round trips and
+// ~75 VALU for 64-wide layers, which made packs of knapsack-like BDDs instruction- and latency-bound (185 VALU per wave and hop).
+// sM: 128 REALs of LDS owned by this wave ([0, 64) for a, [64, 128) for b); a wave's LDS operations execute in order, so only the
+// compiler needs the fences.
+__device__ __forceinline__ void seg_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <typename REAL>
-__device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, uint32_t pos, uint32_t len, int steps)
+__device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, uint32_t pos, uint32_t len, int steps, REAL* sM)
 {
     if (steps <= 1) {
         // layers of 1 or 2 nodes (simplex / covering / cardinality-1 rows): two DPP moves per value,
@@ -162,18 +175,17 @@ __device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, uint32_t po
         }
         return;
     }
-    const int seg_end = lane - (int)pos + (int)len;
-    for (int s = 0; s < steps; ++s) {
-        const int off = 1 << s;
-        const REAL a2 = __shfl_down(a, off);
-        const REAL b2 = __shfl_down(b, off);
-        if (lane + off < seg_end) {
-            a = rmin(a, a2);
-            b = rmin(b, b2);
-        }
-    }
-    a = __shfl(a, lane - (int)pos);
-    b = __shfl(b, lane - (int)pos);
+    const REAL INF = inf_v<REAL>();
+    const uint32_t head = (uint32_t)lane - pos;
+    sM[lane] = INF;
+    sM[64 + lane] = INF;
+    seg_fence();
+    __hip_atomic_fetch_min(&sM[head], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_min(&sM[64 + head], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    seg_fence();
+    a = sM[head];
+    b = sM[64 + head];
+    seg_fence();  // the next group's reset must not overtake these reads
 }
 
 // ---- buffer-descriptor memory ops ---------------------------------------------------------------
@@ -398,6 +410,9 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDe
     const uint32_t tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int lane = tid & 63;
+    // per-wave scratch of the segmented minimum (seg_min2): behind the rest of the dynamic LDS, only reserved when a pack has layers
+    // wider than two nodes (pk.seg_off; never dereferenced otherwise)
+    REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
     auto& sF = sF_[wave];
     auto& sT = sT_[wave];
     auto& sAct = sAct_[wave];
@@ -507,7 +522,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDe
                         const P2 dd = sDw[act ? sl : 0];
                         REAL m0 = act ? (f[r] + lc) + tl : INF;
                         REAL m1 = act ? (f[r] + hc) + th : INF;
-                        seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps);
+                        seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
                         const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
                         nlo = (lc + rmin(mm, REAL(0))) + dd.x;
                         nhi = (hc + rmin(-mm, REAL(0))) + dd.y;
@@ -573,6 +588,9 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDe
     const uint32_t tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int lane = tid & 63;
+    // per-wave scratch of the segmented minimum (seg_min2): behind the rest of the dynamic LDS, only reserved when a pack has layers
+    // wider than two nodes (pk.seg_off; never dereferenced otherwise)
+    REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
     auto& sT = sT_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
     const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
@@ -657,7 +675,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDe
                     const P2 dd = sDw[act ? sl : 0];
                     REAL m0 = act ? (fa[r] + lc) + tl : INF;
                     REAL m1 = act ? (fa[r] + hc) + th : INF;
-                    seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps);
+                    seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
                     const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
                     const REAL nlo = (lc + rmin(mm, REAL(0))) + dd.x;
                     const REAL nhi = (hc + rmin(-mm, REAL(0))) + dd.y;
@@ -674,7 +692,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDe
                     if (MODE == BWD_MARGINALS) {
                         REAL lp = act ? fa[r] + cl : INF;  // backward_step_with_path_costs, :633-641
                         REAL hp = act ? fa[r] + ch : INF;
-                        seg_min2(lp, hp, lane, nw_pos(w), nw_len(w), steps);
+                        seg_min2(lp, hp, lane, nw_pos(w), nw_len(w), steps, sM);
                         if (nw_head(w)) {
                             d.mm0_out[La.lg[r]] = lp;
                             d.mm1_out[La.lg[r]] = hp;
@@ -767,6 +785,9 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
     const uint32_t tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int lane = tid & 63;
+    // per-wave scratch of the segmented minimum (seg_min2): behind the rest of the dynamic LDS, only reserved when a pack has layers
+    // wider than two nodes (pk.seg_off; never dereferenced otherwise)
+    REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
     auto& sF = sF_[wave];
     uint32_t* sOffN = sOffN_[wave];
     uint32_t* sOffL = sOffL_[wave];
@@ -843,7 +864,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
             const P2 dd = sDw[ll];
             REAL m0 = act ? (f[r] + c.x) + tl : INF;
             REAL m1 = act ? (f[r] + c.y) + th : INF;
-            seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps);
+            seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
             const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
             const REAL nlo = (c.x + rmin(mm, REAL(0))) + dd.x;
             const REAL nhi = (c.y + rmin(-mm, REAL(0))) + dd.y;
@@ -877,6 +898,9 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev p
     const uint32_t tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int lane = tid & 63;
+    // per-wave scratch of the segmented minimum (seg_min2): behind the rest of the dynamic LDS, only reserved when a pack has layers
+    // wider than two nodes (pk.seg_off; never dereferenced otherwise)
+    REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
     auto& sT = sT_[wave];
     uint32_t* sOffN = sOffN_[wave];
     uint32_t* sOffL = sOffL_[wave];
@@ -935,7 +959,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev p
             const P2 dd = sDw[ll];
             REAL m0 = act ? (fa + c.x) + tl : INF;
             REAL m1 = act ? (fa + c.y) + th : INF;
-            seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps);
+            seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
             const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
             const REAL nlo = (c.x + rmin(mm, REAL(0))) + dd.x;
             const REAL nhi = (c.y + rmin(-mm, REAL(0))) + dd.y;
