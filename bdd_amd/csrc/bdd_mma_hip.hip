@@ -73,6 +73,12 @@ struct SolverT final : SolverBase {
         uint32_t n_packs = 0;
     } nb_, wb_, hb_;  // narrow, wide, huge packs
     uint32_t wide_lds = 0, wide_threads = 256, wide_npt = 1;
+    bool mixed = false;      // narrow (streaming) and wide solve sweeps in one launch (kernels.hpp: k_fwd_mixed / k_bwd_mixed)
+    // Measured on the knapsack benchmark (3 604 narrow + 389 wide packs): backward 44.7 -> 37.4 us in one launch, forward 56.1 -> 58.6 us —
+    // the forward sweeps of both kinds are bound by the LDS ds_min pushes into the next frontier, so sharing the CUs returns nothing
+    // there.  Hence: backward mixed, forward as two launches.
+    static constexpr bool mixed_fwd = false;
+    uint32_t mixed_npt = 1, mixed_lds = 0;
     // (Running the wide launch on a second stream next to the narrow one was measured and dropped: the event fork / join costs ~10 us
     // per pass on this platform, more than the overlap returns — knapsack benchmark 8 990 -> 8 261 it/s.)
     // resident sweeps of the narrow packs (kernels.hpp: k_fwd_res / k_bwd_res)
@@ -312,6 +318,18 @@ struct SolverT final : SolverBase {
 #undef SET_LDS_N
 #undef SET_LDS
         }
+        // one launch for narrow + wide solve sweeps when the wide packs fit the narrow workgroup size (<= 4 nodes per thread) and their
+        // LDS frontier does not cost the narrow workgroups their occupancy
+        if (wb_.n_packs && nb_.n_packs && !use_res && !(opts && opts->reserved[0] == 1)) {
+            const uint32_t threads = 64 * wpb;
+            const uint32_t npt = (wide_pack_width + threads - 1) / threads;
+            const uint32_t narrow_dyn = stage_lds + seg_bytes(wpb);
+            if (npt <= 4 && wide_lds <= narrow_dyn + 16 * 1024) {
+                mixed = true;
+                mixed_npt = npt <= 1 ? 1 : (npt <= 2 ? 2 : 4);
+                mixed_lds = std::max(narrow_dyn, wide_lds);
+            }
+        }
         HIPCHK(hipStreamSynchronize(stream));
         return BDDMMA_OK;
     }
@@ -343,6 +361,26 @@ struct SolverT final : SolverBase {
         DevPtrs<REAL> d = ptrs(delta_lay);
         prof_begin(kclass);
         hipStream_t sw = stream;
+        if (mixed && mixed_fwd && MODE == FWD_SOLVE) {
+            const PackDev pkw = pdev(wb_, nb_.n_packs), pkn = pdev(nb_, 0, stage_lds);
+            const uint32_t nw8 = (wb_.n_packs + 7u) & ~7u;
+            const dim3 grid(nw8 + 8 * cdiv(cdiv(nb_.n_packs, wpb), 8)), block(64 * wpb);
+#define LAUNCH_M(R_, W_)                                                                                                                                   \
+    switch (mixed_npt) {                                                                                                                                   \
+        case 1: hipLaunchKernelGGL((k_fwd_mixed<REAL, R_, W_, 1>), grid, block, mixed_lds, stream, d, pkn, pkw, omega, wide_pack_width); break;            \
+        case 2: hipLaunchKernelGGL((k_fwd_mixed<REAL, R_, W_, 2>), grid, block, mixed_lds, stream, d, pkn, pkw, omega, wide_pack_width); break;            \
+        default: hipLaunchKernelGGL((k_fwd_mixed<REAL, R_, W_, 4>), grid, block, mixed_lds, stream, d, pkn, pkw, omega, wide_pack_width); break;           \
+    }
+#define LAUNCH_MW(R_) \
+    switch (wpb) { case 1: LAUNCH_M(R_, 1) break; case 2: LAUNCH_M(R_, 2) break; case 4: LAUNCH_M(R_, 4) break; default: LAUNCH_M(R_, 8) break; }
+            switch (pack_width) {
+                case 64: LAUNCH_MW(1) break;
+                case 128: LAUNCH_MW(2) break;
+                default: LAUNCH_MW(4) break;
+            }
+#undef LAUNCH_MW
+#undef LAUNCH_M
+        } else {
         if (wb_.n_packs) {
             const PackDev pk = pdev(wb_, nb_.n_packs);
             const dim3 g(wb_.n_packs), b(wide_threads);
@@ -374,6 +412,7 @@ struct SolverT final : SolverBase {
 #undef LAUNCH_W
 #undef LAUNCH_N
         }
+        }  // !mixed
         if (hb_.n_packs) {
             const PackDev pk = pdev(hb_, nb_.n_packs + wb_.n_packs);
             hipLaunchKernelGGL((k_fwd_wide<REAL, MODE, true>), dim3(hb_.n_packs), dim3(WIDE_THREADS), 0, stream, d, pk, omega, huge_pack_width, d_huge_scratch);
@@ -388,6 +427,26 @@ struct SolverT final : SolverBase {
         DevPtrs<REAL> d = ptrs(delta_lay);
         prof_begin(kclass);
         hipStream_t sw = stream;
+        if (mixed && MODE == BWD_SOLVE) {
+            const PackDev pkw = pdev(wb_, nb_.n_packs), pkn = pdev(nb_, 0, stage_lds);
+            const uint32_t nw8 = (wb_.n_packs + 7u) & ~7u;
+            const dim3 grid(nw8 + 8 * cdiv(cdiv(nb_.n_packs, wpb), 8)), block(64 * wpb);
+#define LAUNCH_M(R_, W_)                                                                                                                                   \
+    switch (mixed_npt) {                                                                                                                                   \
+        case 1: hipLaunchKernelGGL((k_bwd_mixed<REAL, R_, W_, 1>), grid, block, mixed_lds, stream, d, pkn, pkw, omega, wide_pack_width); break;            \
+        case 2: hipLaunchKernelGGL((k_bwd_mixed<REAL, R_, W_, 2>), grid, block, mixed_lds, stream, d, pkn, pkw, omega, wide_pack_width); break;            \
+        default: hipLaunchKernelGGL((k_bwd_mixed<REAL, R_, W_, 4>), grid, block, mixed_lds, stream, d, pkn, pkw, omega, wide_pack_width); break;           \
+    }
+#define LAUNCH_MW(R_) \
+    switch (wpb) { case 1: LAUNCH_M(R_, 1) break; case 2: LAUNCH_M(R_, 2) break; case 4: LAUNCH_M(R_, 4) break; default: LAUNCH_M(R_, 8) break; }
+            switch (pack_width) {
+                case 64: LAUNCH_MW(1) break;
+                case 128: LAUNCH_MW(2) break;
+                default: LAUNCH_MW(4) break;
+            }
+#undef LAUNCH_MW
+#undef LAUNCH_M
+        } else {
         if (wb_.n_packs) {
             const PackDev pk = pdev(wb_, nb_.n_packs);
             const dim3 g(wb_.n_packs), b(wide_threads);
@@ -419,6 +478,7 @@ struct SolverT final : SolverBase {
 #undef LAUNCH_W
 #undef LAUNCH_N
         }
+        }  // !mixed
         if (hb_.n_packs) {
             const PackDev pk = pdev(hb_, nb_.n_packs + wb_.n_packs);
             hipLaunchKernelGGL((k_bwd_wide<REAL, MODE, true>), dim3(hb_.n_packs), dim3(WIDE_THREADS), 0, stream, d, pk, omega, huge_pack_width, d_huge_scratch);

@@ -89,6 +89,8 @@ __device__ __forceinline__ void lds_min(REAL* p, REAL v)
     __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_min_f32 / ds_min_f64
 }
 
+// (Measured and dropped: the forward frontier as order-preserving integers with ds_min_u32 / ds_min_u64 instead of ds_min_f32 / f64 —
+// same speed on every benchmark, so the float LDS minimum is not what makes the forward pushes slower than the backward gathers.)
 // frontier minimum of the workgroup-per-pack kernels: LDS (ds_min) or, for huge packs whose frontier does not fit
 // in LDS, global scratch memory (L2 atomic; a CAS loop where the hardware has no float minimum)
 template <bool GLOBAL, typename REAL>
@@ -394,7 +396,7 @@ __device__ __forceinline__ void load_vals(REAL (&v)[R], rsrc_t src, uint32_t nb,
 }
 
 template <typename REAL, int R, int MODE, int WPB>
-__global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
+__device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t block_id)
 {
     constexpr int W = 64 * R;
     constexpr bool NEED_T = (MODE != FWD_PLAIN);
@@ -417,7 +419,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDe
     auto& sT = sT_[wave];
     auto& sAct = sAct_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
+    const uint32_t quad = block_to_pack(block_id, n_quads);
     if (quad >= n_quads) return;  // uniform for the workgroup
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;  // the last quad may be partial: such a wave only helps staging
@@ -576,7 +578,13 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDe
 }
 
 template <typename REAL, int R, int MODE, int WPB>
-__global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
+__global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
+{
+    fwd_narrow_body<REAL, R, MODE, WPB>(d, pk, omega, blockIdx.x);
+}
+
+template <typename REAL, int R, int MODE, int WPB>
+__device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t block_id)
 {
     constexpr int W = 64 * R;
     constexpr bool NEED_F = (MODE != BWD_PLAIN);
@@ -593,7 +601,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDe
     REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
     auto& sT = sT_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
+    const uint32_t quad = block_to_pack(block_id, n_quads);
     if (quad >= n_quads) return;
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
@@ -737,6 +745,12 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDe
     }
     for (int off2 = 32; off2 > 0; off2 >>= 1) s += __shfl_down(s, off2);
     if (lane == 0) d.lb_partial[pk.lb_base + p] = s;
+}
+
+template <typename REAL, int R, int MODE, int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
+{
+    bwd_narrow_body<REAL, R, MODE, WPB>(d, pk, omega, blockIdx.x);
 }
 
 // =============================================================================================
@@ -1271,13 +1285,12 @@ __device__ __forceinline__ void wide_load_vals(REAL (&v)[NPT], rsrc_t src, uint3
 }
 
 template <typename REAL, int MODE, int NPT>
-__global__ void __launch_bounds__(1024) k_fwd_wide2(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
+__device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t ww, uint32_t p)
 {
     using P2 = typename Pair<REAL>::type;
     constexpr bool NEED_T = (MODE != FWD_PLAIN);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, T = blockDim.x;
-    const uint32_t p = blockIdx.x;
     if (p >= pk.n_packs) return;
     const uint32_t S = ww + 2;
     // All LDS arrays are addressed as lds[offset + index] with integer offsets that rotate from hop to hop: with rotating POINTERS the
@@ -1452,7 +1465,13 @@ __global__ void __launch_bounds__(1024) k_fwd_wide2(DevPtrs<REAL> d, PackDev pk,
 }
 
 template <typename REAL, int MODE, int NPT>
-__global__ void __launch_bounds__(1024) k_bwd_wide2(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
+__global__ void __launch_bounds__(1024) k_fwd_wide2(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
+{
+    fwd_wide2_body<REAL, MODE, NPT>(d, pk, omega, ww, blockIdx.x);
+}
+
+template <typename REAL, int MODE, int NPT>
+__device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t ww, uint32_t p)
 {
     using P2 = typename Pair<REAL>::type;
     constexpr bool NEED_F = (MODE != BWD_PLAIN);
@@ -1460,7 +1479,6 @@ __global__ void __launch_bounds__(1024) k_bwd_wide2(DevPtrs<REAL> d, PackDev pk,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double red[16];
     const uint32_t tid = threadIdx.x, T = blockDim.x;
-    const uint32_t p = blockIdx.x;
     if (p >= pk.n_packs) return;
     const uint32_t S = ww + 2;
     REAL* const lds = reinterpret_cast<REAL*>(smem);  // integer offsets instead of rotating pointers, see k_fwd_wide2
@@ -1613,6 +1631,32 @@ __global__ void __launch_bounds__(1024) k_bwd_wide2(DevPtrs<REAL> d, PackDev pk,
         for (uint32_t i = 0; i < T / 64; ++i) t += red[i];
         d.lb_partial[pk.lb_base + p] = t;
     }
+}
+
+template <typename REAL, int MODE, int NPT>
+__global__ void __launch_bounds__(1024) k_bwd_wide2(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
+{
+    bwd_wide2_body<REAL, MODE, NPT>(d, pk, omega, ww, blockIdx.x);
+}
+
+// Instances with narrow AND wide packs: one launch for both.  The first n_wide workgroups sweep one wide pack each (they are the
+// long pole, so they start first), the rest are the narrow launch unchanged; the workgroup size is the narrow one (64 * WPB threads,
+// NPT = nodes of a wide hop per thread).  Sequential launches add their times (61 us = 36 + 20 + boundary on the knapsack
+// benchmark), a second stream costs more in event fork / join than it returns; inside one grid the two kinds of workgroups simply
+// share the CUs.
+template <typename REAL, int R, int WPB, int NPT>
+__global__ void __launch_bounds__(64 * WPB) k_fwd_mixed(DevPtrs<REAL> d, PackDev pkn, PackDev pkw, REAL omega, uint32_t ww)
+{
+    const uint32_t nw8 = (pkw.n_packs + 7u) & ~7u;  // a multiple of 8, so that the narrow workgroups keep their XCD-aware block -> pack map
+    if (blockIdx.x < nw8) fwd_wide2_body<REAL, FWD_SOLVE, NPT>(d, pkw, omega, ww, blockIdx.x);
+    else fwd_narrow_body<REAL, R, FWD_SOLVE, WPB>(d, pkn, omega, blockIdx.x - nw8);
+}
+template <typename REAL, int R, int WPB, int NPT>
+__global__ void __launch_bounds__(64 * WPB) k_bwd_mixed(DevPtrs<REAL> d, PackDev pkn, PackDev pkw, REAL omega, uint32_t ww)
+{
+    const uint32_t nw8 = (pkw.n_packs + 7u) & ~7u;
+    if (blockIdx.x < nw8) bwd_wide2_body<REAL, BWD_SOLVE, NPT>(d, pkw, omega, ww, blockIdx.x);
+    else bwd_narrow_body<REAL, R, BWD_SOLVE, WPB>(d, pkn, omega, blockIdx.x - nw8);
 }
 
 // =============================================================================================
