@@ -672,33 +672,31 @@ struct SolverT final : SolverBase {
     }
 
     template <typename TIN>
-    int update_side(REAL* cost, const void* c, uint64_t n, int on_device)
+    int update_both(const void* lo, uint64_t n_lo, const void* hi, uint64_t n_hi, int on_device)
     {
-        if (n == 0) return BDDMMA_OK;
-        if (n > n_vars) { err = "cost vector longer than nr_variables()"; return BDDMMA_ERR_INVALID_ARGUMENT; }
-        const TIN* dc = (const TIN*)c;
+        if (n_lo == 0 && n_hi == 0) return BDDMMA_OK;
+        if (n_lo > n_vars || n_hi > n_vars) { err = "cost vector longer than nr_variables()"; return BDDMMA_ERR_INVALID_ARGUMENT; }
+        const TIN *dlo = (const TIN*)lo, *dhi = (const TIN*)hi;
         TIN* tmp = nullptr;
-        if (!on_device) {
-            HIPCHK(hipMalloc((void**)&tmp, n * sizeof(TIN)));
-            hipError_t e = hipMemcpyAsync(tmp, c, n * sizeof(TIN), hipMemcpyHostToDevice, stream);
+        if (!on_device) {  // one staging buffer for both sides
+            HIPCHK(hipMalloc((void**)&tmp, (n_lo + n_hi) * sizeof(TIN)));
+            hipError_t e = hipSuccess;
+            if (n_lo) e = hipMemcpyAsync(tmp, lo, n_lo * sizeof(TIN), hipMemcpyHostToDevice, stream);
+            if (n_hi && e == hipSuccess) e = hipMemcpyAsync(tmp + n_lo, hi, n_hi * sizeof(TIN), hipMemcpyHostToDevice, stream);
             if (e != hipSuccess) { (void)hipFree(tmp); HIPCHK(e); }
-            dc = tmp;
+            dlo = tmp;
+            dhi = tmp + n_lo;
         }
-        hipLaunchKernelGGL((k_update_costs<REAL, TIN>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, cost, d_var, d_nbdds, dc, n, (uint32_t)n_layers);
+        hipLaunchKernelGGL((k_update_costs<REAL, TIN>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lohi, d_var, d_nbdds, dlo, n_lo, dhi, n_hi,
+                           (uint32_t)n_layers);
         if (tmp) { HIPCHK(hipStreamSynchronize(stream)); (void)hipFree(tmp); }
         return BDDMMA_OK;
     }
     int update_costs(const void* lo, uint64_t n_lo, const void* hi, uint64_t n_hi, int elem_precision, int on_device) override
     {
         HIPCHK(hipSetDevice(device));
-        int rc;
-        if (elem_precision == BDDMMA_F64) {
-            if ((rc = update_side<double>(d_lo, lo, n_lo, on_device))) return rc;
-            if ((rc = update_side<double>(d_hi, hi, n_hi, on_device))) return rc;
-        } else {
-            if ((rc = update_side<float>(d_lo, lo, n_lo, on_device))) return rc;
-            if ((rc = update_side<float>(d_hi, hi, n_hi, on_device))) return rc;
-        }
+        int rc = elem_precision == BDDMMA_F64 ? update_both<double>(lo, n_lo, hi, n_hi, on_device) : update_both<float>(lo, n_lo, hi, n_hi, on_device);
+        if (rc) return rc;
         fwd_valid = bwd_valid = false;
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;

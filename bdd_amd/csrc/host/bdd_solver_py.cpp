@@ -71,13 +71,25 @@ struct hip_solver {
         ck(rc, nullptr);
         return s;
     }
+    // a scratch file for the archive: memory-backed when /dev/shm exists, else under TMPDIR or /tmp
+    static std::string scratch_file()
+    {
+        const char* tmpdir = std::getenv("TMPDIR");
+        for (const std::string& dir : {std::string("/dev/shm"), std::string(tmpdir ? tmpdir : "/tmp"), std::string("/tmp")}) {
+            std::string path = dir + "/bddmma_pickle_XXXXXX";
+            const int fd = mkstemp(&path[0]);
+            if (fd >= 0) {
+                close(fd);
+                return path;
+            }
+        }
+        throw std::runtime_error("cannot create a temporary file for (un)pickling");
+    }
     // pickle (bdd_cuda_parallel_mma_py.cu:15-37): the solver's own archive (bddmma_save / bddmma_load) as bytes
     py::bytes dumps() const
     {
-        char path[] = "/dev/shm/bddmma_pickle_XXXXXX";
-        const int fd = mkstemp(path);
-        if (fd < 0) throw std::runtime_error("cannot create a temporary file for pickling");
-        close(fd);
+        const std::string path_s = scratch_file();
+        const char* path = path_s.c_str();
         const int rc = bddmma_save(h, path);
         std::string blob;
         if (rc == BDDMMA_OK) {
@@ -91,10 +103,8 @@ struct hip_solver {
     static std::unique_ptr<hip_solver> loads(const py::bytes& b, int device)
     {
         const std::string blob = b;
-        char path[] = "/dev/shm/bddmma_pickle_XXXXXX";
-        const int fd = mkstemp(path);
-        if (fd < 0) throw std::runtime_error("cannot create a temporary file for unpickling");
-        close(fd);
+        const std::string path_s = scratch_file();
+        const char* path = path_s.c_str();
         { std::ofstream f(path, std::ios::binary); f.write(blob.data(), (std::streamsize)blob.size()); }
         auto s = std::make_unique<hip_solver>();
         const int rc = bddmma_load(&s->h, device, path);

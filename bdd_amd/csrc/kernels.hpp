@@ -1940,17 +1940,19 @@ __global__ void k_layers_to_entries(const REAL* __restrict__ in, const uint32_t*
 // set_vars_costs_func (bdd_cuda_base.cu:457-474).  Quotient and sum are formed in double and rounded
 // once to REAL, as the reference CPU solver does (bdd_parallel_mma_base.cpp:640,651,674-677).
 template <typename REAL, typename TIN>
-__global__ void k_update_costs(REAL* __restrict__ cost, const int32_t* __restrict__ var, const int32_t* __restrict__ nbdds,
-                               const TIN* __restrict__ c, uint64_t n_c, uint32_t n_layers)
+__global__ void k_update_costs(REAL* __restrict__ lohi, const int32_t* __restrict__ var, const int32_t* __restrict__ nbdds,
+                               const TIN* __restrict__ c_lo, uint64_t n_lo, const TIN* __restrict__ c_hi, uint64_t n_hi, uint32_t n_layers)
 {
+    // both sides in one pass over the interleaved {lo, hi} array: one read of the layer's variable and BDD count, one 2 x REAL read-modify-write
+    using P2 = typename Pair<REAL>::type;
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= n_layers) return;
     const int v = var[l];
-    if ((uint64_t)v >= n_c) {
-        cost[2 * (size_t)l] = REAL(0);  // :465-469
-        return;
-    }
-    cost[2 * (size_t)l] = REAL((double)cost[2 * (size_t)l] + (double)c[v] / (double)nbdds[v]);
+    P2 c = reinterpret_cast<P2*>(lohi)[l];
+    const double nb = (double)nbdds[v];
+    if (n_lo) c.x = (uint64_t)v >= n_lo ? REAL(0) : REAL((double)c.x + (double)c_lo[v] / nb);  // :465-469: past the vector's end the cost is SET to 0
+    if (n_hi) c.y = (uint64_t)v >= n_hi ? REAL(0) : REAL((double)c.y + (double)c_hi[v] / nb);
+    reinterpret_cast<P2*>(lohi)[l] = c;
 }
 
 template <typename REAL>

@@ -4,6 +4,8 @@
 //   test/test_bdd_bipartite_matching_problem.cpp:8-59, test/test_loose_covering_problem.cpp:8-88.
 // Needs a GPU; run by tests/test_gpu_cpp.py.  Exit code 0 = all passed.
 #include <cmath>
+#include <hip/hip_runtime_api.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -114,6 +116,47 @@ static void test_explicit_mm_and_distribute()
     s.distribute_delta();
     const auto obj = s.get_primal_objective_vector_host();
     for (size_t v = 0; v < 9; ++v) CHECK_NEAR(obj[v], c[v], sizeof(REAL) == 8 ? 1e-9 : 1e-4);
+}
+
+// the thrust::device_vector overloads of the reference (test/test_cuda_parallel_mma.cu:71-99 passes delta_lo_hi as a device vector):
+// raw device pointers here; same protocol on a host vector and on a device buffer, results must agree
+template <typename REAL>
+static void test_device_vectors()
+{
+    std::vector<double> c(9, -1.0);
+    c[0] = c[3] = c[6] = -2.0;
+    bdd_hip_parallel_mma<REAL> a(matching(3), c), b(matching(3), c);
+    const size_t n = 2 * a.nr_variables();
+    std::vector<REAL> ha(n, REAL(0)), hb(n);
+    REAL* dev = nullptr;
+    CHECK(hipMalloc((void**)&dev, n * sizeof(REAL)) == hipSuccess);
+    CHECK(hipMemset(dev, 0, n * sizeof(REAL)) == hipSuccess);
+    CHECK(hipDeviceSynchronize() == hipSuccess);
+    for (int it = 0; it < 5; ++it) {
+        a.forward_mm(REAL(0.5), ha);
+        b.forward_mm(REAL(0.5), dev);
+        CHECK(hipMemcpy(hb.data(), dev, n * sizeof(REAL), hipMemcpyDeviceToHost) == hipSuccess);
+        for (size_t i = 0; i < n; ++i) CHECK_NEAR(hb[i], ha[i], sizeof(REAL) == 8 ? 1e-12 : 1e-5);
+        for (size_t v = 0; v < a.nr_variables(); ++v) { ha[2 * v] /= a.nr_bdds(v); ha[2 * v + 1] /= a.nr_bdds(v); }
+        b.normalize_delta(dev);
+        a.backward_mm(REAL(0.5), ha);
+        b.backward_mm(REAL(0.5), dev);
+        CHECK(hipMemcpy(hb.data(), dev, n * sizeof(REAL), hipMemcpyDeviceToHost) == hipSuccess);
+        for (size_t i = 0; i < n; ++i) CHECK_NEAR(hb[i], ha[i], sizeof(REAL) == 8 ? 1e-12 : 1e-5);
+        for (size_t v = 0; v < a.nr_variables(); ++v) { ha[2 * v] /= a.nr_bdds(v); ha[2 * v + 1] /= a.nr_bdds(v); }
+        b.normalize_delta(dev);
+    }
+    CHECK_NEAR(a.lower_bound(), b.lower_bound(), 1e-6);
+    // L-BFGS support on device vectors: net_solver_costs -> make_dual_feasible -> gradient_step
+    REAL* g = nullptr;
+    CHECK(hipMalloc((void**)&g, a.nr_layers() * sizeof(REAL)) == hipSuccess);
+    b.net_solver_costs(g);
+    b.make_dual_feasible(g);
+    const double lb0 = b.lower_bound();
+    b.gradient_step(g, 0.0);
+    CHECK_NEAR(b.lower_bound(), lb0, 1e-9);
+    (void)hipFree(g);
+    (void)hipFree(dev);
 }
 
 template <typename REAL>
@@ -248,6 +291,8 @@ int main()
         {"costs / min-marginals / solution <float>", test_costs_marginals_solution<float>},
         {"explicit forward_mm / backward_mm / distribute_delta <double>", test_explicit_mm_and_distribute<double>},
         {"explicit forward_mm / backward_mm / distribute_delta <float>", test_explicit_mm_and_distribute<float>},
+        {"device-vector overloads <double>", test_device_vectors<double>},
+        {"device-vector overloads <float>", test_device_vectors<float>},
         {"L-BFGS wrapper, move construction <double>", test_lbfgs_and_move<double>},
         {"L-BFGS wrapper, move construction <float>", test_lbfgs_and_move<float>},
         {"facades bdd_hip / bdd_lbfgs_hip_mma <double>", test_facades<double>},
