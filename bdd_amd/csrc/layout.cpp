@@ -146,7 +146,9 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
     int rc = build_layout_w(instr, delims, n_bdds, opts, L, err, keep_debug_maps, real_size);
     // Few packs (small instance, or few but long BDDs): a sweep is then bound by the latency of one pack's
     // hop chain, so prefer more, narrower packs.  Only when the caller left pack_width open.
-    if (rc == BDDMMA_OK && !(opts && opts->pack_width) && L.narrow.n_packs() < 4000 && L.narrow.n_packs() > 0) {
+    // (threshold measured on random set cover: 2.1 M nodes = 1 563 packs of 128: 64-wide 18.5 / 19.1 us per sweep vs 19.7 / 18.3; 4.2 M nodes =
+    // 3 125 packs: 29.4 / 29.6 vs 27.3 / 25.5 — so 128 stays from ~2 000 packs on)
+    if (rc == BDDMMA_OK && !(opts && opts->pack_width) && L.narrow.n_packs() < 2048 && L.narrow.n_packs() > 0) {
         bddmma_options o = opts ? *opts : bddmma_options{};
         o.pack_width = 64;
         HostLayout L2;

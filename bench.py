@@ -173,7 +173,7 @@ def main():
                 "workload": workload_name(sizes, args),
                 "precision": args.precision,
                 "omega": 0.5,
-                "pack_width": args.pack_width or "auto (128; 64 when fewer than 4000 packs)",
+                "pack_width": args.pack_width or "auto (128; 64 when fewer than 2048 packs)",
                 "waves_per_block": args.wpb or "auto",
                 "packs": packs,
                 "hops": hops,
