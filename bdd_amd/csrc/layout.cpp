@@ -638,6 +638,9 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         // in the entry arrays shrink with the bins, take 23.8 / 22.9 / 22.1 us)
         const uint32_t min_vb = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(64, one_chunk_vars / 64 * 64));
         auto_vb = std::min(std::max(auto_vb, min_vb), max_vb);
+        // up to 1024 variables per bin the exchange runs its 256-thread variant (kernels.hpp: EXS_*), which is also the better choice
+        // a little beyond (V = 300-400 k: 1024 per bin 9.1-9.7 us, the 1024-thread kernel on 1216-1600 per bin 10.8-11.2 us)
+        if (auto_vb > 1024 && auto_vb <= 2048) auto_vb = 1024;
         X.vars_per_bin = opts && opts->vars_per_bin ? opts->vars_per_bin : auto_vb;
         // stage groups hold <= stage_cap layers of one pack; the default is the largest pack's layer count (one group per pack) up to
         // 640, so that small packs do not reserve LDS staging space they never use
