@@ -5,7 +5,7 @@ iterations/s and lower bound vs iteration / time, next to plain MMA.  Writes pro
 """
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bdd_amd.instances import random_set_cover, set_cover_sizes
+from bdd_amd.instances import random_set_cover_mt as random_set_cover, set_cover_sizes
 from bdd_amd.solver import bdd_hip_lbfgs, bdd_hip_parallel_mma
 
 ap = argparse.ArgumentParser()
@@ -13,7 +13,7 @@ ap.add_argument("--precision", default="double")
 ap.add_argument("--iters", type=int, default=150)
 ap.add_argument("--vars", type=int, default=1_000_000)
 ap.add_argument("--rows", type=int, default=500_000)
-ap.add_argument("--tag", default="r01")
+ap.add_argument("--tag", default="r02")
 a = ap.parse_args()
 col, costs = random_set_cover(a.vars, a.rows, 10, seed=12345)
 out = {"workload": f"random set cover k=10, V={a.vars}, B={a.rows}: {set_cover_sizes(a.vars, a.rows, 10)['N']} BDD nodes",
