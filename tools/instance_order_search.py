@@ -1,0 +1,40 @@
+"""Which draw order did the survey's driver use for the mt19937_64(12345) set-cover instance of BASELINE.md §2?
+
+BASELINE.md quotes LB(20 iterations, 1.05 M nodes, double) = 24594.218672 from the unmodified reference, but the driver that
+drew the rows was not kept.  This script builds the instance in the draw orders of tools/instance_order_search.cpp (rows before /
+after the costs, per-element vs per-row rejection of duplicates, uniform_int_distribution vs modulo vs scaled doubles, the cost
+engine shared / re-seeded / seed + 1 / 32-bit, a 32-bit row engine) and runs the CPU oracle for 20 iterations on each.  Result
+(DESIGN.md §4): no order reproduces the value; the closest is 24597.052681 (rows first, per-element rejection, costs afterwards),
+which is the order bdd_amd/csrc/host/instances.cpp documents as the benchmark instance.
+
+    g++ -O2 -std=c++17 -shared -fPIC -o build/libinstance_order_search.so tools/instance_order_search.cpp
+    python tools/instance_order_search.py
+"""
+import ctypes as C
+import itertools
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bdd_amd.bdd_collection import BddCollection  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+
+L = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "libinstance_order_search.so"))
+V, B, k, target = 100_000, 50_000, 10, 24594.218672
+for r32, crng, drawm, dup, order in itertools.product([0, 1], [0, 1, 2, 3], [0, 1, 2], [0, 1], [0, 1]):
+    if r32 and drawm == 2:
+        continue
+    variant = order | (dup << 1) | (drawm << 2) | (crng << 4) | (r32 << 6)
+    rows = np.zeros((B, k), np.uint64)
+    costs = np.zeros(V)
+    L.gen(C.c_uint64(V), C.c_uint64(B), C.c_uint64(k), C.c_uint64(12345), C.c_int(variant), rows.ctypes.data_as(C.c_void_p), costs.ctypes.data_as(C.c_void_p))
+    col = BddCollection()
+    col.add_covering(rows)
+    o = Oracle(col, costs, "double", threads=8)
+    for _ in range(20):
+        o.iteration()
+    lb = o.lower_bound()
+    print(dict(row_engine_32bit=r32, cost_engine=crng, draw=drawm, per_row_rejection=dup, costs_first=order), round(lb, 6),
+          "  <<< MATCH" if abs(lb - target) < 1e-4 else "", flush=True)
