@@ -320,7 +320,7 @@ struct SolverT final : SolverBase {
         }
         // one launch for narrow + wide solve sweeps when the wide packs fit the narrow workgroup size (<= 4 nodes per thread) and their
         // LDS frontier does not cost the narrow workgroups their occupancy
-        if (wb_.n_packs && nb_.n_packs && !use_res && !(opts && opts->reserved[0] == 1)) {
+        if (wb_.n_packs && nb_.n_packs && !use_res && !(opts && (opts->variant_flags & 1u))) {
             const uint32_t threads = 64 * wpb;
             const uint32_t npt = (wide_pack_width + threads - 1) / threads;
             const uint32_t narrow_dyn = stage_lds + seg_bytes(wpb);

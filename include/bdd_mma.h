@@ -80,7 +80,9 @@ typedef struct bddmma_options {
                                   per variable over a contiguous run: deterministic, no LDS accumulators, a shorter exchange launch; but
                                   the sweeps' accesses to the entry arrays lose their locality (slower overall on every instance
                                   measured).  Default (0 / 1): binned order */
-    uint32_t reserved[3];
+    uint32_t variant_flags;    /* switches between equivalent code paths, for A/B measurements and the differential tests (default 0):
+                                  bit 0: narrow and wide backward sweeps as two launches (default: one, k_bwd_mixed) */
+    uint32_t reserved[2];
 } bddmma_options;
 
 /* ---- construction ------------------------------------------------------- */
