@@ -869,6 +869,27 @@ struct SolverT final : SolverBase {
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
+    // make_dual_feasible + gradient_step for a device vector that is only applied, never read back (lbfgs.hip): the means once ...
+    REAL* d_proj_q = nullptr;
+    int projection_means(const void* g) override
+    {
+        HIPCHK(hipSetDevice(device));
+        int rc;
+        if (!d_proj_q && (rc = dalloc(&d_proj_q, n_vars))) return rc;
+        hipLaunchKernelGGL((k_projection_means<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, (const REAL*)g, d_var_ptr, d_var_layers, d_proj_q, (uint32_t)n_vars);
+        HIPCHK(hipGetLastError());
+        return BDDMMA_OK;
+    }
+    // ... then any number of steps along the projected vector
+    int gradient_step_projected(const void* g, double step) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (!d_proj_q) { err = "gradient_step_projected without projection_means"; return BDDMMA_ERR_INVALID_ARGUMENT; }
+        hipLaunchKernelGGL((k_gradient_step_projected<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_hi, (const REAL*)g, d_proj_q, (const uint32_t*)d_var, REAL(step), (uint32_t)n_layers);
+        fwd_valid = bwd_valid = false;
+        HIPCHK(hipGetLastError());
+        return BDDMMA_OK;
+    }
     void* stream_handle() override { return (void*)stream; }
     int rounding_scratch(void** c0_dev, void** c1_dev) override
     {

@@ -2045,6 +2045,40 @@ __global__ void k_make_dual_feasible(REAL* __restrict__ g, const uint32_t* __res
     for (uint32_t k = k0 + MAXR; k < k1; ++k) g[var_layers[k]] -= q;
 }
 
+// The two halves of make_dual_feasible for a vector that is only ever applied as a cost update (the L-BFGS direction): the
+// per-variable means are gathered once (no scattered write-back of the projected vector) ...
+template <typename REAL>
+__global__ void k_projection_means(const REAL* __restrict__ g, const uint32_t* __restrict__ var_ptr, const uint32_t* __restrict__ var_layers,
+                                   REAL* __restrict__ q, uint32_t n_vars)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vars) return;
+    const uint32_t k0 = var_ptr[v], k1 = var_ptr[v + 1];
+    if (k1 == k0) { q[v] = REAL(0); return; }
+    constexpr int MAXR = 8;
+    uint32_t idx[MAXR];
+    REAL val[MAXR];
+#pragma unroll
+    for (int u = 0; u < MAXR; ++u) idx[u] = k0 + u < k1 ? var_layers[k0 + u] : 0u;
+#pragma unroll
+    for (int u = 0; u < MAXR; ++u) val[u] = k0 + u < k1 ? g[idx[u]] : REAL(0);
+    REAL s = 0;
+#pragma unroll
+    for (int u = 0; u < MAXR; ++u) s += val[u];
+    for (uint32_t k = k0 + MAXR; k < k1; ++k) s += g[var_layers[k]];
+    q[v] = s / REAL(k1 - k0);   // same summation order and quotient as k_make_dual_feasible
+}
+// ... and subtracted where the step is applied: hi += step * (g[l] - q[var(l)]), the value k_make_dual_feasible + k_gradient_step produce
+template <typename REAL>
+__global__ void k_gradient_step_projected(REAL* __restrict__ hi, const REAL* __restrict__ g, const REAL* __restrict__ q,
+                                          const uint32_t* __restrict__ layer_var, REAL step, uint32_t n)
+{
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n) return;
+    const REAL gp = g[l] - q[layer_var[l]];
+    hi[2 * (size_t)l] = hi[2 * (size_t)l] + step * gp;
+}
+
 // compute_primal_objective_vec (bdd_cuda_base.cu:1352-1362)
 template <typename REAL>
 __global__ void k_primal_objective(const REAL* __restrict__ lo, const REAL* __restrict__ hi, const uint32_t* __restrict__ var_ptr,

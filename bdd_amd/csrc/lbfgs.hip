@@ -44,7 +44,7 @@ namespace {
     } while (0)
 
 // Scalars of the two-loop recursion stay on the device (no host round trip per dot product):
-//   sc[i] = alpha_i (i < 32), sc[SC_DOT] = last dot product, sc[SC_YNORM] = |y_last|^2, sc[SC_COEF] = coefficient of the next axpy
+//   sc[i] = alpha_i (i < 32), sc[SC_DOT] = last dot product, sc[SC_YNORM] = |y_last|^2, sc[SC_COEF] = coefficient of an unfused axpy
 enum : int { SC_DOT = 32, SC_YNORM = 33, SC_COEF = 34, SC_COUNT = 40 };
 // What the last block of a dot product does with the result r (the scalar kernels of the recursion, fused):
 //   FIN_STORE : sc[slot] = r
@@ -83,11 +83,96 @@ static __global__ void __launch_bounds__(1024) k_reduce_fin(const double* __rest
         sc[SC_COEF] = sc[fin.i] - rho * r;
     }
 }
-template <typename REAL, typename TX>
-static __global__ void k_axpy_dev(REAL* __restrict__ y, const TX* __restrict__ x, const double* __restrict__ coef, uint32_t n)
+// Fused passes of the L-BFGS vector algebra.  The two-loop recursion is a chain of 2m (dot product -> coefficient -> axpy) steps over
+// vectors of nr_layers entries; as separate launches every step reads the direction twice.  Here the axpy of step k and the dot
+// product of step k + 1 are one pass: d += coef * x, then partial sums of <a, d> (same per-block partition and summation order as
+// k_dot, so the results are bit-identical to the unfused version).
+// The coefficient of the axpy is the finalised previous dot product (DotFin, as k_reduce_fin): every block adds the previous
+// kernel's partial sums itself, in the same fixed order, instead of a 1-block launch in between.  Partial sums alternate between
+// two buffers (a block may still be reading the previous ones while another already writes its own).
+template <typename REAL, typename TX, typename TA, bool DOT>
+static __global__ void __launch_bounds__(256) k_axpy_dot(REAL* __restrict__ d, const TX* __restrict__ x, const TA* __restrict__ a, const double* __restrict__ prev_partial,
+                                                         uint32_t n_partial, double* __restrict__ sc, DotFin fin, double* __restrict__ partial, uint32_t n)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] += REAL(*coef) * REAL(x[i]);
+    __shared__ double red[4];
+    __shared__ double s_coef;
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_partial; i += 256) acc += prev_partial[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double r = (red[0] + red[1]) + (red[2] + red[3]);
+        if (fin.op == FIN_ALPHA) {
+            const double al = r / fin.rho_inv;
+            if (blockIdx.x == 0) sc[fin.i] = al;
+            s_coef = -al;
+        } else {
+            double rho = 1.0 / fin.rho_inv;
+            if (fin.first) rho *= fin.rho_inv_last / (1e-8 + sc[SC_YNORM]);
+            s_coef = sc[fin.i] - rho * r;
+        }
+    }
+    __syncthreads();
+    const REAL c = REAL(s_coef);
+    acc = 0.0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const REAL v = d[i] + c * REAL(x[i]);
+        d[i] = v;
+        if (DOT) acc += (double)a[i] * (double)v;
+    }
+    if (!DOT) return;
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// d = g (the subgradient, char-valued) and partial sums of <a, d>: the start of the recursion
+template <typename REAL, typename TA>
+static __global__ void k_init_dot(REAL* __restrict__ d, const char* __restrict__ g, const TA* __restrict__ a, double* __restrict__ partial, uint32_t n)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const REAL v = REAL(0) + REAL(1) * REAL(g[i]);  // as fill(0) followed by axpy(1, g)
+        d[i] = v;
+        acc += (double)a[i] * (double)v;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (uint32_t i = 0; i < blockDim.x / 64; ++i) t += red[i];
+        partial[blockIdx.x] = t;
+    }
+}
+// store_iterate in one pass (lbfgs_impl.h:78-134): s = x - x_prev, y = g_prev - g, partial sums of <s, y>, and the new "previous" state
+template <typename REAL>
+static __global__ void k_store_iterate(const REAL* __restrict__ cur_x, REAL* __restrict__ prev_x, const char* __restrict__ cur_g, char* __restrict__ prev_g,
+                                       REAL* __restrict__ s_out, char* __restrict__ y_out, double* __restrict__ partial, uint32_t n)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const REAL x = cur_x[i];
+        const char g = cur_g[i];
+        const REAL sv = REAL(x - prev_x[i]);
+        const char yv = (char)(prev_g[i] - g);
+        s_out[i] = sv;
+        y_out[i] = yv;
+        prev_x[i] = x;
+        prev_g[i] = g;
+        acc += (double)sv * (double)yv;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (uint32_t i = 0; i < blockDim.x / 64; ++i) t += red[i];
+        partial[blockIdx.x] = t;
+    }
 }
 
 template <typename REAL>
@@ -137,7 +222,7 @@ struct Lbfgs final : bddmma_lbfgs {
         step_size = p.init_step_size;
         int rc;
         if ((rc = alloc(&prev_x, n)) || (rc = alloc(&cur_x, n)) || (rc = alloc(&dir, n)) || (rc = alloc(&prev_g, n)) ||
-            (rc = alloc(&cur_g, n)) || (rc = alloc(&d_partial, 1024)) || (rc = alloc(&d_scalar, SC_COUNT)))
+            (rc = alloc(&cur_g, n)) || (rc = alloc(&d_partial, 2048)) || (rc = alloc(&d_scalar, SC_COUNT)))
             return rc;
         if (p.history_size >= SC_DOT) { err = "history size must be < 32"; return BDDMMA_ERR_INVALID_ARGUMENT; }
         for (int i = 0; i < p.history_size + 1; ++i) {
@@ -174,10 +259,11 @@ struct Lbfgs final : bddmma_lbfgs {
         return 0;
     }
     // dot product consumed on the device (see DotFin); ordered on the stream, no synchronisation
+    uint32_t dot_blocks() const { return std::min<uint32_t>(1024, (n + 255) / 256 ? (n + 255) / 256 : 1); }
     template <typename TA, typename TB>
     void dot_dev(const TA* a, const TB* b, const DotFin& fin)
     {
-        const uint32_t blocks = std::min<uint32_t>(1024, (n + 255) / 256 ? (n + 255) / 256 : 1);
+        const uint32_t blocks = dot_blocks();
         hipLaunchKernelGGL((k_dot<TA, TB>), dim3(blocks), dim3(256), 0, st, a, b, d_partial, n);
         hipLaunchKernelGGL(k_reduce_fin, dim3(1), dim3(1024), 0, st, d_partial, blocks, d_scalar, fin);
     }
@@ -204,9 +290,12 @@ struct Lbfgs final : bddmma_lbfgs {
         }
         Hist h = free_slots.back();
         free_slots.pop_back();
-        hipLaunchKernelGGL((k_diff<REAL, REAL>), grid(), dim3(256), 0, st, h.s, cur_x, prev_x, n);   // x_k - x_{k-1}
-        hipLaunchKernelGGL((k_diff<char, char>), grid(), dim3(256), 0, st, h.y, prev_g, cur_g, n);   // g_{k-1} - g_k
-        if ((rc = dot(h.s, h.y, &h.rho_inv))) { free_slots.push_back(h); return rc; }
+        // x_k - x_{k-1}, g_{k-1} - g_k, <s, y> and prev <- cur in one pass
+        const uint32_t blocks = dot_blocks();
+        hipLaunchKernelGGL((k_store_iterate<REAL>), dim3(blocks), dim3(256), 0, st, cur_x, prev_x, cur_g, prev_g, h.s, h.y, d_partial, n);
+        hipLaunchKernelGGL(k_reduce_fin, dim3(1), dim3(1024), 0, st, d_partial, blocks, d_scalar, DotFin{FIN_STORE, SC_DOT, 0, 0, 0.0, 0.0});
+        LHIP(hipMemcpyAsync(&h.rho_inv, d_scalar + SC_DOT, sizeof(double), hipMemcpyDeviceToHost, st));
+        LHIP(hipStreamSynchronize(st));
         if (h.rho_inv > 1e-8) {
             history.push_back(h);
             if ((int)history.size() > p.history_size) {
@@ -217,8 +306,6 @@ struct Lbfgs final : bddmma_lbfgs {
             free_slots.push_back(h);
             prev_stored = false;
         }
-        LHIP(hipMemcpyAsync(prev_x, cur_x, n * sizeof(REAL), hipMemcpyDeviceToDevice, st));
-        LHIP(hipMemcpyAsync(prev_g, cur_g, n, hipMemcpyDeviceToDevice, st));
         return 0;
     }
 
@@ -227,17 +314,31 @@ struct Lbfgs final : bddmma_lbfgs {
     // compute_update_direction, :226-316 — everything queued on the stream, the scalars never leave the device
     int compute_direction()
     {
-        hipLaunchKernelGGL((k_fill<REAL>), grid(), dim3(256), 0, st, dir, REAL(0), (uint64_t)n);
-        hipLaunchKernelGGL((k_axpy<REAL, char>), grid(), dim3(256), 0, st, dir, cur_g, REAL(1), n);  // direction = grad_f
-        const double* coef = d_scalar + SC_COEF;
-        for (int i = (int)history.size() - 1; i >= 0; --i) {
-            dot_dev(history[i].s, dir, DotFin{FIN_ALPHA, 0, i, 0, history[i].rho_inv, 0.0});
-            hipLaunchKernelGGL((k_axpy_dev<REAL, char>), grid(), dim3(256), 0, st, dir, history[i].y, coef, n);
-        }
+        const int m = (int)history.size();
+        const uint32_t nb = dot_blocks();
+        const dim3 g(nb), b(256);
+        double* part[2] = {d_partial, d_partial + 1024};
+        int cur = 0;
+        // |y_last|^2 does not depend on the direction: first
         dot_dev(history.back().y, history.back().y, DotFin{FIN_STORE, SC_YNORM, 0, 0, 0.0, 0.0});
-        for (size_t i = 0; i < history.size(); ++i) {
-            dot_dev(history[i].y, dir, DotFin{FIN_BETA, 0, (int)i, i == 0 ? 1 : 0, history[i].rho_inv, history.back().rho_inv});
-            hipLaunchKernelGGL((k_axpy_dev<REAL, REAL>), grid(), dim3(256), 0, st, dir, history[i].s, coef, n);
+        // direction = grad_f; <s_{m-1}, d>
+        hipLaunchKernelGGL((k_init_dot<REAL, REAL>), g, b, 0, st, dir, cur_g, history[m - 1].s, part[cur], n);
+        // first loop: d -= alpha_i y_i with alpha_i from the pending dot product, fused with the next one
+        // (<s_{i-1}, d>, or <y_0, d> when the second loop starts)
+        for (int i = m - 1; i >= 0; --i, cur ^= 1) {
+            const DotFin f{FIN_ALPHA, 0, i, 0, history[i].rho_inv, 0.0};
+            if (i > 0)
+                hipLaunchKernelGGL((k_axpy_dot<REAL, char, REAL, true>), g, b, 0, st, dir, history[i].y, history[i - 1].s, part[cur], nb, d_scalar, f, part[cur ^ 1], n);
+            else
+                hipLaunchKernelGGL((k_axpy_dot<REAL, char, char, true>), g, b, 0, st, dir, history[0].y, history[0].y, part[cur], nb, d_scalar, f, part[cur ^ 1], n);
+        }
+        // second loop: d += (alpha_i - beta_i) s_i fused with <y_{i+1}, d>
+        for (int i = 0; i < m; ++i, cur ^= 1) {
+            const DotFin f{FIN_BETA, 0, i, i == 0 ? 1 : 0, history[i].rho_inv, history.back().rho_inv};
+            if (i + 1 < m)
+                hipLaunchKernelGGL((k_axpy_dot<REAL, REAL, char, true>), g, b, 0, st, dir, history[i].s, history[i + 1].y, part[cur], nb, d_scalar, f, part[cur ^ 1], n);
+            else
+                hipLaunchKernelGGL((k_axpy_dot<REAL, REAL, char, false>), g, b, 0, st, dir, history[i].s, (const char*)nullptr, part[cur], nb, d_scalar, f, part[cur ^ 1], n);
         }
         LHIP(hipGetLastError());
         return 0;
@@ -264,7 +365,7 @@ struct Lbfgs final : bddmma_lbfgs {
         auto apply = [&](double new_step) -> int {
             const double net = new_step - prev_step;
             if (net != 0.0) {
-                int r = b->gradient_step(dir, net, 1);
+                int r = b->gradient_step_projected(dir, net);
                 if (r) { err = b->err; return r; }
                 ++last_trials;
             }
@@ -312,7 +413,7 @@ struct Lbfgs final : bddmma_lbfgs {
         if ((rc = store_iterate())) return rc;
         if (update_possible() && (int)lb_history.size() >= p.history_size) {  // choose_solver, :409-417
             if ((rc = compute_direction())) return rc;
-            if ((rc = b->make_dual_feasible(dir, 1))) { err = b->err; return rc; }
+            if ((rc = b->projection_means(dir))) { err = b->err; return rc; }  // make_dual_feasible(direction), applied inside the steps
             if ((rc = search_step_size_and_apply())) return rc;
             last_kind = 1;
             ++lbfgs_iterations;

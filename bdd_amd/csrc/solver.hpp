@@ -63,6 +63,8 @@ struct SolverBase {
     virtual int net_solver_costs(void* out, int on_device) = 0;
     virtual int make_dual_feasible(void* g, int on_device) = 0;
     virtual int gradient_step(const void* g, double step, int on_device) = 0;
+    virtual int projection_means(const void* g_dev) = 0;                       // per-variable means of a device vector, kept inside the solver
+    virtual int gradient_step_projected(const void* g_dev, double step) = 0;   // costs += step * (g - its per-variable mean)
     virtual void* stream_handle() = 0;
     virtual int time_kernel(int kind, uint64_t reps, double* ms) = 0;
     // one round of perturb_primal_costs (incremental_mm_agreement_rounding_cuda.cu:262-331); counts = #one,#zero,#equal,#inconsistent
