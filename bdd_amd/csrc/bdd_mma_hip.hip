@@ -59,7 +59,8 @@ struct SolverT final : SolverBase {
     uint16_t* d_cs_slot = nullptr;
     uint32_t wpb = 1;
     bool entry_by_var = false;  // entries ordered by (variable, bdd): exchange = k_exchange_byvar
-    bool exch_small = false;
+    bool exch_small = false, exch_medium = false;
+    uint32_t opts_variant = 0;  // bddmma_options.variant_flags (A/B switches of kernel variants)
     bool narrow_seg = false;  // some narrow pack has layers wider than two nodes: seg_min2 goes through LDS and needs scratch
     uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0, stage_lds = 0, exch_lds = 0, n_narrow_layers = 0;
     double *d_lb_partial = nullptr, *d_lb = nullptr;
@@ -265,7 +266,9 @@ struct SolverT final : SolverBase {
 #define SET_DYN(K, BYTES) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
         SET_DYN((k_exchange_reduce<REAL, double, EX_ITER>), exch_lds);
         SET_DYN((k_exchange_reduce<REAL, double, EX_RAW>), exch_lds);
+        opts_variant = opts ? opts->variant_flags : 0u;
         exch_small = vars_per_bin <= EXS_MAX_VARS_PER_BIN;  // 256-thread workgroups (kernels.hpp: EXS_*)
+        exch_medium = !exch_small && vars_per_bin <= EXM_MAX_VARS_PER_BIN;  // 512-thread workgroups (EXM_*)
 #undef SET_DYN
         // resident sweeps: chosen when every narrow pack fits its wave's LDS slice and the instance is small enough that the streaming
         // kernels are latency-bound (few waves per SIMD); resident_sweeps = 1 turns them off, = 2 forces them on
@@ -517,7 +520,11 @@ struct SolverT final : SolverBase {
             launch_bcast(d_delta_var, d_delta_lay);
             delta_var_valid = true;
         } else {
-            if (exch_small)
+            if (exch_medium)
+                hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, EXM_THREADS, EXM_UNROLL, EXM_NPT>), dim3(n_bins), dim3(EXM_THREADS), exch_lds,
+                                   stream, d_mm_binned, d_bin_ptr, d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars,
+                                   (uint32_t)n_layers);
+            else if (exch_small)
                 hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, EXS_THREADS, EXS_UNROLL, EXS_NPT>), dim3(n_bins), dim3(EXS_THREADS), exch_lds,
                                    stream, d_mm_binned, d_bin_ptr, d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars,
                                    (uint32_t)n_layers);

@@ -318,7 +318,10 @@ __device__ __forceinline__ void wave_sync()
 }
 
 constexpr uint32_t HOP_WIN = 64;
-constexpr int HOP_UNROLL = 2;  // hops per trip of the narrow kernels' hop loops (see k_fwd_narrow)
+#ifndef BDDMMA_HOP_UNROLL
+#define BDDMMA_HOP_UNROLL 2
+#endif
+constexpr int HOP_UNROLL = BDDMMA_HOP_UNROLL;  // hops per trip of the narrow kernels' hop loops (see k_fwd_narrow)
 struct HopWindow {
     uint32_t* node;   // LDS [HOP_WIN]
     uint32_t* layer;  // LDS [HOP_WIN]
@@ -395,7 +398,10 @@ __device__ __forceinline__ void load_vals(REAL (&v)[R], rsrc_t src, uint32_t nb,
     }
 }
 
-template <typename REAL, int R, int MODE, int WPB>
+#ifndef BDDMMA_LOOKAHEAD
+#define BDDMMA_LOOKAHEAD 1
+#endif
+template <typename REAL, int R, int MODE, int WPB, int LA = BDDMMA_LOOKAHEAD>
 __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t block_id)
 {
     constexpr int W = 64 * R;
@@ -406,7 +412,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     // per wave; +2: constant sink entries at index TOP = W (cost-from-terminal 0) and BOT = W + 1 (+inf);
     // for sF they are dummy push targets, so sink children need no branch
     __shared__ REAL sF_[WPB][2][W + 2];
-    __shared__ REAL sT_[WPB][W + 2];
+    __shared__ REAL sT_[WPB][2][W + 2];  // costs-from-terminal of the next hop, written one hop ahead (double buffer)
     __shared__ unsigned char sAct_[WPB][2][MODE == FWD_SOLUTION ? W + 2 : 1];
     __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN];
     const uint32_t tid = threadIdx.x;
@@ -433,27 +439,52 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     auto off = [&](uint32_t q) { return hw.node_off(q); };
     // word address of slot s of this pack = s + wd (the pack's words live in a sequence shared by all packs of its structure)
     const uint32_t wd = has_pack ? pk.pack_word_off[p] - pk.hop_node_off[q0] : 0;
-    uint32_t nb = 0, ne = 0;
-    // pipeline prologue
-    uint32_t wa[R], wb[R];
-    REAL ta[R];
-    HopLayer<REAL, R> La;
+    // Software pipeline with a look-ahead of D hops: at the start of hop q the wave holds the node words of hops q .. q+2D-1, the
+    // costs-from-terminal of hops q+2 .. q+D+1 (those of hop q+1 are already in LDS) and the layer data of hops q .. q+D-1; during hop q
+    // it requests the words of hop q+2D, T of hop q+D+2 and — from the words of hop q+D, which were requested D hops ago — the layer
+    // data of hop q+D.  Every request has D hop times to arrive.  o[i] = first slot of hop q+i (uniform); the newest offset and the
+    // layer offset of the next hop are read from the LDS window one hop before they are used, in the hop's single batch of LDS reads.
+    constexpr int D = LA;
+    uint32_t o[2 * D + 3];
+    uint32_t lcur = 0;  // first layer of hop q+D
+    uint32_t wr[2 * D + 1][R];
+    REAL tr[D + 1][R];
+    HopLayer<REAL, R> Lr[D + 1];
+#pragma unroll
+    for (int i = 0; i < 2 * D + 3; ++i) o[i] = 0;
     if (has_pack) {
         hw.fill(pk, q0, lane);
-        nb = off(q0);
-        ne = off(q0 + 1);
+#pragma unroll
+        for (int i = 0; i < 2 * D + 3; ++i) o[i] = off(q0 + i);
+        lcur = hw.layer_off(q0 + D);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t j = lane + 64 * r;
-            sF[0][j] = (j < ne - nb) ? REAL(0) : INF;  // every slot of hop 0 is a root (flush_costs_from_root)
-            if (MODE == FWD_SOLUTION) sAct[0][j] = (j < ne - nb) ? 1 : 0;
+            sF[0][j] = (j < o[1] - o[0]) ? REAL(0) : INF;  // every slot of hop 0 is a root (flush_costs_from_root)
+            if (MODE == FWD_SOLUTION) sAct[0][j] = (j < o[1] - o[0]) ? 1 : 0;
         }
-        if (lane < 2) sT[W + lane] = lane == 0 ? REAL(0) : INF;
-        load_words<R>(wa, rs.words, nb + wd, ne - nb, lane);
-        const uint32_t ne2 = off(q0 + 2);
-        load_words<R>(wb, rs.words, ne + wd, ne2 - ne, lane);                // words of hop q0+1 (none if q0+1 == q1)
-        if (NEED_T) load_vals<REAL, R>(ta, rs.T, ne, ne2 - ne, lane);         // T of hop q0+1
-        load_layer<REAL, R>(La, wa, hw.layer_off(q0), rs);
+        if (lane < 4) sT[lane >> 1][W + (lane & 1)] = (lane & 1) ? INF : REAL(0);
+#pragma unroll
+        for (int i = 0; i < 2 * D; ++i) load_words<R>(wr[i], rs.words, o[i] + wd, o[i + 1] - o[i], lane);   // none past the last hop
+        if (NEED_T) {
+            REAL t1[R];
+            load_vals<REAL, R>(t1, rs.T, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
+#pragma unroll
+            for (int i = 0; i < D; ++i) load_vals<REAL, R>(tr[i], rs.T, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t j = lane + 64 * r;
+                if (j < o[2] - o[1]) sT[0][j] = t1[r];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) load_layer<REAL, R>(Lr[i], wr[i], hw.layer_off(q0 + i), rs);
+        wave_sync();
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2 * D; ++i)
+#pragma unroll
+            for (int r = 0; r < R; ++r) wr[i][r] = nw_pad_word(64 * R);
     }
     int cur = 0;
     uint32_t q = q0;
@@ -482,86 +513,120 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
         // finished), so the chain "wait, LDS round trips, stores" is paid once per trip; inside a trip the waits are
         // counted and the pipeline-register rotation is renamed away.  Latency-bound cases gain most: sweeps of
         // 100-variable rows -10 % (solve) / -22 % (plain), the 1 M-node benchmark -6 %; the saturated 10.5 M one +-1 %.
+        // One hop of the pack.  A wave's hop used to be a chain of ~9 dependent LDS round trips (offsets, frontier, T set-up -> gather,
+        // staged pairs, per 64-lane group in turn), ~130 cycles each: with few waves per SIMD that chain, not HBM, set the hop time.
+        // Now everything a hop reads from LDS — the frontier, the children's costs-from-terminal (written one hop ahead), the staged
+        // pairs, the next hop's offsets — is one batch of reads for all R groups, followed by the arithmetic, followed by the writes.
         auto hop = [&]() {
-            if (q + 3 >= hw.base + HOP_WIN && hw.base + HOP_WIN <= q1) hw.fill(pk, q, lane);
-            const uint32_t ne2 = off(q + 2);
-            const uint32_t n2 = ne2 - ne;
-            // ---- prefetch: layer data of hop q+1 (its words were requested one hop ago), words of hop q+2, T of hop q+2
-            uint32_t wc[R];
-            REAL tb[R];
-            HopLayer<REAL, R> Lb;
-            {
-                const uint32_t ne3 = off(q + 3);
-                load_words<R>(wc, rs.words, ne2 + wd, ne3 - ne2, lane);
-                if (NEED_T) load_vals<REAL, R>(tb, rs.T, ne2, ne3 - ne2, lane);
-                const uint32_t lbase_next = hw.layer_off(q + 1);
-                load_layer<REAL, R>(Lb, wb, lbase_next, rs);  // wb is all padding past the last hop: no loads
-            }
-            // ---- LDS set-up of this hop
-            REAL f[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t j = lane + 64 * r;
-                if (NEED_T && j < n2) sT[j] = ta[r];
-                sF[cur ^ 1][j] = INF;
-                if (MODE == FWD_SOLUTION) sAct[cur ^ 1][j] = 0;
-                f[r] = sF[cur][j];
-            }
-            wave_sync();  // orders this wave's LDS stores above before the reads below
+            if (q + 2 * D + 3 >= hw.base + HOP_WIN && hw.base + HOP_WIN <= q1) hw.fill(pk, q, lane);
+            const uint32_t nb = o[0];
+            const uint32_t n3 = o[3] - o[2];  // slots of hop q+2
+            // ---- global prefetch
+            load_words<R>(wr[2 * D], rs.words, o[2 * D] + wd, o[2 * D + 1] - o[2 * D], lane);
+            if (NEED_T) load_vals<REAL, R>(tr[D], rs.T, o[D + 2], o[D + 3] - o[D + 2], lane);
+            load_layer<REAL, R>(Lr[D], wr[D], lcur, rs);  // all padding past the last hop: no loads
+            uint32_t (&wa)[R] = wr[0];
+            HopLayer<REAL, R>& La = Lr[0];
+            // ---- the hop's LDS reads, one batch
+            REAL f[R], tl[R], th[R];
+            P2 dd[R];
+            bool on_path[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t j = lane + 64 * r;
                 const uint32_t w = wa[r];
                 const bool act = !(w & NW_PAD);
                 const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
+                f[r] = sF[cur][j];
+                if (NEED_T) {
+                    tl[r] = sT[cur][lo_i];  // sinks: [W] = 0, [W+1] = +inf
+                    th[r] = sT[cur][hi_i];
+                }
+                if (MODE == FWD_SOLVE) dd[r] = sDw[act ? La.lg[r] - gl0 : 0];  // staging index: position of the layer inside its group
+                if (MODE == FWD_SOLUTION) on_path[r] = act && sAct[cur][j];
+            }
+            const uint32_t o_new = off(q + 2 * D + 3);
+            const uint32_t l_next = hw.layer_off(q + D + 1);
+            // ---- set-up of the next hop's buffers (nothing above depends on it)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t j = lane + 64 * r;
+                if (NEED_T && j < n3) sT[cur ^ 1][j] = tr[0][r];  // T of hop q+2, gathered by hop q+1
+                sF[cur ^ 1][j] = INF;
+                if (MODE == FWD_SOLUTION) sAct[cur ^ 1][j] = 0;
+            }
+            wave_sync();
+            // ---- arithmetic
+            REAL nlo[R], nhi[R], mmv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t w = wa[r];
+                const bool act = !(w & NW_PAD);
                 const REAL lc = La.c[r].x, hc = La.c[r].y;
-                REAL nlo = lc, nhi = hc;
-                const uint32_t sl = La.lg[r] - gl0;  // staging index: position of the layer inside its group
-                if (MODE == FWD_SOLVE || MODE == FWD_SOLUTION) {
-                    const REAL tl = sT[lo_i];  // sinks: sT[W] = 0, sT[W+1] = +inf
-                    const REAL th = sT[hi_i];
-                    if (MODE == FWD_SOLVE) {
-                        const P2 dd = sDw[act ? sl : 0];
-                        REAL m0 = act ? (f[r] + lc) + tl : INF;
-                        REAL m1 = act ? (f[r] + hc) + th : INF;
-                        seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
-                        const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
-                        nlo = (lc + rmin(mm, REAL(0))) + dd.x;
-                        nhi = (hc + rmin(-mm, REAL(0))) + dd.y;
-                        const bool head = nw_head(w);
-                        P2 nc;
-                        nc.x = nlo;
-                        nc.y = nhi;
-                        bstore(nc, rs.lohi, head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB);
-                        if (head) sDw[sl].x = mm;  // every lane of the layer has read its pair above (same wave, in order)
-                    } else {
-                        // compute_bdd_sol_func, bdd_cuda_base.cu:1103-1137 (with the `< 0` fix of SURVEY.md §8)
-                        if (act && sAct[cur][j]) {
-                            const REAL hi_path = f[r] + (th + hc);  // backward_step_with_path_costs, :633-640
-                            const REAL lo_path = f[r] + (tl + lc);
-                            const bool take_lo = (hi_path - lo_path) > 0;
-                            d.sol_out[La.lg[r]] = take_lo ? 0 : 1;
-                            sAct[cur ^ 1][take_lo ? lo_i : hi_i] = 1;  // sink entries are dummies
-                        }
+                nlo[r] = lc;
+                nhi[r] = hc;
+                if (MODE == FWD_SOLVE) {
+                    REAL m0 = act ? (f[r] + lc) + tl[r] : INF;
+                    REAL m1 = act ? (f[r] + hc) + th[r] : INF;
+                    seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
+                    const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
+                    mmv[r] = mm;
+                    nlo[r] = (lc + rmin(mm, REAL(0))) + dd[r].x;
+                    nhi[r] = (hc + rmin(-mm, REAL(0))) + dd[r].y;
+                }
+            }
+            // ---- writes: staged min-marginal differences, pushes into the next frontier, global stores
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t j = lane + 64 * r;
+                const uint32_t w = wa[r];
+                const bool act = !(w & NW_PAD);
+                const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
+                if (MODE == FWD_SOLVE) {
+                    const bool head = nw_head(w);
+                    P2 nc;
+                    nc.x = nlo[r];
+                    nc.y = nhi[r];
+                    bstore(nc, rs.lohi, head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB);
+                    if (head) sDw[La.lg[r] - gl0].x = mmv[r];  // every lane of the layer has read its pair above (same wave, in order)
+                }
+                if (MODE == FWD_SOLUTION) {
+                    // compute_bdd_sol_func, bdd_cuda_base.cu:1103-1137 (with the `< 0` fix of SURVEY.md §8)
+                    if (on_path[r]) {
+                        const REAL hi_path = f[r] + (th[r] + La.c[r].y);  // backward_step_with_path_costs, :633-640
+                        const REAL lo_path = f[r] + (tl[r] + La.c[r].x);
+                        const bool take_lo = (hi_path - lo_path) > 0;
+                        d.sol_out[La.lg[r]] = take_lo ? 0 : 1;
+                        sAct[cur ^ 1][take_lo ? lo_i : hi_i] = 1;  // sink entries are dummies
                     }
                 }
-                // pushes into the sink entries (and from padding lanes, whose children are BOT) land in dummies
-                lds_min(&sF[cur ^ 1][lo_i], f[r] + nlo);
-                lds_min(&sF[cur ^ 1][hi_i], f[r] + nhi);
+                // Pushes into the sinks (and from padding lanes, whose children are BOT) have no reader: they are masked out.  As plain
+                // pushes into two dummy entries they were the slowest instructions of the sweep — same-address LDS atomics serialise
+                // at 20-100 cycles per lane (measured with half-empty packs: +0.56 us per hop for 64 such lane-ops), and in a pack of
+                // equal rows every lane's last hop pushes into a sink.
+                if (lo_i < (uint32_t)W) lds_min(&sF[cur ^ 1][lo_i], f[r] + nlo[r]);
+                if (hi_i < (uint32_t)W) lds_min(&sF[cur ^ 1][hi_i], f[r] + nhi[r]);
                 bstore(f[r], rs.F, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
             }
             wave_sync();
             cur ^= 1;
-            nb = ne;
-            ne = ne2;
             // ---- rotate the pipeline registers
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                wa[r] = wb[r];
-                wb[r] = wc[r];
-                if (NEED_T) ta[r] = tb[r];
+            for (int i = 0; i < 2 * D + 2; ++i) o[i] = o[i + 1];
+            o[2 * D + 2] = o_new;
+            lcur = l_next;
+#pragma unroll
+            for (int i = 0; i < 2 * D; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r) wr[i][r] = wr[i + 1][r];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                Lr[i] = Lr[i + 1];
+                if (NEED_T) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) tr[i][r] = tr[i + 1][r];
+                }
             }
-            La = Lb;
             ++q;
         };
         while (q + HOP_UNROLL <= qe) {
@@ -583,7 +648,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDe
     fwd_narrow_body<REAL, R, MODE, WPB>(d, pk, omega, blockIdx.x);
 }
 
-template <typename REAL, int R, int MODE, int WPB>
+template <typename REAL, int R, int MODE, int WPB, int LA = BDDMMA_LOOKAHEAD>
 __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t block_id)
 {
     constexpr int W = 64 * R;
@@ -613,25 +678,41 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     // node range of hop q; hops below q0 (pipeline run-off) are empty
     auto nb_of = [&](uint32_t q) { return hw.node_off(q); };
     const uint32_t wd = has_pack ? pk.pack_word_off[p] - pk.hop_node_off[q0] : 0;  // see k_fwd_narrow
-    // pipeline prologue: hop q1-1 fully, words of hop q1-2
-    uint32_t wa[R], wb[R];
-    REAL fa[R], fb[R];
-    HopLayer<REAL, R> La;
+    // Software pipeline with a look-ahead of D hops, mirrored from k_fwd_narrow: before hop q is processed (q counts down) the wave
+    // holds the node words of hops q .. q-2D+1, the costs-from-root of hops q .. q-D and the layer data of hops q .. q-D+1; during the hop
+    // it requests the words of hop q-2D, F of hop q-D-1 and the layer data of hop q-D.  o[i] = first slot of hop q+1-i (hops below q0
+    // are empty: their offset is the one of q0); the offsets the next hop needs are read one hop ahead, in the hop's LDS batch.
+    constexpr int D = LA;
+    uint32_t o[2 * D + 2];
+    uint32_t lcur = 0;  // first layer of hop q-D
+    uint32_t wr[2 * D + 1][R];
+    REAL fr[D + 2][R];
+    HopLayer<REAL, R> Lr[D + 1];
+#pragma unroll
+    for (int i = 0; i < 2 * D + 2; ++i) o[i] = 0;
+    uint32_t q = q1;
     if (has_pack) {
         if (lane < 4) sT[lane >> 1][W + (lane & 1)] = (lane & 1) ? INF : REAL(0);
         hw.fill(pk, q1 + 1 > q0 + HOP_WIN ? q1 + 1 - HOP_WIN : q0, lane);  // window ends at record q1
-        const uint32_t nb = nb_of(q1 - 1);
-        const uint32_t n = nb_of(q1) - nb;
-        load_words<R>(wa, rs.words, nb + wd, n, lane);
-        if (NEED_F) load_vals<REAL, R>(fa, rs.F, nb, n, lane);
-        const bool has = (q1 - 1 > q0);
-        const uint32_t nb2 = has ? nb_of(q1 - 2) : nb, n2 = has ? nb - nb2 : 0;
-        load_words<R>(wb, rs.words, nb2 + wd, n2, lane);
-        if (NEED_F) load_vals<REAL, R>(fb, rs.F, nb2, n2, lane);
-        load_layer<REAL, R>(La, wa, hw.layer_off(q1 - 1), rs);
+        // state of the first hop, q = q1-1: o[i] = nb_of(q1 - i)
+#pragma unroll
+        for (int i = 0; i < 2 * D + 2; ++i) o[i] = nb_of(q1 >= q0 + i ? q1 - i : q0);
+        lcur = hw.layer_off(q1 >= q0 + D + 1 ? q1 - 1 - D : q0);
+#pragma unroll
+        for (int i = 0; i < 2 * D; ++i) load_words<R>(wr[i], rs.words, o[i + 1] + wd, o[i] - o[i + 1], lane);  // hop q1-1-i (none below q0)
+        if (NEED_F) {
+#pragma unroll
+            for (int i = 0; i < D + 1; ++i) load_vals<REAL, R>(fr[i], rs.F, o[i + 1], o[i] - o[i + 1], lane);   // F of hop q1-1-i
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) load_layer<REAL, R>(Lr[i], wr[i], hw.layer_off(q1 >= q0 + i + 1 ? q1 - 1 - i : q0), rs);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2 * D; ++i)
+#pragma unroll
+            for (int r = 0; r < R; ++r) wr[i][r] = nw_pad_word(64 * R);
     }
     int cur = 0;
-    uint32_t q = q1;
     const uint32_t g0 = (MODE == BWD_SOLVE && has_pack) ? pk.pack_group_ptr[p] : 0;
     const uint32_t ng = (MODE == BWD_SOLVE && has_pack) ? pk.pack_group_ptr[p + 1] - g0 : 0;
     const uint32_t r0 = (MODE == BWD_SOLVE) ? pk.quad_round_ptr[quad] : 0;
@@ -652,76 +733,99 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             }
             if (WPB > 1) __syncthreads(); else wave_sync();
         }
-        auto hop = [&]() {  // see k_fwd_narrow
+        auto hop = [&]() {  // see k_fwd_narrow: one batch of LDS reads, the arithmetic, the writes
             --q;
-            if (q < hw.base + 2 && hw.base > q0) hw.fill(pk, q + 1 > q0 + HOP_WIN ? q + 1 - HOP_WIN : q0, lane);
-            const uint32_t nb = nb_of(q);
-            // ---- prefetch: layer data of hop q-1, words / F of hop q-2
-            uint32_t wc[R];
-            REAL fc[R];
-            HopLayer<REAL, R> Lb;
-            {
-                const bool has2 = (q >= q0 + 2);
-                const uint32_t nb3 = has2 ? nb_of(q - 2) : nb, n3 = has2 ? nb_of(q - 1) - nb3 : 0;
-                load_words<R>(wc, rs.words, nb3 + wd, n3, lane);
-                if (NEED_F) load_vals<REAL, R>(fc, rs.F, nb3, n3, lane);
-                const uint32_t lbase_prev = hw.layer_off(q > q0 ? q - 1 : q);
-                load_layer<REAL, R>(Lb, wb, lbase_prev, rs);  // wb is all padding below the first hop
+            // o[i] = nb_of(q + 1 - i), i <= 2D+1; the next hop adds nb_of(q - 1 - 2D) and the first layer of hop q - 1 - D
+            if (q < hw.base + 2 * D + 1 && hw.base > q0) hw.fill(pk, q + 1 > q0 + HOP_WIN ? q + 1 - HOP_WIN : q0, lane);
+            const uint32_t nb = o[1];
+            // ---- prefetch: words of hop q-2D, F of hop q-D-1, layer data of hop q-D
+            load_words<R>(wr[2 * D], rs.words, o[2 * D + 1] + wd, o[2 * D] - o[2 * D + 1], lane);
+            if (NEED_F) load_vals<REAL, R>(fr[D + 1], rs.F, o[D + 2], o[D + 1] - o[D + 2], lane);
+            load_layer<REAL, R>(Lr[D], wr[D], lcur, rs);  // all padding below the first hop: no loads
+            uint32_t (&wa)[R] = wr[0];
+            REAL (&fa)[R] = fr[0];
+            HopLayer<REAL, R>& La = Lr[0];
+            // ---- LDS reads
+            REAL tl[R], th[R];
+            P2 dd[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t w = wa[r];
+                const bool act = !(w & NW_PAD);
+                const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
+                tl[r] = sT[cur][lo_i];  // sinks: [W] = 0, [W+1] = +inf
+                th[r] = sT[cur][hi_i];
+                if (MODE == BWD_SOLVE) dd[r] = sDw[act ? La.lg[r] - gl0 : 0];
             }
+            const uint32_t o_new = (q >= q0 + 2 * D + 1) ? nb_of(q - 1 - 2 * D) : o[2 * D + 1];
+            const uint32_t l_next = hw.layer_off(q >= q0 + D + 1 ? q - 1 - D : q0);
+            // ---- arithmetic
+            REAL t[R], nlo[R], nhi[R], mmv[R], lp[R], hp[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t w = wa[r];
+                const bool act = !(w & NW_PAD);
+                const REAL lc = La.c[r].x, hc = La.c[r].y;
+                if (MODE == BWD_SOLVE) {
+                    REAL m0 = act ? (fa[r] + lc) + tl[r] : INF;
+                    REAL m1 = act ? (fa[r] + hc) + th[r] : INF;
+                    seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
+                    const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
+                    mmv[r] = mm;
+                    nlo[r] = (lc + rmin(mm, REAL(0))) + dd[r].x;
+                    nhi[r] = (hc + rmin(-mm, REAL(0))) + dd[r].y;
+                    t[r] = rmin(nhi[r] + th[r], nlo[r] + tl[r]);
+                } else {
+                    const REAL ch = th[r] + hc, cl = tl[r] + lc;  // backward_step, bdd_cuda_base.cu:646-667
+                    t[r] = rmin(ch, cl);
+                    if (MODE == BWD_MARGINALS) {
+                        lp[r] = act ? fa[r] + cl : INF;  // backward_step_with_path_costs, :633-641
+                        hp[r] = act ? fa[r] + ch : INF;
+                        seg_min2(lp[r], hp[r], lane, nw_pos(w), nw_len(w), steps, sM);
+                    }
+                }
+            }
+            // ---- writes
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t j = lane + 64 * r;
                 const uint32_t w = wa[r];
                 const bool act = !(w & NW_PAD);
-                const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
-                const REAL lc = La.c[r].x, hc = La.c[r].y;
-                const uint32_t sl = La.lg[r] - gl0;
-                const REAL tl = sT[cur][lo_i];  // sinks: [W] = 0, [W+1] = +inf
-                const REAL th = sT[cur][hi_i];
-                REAL t;
                 if (MODE == BWD_SOLVE) {
-                    const P2 dd = sDw[act ? sl : 0];
-                    REAL m0 = act ? (fa[r] + lc) + tl : INF;
-                    REAL m1 = act ? (fa[r] + hc) + th : INF;
-                    seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
-                    const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
-                    const REAL nlo = (lc + rmin(mm, REAL(0))) + dd.x;
-                    const REAL nhi = (hc + rmin(-mm, REAL(0))) + dd.y;
-                    t = rmin(nhi + th, nlo + tl);
                     const bool head = nw_head(w);
                     P2 nc;
-                    nc.x = nlo;
-                    nc.y = nhi;
+                    nc.x = nlo[r];
+                    nc.y = nhi[r];
                     bstore(nc, rs.lohi, head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB);
-                    if (head) sDw[sl].x = mm;
-                } else {
-                    const REAL ch = th + hc, cl = tl + lc;  // backward_step, bdd_cuda_base.cu:646-667
-                    t = rmin(ch, cl);
-                    if (MODE == BWD_MARGINALS) {
-                        REAL lp = act ? fa[r] + cl : INF;  // backward_step_with_path_costs, :633-641
-                        REAL hp = act ? fa[r] + ch : INF;
-                        seg_min2(lp, hp, lane, nw_pos(w), nw_len(w), steps, sM);
-                        if (nw_head(w)) {
-                            d.mm0_out[La.lg[r]] = lp;
-                            d.mm1_out[La.lg[r]] = hp;
-                        }
+                    if (head) sDw[La.lg[r] - gl0].x = mmv[r];
+                }
+                if (MODE == BWD_MARGINALS) {
+                    if (nw_head(w)) {
+                        d.mm0_out[La.lg[r]] = lp[r];
+                        d.mm1_out[La.lg[r]] = hp[r];
                     }
                 }
-                if (act) sT[cur ^ 1][j] = t;
-                bstore(t, rs.T, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
+                if (act) sT[cur ^ 1][j] = t[r];
+                bstore(t[r], rs.T, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
             }
             wave_sync();
             cur ^= 1;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                wa[r] = wb[r];
-                wb[r] = wc[r];
-                if (NEED_F) {
-                    fa[r] = fb[r];
-                    fb[r] = fc[r];
-                }
+            for (int i = 0; i < 2 * D + 1; ++i) o[i] = o[i + 1];
+            o[2 * D + 1] = o_new;
+            lcur = l_next;
+#pragma unroll
+            for (int i = 0; i < 2 * D; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r) wr[i][r] = wr[i + 1][r];
+#pragma unroll
+            for (int i = 0; i < D; ++i) Lr[i] = Lr[i + 1];
+            if (NEED_F) {
+#pragma unroll
+                for (int i = 0; i < D + 1; ++i)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) fr[i][r] = fr[i + 1][r];
             }
-            La = Lb;
         };
         while (q >= qs + HOP_UNROLL) {
 #pragma unroll
@@ -888,8 +992,8 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
             nc.y = nhi;
             bstore(nc, rs.lohi, head ? (layer0 + ll) * (uint32_t)sizeof(P2) : OOB);
             if (head) sDw[ll].x = mm;  // every lane of the layer has read its pair above (same wave, in order)
-            lds_min(&sF[cur ^ 1][lo_i], f[r] + nlo);  // sink children and padding lanes push into the dummies
-            lds_min(&sF[cur ^ 1][hi_i], f[r] + nhi);
+            if (lo_i < (uint32_t)W) lds_min(&sF[cur ^ 1][lo_i], f[r] + nlo);  // sink children and padding lanes: no push (see k_fwd_narrow)
+            if (hi_i < (uint32_t)W) lds_min(&sF[cur ^ 1][hi_i], f[r] + nhi);
             bstore(f[r], rs.F, act ? (slot0 + nb + j) * (uint32_t)sizeof(REAL) : OOB);
         }
         wave_sync();
@@ -1395,8 +1499,10 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
             }
             if (MODE == FWD_SOLVE) {
                 const uint32_t l = ww_layer(W0[i]);
-                lds_min(&lds[oMa + l], act ? (f[i] + C0[i].x) + tl[i] : INF);
-                lds_min(&lds[oMb + l], act ? (f[i] + C0[i].y) + th[i] : INF);
+                if (act) {  // inactive lanes have nothing to contribute (and would all hit one address)
+                    lds_min(&lds[oMa + l], (f[i] + C0[i].x) + tl[i]);
+                    lds_min(&lds[oMb + l], (f[i] + C0[i].y) + th[i]);
+                }
             }
         }
         if (MODE == FWD_SOLVE) __syncthreads();
@@ -1428,8 +1534,8 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
                     ldsA[oFn + (take_lo ? lo_i : hi_i)] = 1;  // sink entries are dummies
                 }
             }
-            lds_min(&lds[oFn + lo_i], f[i] + nlo);  // inactive lanes push +inf into the bot-sink dummy
-            lds_min(&lds[oFn + hi_i], f[i] + nhi);
+            if (lo_i < ww) lds_min(&lds[oFn + lo_i], f[i] + nlo);  // sink children and inactive lanes: no push (see k_fwd_narrow)
+            if (hi_i < ww) lds_min(&lds[oFn + hi_i], f[i] + nhi);
             bstore(f[i], rs.F, act ? (nv[0] + j) * (uint32_t)sizeof(REAL) : OOB);
         }
         // set-up of later hops: the frontier after next is cleared, T of hop q+2 goes to LDS (phase A of the next hop reads it),
@@ -1568,8 +1674,10 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
                     a = F0[i] + (tl[i] + C0[i].x);
                     b = F0[i] + (th[i] + C0[i].y);
                 }
-                lds_min(&lds[oMa + l], act ? a : INF);
-                lds_min(&lds[oMb + l], act ? b : INF);
+                if (act) {
+                    lds_min(&lds[oMa + l], a);
+                    lds_min(&lds[oMb + l], b);
+                }
             }
         }
         if (NEED_M) __syncthreads();
@@ -1666,7 +1774,13 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_mixed(DevPtrs<REAL> d, PackDev
 template <typename REAL>
 __device__ __forceinline__ void lds_add(REAL* p, REAL v)
 {
+#if defined(EXP_EX) && EXP_EX == 1
+    *p = v;   // timing experiment only (wrong results): plain LDS store instead of the atomic
+#elif defined(EXP_EX) && EXP_EX == 2
+    (void)p; (void)v;
+#else
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f32 / ds_add_f64
+#endif
 }
 
 // Exchange kernel: one workgroup per bin of variables; the bin's 2*vars_per_bin accumulators live in LDS.
@@ -1679,7 +1793,8 @@ __device__ __forceinline__ void lds_add(REAL* p, REAL v)
 // and round once per variable.
 enum : int { EX_ITER = 0, EX_RAW = 1 };
 constexpr int EX_THREADS = 1024;
-constexpr int EX_UNROLL = 12;  // entries per thread and chunk: a bin of <= 12288 entries is one chunk, all loads in flight at once
+constexpr int EX_UNROLL = 12;  // entries per thread and chunk: a bin of <= 24576 entries is one chunk — every load of the bin in flight at once,
+                               // and the local variable indices stay in registers for the broadcast (no second round trip)
 constexpr int EX_NPT = 19;     // 2 * vars_per_bin <= EX_NPT * EX_THREADS
 // Small instances (few hundred bins of 1024 threads would leave most CUs idle and pay 16-wave barriers for a handful of entries per
 // thread): the same kernel with 256-thread workgroups over bins of <= 1024 variables.
@@ -1687,6 +1802,13 @@ constexpr int EXS_THREADS = 256;
 constexpr int EXS_UNROLL = 12;
 constexpr int EXS_NPT = 8;
 constexpr uint32_t EXS_MAX_VARS_PER_BIN = EXS_THREADS * EXS_NPT / 2;
+// Bins of <= 2048 variables: 512-thread workgroups.  The 1024-thread kernel holds ~100 VGPRs per lane, i.e. ONE workgroup per CU, so
+// with more bins than CUs its workgroups run in rounds, each paying the whole latency chain (bin range -> loads -> accumulate ->
+// normalise -> broadcast); two 512-thread workgroups per CU overlap one bin's broadcast with the other's loads.
+constexpr int EXM_THREADS = 512;
+constexpr int EXM_UNROLL = 12;
+constexpr int EXM_NPT = 8;
+constexpr uint32_t EXM_MAX_VARS_PER_BIN = EXM_THREADS * EXM_NPT / 2;
 
 template <typename REAL, typename ACC, int MODE, int EX_THREADS = bddmma::EX_THREADS, int EX_UNROLL = bddmma::EX_UNROLL, int NPT = bddmma::EX_NPT>
 __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,

@@ -65,6 +65,7 @@ struct PackBuilder {
     // fits below `width` slots without straddling a `group`-slot boundary (group = 64 for narrow
     // packs so that a layer lives inside one wavefront group; 0 = no such rule).
     uint32_t width, group;
+    uint32_t fill = 0;  // a BDD joins an OPEN pack only below `fill` slots (0: = width); an empty pack takes anything up to `width`
     std::vector<uint32_t> used;     // slots used per hop in the open pack
     std::vector<uint32_t> nlayers;  // layers per hop in the open pack
     uint32_t maxw = 0;
@@ -106,7 +107,7 @@ struct PackBuilder {
             bool fits = true;
             for (uint32_t h = 0; h < n && fits; ++h) {
                 const uint32_t u = h < used.size() ? used[h] : 0;
-                if (place(u, widths[h]) + widths[h] > width) fits = false;
+                if (place(u, widths[h]) + widths[h] > (fill ? fill : width)) fits = false;
             }
             if (!fits) close();
         }
@@ -183,6 +184,10 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     }
     if (WW < 64 || WW > 4096) {
         err = "wide_pack_width must be in [64, 4096]";
+        return BDDMMA_ERR_INVALID_ARGUMENT;
+    }
+    if (opts && opts->pack_fill && (opts->pack_fill > W || opts->pack_fill < 2)) {
+        err = "pack_fill must be in [2, pack_width]";
         return BDDMMA_ERR_INVALID_ARGUMENT;
     }
     L.pack_width = W;
@@ -381,6 +386,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     }
     L.wide_pack_width = WWe;
     PackBuilder pn{W, 64}, pw{WWe, 0}, ph{std::max(HW, 1u), 0};
+    pn.fill = opts && opts->pack_fill ? opts->pack_fill : 0;
     std::vector<uint32_t> widths;
     auto form = [&](PackBuilder& pb, const std::vector<uint32_t>& order) {
         for (uint32_t k = 0; k < order.size(); ++k) {
@@ -444,8 +450,9 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
             for (uint32_t h = 0; h < n; ++h) maxw = std::max(maxw, rep_w[h]);
             for (;;) {
                 bool fits = true;
+                const uint32_t limit = pos.empty() || !pb.fill ? pb.width : pb.fill;  // the first BDD of a pack may use the whole width
                 for (uint32_t h = 0; h < n && fits; ++h)
-                    if (pb.place(used[h], rep_w[h]) + rep_w[h] > pb.width) fits = false;
+                    if (pb.place(used[h], rep_w[h]) + rep_w[h] > limit) fits = false;
                 if (!fits) break;
                 pos.emplace_back(n);
                 for (uint32_t h = 0; h < n; ++h) {

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Experimental build of the library with extra -D flags (kernel A/B experiments on one GPU box):
+#   tools/build_variant.sh NAME -DEXP_EX=1      ->  build/libNAME.so, selected at run time with BDDMMA_LIB=build/libNAME.so
+set -e
+name=$1; shift
+cd "$(dirname "$0")/../bdd_amd/csrc"
+mkdir -p ../../build/$name
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -munsafe-fp-atomics -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c bdd_mma_hip.hip -o ../../build/$name/bdd_mma_hip.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/lib$name.so layout.o capi.o ../../build/$name/bdd_mma_hip.o lbfgs.o host/bdd_store.o host/ilp.o host/ilp_capi.o host/instances.o
+echo built build/lib$name.so

@@ -17,10 +17,11 @@ ap.add_argument("--rows", type=int, default=500_000)
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--res", type=int, default=0, help="resident sweeps: 0 auto, 1 off, 2 on")
 ap.add_argument("--byvar", type=int, default=0, help="entries by (variable, bdd): 0 auto, 1 off, 2 on")
+ap.add_argument("--fill", type=int, default=0, help="bddmma_options.pack_fill")
 ap.add_argument("--variant", type=int, default=0, help="bddmma_options.variant_flags")
 a = ap.parse_args()
 col, costs = random_set_cover(a.vars, a.rows, a.k, seed=12345)
-s = bdd_hip_parallel_mma(col, costs, precision=a.precision, pack_width=a.pack_width, vars_per_bin=a.vars_per_bin, stage_cap=a.stage_cap, waves_per_block=a.wpb, resident_sweeps=a.res, exchange_by_variable=a.byvar, variant_flags=a.variant)
+s = bdd_hip_parallel_mma(col, costs, precision=a.precision, pack_width=a.pack_width, vars_per_bin=a.vars_per_bin, stage_cap=a.stage_cap, waves_per_block=a.wpb, resident_sweeps=a.res, exchange_by_variable=a.byvar, variant_flags=a.variant, pack_fill=a.fill)
 s.iterations(3)
 names = ["fwd_plain", "bwd_plain", "fwd_solve", "bwd_solve", "exch_reduce", "exch_bcast"]
 print(vars(a))
