@@ -604,8 +604,11 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                 // pushes into two dummy entries they were the slowest instructions of the sweep — same-address LDS atomics serialise
                 // at 20-100 cycles per lane (measured with half-empty packs: +0.56 us per hop for 64 such lane-ops), and in a pack of
                 // equal rows every lane's last hop pushes into a sink.
-                if (lo_i < (uint32_t)W) lds_min(&sF[cur ^ 1][lo_i], f[r] + nlo[r]);
-                if (hi_i < (uint32_t)W) lds_min(&sF[cur ^ 1][hi_i], f[r] + nhi[r]);
+                // (Branch-free: a masked lane "pushes" +inf into its own slot j — a no-op on a distinct address.  As `if (child < W)` the
+                // compiler moved every push out of line, two taken branches each.)
+                const bool plo = lo_i < (uint32_t)W, phi = hi_i < (uint32_t)W;
+                lds_min(&sF[cur ^ 1][plo ? lo_i : j], plo ? f[r] + nlo[r] : INF);
+                lds_min(&sF[cur ^ 1][phi ? hi_i : j], phi ? f[r] + nhi[r] : INF);
                 bstore(f[r], rs.F, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
             }
             wave_sync();
@@ -992,8 +995,9 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
             nc.y = nhi;
             bstore(nc, rs.lohi, head ? (layer0 + ll) * (uint32_t)sizeof(P2) : OOB);
             if (head) sDw[ll].x = mm;  // every lane of the layer has read its pair above (same wave, in order)
-            if (lo_i < (uint32_t)W) lds_min(&sF[cur ^ 1][lo_i], f[r] + nlo);  // sink children and padding lanes: no push (see k_fwd_narrow)
-            if (hi_i < (uint32_t)W) lds_min(&sF[cur ^ 1][hi_i], f[r] + nhi);
+            const bool plo = lo_i < (uint32_t)W, phi = hi_i < (uint32_t)W;  // sink children and padding lanes: no-op on the own slot (see k_fwd_narrow)
+            lds_min(&sF[cur ^ 1][plo ? lo_i : j], plo ? f[r] + nlo : INF);
+            lds_min(&sF[cur ^ 1][phi ? hi_i : j], phi ? f[r] + nhi : INF);
             bstore(f[r], rs.F, act ? (slot0 + nb + j) * (uint32_t)sizeof(REAL) : OOB);
         }
         wave_sync();
@@ -1534,8 +1538,11 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
                     ldsA[oFn + (take_lo ? lo_i : hi_i)] = 1;  // sink entries are dummies
                 }
             }
-            if (lo_i < ww) lds_min(&lds[oFn + lo_i], f[i] + nlo);  // sink children and inactive lanes: no push (see k_fwd_narrow)
-            if (hi_i < ww) lds_min(&lds[oFn + hi_i], f[i] + nhi);
+            const bool plo = lo_i < ww, phi = hi_i < ww;  // sink children and inactive lanes: no-op on a slot of their own (see k_fwd_narrow)
+            if (act) {
+                lds_min(&lds[oFn + (plo ? lo_i : j)], plo ? f[i] + nlo : INF);
+                lds_min(&lds[oFn + (phi ? hi_i : j)], phi ? f[i] + nhi : INF);
+            }
             bstore(f[i], rs.F, act ? (nv[0] + j) * (uint32_t)sizeof(REAL) : OOB);
         }
         // set-up of later hops: the frontier after next is cleared, T of hop q+2 goes to LDS (phase A of the next hop reads it),
