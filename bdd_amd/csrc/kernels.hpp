@@ -1781,13 +1781,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_mixed(DevPtrs<REAL> d, PackDev
 template <typename REAL>
 __device__ __forceinline__ void lds_add(REAL* p, REAL v)
 {
-#if defined(EXP_EX) && EXP_EX == 1
-    *p = v;   // timing experiment only (wrong results): plain LDS store instead of the atomic
-#elif defined(EXP_EX) && EXP_EX == 2
-    (void)p; (void)v;
-#else
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f32 / ds_add_f64
-#endif
 }
 
 // Exchange kernel: one workgroup per bin of variables; the bin's 2*vars_per_bin accumulators live in LDS.

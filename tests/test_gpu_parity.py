@@ -130,11 +130,12 @@ def oracle_layer_perm(s, o):
 
 
 @pytest.mark.parametrize("precision", ["double", "float"])
-@pytest.mark.parametrize("pack_width,wpb,vars_per_bin", [(64, 4, 0), (128, 4, 64), (128, 1, 8192), (128, 8, 0)])
+@pytest.mark.parametrize("pack_width,wpb,vars_per_bin", [(64, 4, 0), (128, 4, 64), (128, 1, 8192), (128, 8, 0), (128, 2, 2048)])
 def test_random_cover_vs_oracle(precision, pack_width, wpb, vars_per_bin):
-    col, costs = random_set_cover(3000 if vars_per_bin != 8192 else 20000, 2500, 8, seed=5)
+    # vars_per_bin 64 / 2048 / 8192: the 256- / 512- / 1024-thread exchange kernels; (128, 2, 2048) also packs into half the lanes (pack_fill)
+    col, costs = random_set_cover(3000 if vars_per_bin < 2048 else 20000, 2500, 8, seed=5)
     s = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=pack_width, waves_per_block=wpb,
-                             stage_cap=256 if wpb == 8 else 0, vars_per_bin=vars_per_bin)
+                             stage_cap=256 if wpb == 8 else 0, vars_per_bin=vars_per_bin, pack_fill=64 if vars_per_bin == 2048 else 0)
     o = Oracle(col, costs, precision)
     assert s.nr_packs() > 8
     assert close(s.lower_bound(), o.lower_bound(), precision, 10)
@@ -605,7 +606,7 @@ def test_randomised_instances_and_layout_options_vs_oracle(seed):
     opts = dict(pack_width=pw, waves_per_block=wpb, stage_cap=max(cap, pw), vars_per_bin=int(rng.choice([0, 64, 256])),
                 wide_pack_width=int(rng.choice([0, 64])), keep_bdd_order=bool(rng.integers(0, 2)),
                 resident_sweeps=int(rng.choice([0, 1, 2])), exchange_by_variable=int(rng.choice([0, 0, 2])),
-                variant_flags=int(rng.choice([0, 0, 1])))
+                variant_flags=int(rng.choice([0, 0, 1])), pack_fill=int(rng.choice([0, 0, pw // 2, 16])))
     s = bdd_hip_parallel_mma(col, costs, precision="double", **opts)
     o = Oracle(col, costs, "double")
     assert abs(s.lower_bound() - o.lower_bound()) <= 1e-9 * max(1.0, abs(o.lower_bound())), opts

@@ -17,13 +17,14 @@ BOT = np.uint64(2**64 - 2)
 
 
 class Layout:
-    def __init__(self, col, pack_width=0, wide_pack_width=0, vars_per_bin=0, stage_cap=0, waves_per_block=0, exchange_by_variable=0):
+    def __init__(self, col, pack_width=0, wide_pack_width=0, vars_per_bin=0, stage_cap=0, waves_per_block=0, exchange_by_variable=0, pack_fill=0):
         L = capi.lib()
         instr = np.ascontiguousarray(col.instr, dtype=np.uint64)
         delims = np.ascontiguousarray(col.delims, dtype=np.uint64)
         h = C.c_void_p()
         opts = capi.Options(pack_width, wide_pack_width, 0, vars_per_bin, stage_cap, waves_per_block)
         opts.exchange_by_variable = exchange_by_variable
+        opts.pack_fill = pack_fill
         rc = L.bddmma_layout_create(C.byref(h), instr.ctypes.data_as(C.c_void_p), delims.ctypes.data_as(C.c_void_p),
                                     col.nr_bdds(), C.byref(opts))
         capi.check(rc, None)
@@ -359,3 +360,22 @@ def test_uniform_shape_runs_are_packed_in_closed_form(pack_width):
     assert sizes.count(full7) == 700 // per_pack7
     n_unique = int(lay.L.bddmma_layout_size(lay.h, 20))
     assert n_unique < sum(sizes) / 3                 # the family's packs share their word sequence
+
+
+def test_pack_fill_trades_lanes_for_packs():
+    """pack_fill: BDDs join an open pack only below `fill` slots per hop (more, emptier packs for latency-bound instances); an empty
+    pack still takes any narrow BDD.  Both packing paths (greedy and closed form) honour it, all layout invariants hold."""
+    from bdd_amd.instances import random_set_cover
+    col, _ = random_set_cover(3000, 2000, 6, seed=7)         # 2000 covering rows, 2 nodes wide
+    col.add_linear(np.arange(1, 13), "<=", 30, np.arange(12))  # a knapsack row wider than the fill
+    full = check_roundtrip(col, pack_width=64)
+    half = check_roundtrip(col, pack_width=64, pack_fill=32)
+    quarter = check_roundtrip(col, pack_width=64, pack_fill=16, waves_per_block=2)
+    assert full.np_n < half.np_n < quarter.np_n and quarter.np_n >= 3 * full.np_n
+    S = quarter.sets[0]
+    widths = np.diff(S["hop_node_off"])
+    wide_hops = widths > 16                                   # only the pack that starts with the knapsack row may exceed the fill
+    packs_over = {int(np.searchsorted(S["pack_hop_ptr"], q, side="right") - 1) for q in np.nonzero(wide_hops)[0]}
+    assert len(packs_over) <= 1
+    with pytest.raises(capi.BddMmaError, match="pack_fill"):
+        Layout(col, pack_width=64, pack_fill=65)
