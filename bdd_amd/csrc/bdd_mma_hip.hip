@@ -236,7 +236,7 @@ struct SolverT final : SolverBase {
         }
         if (stage_lds + narrow_static > 64 * 1024) {
 #define SET_N1(K_) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(stage_lds + seg_bytes(L.ex.waves_per_block))));
-#define SET_N(R_, W_) SET_N1((k_fwd_narrow<REAL, R_, FWD_SOLVE, W_>)) SET_N1((k_bwd_narrow<REAL, R_, BWD_SOLVE, W_>))
+#define SET_N(R_, W_) SET_N1((k_fwd_narrow<REAL, R_, FWD_SOLVE, W_>)) SET_N1((k_bwd_narrow<REAL, R_, BWD_SOLVE, W_>)) SET_N1((k_fwd_narrow<REAL, R_, FWD_SOLVE, W_, false>)) SET_N1((k_bwd_narrow<REAL, R_, BWD_SOLVE, W_, false>))
 #define SET_N_W(R_) \
     switch (L.ex.waves_per_block) { case 1: SET_N(R_, 1) break; case 2: SET_N(R_, 2) break; case 4: SET_N(R_, 4) break; default: SET_N(R_, 8) break; }
             switch (pack_width) {
@@ -397,6 +397,7 @@ struct SolverT final : SolverBase {
             // SOLVE sweeps: `wpb` packs per workgroup with cooperative staging; the other modes stage nothing
             const uint32_t w = (MODE == FWD_SOLVE) ? wpb : 1;
             const bool res = use_res && MODE == FWD_SOLVE;
+            const bool two_node = MODE == FWD_SOLVE && !narrow_seg;  // SEG = false instantiation (kernels.hpp); other modes: <..., true> again
             const uint32_t base_lds = res ? res_lds : ((MODE == FWD_SOLVE) ? stage_lds : 0);
             const uint32_t dyn = base_lds + seg_bytes(w);
             const PackDev pk = pdev(nb_, 0, base_lds);
@@ -404,6 +405,7 @@ struct SolverT final : SolverBase {
             const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
 #define LAUNCH_N(R_, W_)                                                                                                      \
     if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, d, pk, rd, omega);                           \
+    else if (two_node) hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_, MODE != FWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
     else hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
     switch (w) { case 1: LAUNCH_N(R_, 1); break; case 2: LAUNCH_N(R_, 2); break; case 4: LAUNCH_N(R_, 4); break; default: LAUNCH_N(R_, 8); break; }
@@ -463,6 +465,7 @@ struct SolverT final : SolverBase {
             // SOLVE sweeps: `wpb` packs per workgroup with cooperative staging; the other modes stage nothing
             const uint32_t w = (MODE == BWD_SOLVE) ? wpb : 1;
             const bool res = use_res && MODE == BWD_SOLVE;
+            const bool two_node = MODE == BWD_SOLVE && !narrow_seg;
             const uint32_t base_lds = res ? res_lds : ((MODE == BWD_SOLVE) ? stage_lds : 0);
             const uint32_t dyn = base_lds + seg_bytes(w);
             const PackDev pk = pdev(nb_, 0, base_lds);
@@ -470,6 +473,7 @@ struct SolverT final : SolverBase {
             const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
 #define LAUNCH_N(R_, W_)                                                                                                      \
     if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, d, pk, rd, omega);                           \
+    else if (two_node) hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_, MODE != BWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
     else hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
     switch (w) { case 1: LAUNCH_N(R_, 1); break; case 2: LAUNCH_N(R_, 2); break; case 4: LAUNCH_N(R_, 4); break; default: LAUNCH_N(R_, 8); break; }

@@ -376,32 +376,66 @@ __device__ __forceinline__ void load_layer(HopLayer<REAL, R>& L, const uint32_t 
     }
 }
 
+// One hop's slice [nb, nb + n) of a slot-indexed array.  A lane addresses it with its constant byte offset j * sizeof(T); the slice's
+// start goes into the scalar offset of the buffer instruction and the descriptor ends where the slice ends, so the lanes past the
+// hop's last slot drop out by themselves: no per-lane address arithmetic or select in the hop (3 VALU per access before).  (gfx950
+// range-checks voffset + soffset against num_records — measured: with num_records = the slice's length every lane was dropped.)
+template <typename T>
+__device__ __forceinline__ rsrc_t hop_rsrc(const T* base, uint32_t nb, uint32_t n)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (nb + n) * (uint32_t)sizeof(T), 0x00020000);
+}
 template <int R>
-__device__ __forceinline__ void load_words(uint32_t (&w)[R], rsrc_t words, uint32_t nb, uint32_t n, int lane)
+__device__ __forceinline__ void load_words(uint32_t (&w)[R], const uint32_t* words, uint32_t nb, uint32_t n, int lane)
 {
     constexpr uint32_t PADW = nw_pad_word(64 * R);
+    const rsrc_t rh = hop_rsrc(words, nb, n);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t j = lane + 64 * r;
-        const uint32_t x = bload_u32(words, j < n ? (nb + j) * 4u : OOB);
+        const uint32_t x = __builtin_amdgcn_raw_buffer_load_b32(rh, j * 4u, nb * 4u, BDDMMA_LD_AUX);
         w[r] = (j < n) ? x : PADW;
     }
 }
-
-template <typename REAL, int R>
-__device__ __forceinline__ void load_vals(REAL (&v)[R], rsrc_t src, uint32_t nb, uint32_t n, int lane)
+__device__ __forceinline__ void hop_load(float& v, rsrc_t rh, uint32_t voff, uint32_t soff)
 {
+    v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, voff, soff, BDDMMA_LD_AUX));
+}
+__device__ __forceinline__ void hop_load(double& v, rsrc_t rh, uint32_t voff, uint32_t soff)
+{
+    v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rh, voff, soff, BDDMMA_LD_AUX));
+}
+__device__ __forceinline__ void hop_store(float v, rsrc_t rh, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rh, voff, soff, BDDMMA_ST_AUX);
+}
+__device__ __forceinline__ void hop_store(double v, rsrc_t rh, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rh, 0, 0, 0)), v), rh, voff, soff, BDDMMA_ST_AUX);
+}
+// values of the hop's slots; lanes past the last slot read 0
+template <typename REAL, int R>
+__device__ __forceinline__ void load_vals(REAL (&v)[R], const REAL* src, uint32_t nb, uint32_t n, int lane)
+{
+    const rsrc_t rh = hop_rsrc(src, nb, n);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t j = lane + 64 * r;
-        bload(v[r], src, j < n ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
-    }
+    for (int r = 0; r < R; ++r) hop_load(v[r], rh, (lane + 64 * r) * (uint32_t)sizeof(REAL), nb * (uint32_t)sizeof(REAL));
+}
+// ... and the store of one value per slot of the hop (padding slots inside the hop included: nothing reads them)
+template <typename REAL, int R>
+__device__ __forceinline__ void store_vals(const REAL (&v)[R], REAL* dst, uint32_t nb, uint32_t n, int lane)
+{
+    const rsrc_t rh = hop_rsrc(dst, nb, n);
+#pragma unroll
+    for (int r = 0; r < R; ++r) hop_store(v[r], rh, (lane + 64 * r) * (uint32_t)sizeof(REAL), nb * (uint32_t)sizeof(REAL));
 }
 
 #ifndef BDDMMA_LOOKAHEAD
 #define BDDMMA_LOOKAHEAD 1
 #endif
-template <typename REAL, int R, int MODE, int WPB, int LA = BDDMMA_LOOKAHEAD>
+// SEG = false: no pack of the launch has a layer wider than two nodes — the segmented minimum is the DPP pair, its LDS variant and the
+// per-lane-group branch on the pack's step count are compiled out.
+template <typename REAL, int R, int MODE, int WPB, int LA = BDDMMA_LOOKAHEAD, bool SEG = true>
 __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t block_id)
 {
     constexpr int W = 64 * R;
@@ -430,7 +464,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;  // the last quad may be partial: such a wave only helps staging
     const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
-    const int steps = has_pack ? pk.pack_steps[p] : 0;
+    const int steps = SEG ? (has_pack ? pk.pack_steps[p] : 0) : 1;
     const REAL INF = inf_v<REAL>();
     const NarrowRs<REAL> rs(d);
     // hop_node_off / hop_layer_off have one entry past the last hop of the last pack, so index q1 is
@@ -465,12 +499,12 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
         }
         if (lane < 4) sT[lane >> 1][W + (lane & 1)] = (lane & 1) ? INF : REAL(0);
 #pragma unroll
-        for (int i = 0; i < 2 * D; ++i) load_words<R>(wr[i], rs.words, o[i] + wd, o[i + 1] - o[i], lane);   // none past the last hop
+        for (int i = 0; i < 2 * D; ++i) load_words<R>(wr[i], d.nwords, o[i] + wd, o[i + 1] - o[i], lane);   // none past the last hop
         if (NEED_T) {
             REAL t1[R];
-            load_vals<REAL, R>(t1, rs.T, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
+            load_vals<REAL, R>(t1, d.T, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
 #pragma unroll
-            for (int i = 0; i < D; ++i) load_vals<REAL, R>(tr[i], rs.T, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
+            for (int i = 0; i < D; ++i) load_vals<REAL, R>(tr[i], d.T, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t j = lane + 64 * r;
@@ -522,8 +556,8 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             const uint32_t nb = o[0];
             const uint32_t n3 = o[3] - o[2];  // slots of hop q+2
             // ---- global prefetch
-            load_words<R>(wr[2 * D], rs.words, o[2 * D] + wd, o[2 * D + 1] - o[2 * D], lane);
-            if (NEED_T) load_vals<REAL, R>(tr[D], rs.T, o[D + 2], o[D + 3] - o[D + 2], lane);
+            load_words<R>(wr[2 * D], d.nwords, o[2 * D] + wd, o[2 * D + 1] - o[2 * D], lane);
+            if (NEED_T) load_vals<REAL, R>(tr[D], d.T, o[D + 2], o[D + 3] - o[D + 2], lane);
             load_layer<REAL, R>(Lr[D], wr[D], lcur, rs);  // all padding past the last hop: no loads
             uint32_t (&wa)[R] = wr[0];
             HopLayer<REAL, R>& La = Lr[0];
@@ -580,14 +614,17 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             for (int r = 0; r < R; ++r) {
                 const uint32_t j = lane + 64 * r;
                 const uint32_t w = wa[r];
-                const bool act = !(w & NW_PAD);
                 const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
                 if (MODE == FWD_SOLVE) {
                     const bool head = nw_head(w);
                     P2 nc;
                     nc.x = nlo[r];
                     nc.y = nhi[r];
-                    bstore(nc, rs.lohi, head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB);
+                    // the offset goes through an opaque register: otherwise the compiler folds the select into the `if (head)` below and
+                    // emits the store twice, in two out-of-line blocks (four taken branches per lane group and hop)
+                    uint32_t soff = head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB;
+                    asm volatile("" : "+v"(soff));
+                    bstore(nc, rs.lohi, soff);
                     if (head) sDw[La.lg[r] - gl0].x = mmv[r];  // every lane of the layer has read its pair above (same wave, in order)
                 }
                 if (MODE == FWD_SOLUTION) {
@@ -609,8 +646,8 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                 const bool plo = lo_i < (uint32_t)W, phi = hi_i < (uint32_t)W;
                 lds_min(&sF[cur ^ 1][plo ? lo_i : j], plo ? f[r] + nlo[r] : INF);
                 lds_min(&sF[cur ^ 1][phi ? hi_i : j], phi ? f[r] + nhi[r] : INF);
-                bstore(f[r], rs.F, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
             }
+            store_vals<REAL, R>(f, d.F, nb, o[1] - o[0], lane);
             wave_sync();
             cur ^= 1;
             // ---- rotate the pipeline registers
@@ -645,13 +682,13 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     }
 }
 
-template <typename REAL, int R, int MODE, int WPB>
+template <typename REAL, int R, int MODE, int WPB, bool SEG = true>
 __global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
 {
-    fwd_narrow_body<REAL, R, MODE, WPB>(d, pk, omega, blockIdx.x);
+    fwd_narrow_body<REAL, R, MODE, WPB, BDDMMA_LOOKAHEAD, SEG>(d, pk, omega, blockIdx.x);
 }
 
-template <typename REAL, int R, int MODE, int WPB, int LA = BDDMMA_LOOKAHEAD>
+template <typename REAL, int R, int MODE, int WPB, int LA = BDDMMA_LOOKAHEAD, bool SEG = true>
 __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t block_id)
 {
     constexpr int W = 64 * R;
@@ -674,7 +711,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
     const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
-    const int steps = has_pack ? pk.pack_steps[p] : 0;
+    const int steps = SEG ? (has_pack ? pk.pack_steps[p] : 0) : 1;
     const REAL INF = inf_v<REAL>();
     const NarrowRs<REAL> rs(d);
     HopWindow hw{sOffN_[wave], sOffL_[wave], q0, q1};
@@ -702,10 +739,10 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
         for (int i = 0; i < 2 * D + 2; ++i) o[i] = nb_of(q1 >= q0 + i ? q1 - i : q0);
         lcur = hw.layer_off(q1 >= q0 + D + 1 ? q1 - 1 - D : q0);
 #pragma unroll
-        for (int i = 0; i < 2 * D; ++i) load_words<R>(wr[i], rs.words, o[i + 1] + wd, o[i] - o[i + 1], lane);  // hop q1-1-i (none below q0)
+        for (int i = 0; i < 2 * D; ++i) load_words<R>(wr[i], d.nwords, o[i + 1] + wd, o[i] - o[i + 1], lane);  // hop q1-1-i (none below q0)
         if (NEED_F) {
 #pragma unroll
-            for (int i = 0; i < D + 1; ++i) load_vals<REAL, R>(fr[i], rs.F, o[i + 1], o[i] - o[i + 1], lane);   // F of hop q1-1-i
+            for (int i = 0; i < D + 1; ++i) load_vals<REAL, R>(fr[i], d.F, o[i + 1], o[i] - o[i + 1], lane);   // F of hop q1-1-i
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) load_layer<REAL, R>(Lr[i], wr[i], hw.layer_off(q1 >= q0 + i + 1 ? q1 - 1 - i : q0), rs);
@@ -742,8 +779,8 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             if (q < hw.base + 2 * D + 1 && hw.base > q0) hw.fill(pk, q + 1 > q0 + HOP_WIN ? q + 1 - HOP_WIN : q0, lane);
             const uint32_t nb = o[1];
             // ---- prefetch: words of hop q-2D, F of hop q-D-1, layer data of hop q-D
-            load_words<R>(wr[2 * D], rs.words, o[2 * D + 1] + wd, o[2 * D] - o[2 * D + 1], lane);
-            if (NEED_F) load_vals<REAL, R>(fr[D + 1], rs.F, o[D + 2], o[D + 1] - o[D + 2], lane);
+            load_words<R>(wr[2 * D], d.nwords, o[2 * D + 1] + wd, o[2 * D] - o[2 * D + 1], lane);
+            if (NEED_F) load_vals<REAL, R>(fr[D + 1], d.F, o[D + 2], o[D + 1] - o[D + 2], lane);
             load_layer<REAL, R>(Lr[D], wr[D], lcur, rs);  // all padding below the first hop: no loads
             uint32_t (&wa)[R] = wr[0];
             REAL (&fa)[R] = fr[0];
@@ -799,7 +836,9 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                     P2 nc;
                     nc.x = nlo[r];
                     nc.y = nhi[r];
-                    bstore(nc, rs.lohi, head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB);
+                    uint32_t soff = head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB;  // see k_fwd_narrow
+                    asm volatile("" : "+v"(soff));
+                    bstore(nc, rs.lohi, soff);
                     if (head) sDw[La.lg[r] - gl0].x = mmv[r];
                 }
                 if (MODE == BWD_MARGINALS) {
@@ -809,8 +848,8 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                     }
                 }
                 if (act) sT[cur ^ 1][j] = t[r];
-                bstore(t[r], rs.T, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
             }
+            store_vals<REAL, R>(t, d.T, nb, o[0] - o[1], lane);
             wave_sync();
             cur ^= 1;
 #pragma unroll
@@ -854,10 +893,10 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     if (lane == 0) d.lb_partial[pk.lb_base + p] = s;
 }
 
-template <typename REAL, int R, int MODE, int WPB>
+template <typename REAL, int R, int MODE, int WPB, bool SEG = true>
 __global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
 {
-    bwd_narrow_body<REAL, R, MODE, WPB>(d, pk, omega, blockIdx.x);
+    bwd_narrow_body<REAL, R, MODE, WPB, BDDMMA_LOOKAHEAD, SEG>(d, pk, omega, blockIdx.x);
 }
 
 // =============================================================================================
