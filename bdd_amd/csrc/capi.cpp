@@ -340,7 +340,7 @@ int bddmma_incremental_mm_agreement_rounding(bddmma_solver* s, bddmma_lbfgs* lbf
 // File: magic, header {precision, #arrays, sizeof(LayoutScalars), sizeof(bddmma_options)}, LayoutScalars, options, the layout arrays
 // as {id, element size, count, data} records (layout.hpp: visit_layout_arrays), then lo / hi / deferred mm / delta.  Loading
 // uploads the arrays as they are: build_layout does not run again.
-static const char kMagic[8] = {'B', 'D', 'D', 'M', 'M', 'A', '0', '3'};
+static const char kMagic[8] = {'B', 'D', 'D', 'M', 'M', 'A', '0', '4'};  // 04: narrow node words carry the layer index (layout.hpp)
 
 namespace {
 struct FileCloser {

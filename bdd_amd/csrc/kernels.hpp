@@ -356,7 +356,8 @@ struct HopLayer {
 };
 
 __device__ __forceinline__ uint32_t nw_pos(uint32_t w) { return (w >> NW_POS_SHIFT) & NW_FIELD6; }
-__device__ __forceinline__ uint32_t nw_len(uint32_t w) { return ((w >> NW_LEN_SHIFT) & NW_FIELD6) + 1; }
+__device__ __forceinline__ uint32_t nw_lidx(uint32_t w) { return (w >> NW_LIDX_SHIFT) & NW_FIELD6; }  // layer index inside the lane group
+__device__ __forceinline__ uint32_t nw_len(uint32_t w) { return (w & NW_TWO) ? 2u : 0u; }  // only "is it a two-node layer" is stored
 __device__ __forceinline__ bool nw_head(uint32_t w) { return (w & (NW_PAD | (NW_FIELD6 << NW_POS_SHIFT))) == 0; }
 
 template <typename REAL, int R>
@@ -367,11 +368,8 @@ __device__ __forceinline__ void load_layer(HopLayer<REAL, R>& L, const uint32_t 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const bool act = !(w[r] & NW_PAD);
-        // layer index = number of layer heads in the lanes below (minus one for non-head lanes)
-        const unsigned long long heads = __ballot(nw_head(w[r]));
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(heads >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)heads, 0u));
-        L.lg[r] = base + below - (nw_pos(w[r]) != 0 ? 1u : 0u);
-        base += (uint32_t)__popcll(heads);
+        L.lg[r] = base + nw_lidx(w[r]);
+        if (r + 1 < R) base += (uint32_t)__popcll(__ballot(nw_head(w[r])));  // layers of this lane group
         bload(L.c[r], rs.lohi, act ? L.lg[r] * (uint32_t)sizeof(P2) : OOB);
     }
 }
@@ -1013,11 +1011,9 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
             const uint32_t w = j < n ? sW[nb + j] : PADW;
             const bool act = !(w & NW_PAD);
             const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
-            // layer index inside the pack = layers of the hops before + layer heads in the lanes below
-            const unsigned long long heads = __ballot(nw_head(w));
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(heads >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)heads, 0u));
-            const uint32_t ll = act ? lb + below - (nw_pos(w) != 0 ? 1u : 0u) : 0u;
-            lb += (uint32_t)__popcll(heads);
+            // layer index inside the pack = layers of the hops and lane groups before + the word's index inside its lane group
+            const uint32_t ll = act ? lb + nw_lidx(w) : 0u;
+            lb += (uint32_t)__popcll(__ballot(nw_head(w)));
             const P2 c = sC[ll];
             const REAL tl = sTa[lo_i < (uint32_t)W ? ne + lo_i : rd.ns + (lo_i - W)];
             const REAL th = sTa[hi_i < (uint32_t)W ? ne + hi_i : rd.ns + (hi_i - W)];
@@ -1109,10 +1105,8 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev p
             const uint32_t w = j < n ? sW[nb + j] : PADW;
             const bool act = !(w & NW_PAD);
             const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
-            const unsigned long long heads = __ballot(nw_head(w));
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(heads >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)heads, 0u));
-            const uint32_t ll = act ? lb + below - (nw_pos(w) != 0 ? 1u : 0u) : 0u;
-            lb += (uint32_t)__popcll(heads);
+            const uint32_t ll = act ? lb + nw_lidx(w) : 0u;
+            lb += (uint32_t)__popcll(__ballot(nw_head(w)));
             const P2 c = sC[ll];
             const REAL fa = sFa[act ? nb + j : 0];
             const REAL tl = sT[cur][lo_i];  // sinks: [W] = 0, [W + 1] = +inf

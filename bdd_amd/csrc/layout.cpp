@@ -530,11 +530,13 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         ps.hop_node_off[n_rec] = slot_cursor;
         ps.hop_layer_off[n_rec] = layer_cursor;
         par.run(P, [&](uint64_t p0, uint64_t p1, unsigned t) {  // min_parallel below: a pack is hundreds of nodes
-            std::vector<uint32_t> lcount;
+            std::vector<uint32_t> lcount, gcur, gfirst;
             for (uint32_t p = (uint32_t)p0; p < (uint32_t)p1; ++p) {
                 const uint32_t base_q = pb.pack_hop_ptr[p];
                 const uint32_t H = pb.pack_hop_ptr[p + 1] - base_q;
                 lcount.assign(H, 0);
+                gcur.assign(H, 0);    // lane group of the hop's latest layer, and the hop-local index of that group's first layer
+                gfirst.assign(H, 0);
                 for (uint32_t k = pb.pack_first_bdd[p]; k < pb.pack_first_bdd[p + 1]; ++k) {
                     const uint64_t b = order[k];
                     const uint32_t l0 = bdd_lay_ptr[b], n = bdd_lay_ptr[b + 1] - l0;
@@ -542,6 +544,12 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
                         const uint32_t l = l0 + h;
                         const uint64_t f = lay_first[l], e = layer_end(b, l);
                         const uint32_t lloc = lcount[h]++;
+                        // index of the layer inside its 64-lane group of the hop (the BDDs of a pack are placed left to right)
+                        if (!wide) {
+                            const uint32_t grp = lay_pos[l] / 64;
+                            if (grp != gcur[h]) { gcur[h] = grp; gfirst[h] = lloc; }
+                        }
+                        const uint32_t lgrp = wide ? 0u : lloc - gfirst[h];
                         const uint32_t lg = ps.hop_layer_off[base_q + h] + lloc;
                         in_layer_to_internal[l] = lg;
                         L.layer_var[lg] = (int32_t)instr[f].index;
@@ -568,7 +576,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
                                     ch[0] | (ch[1] << WW_CHILD_BITS) | ((uint64_t)lloc << (2 * WW_CHILD_BITS)) | (i == f ? WW_HEAD : 0);
                             } else {
                                 L.narrow_words[slot] = (uint32_t)ch[0] | ((uint32_t)ch[1] << NW_CHILD_BITS) |
-                                                       ((uint32_t)(i - f) << NW_POS_SHIFT) | ((uint32_t)(e - f - 1) << NW_LEN_SHIFT);
+                                                       ((uint32_t)(i - f) << NW_POS_SHIFT) | (lgrp << NW_LIDX_SHIFT) | (e - f == 2 ? NW_TWO : 0u);
                             }
                         }
                     }

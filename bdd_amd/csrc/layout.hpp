@@ -24,15 +24,17 @@ namespace bddmma {
 //  bits  0..8   lo child: local index inside the NEXT hop of the same pack, or the pack's TOP / BOT code
 //  bits  9..17  hi child
 //  bits 18..23  position of the node inside its layer (0 = head)
-//  bits 24..29  layer width - 1
+//  bits 24..29  index of the node's layer among the layers of its 64-lane group of the hop
+//  bit  30      the layer has exactly two nodes (the DPP-pair segmented minimum)
 //  bit  31      padding slot (no node)
 // The sink codes are TOP = pack_width and BOT = pack_width + 1: the kernels keep two constant entries
-// behind the LDS frontier arrays (cost-from-terminal 0 / +inf, dummy push targets), so sink children need
-// no branch.  The layer index local to (pack, hop) is not stored: it is the number of layer heads in the
-// lanes below (v_mbcnt of the head ballot) — segment bounds come from pos / width without mask arithmetic.
+// behind the LDS frontier arrays (cost-from-terminal 0 / +inf), so sink children need no branch.  The
+// layer of a node is hop_layer_off[q] + (layers of the lower lane groups) + bits 24..29: two VALU; the first
+// format stored the layer width instead and derived the index from the head ballot (v_mbcnt), nine.
 constexpr uint32_t NW_CHILD_BITS = 9;
 constexpr uint32_t NW_CHILD_MASK = (1u << NW_CHILD_BITS) - 1;
-constexpr uint32_t NW_POS_SHIFT = 18, NW_LEN_SHIFT = 24, NW_FIELD6 = 63;
+constexpr uint32_t NW_POS_SHIFT = 18, NW_LIDX_SHIFT = 24, NW_FIELD6 = 63;
+constexpr uint32_t NW_TWO = 1u << 30;
 constexpr uint32_t NW_PAD = 1u << 31;
 constexpr uint32_t nw_top(uint32_t pack_width) { return pack_width; }
 constexpr uint32_t nw_bot(uint32_t pack_width) { return pack_width + 1; }

@@ -45,7 +45,7 @@ def test_load_rejects_files_that_are_not_checkpoints(tmp_path):
     L = capi.lib()
     h = C.c_void_p()
     p = tmp_path / "x.bin"
-    for blob in (b"", b"BDDMMA03", b"BDDMMA03" + b"\xff" * 64, b"BDDMMA01" + b"\0" * 400, bytes(range(256)) * 8):
+    for blob in (b"", b"BDDMMA04", b"BDDMMA04" + b"\xff" * 64, b"BDDMMA03" + b"\0" * 400, b"BDDMMA01" + b"\0" * 400, bytes(range(256)) * 8):
         p.write_bytes(blob)
         assert L.bddmma_load(C.byref(h), 0, str(p).encode()) == -6 and not h.value      # BDDMMA_ERR_IO, before any device work
     assert L.bddmma_load(C.byref(h), 0, str(tmp_path / "missing.bin").encode()) == -6

@@ -80,7 +80,9 @@ class Layout:
         """-> dict slot -> (lo_slot|'T'|'B', hi_slot|..., layer_global, head)"""
         out = {}
         widths = {}
+        twos = {}
         self.widths = widths
+        self.twos = twos
         for wide, S in enumerate(self.sets):
             for p in range(S["P"]):
                 q0, q1 = int(S["pack_hop_ptr"][p]), int(S["pack_hop_ptr"][p + 1])
@@ -96,14 +98,18 @@ class Layout:
                             head, pad, BOTC, TOPC = bool(w >> 63), False, 0x1FFFFF, 0x1FFFFE
                         else:
                             w = int(self.nwords[slot])
-                            lo, hi, pos, ln = w & 511, (w >> 9) & 511, (w >> 18) & 63, ((w >> 24) & 63) + 1
+                            lo, hi, pos, lidx, two = w & 511, (w >> 9) & 511, (w >> 18) & 63, (w >> 24) & 63, bool((w >> 30) & 1)
                             pad, TOPC, BOTC = bool(w >> 31), self.pack_width, self.pack_width + 1
                             head = pos == 0
+                            if j % 64 == 0:
+                                gbase = lcount              # layers of the lower 64-lane groups of this hop
                             if not pad:
                                 if head:
                                     lcount += 1
                                 l = lcount - 1
-                                widths[(q, l)] = ln
+                                assert lidx == l - gbase, "layer index inside the lane group"
+                                widths[(q, l)] = widths.get((q, l), 0) + 1
+                                twos[(q, l)] = two
                             else:
                                 l = 0
                         if pad:
@@ -227,6 +233,7 @@ def check_roundtrip(col, **kw):
             S = lay.sets[0]
             q = int(S["pack_hop_ptr"][p_]) + h_
             assert lay.widths[(q, lg - int(S["hop_layer_off"][q]))] == len(slots)
+            assert lay.twos[(q, lg - int(S["hop_layer_off"][q]))] == (len(slots) == 2)     # the "two-node layer" bit of the words
         if not lst[0][1][0]:
             js = [w[3] for _, w in lst]
             assert min(js) // 64 == max(js) // 64
