@@ -159,22 +159,50 @@ __device__ __forceinline__ void seg_fence()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// layers of 1 or 2 nodes (simplex / covering / cardinality-1 rows): the head takes the minimum with its right neighbour, the second
+// node copies the head's result — DPP moves, no LDS crossbar traffic.  A 2-node layer never straddles the 64-lane group.
+__device__ __forceinline__ void seg_pair_min(double& a, double& b, uint32_t pos, uint32_t len)
+{
+    const double a2 = dpp_from_next(a), b2 = dpp_from_next(b);
+    if (pos == 0 && len == 2) {
+        a = rmin(a, a2);
+        b = rmin(b, b2);
+    }
+    const double a1 = dpp_from_prev(a), b1 = dpp_from_prev(b);
+    if (pos == 1) {
+        a = a1;
+        b = b1;
+    }
+}
+// float: the minimum with the DPP-shifted operand is one instruction (v_min_f32_dpp).  Through the builtins the compiler emits
+// v_mov_b32_dpp, two v_max x, x canonicalisations and v_min per value (it cannot see that a moved float is canonical): 16 VALU per lane
+// group and hop instead of 8.  s_nop 1: a DPP operand written by the preceding VALU instruction needs two wait states, and the hazard
+// recogniser does not look into inline assembly.  The DPP ops run with all lanes enabled (a source lane masked out by EXEC would
+// count as invalid); the selects apply the layer structure.
+__device__ __forceinline__ void seg_pair_min(float& a, float& b, uint32_t pos, uint32_t len)
+{
+    float ta, tb;
+    asm volatile("s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_f32_dpp %1, %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(ta), "=&v"(tb)
+                 : "v"(a), "v"(b));
+    const bool head2 = pos == 0 && len == 2;
+    a = head2 ? ta : a;
+    b = head2 ? tb : b;
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(ta), "=&v"(tb)
+                 : "v"(a), "v"(b));
+    a = pos == 1 ? ta : a;
+    b = pos == 1 ? tb : b;
+}
 template <typename REAL>
 __device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, uint32_t pos, uint32_t len, int steps, REAL* sM)
 {
     if (steps <= 1) {
-        // layers of 1 or 2 nodes (simplex / covering / cardinality-1 rows): two DPP moves per value,
-        // no LDS crossbar traffic.  A 2-node layer never straddles the 64-lane group.
-        const REAL a2 = dpp_from_next(a), b2 = dpp_from_next(b);
-        if (pos == 0 && len == 2) {
-            a = rmin(a, a2);
-            b = rmin(b, b2);
-        }
-        const REAL a1 = dpp_from_prev(a), b1 = dpp_from_prev(b);
-        if (pos == 1) {
-            a = a1;
-            b = b1;
-        }
+        seg_pair_min(a, b, pos, len);
         return;
     }
     const REAL INF = inf_v<REAL>();
