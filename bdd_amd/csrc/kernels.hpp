@@ -83,6 +83,32 @@ __device__ __forceinline__ double rmin(double a, double b) { return __builtin_fm
 __device__ __forceinline__ bool rfinite(float a) { return __builtin_isfinite(a); }
 __device__ __forceinline__ bool rfinite(double a) { return __builtin_isfinite(a); }
 
+// mm = omega * (m1 - m0), or 0 unless both minima are finite (bdd_cuda_parallel_mma.cu:36-39).  Branch-free: with `&&` the compiler
+// built two nested exec regions with a skip branch around one subtraction.
+template <typename REAL>
+__device__ __forceinline__ REAL mm_diff(REAL m0, REAL m1, REAL omega)
+{
+    const bool fin = (int)rfinite(m0) & (int)rfinite(m1);
+    const REAL t = omega * (m1 - m0);
+    return fin ? t : REAL(0);
+}
+// min(x, 0) and min(-x, 0) of a min-marginal difference (never NaN).  One instruction; __builtin_fminf on a value that went through a
+// select costs a v_max x, x canonicalisation first.
+__device__ __forceinline__ float min0(float x)
+{
+    float r;
+    asm("v_min_f32_e64 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ float min0_neg(float x)
+{
+    float r;
+    asm("v_min_f32_e64 %0, -%1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ double min0(double x) { return rmin(x, 0.0); }
+__device__ __forceinline__ double min0_neg(double x) { return rmin(-x, 0.0); }
+
 template <typename REAL>
 __device__ __forceinline__ void lds_min(REAL* p, REAL v)
 {
@@ -388,6 +414,14 @@ __device__ __forceinline__ uint32_t nw_lidx(uint32_t w) { return (w >> NW_LIDX_S
 __device__ __forceinline__ uint32_t nw_len(uint32_t w) { return (w & NW_TWO) ? 2u : 0u; }  // only "is it a two-node layer" is stored
 __device__ __forceinline__ bool nw_head(uint32_t w) { return (w & (NW_PAD | (NW_FIELD6 << NW_POS_SHIFT))) == 0; }
 
+__device__ __forceinline__ void hop_load(float2& v, rsrc_t rh, uint32_t voff, uint32_t soff)
+{
+    v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rh, voff, soff, BDDMMA_LD_AUX));
+}
+__device__ __forceinline__ void hop_load(double2& v, rsrc_t rh, uint32_t voff, uint32_t soff)
+{
+    v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rh, voff, soff, 0));
+}
 template <typename REAL, int R>
 __device__ __forceinline__ void load_layer(HopLayer<REAL, R>& L, const uint32_t (&w)[R], uint32_t lbase, const NarrowRs<REAL>& rs)
 {
@@ -395,10 +429,11 @@ __device__ __forceinline__ void load_layer(HopLayer<REAL, R>& L, const uint32_t 
     uint32_t base = lbase;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const bool act = !(w[r] & NW_PAD);
-        L.lg[r] = base + nw_lidx(w[r]);
+        const uint32_t li = nw_lidx(w[r]);
+        L.lg[r] = base + li;
+        // the group's first layer goes into the scalar offset; padding lanes (index 0) read that layer's pair and ignore it
+        hop_load(L.c[r], rs.lohi, li * (uint32_t)sizeof(P2), base * (uint32_t)sizeof(P2));
         if (r + 1 < R) base += (uint32_t)__popcll(__ballot(nw_head(w[r])));  // layers of this lane group
-        bload(L.c[r], rs.lohi, act ? L.lg[r] * (uint32_t)sizeof(P2) : OOB);
     }
 }
 
@@ -629,10 +664,10 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                     REAL m0 = act ? (f[r] + lc) + tl[r] : INF;
                     REAL m1 = act ? (f[r] + hc) + th[r] : INF;
                     seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
-                    const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
+                    const REAL mm = mm_diff(m0, m1, omega);
                     mmv[r] = mm;
-                    nlo[r] = (lc + rmin(mm, REAL(0))) + dd[r].x;
-                    nhi[r] = (hc + rmin(-mm, REAL(0))) + dd[r].y;
+                    nlo[r] = (lc + min0(mm)) + dd[r].x;
+                    nhi[r] = (hc + min0_neg(mm)) + dd[r].y;
                 }
             }
             // ---- writes: staged min-marginal differences, pushes into the next frontier, global stores
@@ -836,10 +871,10 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                     REAL m0 = act ? (fa[r] + lc) + tl[r] : INF;
                     REAL m1 = act ? (fa[r] + hc) + th[r] : INF;
                     seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
-                    const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
+                    const REAL mm = mm_diff(m0, m1, omega);
                     mmv[r] = mm;
-                    nlo[r] = (lc + rmin(mm, REAL(0))) + dd[r].x;
-                    nhi[r] = (hc + rmin(-mm, REAL(0))) + dd[r].y;
+                    nlo[r] = (lc + min0(mm)) + dd[r].x;
+                    nhi[r] = (hc + min0_neg(mm)) + dd[r].y;
                     t[r] = rmin(nhi[r] + th[r], nlo[r] + tl[r]);
                 } else {
                     const REAL ch = th[r] + hc, cl = tl[r] + lc;  // backward_step, bdd_cuda_base.cu:646-667
@@ -1049,9 +1084,9 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
             REAL m0 = act ? (f[r] + c.x) + tl : INF;
             REAL m1 = act ? (f[r] + c.y) + th : INF;
             seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
-            const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
-            const REAL nlo = (c.x + rmin(mm, REAL(0))) + dd.x;
-            const REAL nhi = (c.y + rmin(-mm, REAL(0))) + dd.y;
+            const REAL mm = mm_diff(m0, m1, omega);
+            const REAL nlo = (c.x + min0(mm)) + dd.x;
+            const REAL nhi = (c.y + min0_neg(mm)) + dd.y;
             const bool head = nw_head(w);
             P2 nc;
             nc.x = nlo;
@@ -1143,9 +1178,9 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev p
             REAL m0 = act ? (fa + c.x) + tl : INF;
             REAL m1 = act ? (fa + c.y) + th : INF;
             seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
-            const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
-            const REAL nlo = (c.x + rmin(mm, REAL(0))) + dd.x;
-            const REAL nhi = (c.y + rmin(-mm, REAL(0))) + dd.y;
+            const REAL mm = mm_diff(m0, m1, omega);
+            const REAL nlo = (c.x + min0(mm)) + dd.x;
+            const REAL nhi = (c.y + min0_neg(mm)) + dd.y;
             const REAL t = rmin(nhi + th, nlo + tl);
             const bool head = nw_head(w);
             P2 nc;
@@ -1269,9 +1304,9 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, Pack
             if (MODE == FWD_SOLVE) {
                 const REAL m0 = frontier_load<GLOBAL>(&s.m0[l]), m1 = frontier_load<GLOBAL>(&s.m1[l]);
                 const uint32_t e = d.lpos[lbase + l];
-                const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
-                nlo = (nlo + rmin(mm, REAL(0))) + d.delta_lay[2 * (size_t)e];
-                nhi = (nhi + rmin(-mm, REAL(0))) + d.delta_lay[2 * (size_t)e + 1];
+                const REAL mm = mm_diff(m0, m1, omega);
+                nlo = (nlo + min0(mm)) + d.delta_lay[2 * (size_t)e];
+                nhi = (nhi + min0_neg(mm)) + d.delta_lay[2 * (size_t)e + 1];
                 if (w & WW_HEAD) {
                     d.lohi[2 * (size_t)(lbase + l)] = nlo;
                     d.lohi[2 * (size_t)(lbase + l) + 1] = nhi;
@@ -1354,9 +1389,9 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
             if (MODE == BWD_SOLVE) {
                 const REAL m0 = frontier_load<GLOBAL>(&s.m0[l]), m1 = frontier_load<GLOBAL>(&s.m1[l]);
                 const uint32_t e = d.lpos[lbase + l];
-                const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
-                const REAL nlo = (s.lc[l] + rmin(mm, REAL(0))) + d.delta_lay[2 * (size_t)e];
-                const REAL nhi = (s.hc[l] + rmin(-mm, REAL(0))) + d.delta_lay[2 * (size_t)e + 1];
+                const REAL mm = mm_diff(m0, m1, omega);
+                const REAL nlo = (s.lc[l] + min0(mm)) + d.delta_lay[2 * (size_t)e];
+                const REAL nhi = (s.hc[l] + min0_neg(mm)) + d.delta_lay[2 * (size_t)e + 1];
                 t = rmin(nhi + th, nlo + tl);
                 if (w & WW_HEAD) {
                     d.lohi[2 * (size_t)(lbase + l)] = nlo;
@@ -1581,9 +1616,9 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
             REAL nlo = C0[i].x, nhi = C0[i].y;
             if (MODE == FWD_SOLVE) {
                 const REAL m0 = lds[oMa + l], m1 = lds[oMb + l];
-                const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
-                nlo = (nlo + rmin(mm, REAL(0))) + D0[i].x;
-                nhi = (nhi + rmin(-mm, REAL(0))) + D0[i].y;
+                const REAL mm = mm_diff(m0, m1, omega);
+                nlo = (nlo + min0(mm)) + D0[i].x;
+                nhi = (nhi + min0_neg(mm)) + D0[i].y;
                 const bool head = act && (w & WW_HEAD);
                 P2 nc;
                 nc.x = nlo;
@@ -1760,9 +1795,9 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
             REAL t;
             if (MODE == BWD_SOLVE) {
                 const REAL m0 = lds[oMa + l], m1 = lds[oMb + l];
-                const REAL mm = (rfinite(m0) && rfinite(m1)) ? omega * (m1 - m0) : REAL(0);
-                const REAL nlo = (C0[i].x + rmin(mm, REAL(0))) + D0[i].x;
-                const REAL nhi = (C0[i].y + rmin(-mm, REAL(0))) + D0[i].y;
+                const REAL mm = mm_diff(m0, m1, omega);
+                const REAL nlo = (C0[i].x + min0(mm)) + D0[i].x;
+                const REAL nhi = (C0[i].y + min0_neg(mm)) + D0[i].y;
                 t = rmin(nhi + th[i], nlo + tl[i]);
                 P2 nc;
                 nc.x = nlo;
