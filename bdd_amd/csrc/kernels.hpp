@@ -1907,23 +1907,11 @@ constexpr int EXM_UNROLL = 12;
 constexpr int EXM_NPT = 8;
 constexpr uint32_t EXM_MAX_VARS_PER_BIN = EXM_THREADS * EXM_NPT / 2;
 
-// pair stores with the slice start in the scalar offset (see hop_rsrc)
-__device__ __forceinline__ void hop_store(float2 v, rsrc_t rh, uint32_t voff, uint32_t soff)
-{
-    using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(rh, 0, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rh, voff, soff, BDDMMA_ST_AUX);
-}
-__device__ __forceinline__ void hop_store(double2 v, rsrc_t rh, uint32_t voff, uint32_t soff)
-{
-    using u4 = decltype(__builtin_amdgcn_raw_buffer_load_b128(rh, 0, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rh, voff, soff, 0);
-}
-
-// The entry accesses of the exchange carry no per-lane address arithmetic: a lane's byte offset is tid * sizeof (constant), the chunk's
-// first entry goes into the scalar offset, and the descriptors end at the bin's last entry, so the lanes past it read 0 and their
-// stores are dropped.  The accumulation is one predicated LDS atomic per entry (slot 2 v + [mm > 0], value |mm|).  The first version
-// selected OOB offsets per lane (3 VALU per access) and branched twice per entry around two atomics: ~30 VALU and 2-4 taken branches per
-// entry and wave, in a kernel that runs one workgroup per CU.
+// (A version of this kernel with scalar-offset entry addressing — descriptors ending at the bin's last entry, no per-lane offset
+// selects — and one predicated atomic per entry was 4-16 % faster on small instances and passed every serial test, but with several
+// processes sharing the GPU (pytest -n 4) about 1 % of the differential fuzz runs came out with 1e-7 errors; the cause was not found
+// (buffer range checks with the scalar offset at or beyond the descriptor's end are reliable in isolation and under the same load,
+// tools/rangestress.hip), so the kernel stays as it was.)
 template <typename REAL, typename ACC, int MODE, int EX_THREADS = bddmma::EX_THREADS, int EX_UNROLL = bddmma::EX_UNROLL, int NPT = bddmma::EX_NPT>
 __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
                                                                   const uint16_t* __restrict__ bvar, const int32_t* __restrict__ nbdds,
@@ -1937,32 +1925,18 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
     const uint32_t v0 = b * vars_per_bin;
     const uint32_t nv = min(vars_per_bin, n_vars - v0);
     const uint32_t e0 = bin_ptr[b], e1 = bin_ptr[b + 1];
-    (void)n_entries;
-    const rsrc_t rmm = make_rsrc(mm_binned, e1), rev = make_rsrc(bvar, e1);  // end at the bin's last entry
+    const rsrc_t rmm = make_rsrc(mm_binned, n_entries), rev = make_rsrc(bvar, n_entries);
     const rsrc_t rnb = make_rsrc(nbdds, n_vars);
-    const uint32_t vo_m = tid * (uint32_t)sizeof(REAL), vo_v = tid * 2u, vo_p = tid * (uint32_t)sizeof(P2);
-    constexpr uint32_t CH = EX_THREADS * EX_UNROLL;
-    const bool one_chunk = (e1 - e0) <= CH;
-    auto load_chunk = [&](REAL (&mm_)[EX_UNROLL], uint32_t (&lv_)[EX_UNROLL], uint32_t start) {
-#pragma unroll
-        for (int u = 0; u < EX_UNROLL; ++u) {
-            const uint32_t e = start + u * EX_THREADS;  // uniform
-            hop_load(mm_[u], rmm, vo_m, e * (uint32_t)sizeof(REAL));  // past the bin: 0 -> no contribution
-            lv_[u] = __builtin_amdgcn_raw_buffer_load_b16(rev, vo_v, e * 2u, 0);
-        }
-    };
-    auto accumulate = [&](const REAL (&mm_)[EX_UNROLL], const uint32_t (&lv_)[EX_UNROLL]) {
-#pragma unroll
-        for (int u = 0; u < EX_UNROLL; ++u) {
-            const REAL m = mm_[u];
-            const uint32_t slot = 2 * lv_[u] + (m > 0 ? 1u : 0u);
-            if (m != 0) lds_add(&tile[slot], ACC(m > 0 ? m : -m));
-        }
-    };
+    const bool one_chunk = (e1 - e0) <= EX_THREADS * EX_UNROLL;
     // first chunk: every load of the workgroup is issued before anything is consumed
     REAL m[EX_UNROLL];
     uint32_t lv[EX_UNROLL];
-    load_chunk(m, lv, e0);
+#pragma unroll
+    for (int u = 0; u < EX_UNROLL; ++u) {
+        const uint32_t e = e0 + tid + u * EX_THREADS;
+        bload(m[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);  // out of range: 0 -> no contribution
+        lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
+    }
     // number of BDDs of the variables this thread normalises (needed only after the accumulation)
     int nb[NPT];
     if (MODE == EX_ITER) {
@@ -1975,6 +1949,22 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
     for (uint32_t i = tid; i < 2 * nv; i += EX_THREADS) tile[i] = ACC(0);
     __syncthreads();
     // bins larger than one chunk: the loads of chunk c+1 are in flight while chunk c is accumulated
+    constexpr uint32_t CH = EX_THREADS * EX_UNROLL;
+    auto load_chunk = [&](REAL (&mm_)[EX_UNROLL], uint32_t (&lv_)[EX_UNROLL], uint32_t start) {
+#pragma unroll
+        for (int u = 0; u < EX_UNROLL; ++u) {
+            const uint32_t e = start + tid + u * EX_THREADS;
+            bload(mm_[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
+            lv_[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
+        }
+    };
+    auto accumulate = [&](const REAL (&mm_)[EX_UNROLL], const uint32_t (&lv_)[EX_UNROLL]) {
+#pragma unroll
+        for (int u = 0; u < EX_UNROLL; ++u) {
+            if (mm_[u] > 0) lds_add(&tile[2 * lv_[u] + 1], ACC(mm_[u]));
+            else if (mm_[u] < 0) lds_add(&tile[2 * lv_[u]], ACC(-mm_[u]));
+        }
+    };
     {
         REAL mc[EX_UNROLL];
         uint32_t lc[EX_UNROLL];
@@ -2012,23 +2002,31 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
     }
     if (MODE != EX_ITER) return;
     __syncthreads();
-    const rsrc_t rdl = make_rsrc(delta_lay, 2ull * e1);  // stores past the bin's last entry are dropped
-    auto broadcast = [&](const uint32_t (&lv_)[EX_UNROLL], uint32_t start) {
+    const rsrc_t rdl = make_rsrc(delta_lay, 2ull * n_entries);
 #pragma unroll
-        for (int u = 0; u < EX_UNROLL; ++u) {
-            P2 pr;
-            pr.x = REAL(tile[2 * lv_[u]]);
-            pr.y = REAL(tile[2 * lv_[u] + 1]);
-            hop_store(pr, rdl, vo_p, (start + u * EX_THREADS) * (uint32_t)sizeof(P2));
-        }
-    };
-    broadcast(lv, e0);  // first chunk: the local variable indices are still in registers
+    for (int u = 0; u < EX_UNROLL; ++u) {  // first chunk: the local variable indices are still in registers
+        const uint32_t e = e0 + tid + u * EX_THREADS;
+        P2 pr;
+        pr.x = REAL(tile[2 * lv[u]]);
+        pr.y = REAL(tile[2 * lv[u] + 1]);
+        bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
+    }
     if (one_chunk) return;
-    for (uint32_t cs = e0 + CH; cs < e1; cs += CH) {
+    for (uint32_t base = e0 + EX_THREADS * EX_UNROLL + tid; base < e1; base += EX_THREADS * EX_UNROLL) {
         uint32_t lv2[EX_UNROLL];
 #pragma unroll
-        for (int u = 0; u < EX_UNROLL; ++u) lv2[u] = __builtin_amdgcn_raw_buffer_load_b16(rev, vo_v, (cs + u * EX_THREADS) * 2u, 0);
-        broadcast(lv2, cs);
+        for (int u = 0; u < EX_UNROLL; ++u) {
+            const uint32_t e = base + u * EX_THREADS;
+            lv2[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
+        }
+#pragma unroll
+        for (int u = 0; u < EX_UNROLL; ++u) {
+            const uint32_t e = base + u * EX_THREADS;
+            P2 pr;
+            pr.x = REAL(tile[2 * lv2[u]]);
+            pr.y = REAL(tile[2 * lv2[u] + 1]);
+            bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
+        }
     }
 }
 
