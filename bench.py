@@ -282,8 +282,11 @@ def measured_traffic(kernel, args, sfx):
             return None
         want = "k_fwd_narrow" if kernel == "forward_mm" else "k_bwd_narrow"
         for name, v in d.items():
-            m = re.search(want + r"<\w+, \d+, (\d+), \d+>", name)   # <REAL, R, MODE, waves per block>; MODE 1 = solve
+            m = re.search(want + r"<\w+, \d+, (\d+), \d+(?:, \w+)?>", name)   # <REAL, R, MODE, waves per block[, SEG]>; MODE 1 = solve
             if m and m.group(1) == "1":
+                return v["hbm_bytes"]
+        for name, v in d.items():   # small instances: the resident sweeps
+            if re.search(want.replace("_narrow", "_res") + r"<", name):
                 return v["hbm_bytes"]
     return None
 
