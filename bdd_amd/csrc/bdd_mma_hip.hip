@@ -281,12 +281,12 @@ struct SolverT final : SolverBase {
             const uint32_t static_lds = wpb * (2 * (pack_width + 2) * (uint32_t)sizeof(REAL) + 512) + seg_bytes(wpb);
             const uint32_t mode = opts ? opts->resident_sweeps : 0;
             const bool fits = res_lds + static_lds <= 160 * 1024 - 512;
-            // automatic choice: small instances only — at most 2 waves per SIMD (2048 packs), all workgroups in flight at once with their
-            // LDS slices.  Measured (float, sweep fwd / bwd in us, streaming vs resident): 1 M nodes (1563 packs) 12.1 / 12.2 vs 11.4 / 10.5;
+            // automatic choice: small instances only — fewer than 3 waves per SIMD (2880 packs: with the round-2 kernels the resident sweeps
+            // win by 3-6 % from 1 900 to 2 800 packs and lose 10 % at 3 125), all workgroups in flight at once with their LDS slices.  Measured (float, sweep fwd / bwd in us, streaming vs resident): 1 M nodes (1563 packs) 12.1 / 12.2 vs 11.4 / 10.5;
             // 2 M 18.5 / 19.1 vs 20.5 / 19.7; 4 M 27.3 / 25.5 vs 41.8 / 39.0; 10.5 M 50 / 45 vs 108 / 98 — with more waves per SIMD the
             // streaming kernels hide their latency and the resident ones only lose occupancy to their LDS footprint.
             const uint64_t wgs_per_cu = fits ? (160 * 1024) / (res_lds + static_lds) : 0;
-            const bool all_in_flight = nb_.n_packs <= 2048 && (uint64_t)cdiv(nb_.n_packs, wpb) <= 256ull * std::min<uint64_t>(wgs_per_cu, 2048 / (64 * wpb));
+            const bool all_in_flight = nb_.n_packs <= 2880 && (uint64_t)cdiv(nb_.n_packs, wpb) <= 256ull * std::min<uint64_t>(wgs_per_cu, 2048 / (64 * wpb));
             use_res = fits && mode != 1 && (mode == 2 || all_in_flight);
             if (use_res) {
 #define SET_RES(R_, W_) \
