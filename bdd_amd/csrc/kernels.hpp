@@ -7,8 +7,8 @@
 //     access of a wave is a contiguous stream (coalesced);
 //   - the frontier (cost-from-root of the current and next hop, cost-from-terminal of the next
 //     hop) lives in LDS; children are addressed by their local index inside the next hop;
-//   - the per-layer min-marginal is a segmented wavefront reduction: __ballot of the layer-head
-//     flags gives the segment boundaries, __shfl_down halving steps do the min, __shfl broadcasts;
+//   - the per-layer min-marginal is a segmented minimum over the lanes of the layer (position inside the layer and layer index
+//     come from the node word): a DPP pair for layers of <= 2 nodes, one LDS slot per layer (ds_min) for wider ones;
 //   - no MFMA: this is an HBM-bound gather/scan (2 flops per 4-8 bytes).
 //
 // Arithmetic order follows the reference exactly (SURVEY.md §8 a'):

@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--clock-warm", type=float, default=0.3, dest="clock_warm",
+                    help="seconds of untimed iterations before the warm-up steps, so that the shader clocks are up (0: none)")
     ap.add_argument("--precision", default="float", choices=["float", "double"], help="precision of `value` (the other one is value_f64 / value_f32)")
     ap.add_argument("--vars", type=int, default=1_000_000)
     ap.add_argument("--rows", type=int, default=500_000)
@@ -106,11 +108,30 @@ def main():
     col, costs = random_set_cover_mt(args.vars, args.rows, args.k, seed=12345 + rank)
     stride = args.event_stride or max(1, args.steps // 16)
 
+    pre_iterations = {}
+
     def run(precision):
         """warm-up, the timed K steps (barrier + device sync on both sides), hipEvent profile, lower bound"""
         solver = bdd_hip_parallel_mma(col, costs, precision=precision, device=local_rank,
                                       pack_width=args.pack_width, deterministic=args.deterministic,
                                       vars_per_bin=args.vars_per_bin, stage_cap=args.stage_cap, waves_per_block=args.wpb)
+        # Clock ramp: an idle MI355X sits at its lowest shader clock (rocm-smi: sclk 98 MHz) and needs tens of milliseconds of load to
+        # come up; W = 5 warm-up steps are 0.6 ms and a K = 20 run 2.5 ms, and such runs measured 6.5 k instead of 7.9 k it/s from time
+        # to time.  So the device is kept busy with the same iterations for args.clock_warm seconds first (untimed, counted in
+        # lower_bound_after.iterations), then come the W warm-up steps and the K timed ones.
+        pre = 0
+        if "n" in pre_iterations:           # the second precision of the run: the same number of iterations as the first
+            pre = pre_iterations["n"]
+            if pre:
+                solver.iterations(pre)
+                solver.synchronize()
+        else:
+            t_warm = time.perf_counter()
+            while time.perf_counter() - t_warm < args.clock_warm:
+                solver.iterations(64)
+                solver.synchronize()
+                pre += 64
+            pre_iterations["n"] = pre
         solver.iterations(args.warmup)
         solver.synchronize()
         dt = timed_region(lambda: solver.iterations(args.steps),
@@ -183,7 +204,8 @@ def main():
             },
             "roofline": roofline(prof, sizes, R, its / world, args, sfx, triad_gbs, copy_gbs),
             "value_with_lower_bound_every_iteration": lb_rate,
-            "lower_bound_after": {"iterations": args.warmup + 2 * args.steps, "value": lb},
+            "lower_bound_after": {"iterations": pre_iterations.get("n", 0) + args.warmup + 2 * args.steps, "value": lb},
+            "clock_warm_iterations": pre_iterations.get("n", 0),
         }
         if second is not None:
             dt2, prof2, lb2 = second
@@ -192,7 +214,7 @@ def main():
             out["value_" + sfx2] = its2
             out["ms_per_step_" + sfx2] = dt2 / args.steps * 1e3
             out["roofline_" + sfx2] = roofline(prof2, sizes, R2, its2 / world, args, sfx2, triad_gbs, copy_gbs)
-            out["lower_bound_after_" + sfx2] = {"iterations": args.warmup + 2 * args.steps, "value": lb2,
+            out["lower_bound_after_" + sfx2] = {"iterations": pre_iterations.get("n", 0) + args.warmup + 2 * args.steps, "value": lb2,
                                                "rel_diff_to_" + sfx: abs(lb2 - lb) / max(abs(lb), 1e-300)}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(col, costs, args, sizes)
