@@ -82,8 +82,9 @@ typedef struct bddmma_options {
                                   measured).  Default (0 / 1): binned order */
     uint32_t variant_flags;    /* switches between equivalent code paths, for A/B measurements and the differential tests (default 0):
                                   bit 0: narrow and wide backward sweeps as two launches (default: one, k_bwd_mixed) */
-    uint32_t pack_fill;        /* slots of a narrow pack's hop that BDDs are packed into, <= pack_width (default 0: chosen from the number of
-                                  packs — instances with few, deep packs trade lane occupancy for wavefronts, see layout.cpp) */
+    uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
+                                  Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
+                                  instance (the sweeps are bound by instructions issued, not by latency), kept for experiments */
     uint32_t reserved[1];
 } bddmma_options;
 
