@@ -161,6 +161,13 @@ PYBIND11_MODULE(bdd_solver_py, m)
         })
         .def("nr_primal_variables", [](const hip_solver& s) { return bddmma_nr_variables(s.h); })
         .def("nr_layers", [](const hip_solver& s) { return bddmma_nr_layers(s.h); })
+        // bdd_cuda_parallel_mma_py.cu:53: layers of one hop (bdd_cuda_base.h:106-109)
+        .def("nr_layers", [](const hip_solver& s, int64_t hop_index) {
+            std::vector<uint64_t> per_hop(bddmma_nr_hops(s.h));
+            if (hop_index < 0 || (uint64_t)hop_index >= per_hop.size()) throw py::index_error("hop index out of range");
+            ck(bddmma_layers_per_hop(s.h, per_hop.data()), s.h);
+            return per_hop[(size_t)hop_index];
+        }, py::arg("hop_index"))
         .def("nr_hops", [](const hip_solver& s) { return bddmma_nr_hops(s.h); })
         .def("nr_bdds", [](const hip_solver& s) { return bddmma_nr_bdds(s.h); })
         .def("iteration", [](hip_solver& s, double omega) { ck(bddmma_iteration(s.h, omega), s.h); }, py::arg("omega") = 0.5)

@@ -74,6 +74,10 @@ def test_gpu_solver_class_pickle_and_min_marginal_diff():
     lb = s.lower_bound()
     t = pickle.loads(pickle.dumps(s))                       # bdd_cuda_parallel_mma_py.cu:15-37
     assert (t.nr_layers(), t.nr_hops(), t.nr_bdds()) == (s.nr_layers(), s.nr_hops(), s.nr_bdds())
+    # nr_layers(hop_index), bdd_cuda_parallel_mma_py.cu:53: the per-hop counts add up to the total
+    assert sum(s.nr_layers(h) for h in range(s.nr_hops())) == s.nr_layers() and s.nr_layers(0) == s.nr_bdds()
+    with pytest.raises(IndexError):
+        s.nr_layers(s.nr_hops())
     assert t.lower_bound() == lb
     s.iteration(); t.iteration()
     assert abs(t.lower_bound() - s.lower_bound()) <= 1e-6 * max(1.0, abs(s.lower_bound()))
