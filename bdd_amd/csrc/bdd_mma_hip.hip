@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -65,6 +66,11 @@ struct SolverT final : SolverBase {
     uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0, stage_lds = 0, exch_lds = 0, n_narrow_layers = 0;
     double *d_lb_partial = nullptr, *d_lb = nullptr;
     double* h_lb = nullptr;  // pinned, device-visible: the reduce kernel writes the bound straight into host memory
+    // device-resident run_solver (kernels.hpp: run_ctl_step)
+    RunCtl* d_run_ctl = nullptr;
+    RunHost *h_run = nullptr, *d_run_host = nullptr;  // pinned + its device address
+    const uint32_t* run_stop = nullptr;               // &d_run_ctl->stop while run_plain() queues iterations, nullptr otherwise
+    RunStep run_step{};                               // {partials, count, ctl, host}: what the launch that ends an iteration gets
     uint32_t* d_counts = nullptr;
     REAL *d_tmp0 = nullptr, *d_tmp1 = nullptr;        // per-layer scratch (min-marginals, sorted outputs)
     char* d_sol = nullptr;
@@ -96,6 +102,8 @@ struct SolverT final : SolverBase {
         if (device >= 0) (void)hipSetDevice(device);
         for (void* p : allocs) (void)hipFree(p);
         if (h_lb) (void)hipHostFree(h_lb);
+        if (h_run) (void)hipHostFree(h_run);
+        if (d_run_ctl) (void)hipFree(d_run_ctl);
         for (auto& e : ev_pool) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
@@ -266,6 +274,7 @@ struct SolverT final : SolverBase {
 #define SET_DYN(K, BYTES) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
         SET_DYN((k_exchange_reduce<REAL, double, EX_ITER>), exch_lds);
         SET_DYN((k_exchange_reduce<REAL, double, EX_RAW>), exch_lds);
+        SET_DYN((k_exchange_reduce<REAL, double, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, true>), exch_lds);  // run_plain()'s instantiation
         opts_variant = opts ? opts->variant_flags : 0u;
         exch_small = vars_per_bin <= EXS_MAX_VARS_PER_BIN;  // 256-thread workgroups (kernels.hpp: EXS_*)
         exch_medium = !exch_small && vars_per_bin <= EXM_MAX_VARS_PER_BIN;  // 512-thread workgroups (EXM_*)
@@ -347,6 +356,7 @@ struct SolverT final : SolverBase {
         d.n_slots = (uint32_t)n_slots; d.n_layers = (uint32_t)n_layers; d.n_narrow_layers = n_narrow_layers;
         d.lb_partial = d_lb_partial;
         d.mm0_out = d_tmp0; d.mm1_out = d_tmp1; d.sol_out = d_sol;
+        d.stop = run_stop;
         return d;
     }
     PackDev pdev(const PackBufs& b, uint32_t lb_base, uint32_t seg_off = 0) const
@@ -495,46 +505,45 @@ struct SolverT final : SolverBase {
         return BDDMMA_OK;
     }
     // compute_delta + normalize_delta + broadcast to the layers, see kernels.hpp (k_exchange_reduce)
-    void launch_bcast(const REAL* delta_var, REAL* delta_lay)
+    void launch_bcast(const REAL* delta_var, REAL* delta_lay, const uint32_t* stop = nullptr, RunStep run = RunStep{})
     {
         hipLaunchKernelGGL((k_exchange_bcast<REAL>), dim3(cdiv(cdiv(n_layers, 4), 256)), dim3(256), 0, stream, delta_var, d_evar, delta_lay,
-                           (uint32_t)n_layers, (uint32_t)n_vars);
+                           (uint32_t)n_layers, (uint32_t)n_vars, stop, run);
     }
     // un-normalised per-variable sums of the deferred min-marginal differences (compute_delta only)
     void launch_reduce_raw(REAL* delta_var)
     {
         if (deterministic)
             hipLaunchKernelGGL((k_delta_gather<REAL, false>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr,
-                               d_vpos, delta_var, (uint32_t)n_vars);
+                               d_vpos, delta_var, (uint32_t)n_vars, (const uint32_t*)nullptr);
         else
             hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_RAW>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
-                               d_bin_ptr, d_bvar, d_nbdds, delta_var, (REAL*)nullptr, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers);
+                               d_bin_ptr, d_bvar, d_nbdds, delta_var, (REAL*)nullptr, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers,
+                               (const uint32_t*)nullptr);
     }
-    int exchange()
+    int exchange(bool ends_iteration = false)
     {
+        const RunStep rstep = (ends_iteration && run_stop) ? run_step : RunStep{};
         prof_begin(BDDMMA_K_FINISH_DELTA);
         if (entry_by_var) {
             // entries of a variable are consecutive: one thread per variable reduces, normalises and broadcasts (deterministic order)
             hipLaunchKernelGGL((k_exchange_byvar<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr, d_delta_lay,
-                               (uint32_t)n_vars, (uint32_t)n_layers);
+                               (uint32_t)n_vars, (uint32_t)n_layers, run_stop, rstep);
             delta_var_valid = false;
         } else if (deterministic) {
             hipLaunchKernelGGL((k_delta_gather<REAL, true>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr,
-                               d_vpos, d_delta_var, (uint32_t)n_vars);
-            launch_bcast(d_delta_var, d_delta_lay);
+                               d_vpos, d_delta_var, (uint32_t)n_vars, run_stop);
+            launch_bcast(d_delta_var, d_delta_lay, run_stop, rstep);
             delta_var_valid = true;
         } else {
-            if (exch_medium)
-                hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, EXM_THREADS, EXM_UNROLL, EXM_NPT>), dim3(n_bins), dim3(EXM_THREADS), exch_lds,
-                                   stream, d_mm_binned, d_bin_ptr, d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars,
-                                   (uint32_t)n_layers);
-            else if (exch_small)
-                hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, EXS_THREADS, EXS_UNROLL, EXS_NPT>), dim3(n_bins), dim3(EXS_THREADS), exch_lds,
-                                   stream, d_mm_binned, d_bin_ptr, d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars,
-                                   (uint32_t)n_layers);
-            else
-                hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
-                                   d_bin_ptr, d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers);
+#define LAUNCH_EX(T_, U_, N_, RUN_)                                                                                                              \
+    hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, T_, U_, N_, RUN_>), dim3(n_bins), dim3(T_), exch_lds, stream, d_mm_binned, d_bin_ptr, \
+                       d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers, run_stop, rstep)
+            // inside run_plain() the instantiation that honours the stop flag and runs the termination tests; otherwise the plain one
+            if (exch_medium) { if (run_stop) LAUNCH_EX(EXM_THREADS, EXM_UNROLL, EXM_NPT, true); else LAUNCH_EX(EXM_THREADS, EXM_UNROLL, EXM_NPT, false); }
+            else if (exch_small) { if (run_stop) LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, true); else LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false); }
+            else { if (run_stop) LAUNCH_EX(EX_THREADS, EX_UNROLL, EX_NPT, true); else LAUNCH_EX(EX_THREADS, EX_UNROLL, EX_NPT, false); }
+#undef LAUNCH_EX
             delta_var_valid = false;
         }
         prof_end(BDDMMA_K_FINISH_DELTA);
@@ -618,7 +627,96 @@ struct SolverT final : SolverBase {
         if ((rc = mma_forward((REAL)omega, d_delta_lay))) return rc;
         if ((rc = exchange())) return rc;
         if ((rc = mma_backward((REAL)omega, d_delta_lay))) return rc;
-        if ((rc = exchange())) return rc;
+        if ((rc = exchange(true))) return rc;
+        return BDDMMA_OK;
+    }
+    // run_solver for the plain MMA iteration with the termination tests on the device (kernels.hpp: run_ctl_step).  The host
+    // keeps up to `window` iterations queued and reads the published bounds; when the tests fire, the launches queued behind that
+    // iteration return at once, so the state and the iteration count are the ones of the reference's sequential loop
+    // (run_solver_util.h:40-73).  The wall-clock limit is tested on the host after every iteration it sees complete, as the reference
+    // does; close to the limit the window shrinks to one iteration, so no iteration is queued that the sequential loop would not run.
+    int run_plain(uint64_t max_iter, double tolerance, double slope, double time_limit, int verbose, bddmma_run_result* res) override
+    {
+        HIPCHK(hipSetDevice(device));
+        const auto t0 = std::chrono::steady_clock::now();
+        auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+        if (!d_run_ctl) {
+            HIPCHK(hipMalloc((void**)&d_run_ctl, sizeof(RunCtl)));
+            HIPCHK(hipHostMalloc((void**)&h_run, sizeof(RunHost), hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer((void**)&d_run_host, h_run, 0));
+        }
+        double lb_initial;
+        int rc = lower_bound(&lb_initial);
+        if (rc) return rc;
+        if (verbose) std::printf("[bdd solver] initial lower bound = %.10g, time = %.3f s\n", lb_initial, elapsed());
+        RunCtl c{};
+        c.lb_initial = lb_initial;
+        c.lb_first = std::numeric_limits<double>::max();
+        c.lb_post = lb_initial;
+        c.tolerance = tolerance;
+        c.slope = slope;
+        std::memset((void*)h_run, 0, sizeof(RunHost));
+        run_step = RunStep{d_lb_partial, nb_.n_packs + wb_.n_packs + hb_.n_packs, d_run_ctl, d_run_host};
+        HIPCHK(hipMemcpyAsync(d_run_ctl, &c, sizeof(RunCtl), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));  // c is a stack object
+        constexpr uint64_t WINDOW = 6;  // iterations queued ahead of the last bound seen (< RUN_RING)
+        volatile RunHost* hr = h_run;
+        uint64_t queued = 0, seen = 0;
+        int reason = 0;
+        double lb_post = lb_initial;
+        run_stop = &d_run_ctl->stop;
+        while (true) {
+            // near the time limit: one iteration at a time, so that none is queued which the sequential loop would not run
+            const double t = elapsed();
+            const double per_iter = seen ? t / (double)seen : 0.0;
+            const uint64_t window = (seen && t + 4.0 * (double)WINDOW * per_iter < time_limit) ? WINDOW : 1;
+            bool launched = false;
+            while (queued < max_iter && queued - seen < window) {
+                rc = iteration(0.5);  // its last launch also reduces the bound and runs the tests (exchange(true))
+                if (rc) { run_stop = nullptr; return rc; }
+                ++queued;
+                launched = true;
+            }
+            if (queued == 0) break;  // max_iter == 0
+            const uint64_t st = hr->state;
+            const uint64_t done = st & ((1ull << 56) - 1);
+            const int dev_reason = (int)(st >> 56);
+            bool stop = false;
+            for (; seen < done && !stop; ++seen) {
+                lb_post = hr->lb[seen % RUN_RING];
+                const double ts = elapsed();
+                if (verbose) std::printf("[bdd solver] iteration %llu, lower bound = %.10g, time = %.3f s\n", (unsigned long long)seen, lb_post, ts);
+                if (ts > time_limit) { reason = 1; stop = true; }  // run_solver_util.h:50-55 (tested before the bound's criteria)
+            }
+            if (stop) break;
+            if (dev_reason && seen == done) { reason = dev_reason; break; }
+            if (seen == max_iter) break;
+            if (!launched && done == seen) {
+                // nothing new.  An idle stream without progress means a launch failed: leave, the synchronisation below reports it
+                if (hipStreamQuery(stream) != hipErrorNotReady && (hr->state & ((1ull << 56) - 1)) == seen) break;
+                __builtin_ia32_pause();
+            }
+        }
+        run_stop = nullptr;
+        HIPCHK(hipStreamSynchronize(stream));
+        // iterations that were still in flight when the time limit was seen have run too (at most `window` - 1; they are counted)
+        {
+            const uint64_t st = hr->state;
+            const uint64_t done = st & ((1ull << 56) - 1);
+            for (; seen < done; ++seen) lb_post = hr->lb[seen % RUN_RING];
+        }
+        if (reason == 0 && seen < queued) {
+            err = "run_solver: queued iterations did not complete";
+            return BDDMMA_ERR_DEVICE;
+        }
+        if (verbose) std::printf("[bdd solver] final lower bound = %.10g\n", lb_post);
+        if (res) {
+            res->iterations = seen;
+            res->lb_initial = lb_initial;
+            res->lb_final = lb_post;
+            res->seconds = elapsed();
+            res->stop_reason = reason;
+        }
         return BDDMMA_OK;
     }
     int explicit_mm(bool forward, double omega, void* delta, int on_device)

@@ -233,6 +233,14 @@ int bddmma_gradient_step(bddmma_solver* s, const void* g, double step, int on_de
     return guarded(s, [&](SolverBase* b) { return g ? b->gradient_step(g, step, on_device) : BDDMMA_ERR_INVALID_ARGUMENT; });
 }
 
+// BDDMMA_SEQUENTIAL_RUN_SOLVER=1 keeps the reference's literal loop (iteration, lower_bound, tests on the host) for the plain solver
+// too: the twin the device-resident loop is tested against.
+static bool sequential_run_solver()
+{
+    const char* e = std::getenv("BDDMMA_SEQUENTIAL_RUN_SOLVER");
+    return e && e[0] == '1';
+}
+
 // run_solver, include/run_solver_util.h:10-77
 int bddmma_run_solver(bddmma_solver* s, bddmma_lbfgs* lbfgs, uint64_t max_iter, double tolerance,
                       double improvement_slope, double time_limit, int verbose, bddmma_run_result* res)
@@ -242,6 +250,9 @@ int bddmma_run_solver(bddmma_solver* s, bddmma_lbfgs* lbfgs, uint64_t max_iter, 
             b->err = "run_solver: invalid termination criteria";  // asserts at run_solver_util.h:13-15
             return BDDMMA_ERR_INVALID_ARGUMENT;
         }
+        // plain MMA: the loop runs with its termination tests on the device (no host round trip per iteration); the L-BFGS wrapper
+        // decides its steps on the host anyway and keeps the sequential loop below
+        if (!lbfgs && !sequential_run_solver()) return b->run_plain(max_iter, tolerance, improvement_slope, time_limit, verbose, res);
         const auto t0 = std::chrono::steady_clock::now();
         auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
         double lb_initial;

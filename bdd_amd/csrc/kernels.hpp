@@ -51,7 +51,22 @@ struct DevPtrs {
     REAL* mm0_out;           // BWD_MARGINALS outputs, per layer
     REAL* mm1_out;
     char* sol_out;           // FWD_SOLUTION output, per layer
+    // Device-resident run_solver (run_ctl_step): when the termination test of run_solver_util.h:56-73 has fired on the device, the
+    // launches of the iterations the host had already queued return at once.  nullptr outside run_solver (one scalar compare of a
+    // kernel argument); otherwise one scalar load per launch.
+    const uint32_t* stop;
 };
+
+__device__ __forceinline__ bool run_stopped(const uint32_t* stop) { return stop != nullptr && *stop != 0u; }
+// The sweep kernels test the flag together with their first uniform exit: the pointer is a kernel argument, so outside run_solver
+// (nullptr) the test is one more scalar compare on values the kernel loads anyway — no extra dependent round trip at its start.
+#define BDDMMA_EXIT_IF(done_cond, stopp)                                   \
+    {                                                                      \
+        const bool done_ = (done_cond);                                    \
+        if (done_ | ((stopp) != nullptr)) {                                \
+            if (done_ || *(stopp) != 0u) return;                           \
+        }                                                                  \
+    }
 
 struct PackDev {
     const uint32_t* pack_hop_ptr;
@@ -521,7 +536,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     auto& sAct = sAct_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
     const uint32_t quad = block_to_pack(block_id, n_quads);
-    if (quad >= n_quads) return;  // uniform for the workgroup
+    BDDMMA_EXIT_IF(quad >= n_quads, d.stop)  // uniform for the workgroup
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;  // the last quad may be partial: such a wave only helps staging
     const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
@@ -768,7 +783,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     auto& sT = sT_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
     const uint32_t quad = block_to_pack(block_id, n_quads);
-    if (quad >= n_quads) return;
+    BDDMMA_EXIT_IF(quad >= n_quads, d.stop)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
     const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
@@ -1014,7 +1029,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
     uint32_t* sOffL = sOffL_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
     const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
-    if (quad >= n_quads) return;
+    BDDMMA_EXIT_IF(quad >= n_quads, d.stop)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
     // dynamic LDS: [staged {delta_lo, delta_hi} / mm: WPB * stage_cap pairs][per wave: words | T of every slot | {lo, hi} of every layer]
@@ -1126,7 +1141,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev p
     uint32_t* sOffL = sOffL_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
     const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
-    if (quad >= n_quads) return;
+    BDDMMA_EXIT_IF(quad >= n_quads, d.stop)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
     P2* sD = reinterpret_cast<P2*>(dyn_lds);
@@ -1250,7 +1265,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, Pack
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
     const uint32_t p = blockIdx.x;
-    if (p >= pk.n_packs) return;
+    BDDMMA_EXIT_IF(p >= pk.n_packs, d.stop)
     WideLds<REAL> s = carve_lds<REAL>(GLOBAL ? scratch + (size_t)p * wide_lds_bytes(sizeof(REAL), ww, true) : smem, ww);
     const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
     const REAL INF = inf_v<REAL>();
@@ -1343,7 +1358,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
     __shared__ double red[WIDE_THREADS / 64];
     const uint32_t tid = threadIdx.x;
     const uint32_t p = blockIdx.x;
-    if (p >= pk.n_packs) return;
+    BDDMMA_EXIT_IF(p >= pk.n_packs, d.stop)
     WideLds<REAL> s = carve_lds<REAL>(GLOBAL ? scratch + (size_t)p * wide_lds_bytes(sizeof(REAL), ww, true) : smem, ww);
     const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
     const REAL INF = inf_v<REAL>();
@@ -1495,7 +1510,7 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
     constexpr bool NEED_T = (MODE != FWD_PLAIN);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, T = blockDim.x;
-    if (p >= pk.n_packs) return;
+    BDDMMA_EXIT_IF(p >= pk.n_packs, d.stop)
     const uint32_t S = ww + 2;
     // All LDS arrays are addressed as lds[offset + index] with integer offsets that rotate from hop to hop: with rotating POINTERS the
     // compiler loses the address space and emits flat loads / a flat compare-and-swap loop for the float minimum (seen in the ISA).
@@ -1688,7 +1703,7 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double red[16];
     const uint32_t tid = threadIdx.x, T = blockDim.x;
-    if (p >= pk.n_packs) return;
+    BDDMMA_EXIT_IF(p >= pk.n_packs, d.stop)
     const uint32_t S = ww + 2;
     REAL* const lds = reinterpret_cast<REAL*>(smem);  // integer offsets instead of rotating pointers, see k_fwd_wide2
     const uint32_t oM0 = 4 * S, oM1 = 6 * S;
@@ -1874,6 +1889,67 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_mixed(DevPtrs<REAL> d, PackDev
 // small elementwise / per-variable kernels
 // =============================================================================================
 
+// Device-resident run_solver (include/run_solver_util.h:40-73).  The reference's loop is iteration(); lower_bound(); three tests on the
+// bound — a host round trip per iteration that leaves the GPU idle between the reduce kernel and the next forward sweep (119 -> 135 us
+// per iteration at 10.5 M nodes, 33 -> 47 us at 1 M).  Here workgroup 0 of the exchange launch that ends an iteration also reduces the per-pack bounds the
+// backward sweep has just written and runs the tests, in the reference's order and in the same double arithmetic, and latches `stop`:
+// the launches of the iterations the host queued ahead see it and return (DevPtrs::stop), so the solver state is exactly the one
+// after the iteration that met the criterion.  No extra launch, no synchronisation; the host only watches `RunHost` (pinned) for
+// the bounds to print and for the end.  The wall-clock limit stays a host test.
+constexpr uint32_t RUN_RING = 64;
+struct RunCtl {  // device memory
+    double lb_initial, lb_first, lb_post, tolerance, slope;
+    uint64_t iter;
+    uint32_t stop, reason;
+};
+struct RunHost {  // pinned host memory, written by the device
+    uint64_t state;       // (iterations whose bound has been published) | (stop reason << 56): one word, so the host never sees half an update
+    double lb[RUN_RING];  // bound after iteration i at [i % RUN_RING]
+};
+struct RunStep {  // argument of the launch that ends an iteration (ctl == nullptr: nothing to do)
+    const double* part;  // per-pack lower bounds
+    uint32_t n;
+    RunCtl* ctl;
+    RunHost* host;
+};
+// Executed by every thread of ONE workgroup of 256, 512 or 1024 threads.  The sum has the shape and order of k_lb_reduce (1024
+// threads: 16 waves of strided partial sums, an in-wave tree, the 16 results added in order) whatever the workgroup size, so the
+// published bound equals lower_bound() bit for bit.
+__device__ __forceinline__ void run_ctl_step(const RunStep& r)
+{
+    __shared__ double run_red[16];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    // the control block is read while the partial sums are on their way (one round trip instead of two)
+    RunCtl c{};
+    if (threadIdx.x == 0) c = *r.ctl;
+    for (uint32_t vw = wave; vw < 16; vw += nw) {
+        double acc = 0.0;
+        for (uint32_t i = vw * 64 + lane; i < r.n; i += 1024) acc += r.part[i];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) run_red[vw] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    RunCtl* ctl = r.ctl;
+    double t = 0.0;
+    for (uint32_t i = 0; i < 16; ++i) t += run_red[i];
+    const uint64_t it = c.iter;
+    const double lb_prev = c.lb_post, lb_post = t;
+    const double lb_first = it == 0 ? lb_post : c.lb_first, lb_initial = c.lb_initial;
+    if (it == 0) ctl->lb_first = lb_post;
+    ctl->lb_post = lb_post;
+    ctl->iter = it + 1;
+    uint32_t reason = 0;
+    if (__builtin_fabs(lb_prev - lb_post) < __builtin_fabs(c.tolerance * lb_prev)) reason = 2;                // run_solver_util.h:56-61
+    else if (__builtin_fabs(lb_prev - lb_post) < c.slope * __builtin_fabs(lb_initial - lb_first)) reason = 3;  // :62-67
+    else if (lb_post == __builtin_huge_val()) reason = 4;                                                       // :68-73
+    if (reason) { ctl->reason = reason; ctl->stop = 1; }
+    volatile RunHost* h = r.host;
+    h->lb[it % RUN_RING] = lb_post;
+    __threadfence_system();
+    h->state = (it + 1) | ((uint64_t)reason << 56);
+}
+
 template <typename REAL>
 __device__ __forceinline__ void lds_add(REAL* p, REAL v)
 {
@@ -1912,11 +1988,11 @@ constexpr uint32_t EXM_MAX_VARS_PER_BIN = EXM_THREADS * EXM_NPT / 2;
 // processes sharing the GPU (pytest -n 4) about 1 % of the differential fuzz runs came out with 1e-7 errors; the cause was not found
 // (buffer range checks with the scalar offset at or beyond the descriptor's end are reliable in isolation and under the same load,
 // tools/rangestress.hip), so the kernel stays as it was.)
-template <typename REAL, typename ACC, int MODE, int EX_THREADS = bddmma::EX_THREADS, int EX_UNROLL = bddmma::EX_UNROLL, int NPT = bddmma::EX_NPT>
-__global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
-                                                                  const uint16_t* __restrict__ bvar, const int32_t* __restrict__ nbdds,
-                                                                  REAL* __restrict__ delta_var, REAL* __restrict__ delta_lay,
-                                                                  uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries)
+template <typename REAL, typename ACC, int MODE, int EX_THREADS, int EX_UNROLL, int NPT>
+__device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
+                                                     const uint16_t* __restrict__ bvar, const int32_t* __restrict__ nbdds,
+                                                     REAL* __restrict__ delta_var, REAL* __restrict__ delta_lay,
+                                                     uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries)
 {
     using P2 = typename Pair<REAL>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
@@ -2030,6 +2106,27 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
     }
 }
 
+// The launch: `stop` (device-resident run_solver, DevPtrs::stop) makes it return at once when the termination test has fired; `run`
+// (only on the launch that ends an iteration) makes workgroup 0 reduce the lower bound and run the tests after its bin is done —
+// behind the body, where no register of the exchange is live any more (the 1024-thread double instantiation sits at its 128-VGPR limit).
+// RUN = false is the kernel every other caller launches: `stop` and `run` are not looked at, the code is the body alone.
+template <typename REAL, typename ACC, int MODE, int EX_THREADS = bddmma::EX_THREADS, int EX_UNROLL = bddmma::EX_UNROLL, int NPT = bddmma::EX_NPT,
+          bool RUN = false>
+__global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
+                                                                  const uint16_t* __restrict__ bvar, const int32_t* __restrict__ nbdds,
+                                                                  REAL* __restrict__ delta_var, REAL* __restrict__ delta_lay,
+                                                                  uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries,
+                                                                  const uint32_t* stop = nullptr, RunStep run = RunStep{})
+{
+    if (RUN && run_stopped(stop)) return;
+    exchange_reduce_body<REAL, ACC, MODE, EX_THREADS, EX_UNROLL, NPT>(mm_binned, bin_ptr, bvar, nbdds, delta_var, delta_lay, vars_per_bin, n_vars,
+                                                                       n_entries);
+    if (RUN && run.ctl != nullptr && blockIdx.x == 0) {  // uniform
+        __syncthreads();
+        run_ctl_step(run);
+    }
+}
+
 // Exchange for entry arrays ordered by (variable, bdd) (layout.hpp: Exchange::entry_by_var): the entries of variable v are
 // var_ptr[v] .. var_ptr[v + 1], so compute_delta (bdd_cuda_parallel_mma.cu:358-393), normalize_delta (:410-430) and the broadcast of
 // the pair to the variable's layers are one thread per variable over a contiguous run — neighbouring threads read and write
@@ -2038,8 +2135,11 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
 // chain of loads, LDS atomics and three workgroup barriers: 3.5 us instead of 9.7 us at 1 M nodes.
 template <typename REAL>
 __global__ void __launch_bounds__(256) k_exchange_byvar(const REAL* __restrict__ mm, const uint32_t* __restrict__ var_ptr,
-                                                          REAL* __restrict__ delta_lay, uint32_t n_vars, uint32_t n_entries)
+                                                          REAL* __restrict__ delta_lay, uint32_t n_vars, uint32_t n_entries,
+                                                          const uint32_t* stop = nullptr, RunStep run = RunStep{})
 {
+    if (run_stopped(stop)) return;
+    if (run.ctl != nullptr && blockIdx.x == 0) run_ctl_step(run);
     using P2 = typename Pair<REAL>::type;
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     const rsrc_t rvp = make_rsrc(var_ptr, (uint64_t)n_vars + 1), rmm = make_rsrc(mm, n_entries), rdl = make_rsrc(delta_lay, 2ull * n_entries);
@@ -2076,8 +2176,12 @@ __global__ void __launch_bounds__(256) k_exchange_byvar(const REAL* __restrict__
 // Four entries per thread: one 16-byte index load, four independent pair gathers, 16-byte stores.
 template <typename REAL>
 __global__ void __launch_bounds__(256) k_exchange_bcast(const REAL* __restrict__ delta_var, const uint32_t* __restrict__ evar,
-                                                          REAL* __restrict__ delta_lay, uint32_t n_entries, uint32_t n_vars)
+                                                          REAL* __restrict__ delta_lay, uint32_t n_entries, uint32_t n_vars,
+                                                          const uint32_t* stop = nullptr, RunStep run = RunStep{})
 {
+    if (run_stopped(stop)) return;
+    // the deterministic exchange is two launches (k_delta_gather, this one): the tests latch `stop` in the LAST launch of the iteration
+    if (run.ctl != nullptr && blockIdx.x == 0) run_ctl_step(run);
     using P2 = typename Pair<REAL>::type;
     const uint32_t e = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
     if (e >= n_entries) return;
@@ -2115,8 +2219,10 @@ __global__ void k_normalize_delta(REAL* __restrict__ delta, const int32_t* __res
 // (variable,bdd)-sorted entry list (the reduce_by_key variant commented out at bdd_cuda_parallel_mma.cu:395-407).
 template <typename REAL, bool NORMALIZE>
 __global__ void k_delta_gather(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ var_ptr,
-                               const uint32_t* __restrict__ vpos, REAL* __restrict__ delta_var, uint32_t n_vars)
+                               const uint32_t* __restrict__ vpos, REAL* __restrict__ delta_var, uint32_t n_vars,
+                               const uint32_t* stop = nullptr)
 {
+    if (run_stopped(stop)) return;
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_vars) return;
     REAL lo = 0, hi = 0;

@@ -46,6 +46,8 @@ struct SolverBase {
     virtual int lower_bound(double* lb) = 0;
     virtual int lower_bound_per_bdd(void* out, int on_device) = 0;
     virtual int iteration(double omega) = 0;
+    // run_solver (include/run_solver_util.h:10-77) around iteration(): termination tests on the device, see bdd_mma_hip.hip
+    virtual int run_plain(uint64_t max_iter, double tolerance, double slope, double time_limit, int verbose, bddmma_run_result* res) = 0;
     virtual int forward_mm(double omega, void* delta, int on_device) = 0;
     virtual int backward_mm(double omega, void* delta, int on_device) = 0;
     virtual int normalize_delta(void* delta, int on_device) = 0;

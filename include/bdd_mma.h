@@ -213,7 +213,12 @@ typedef struct bddmma_lbfgs_state {
 } bddmma_lbfgs_state;
 int bddmma_lbfgs_get_state(const bddmma_lbfgs* l, bddmma_lbfgs_state* out);
 
-/* ---- run_solver (include/run_solver_util.h:10-77) ------------------------- */
+/* ---- run_solver (include/run_solver_util.h:10-77) -------------------------
+ * Same criteria, same order, same result as the reference's loop (iteration(); lower_bound(); time limit, minimum improvement,
+ * improvement slope, infeasibility).  For the plain solver (lbfgs_or_null == NULL) the three tests on the bound run on the device,
+ * in the launch that ends each iteration; the host keeps a few iterations queued and never synchronises inside the loop, and the
+ * launches queued behind the stopping iteration return without doing anything — the solver is left in exactly the state after the
+ * iteration that met the criterion.  The wall-clock limit is tested on the host after every iteration it sees complete. */
 typedef struct bddmma_run_result {
     uint64_t iterations;
     double lb_initial;
