@@ -66,6 +66,10 @@ struct SolverT final : SolverBase {
     uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0, stage_lds = 0, exch_lds = 0, n_narrow_layers = 0;
     double *d_lb_partial = nullptr, *d_lb = nullptr;
     double* h_lb = nullptr;  // pinned, device-visible: the reduce kernel writes the bound straight into host memory
+    // the bound is a function of the costs-to-terminal, which only launch_bwd() writes: a second lower_bound() without a backward
+    // sweep in between (L-BFGS reads the bound at the end of an iteration and again before its step search) costs nothing
+    bool lb_cached = false;
+    double lb_cache = 0.0;
     // device-resident run_solver (kernels.hpp: run_ctl_step)
     RunCtl* d_run_ctl = nullptr;
     RunHost *h_run = nullptr, *d_run_host = nullptr;  // pinned + its device address
@@ -439,6 +443,7 @@ struct SolverT final : SolverBase {
     template <int MODE>
     int launch_bwd(const REAL* delta_lay, REAL omega, int kclass)
     {
+        lb_cached = false;
         DevPtrs<REAL> d = ptrs(delta_lay);
         prof_begin(kclass);
         hipStream_t sw = stream;
@@ -574,10 +579,15 @@ struct SolverT final : SolverBase {
     {
         int rc = backward_run();
         if (rc) return rc;
+        if (lb_cached) {
+            *lb = lb_cache;
+            return BDDMMA_OK;
+        }
         // no copy-engine round trip: one block writes the 8 bytes to pinned host memory, the host waits for the stream
         hipLaunchKernelGGL(k_lb_reduce, dim3(1), dim3(1024), 0, stream, d_lb_partial, nb_.n_packs + wb_.n_packs + hb_.n_packs, d_lb);
         HIPCHK(hipStreamSynchronize(stream));
-        *lb = *(volatile double*)h_lb;
+        *lb = lb_cache = *(volatile double*)h_lb;
+        lb_cached = true;
         return BDDMMA_OK;
     }
     int lower_bound_per_bdd(void* out, int on_device) override
@@ -708,6 +718,10 @@ struct SolverT final : SolverBase {
         if (reason == 0 && seen < queued) {
             err = "run_solver: queued iterations did not complete";
             return BDDMMA_ERR_DEVICE;
+        }
+        if (seen > 0) {  // the device's bound of the last iteration that ran is lower_bound() of the state it left (same sum, same order)
+            lb_cache = lb_post;
+            lb_cached = true;
         }
         if (verbose) std::printf("[bdd solver] final lower bound = %.10g\n", lb_post);
         if (res) {
