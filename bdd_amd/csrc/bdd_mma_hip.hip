@@ -85,10 +85,10 @@ struct SolverT final : SolverBase {
     } nb_, wb_, hb_;  // narrow, wide, huge packs
     uint32_t wide_lds = 0, wide_threads = 256, wide_npt = 1;
     bool mixed = false;      // narrow (streaming) and wide solve sweeps in one launch (kernels.hpp: k_fwd_mixed / k_bwd_mixed)
-    // Measured on the knapsack benchmark (3 604 narrow + 389 wide packs): backward 44.7 -> 37.4 us in one launch, forward 56.1 -> 58.6 us —
-    // the forward sweeps of both kinds are bound by the LDS ds_min pushes into the next frontier, so sharing the CUs returns nothing
-    // there.  Hence: backward mixed, forward as two launches.
-    static constexpr bool mixed_fwd = false;
+    // Measured on the knapsack benchmark (3 604 narrow + 389 wide packs): backward 44.7 -> 37.4 us in one launch.  The forward sweeps
+    // did not gain at first (56.1 -> 58.6 us: both kinds were bound by same-address LDS pushes into the sink entries); with those
+    // pushes gone the one launch wins there too: 32.7 -> 26.3 us (float), 37.3 -> 30.2 us (double), 14.5 k -> 16.1 k it/s.
+    bool mixed_fwd = true;   // variant_flags bit 1: forward narrow / wide solve sweeps as two launches
     uint32_t mixed_npt = 1, mixed_lds = 0;
     // (Running the wide launch on a second stream next to the narrow one was measured and dropped: the event fork / join costs ~10 us
     // per pass on this platform, more than the overlap returns — knapsack benchmark 8 990 -> 8 261 it/s.)
@@ -280,6 +280,7 @@ struct SolverT final : SolverBase {
         SET_DYN((k_exchange_reduce<REAL, double, EX_RAW>), exch_lds);
         SET_DYN((k_exchange_reduce<REAL, double, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, true>), exch_lds);  // run_plain()'s instantiation
         opts_variant = opts ? opts->variant_flags : 0u;
+        mixed_fwd = (opts_variant & 2u) == 0;
         exch_small = vars_per_bin <= EXS_MAX_VARS_PER_BIN;  // 256-thread workgroups (kernels.hpp: EXS_*)
         exch_medium = !exch_small && vars_per_bin <= EXM_MAX_VARS_PER_BIN;  // 512-thread workgroups (EXM_*)
 #undef SET_DYN
@@ -340,7 +341,8 @@ struct SolverT final : SolverBase {
             const uint32_t threads = 64 * wpb;
             const uint32_t npt = (wide_pack_width + threads - 1) / threads;
             const uint32_t narrow_dyn = stage_lds + seg_bytes(wpb);
-            if (npt <= 4 && wide_lds <= narrow_dyn + 16 * 1024) {
+            // (no launch attribute is set for the mixed kernels: static + dynamic LDS has to stay within the default 64 KiB)
+            if (npt <= 4 && wide_lds <= narrow_dyn + 16 * 1024 && std::max(narrow_dyn, wide_lds) + narrow_static <= 64 * 1024) {
                 mixed = true;
                 mixed_npt = npt <= 1 ? 1 : (npt <= 2 ? 2 : 4);
                 mixed_lds = std::max(narrow_dyn, wide_lds);

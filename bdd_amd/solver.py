@@ -53,7 +53,7 @@ class bdd_hip_parallel_mma:
         opts.resident_sweeps = int(resident_sweeps)         # 0 automatic, 1 off, 2 on
         opts.exchange_by_variable = int(exchange_by_variable)             # 2: entries by (variable, bdd)
         opts.pack_fill = int(pack_fill)
-        opts.variant_flags = int(variant_flags)             # bit 0: backward narrow / wide sweeps as two launches
+        opts.variant_flags = int(variant_flags)             # bit 0 / 1: backward / forward narrow + wide sweeps as two launches
         h = C.c_void_p()
         costs = None if costs_hi is None else np.ascontiguousarray(costs_hi, dtype=np.float64)
         rc = self._L.bddmma_create(C.byref(h), self._prec, device, _ptr(instr), _ptr(delims), bdd_col.nr_bdds(),

@@ -170,7 +170,8 @@ def main():
         lb_rate_host_loop = n_lb / (time.perf_counter() - t0)
         # ... and bddmma_run_solver itself (termination tests on the device, the host only reads the published bounds)
         from bdd_amd.solver import run_solver
-        n_rs = min(args.steps, 500)
+        n_rs = max(200, min(args.steps, 500))
+        run_solver(solver, max_iter=2, tolerance=0.0, improvement_slope=0.0, time_limit=1e9)  # allocates its control block
         rs = run_solver(solver, max_iter=n_rs, tolerance=0.0, improvement_slope=0.0, time_limit=1e9)
         lb_rate = rs["iterations"] / rs["seconds"]
         triad_gbs = 3 * (1 << 30) / (solver.time_kernel(6, 20) * 1e-3) / 1e9

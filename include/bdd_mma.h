@@ -81,7 +81,8 @@ typedef struct bddmma_options {
                                   the sweeps' accesses to the entry arrays lose their locality (slower overall on every instance
                                   measured).  Default (0 / 1): binned order */
     uint32_t variant_flags;    /* switches between equivalent code paths, for A/B measurements and the differential tests (default 0):
-                                  bit 0: narrow and wide backward sweeps as two launches (default: one, k_bwd_mixed) */
+                                  bit 0: narrow and wide backward sweeps as two launches (default: one, k_bwd_mixed)
+                                  bit 1: narrow and wide forward sweeps as two launches (default: one, k_fwd_mixed) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
                                   instance (the sweeps are bound by instructions issued, not by latency), kept for experiments */

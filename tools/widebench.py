@@ -17,8 +17,9 @@ idx = col.instr[:, 2]; idx = idx[idx < 2**63]
 print("built", col.nr_bdds(), "BDDs,", col.nr_bdd_nodes(), "nodes in", round(time.time() - t0, 1), "s")
 costs = -rng.uniform(1, 10, col.nr_variables())
 pw = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 for prec in ("float", "double"):
-    s = bdd_hip_parallel_mma(col, costs, precision=prec, pack_width=pw)
+    s = bdd_hip_parallel_mma(col, costs, precision=prec, pack_width=pw, variant_flags=variant)
     o = Oracle(col, costs, prec, threads=16)
     for _ in range(5):
         s.iteration(); o.iteration()
