@@ -84,6 +84,7 @@ struct SolverT final : SolverBase {
         uint32_t n_packs = 0;
     } nb_, wb_, hb_;  // narrow, wide, huge packs
     uint32_t wide_lds = 0, wide_threads = 256, wide_npt = 1;
+    uint32_t nt_potentials = 0;  // PackDev::nt_potentials (kernels.hpp: hop_store): double, footprint several times the Infinity Cache
     bool mixed = false;      // narrow (streaming) and wide solve sweeps in one launch (kernels.hpp: k_fwd_mixed / k_bwd_mixed)
     // Measured on the knapsack benchmark (3 604 narrow + 389 wide packs): backward 44.7 -> 37.4 us in one launch.  The forward sweeps
     // did not gain at first (56.1 -> 58.6 us: both kinds were bound by same-address LDS pushes into the sink entries); with those
@@ -281,6 +282,8 @@ struct SolverT final : SolverBase {
         SET_DYN((k_exchange_reduce<REAL, double, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, true>), exch_lds);  // run_plain()'s instantiation
         opts_variant = opts ? opts->variant_flags : 0u;
         mixed_fwd = (opts_variant & 2u) == 0;
+        // measured in double: 7.1 M nodes (490 MB resident) lose 12 % with non-temporal potentials, 10.5 M (720 MB) gain 4 %
+        nt_potentials = (sizeof(REAL) == 8 && dev_bytes > (640ull << 20) && (opts_variant & 4u) == 0) ? 1u : 0u;
         exch_small = vars_per_bin <= EXS_MAX_VARS_PER_BIN;  // 256-thread workgroups (kernels.hpp: EXS_*)
         exch_medium = !exch_small && vars_per_bin <= EXM_MAX_VARS_PER_BIN;  // 512-thread workgroups (EXM_*)
 #undef SET_DYN
@@ -368,7 +371,8 @@ struct SolverT final : SolverBase {
     PackDev pdev(const PackBufs& b, uint32_t lb_base, uint32_t seg_off = 0) const
     {
         return PackDev{b.pack_hop_ptr, b.hop_node_off, b.hop_layer_off, b.pack_steps, d_pack_word_off,
-                       d_pack_group_ptr, d_grp_layer_off, d_grp_hop_end, d_quad_round_ptr, d_cs_ptr, stage_cap, seg_off, b.n_packs, lb_base};
+                       d_pack_group_ptr, d_grp_layer_off, d_grp_hop_end, d_quad_round_ptr, d_cs_ptr, stage_cap, seg_off, b.n_packs, lb_base,
+                       nt_potentials};
     }
     // dynamic LDS of a narrow launch with `w` waves per workgroup: `base` bytes of the kernel's own use, then (only when some pack has
     // layers wider than two nodes) the seg_min2 scratch, 128 REALs per wave

@@ -83,6 +83,7 @@ struct PackDev {
     uint32_t seg_off;  // byte offset of the seg_min2 scratch (128 REALs per wave) inside the dynamic LDS
     uint32_t n_packs;
     uint32_t lb_base;  // index of this set's first pack in lb_partial
+    uint32_t nt_potentials;  // streaming narrow sweeps, double: store F / T non-temporally (see hop_store)
 };
 
 template <typename REAL> struct Pair;
@@ -481,13 +482,23 @@ __device__ __forceinline__ void hop_load(double& v, rsrc_t rh, uint32_t voff, ui
 {
     v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rh, voff, soff, BDDMMA_LD_AUX));
 }
+// Cache policy of the potentials' stores (the F / T streams of a streaming sweep).  Double-precision instances whose arrays exceed the
+// Infinity Cache several times store them non-temporally (aux bit 1 = nt; PackDev::nt_potentials, chosen by the solver from the
+// instance's footprint): the 152 MB a sweep writes there no longer displace the arc costs and exchange arrays before the next launch
+// reads them — 10.5 M nodes 3 930 -> 4 095 it/s, row size 32: 3 310 -> 3 485 (A/B on one box).  Instances that fit the cache lose with
+// it (4.2 M nodes: 10 170 -> 9 070), and so does float at every size (10.5 M: 8 290 -> 7 090 it/s — the 4-byte hop slices end in partial
+// lines, which the cached path merges with the next hop's store), hence the run-time switch and double only.
+#ifndef BDDMMA_ST_FT_AUX_F32
+#define BDDMMA_ST_FT_AUX_F32 BDDMMA_ST_AUX
+#endif
 __device__ __forceinline__ void hop_store(float v, rsrc_t rh, uint32_t voff, uint32_t soff)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rh, voff, soff, BDDMMA_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rh, voff, soff, BDDMMA_ST_FT_AUX_F32);
 }
+template <int AUX = BDDMMA_ST_AUX>
 __device__ __forceinline__ void hop_store(double v, rsrc_t rh, uint32_t voff, uint32_t soff)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rh, 0, 0, 0)), v), rh, voff, soff, BDDMMA_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rh, 0, 0, 0)), v), rh, voff, soff, AUX);
 }
 // values of the hop's slots; lanes past the last slot read 0
 template <typename REAL, int R>
@@ -498,12 +509,24 @@ __device__ __forceinline__ void load_vals(REAL (&v)[R], const REAL* src, uint32_
     for (int r = 0; r < R; ++r) hop_load(v[r], rh, (lane + 64 * r) * (uint32_t)sizeof(REAL), nb * (uint32_t)sizeof(REAL));
 }
 // ... and the store of one value per slot of the hop (padding slots inside the hop included: nothing reads them)
-template <typename REAL, int R>
-__device__ __forceinline__ void store_vals(const REAL (&v)[R], REAL* dst, uint32_t nb, uint32_t n, int lane)
+template <int R>
+__device__ __forceinline__ void store_vals(const float (&v)[R], float* dst, uint32_t nb, uint32_t n, int lane, uint32_t /*nt*/)
 {
     const rsrc_t rh = hop_rsrc(dst, nb, n);
 #pragma unroll
-    for (int r = 0; r < R; ++r) hop_store(v[r], rh, (lane + 64 * r) * (uint32_t)sizeof(REAL), nb * (uint32_t)sizeof(REAL));
+    for (int r = 0; r < R; ++r) hop_store(v[r], rh, (lane + 64 * r) * 4u, nb * 4u);
+}
+template <int R>
+__device__ __forceinline__ void store_vals(const double (&v)[R], double* dst, uint32_t nb, uint32_t n, int lane, uint32_t nt)
+{
+    const rsrc_t rh = hop_rsrc(dst, nb, n);
+    if (nt) {  // uniform (a kernel argument)
+#pragma unroll
+        for (int r = 0; r < R; ++r) hop_store<2>(v[r], rh, (lane + 64 * r) * 8u, nb * 8u);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) hop_store<>(v[r], rh, (lane + 64 * r) * 8u, nb * 8u);
+    }
 }
 
 #ifndef BDDMMA_LOOKAHEAD
@@ -723,7 +746,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                 lds_min(&sF[cur ^ 1][plo ? lo_i : j], plo ? f[r] + nlo[r] : INF);
                 lds_min(&sF[cur ^ 1][phi ? hi_i : j], phi ? f[r] + nhi[r] : INF);
             }
-            store_vals<REAL, R>(f, d.F, nb, o[1] - o[0], lane);
+            store_vals<R>(f, d.F, nb, o[1] - o[0], lane, pk.nt_potentials);
             wave_sync();
             cur ^= 1;
             // ---- rotate the pipeline registers
@@ -925,7 +948,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                 }
                 if (act) sT[cur ^ 1][j] = t[r];
             }
-            store_vals<REAL, R>(t, d.T, nb, o[0] - o[1], lane);
+            store_vals<R>(t, d.T, nb, o[0] - o[1], lane, pk.nt_potentials);
             wave_sync();
             cur ^= 1;
 #pragma unroll

@@ -82,7 +82,8 @@ typedef struct bddmma_options {
                                   measured).  Default (0 / 1): binned order */
     uint32_t variant_flags;    /* switches between equivalent code paths, for A/B measurements and the differential tests (default 0):
                                   bit 0: narrow and wide backward sweeps as two launches (default: one, k_bwd_mixed)
-                                  bit 1: narrow and wide forward sweeps as two launches (default: one, k_fwd_mixed) */
+                                  bit 1: narrow and wide forward sweeps as two launches (default: one, k_fwd_mixed)
+                                  bit 2: no non-temporal stores of the potentials (default: on for double instances above 640 MB) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
                                   instance (the sweeps are bound by instructions issued, not by latency), kept for experiments */
