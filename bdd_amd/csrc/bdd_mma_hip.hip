@@ -678,6 +678,7 @@ struct SolverT final : SolverBase {
         constexpr uint64_t WINDOW = 6;  // iterations queued ahead of the last bound seen (< RUN_RING)
         volatile RunHost* hr = h_run;
         uint64_t queued = 0, seen = 0;
+        uint32_t idle_spins = 0;
         int reason = 0;
         double lb_post = lb_initial;
         run_stop = &d_run_ctl->stop;
@@ -708,9 +709,23 @@ struct SolverT final : SolverBase {
             if (dev_reason && seen == done) { reason = dev_reason; break; }
             if (seen == max_iter) break;
             if (!launched && done == seen) {
-                // nothing new.  An idle stream without progress means a launch failed: leave, the synchronisation below reports it
-                if (hipStreamQuery(stream) != hipErrorNotReady && (hr->state & ((1ull << 56) - 1)) == seen) break;
+                // nothing new.  After ~0.2 s without a published bound make sure the device is still alive: a blocking wait for the
+                // stream (harmless if an iteration is simply that long) — still nothing then means the queued launches were lost,
+                // which the checks behind the loop report.  (hipStreamQuery is not used for this: it was seen to report an idle
+                // stream with launches still queued, which ended runs early.)
+                if (++idle_spins > 2000000u) {
+                    const hipError_t e = hipStreamSynchronize(stream);
+                    if (e != hipSuccess) {
+                        run_stop = nullptr;
+                        err = std::string("run_solver: ") + hipGetErrorString(e);
+                        return BDDMMA_ERR_DEVICE;
+                    }
+                    if ((hr->state & ((1ull << 56) - 1)) == seen) break;
+                    idle_spins = 0;
+                }
                 __builtin_ia32_pause();
+            } else {
+                idle_spins = 0;
             }
         }
         run_stop = nullptr;
