@@ -52,6 +52,7 @@ enum : int { SC_DOT = 32, SC_YNORM = 33, SC_COEF = 34, SC_COUNT = 40 };
 //   FIN_BETA  : rho = 1 / rho_inv_i (times the initial H diagonal rho_inv_last / (1e-8 + |y_last|^2) for the first);
 //               sc[SC_COEF] = alpha_i - rho r                                                   (next axpy: d += (alpha_i - beta) s_i)
 enum : int { FIN_STORE = 0, FIN_ALPHA = 1, FIN_BETA = 2 };
+constexpr int LBFGS_UNROLL = 8;  // elements of a thread's strided range whose loads are issued together (k_axpy_dot)
 struct DotFin {
     int op, slot, i, first;
     double rho_inv, rho_inv_last;
@@ -97,7 +98,17 @@ static __global__ void __launch_bounds__(256) k_axpy_dot(REAL* __restrict__ d, c
     __shared__ double red[4];
     __shared__ double s_coef;
     double acc = 0.0;
-    for (uint32_t i = threadIdx.x; i < n_partial; i += 256) acc += prev_partial[i];
+    {   // n_partial <= 1024: the (up to) four partial sums of this thread in one batch of loads, added in the order of the plain loop
+        double pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = threadIdx.x + 256u * u;
+            pp[u] = i < n_partial ? prev_partial[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (threadIdx.x + 256u * u < n_partial) acc += pp[u];
+    }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -116,7 +127,29 @@ static __global__ void __launch_bounds__(256) k_axpy_dot(REAL* __restrict__ d, c
     __syncthreads();
     const REAL c = REAL(s_coef);
     acc = 0.0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    // A thread owns ~20 strided elements (1024 blocks over 5 M entries).  As a plain loop every element was a dependent round trip
+    // (load, fma, store: 22-29 us per pass); LBFGS_UNROLL elements per trip have their loads in flight together.  Same elements per
+    // thread, same order of the additions: the partial sums are bit-identical.
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint64_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (uint64_t)(LBFGS_UNROLL - 1) * stride < n; i += (uint64_t)LBFGS_UNROLL * stride) {
+        REAL dv[LBFGS_UNROLL];
+        TX xv[LBFGS_UNROLL];
+        TA av[LBFGS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < LBFGS_UNROLL; ++u) {
+            dv[u] = d[i + (uint64_t)u * stride];
+            xv[u] = x[i + (uint64_t)u * stride];
+            if (DOT) av[u] = a[i + (uint64_t)u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < LBFGS_UNROLL; ++u) {
+            const REAL v = dv[u] + c * REAL(xv[u]);
+            d[i + (uint64_t)u * stride] = v;
+            if (DOT) acc += (double)av[u] * (double)v;
+        }
+    }
+    for (; i < n; i += stride) {
         const REAL v = d[i] + c * REAL(x[i]);
         d[i] = v;
         if (DOT) acc += (double)a[i] * (double)v;
@@ -133,7 +166,24 @@ static __global__ void k_init_dot(REAL* __restrict__ d, const char* __restrict__
 {
     __shared__ double red[4];
     double acc = 0.0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint64_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (uint64_t)(LBFGS_UNROLL - 1) * stride < n; i += (uint64_t)LBFGS_UNROLL * stride) {  // see k_axpy_dot
+        char gv[LBFGS_UNROLL];
+        TA av[LBFGS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < LBFGS_UNROLL; ++u) {
+            gv[u] = g[i + (uint64_t)u * stride];
+            av[u] = a[i + (uint64_t)u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < LBFGS_UNROLL; ++u) {
+            const REAL v = REAL(0) + REAL(1) * REAL(gv[u]);
+            d[i + (uint64_t)u * stride] = v;
+            acc += (double)av[u] * (double)v;
+        }
+    }
+    for (; i < n; i += stride) {
         const REAL v = REAL(0) + REAL(1) * REAL(g[i]);  // as fill(0) followed by axpy(1, g)
         d[i] = v;
         acc += (double)a[i] * (double)v;
@@ -154,7 +204,32 @@ static __global__ void k_store_iterate(const REAL* __restrict__ cur_x, REAL* __r
 {
     __shared__ double red[4];
     double acc = 0.0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint64_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (uint64_t)(LBFGS_UNROLL - 1) * stride < n; i += (uint64_t)LBFGS_UNROLL * stride) {  // see k_axpy_dot
+        REAL xc[LBFGS_UNROLL], xp[LBFGS_UNROLL];
+        char gc[LBFGS_UNROLL], gp[LBFGS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < LBFGS_UNROLL; ++u) {
+            const uint64_t j = i + (uint64_t)u * stride;
+            xc[u] = cur_x[j];
+            gc[u] = cur_g[j];
+            xp[u] = prev_x[j];
+            gp[u] = prev_g[j];
+        }
+#pragma unroll
+        for (int u = 0; u < LBFGS_UNROLL; ++u) {
+            const uint64_t j = i + (uint64_t)u * stride;
+            const REAL sv = REAL(xc[u] - xp[u]);
+            const char yv = (char)(gp[u] - gc[u]);
+            s_out[j] = sv;
+            y_out[j] = yv;
+            prev_x[j] = xc[u];
+            prev_g[j] = gc[u];
+            acc += (double)sv * (double)yv;
+        }
+    }
+    for (; i < n; i += stride) {
         const REAL x = cur_x[i];
         const char g = cur_g[i];
         const REAL sv = REAL(x - prev_x[i]);
