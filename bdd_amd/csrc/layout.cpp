@@ -754,6 +754,18 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         // small instances: keep at least ~512 workgroups so that every CU has work
         if (!(opts && opts->waves_per_block))
             while (X.waves_per_block > 1 && Pn / X.waves_per_block < 512) X.waves_per_block /= 2;
+        // Instances with a sizeable share of wide packs (>= 10 % of the node slots): their solve sweeps share the narrow packs' launch
+        // (k_fwd_mixed / k_bwd_mixed), so a wide pack gets 64 * waves_per_block threads — more than its hop width leaves threads idle
+        // behind every barrier.  Knapsack benchmark (wide packs of 65-77 nodes): 4 -> 2 packs per workgroup 16.1 k -> 18.1 k it/s
+        // (float), 14.5 k -> 16.5 k (double); 1: 18.0 k / 15.4 k; 8: 12.8 k / 10.7 k.
+        if (!(opts && opts->waves_per_block) && L.wide.n_packs() > 0 && !L.wide.hop_node_off.empty()) {
+            const uint64_t wide_slots = L.wide.hop_node_off.back() - L.wide.hop_node_off.front();
+            if (wide_slots * 10 >= (uint64_t)L.n_slots) {
+                uint32_t fit = 1;
+                while (fit < 4 && 64u * fit < L.wide_pack_width) fit *= 2;
+                X.waves_per_block = std::min(X.waves_per_block, fit);
+            }
+        }
         if (X.waves_per_block != 1 && X.waves_per_block != 2 && X.waves_per_block != 4 && X.waves_per_block != 8) {
             err = "waves_per_block must be 1, 2, 4 or 8";
             return BDDMMA_ERR_INVALID_ARGUMENT;

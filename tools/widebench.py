@@ -18,8 +18,10 @@ print("built", col.nr_bdds(), "BDDs,", col.nr_bdd_nodes(), "nodes in", round(tim
 costs = -rng.uniform(1, 10, col.nr_variables())
 pw = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+wpb = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+vpb = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 for prec in ("float", "double"):
-    s = bdd_hip_parallel_mma(col, costs, precision=prec, pack_width=pw, variant_flags=variant)
+    s = bdd_hip_parallel_mma(col, costs, precision=prec, pack_width=pw, variant_flags=variant, waves_per_block=wpb, vars_per_bin=vpb)
     o = Oracle(col, costs, prec, threads=16)
     for _ in range(5):
         s.iteration(); o.iteration()
