@@ -12,4 +12,6 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAV
   name=$(echo $pmc | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $pmc --output-format csv -d $out/pmc_$name -o pmc -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > /dev/null 2> $out/pmc_$name.err
 done
+# the per-dispatch trace is not needed for the summaries and would push gpurun_out/ over the 64 MiB that travel back
+find $out -name "*kernel_trace.csv" -delete
 find $out -name "*.csv" | head -30
