@@ -94,12 +94,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("BDDMMA_BENCH_SHARE_GPUS") == "1":
+        # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (the ranks then share devices: the numbers mean nothing)
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")   # replicas only: the barrier and the max are host-side, no RCCL communicator is created
+        # replicas only: the barrier and the max are host-side, no RCCL communicator is created.  Gloo announces its connections on
+        # stdout ("[Gloo] Rank 0 is connected to ..."): stdout is the JSON line's, so it is pointed at stderr while the group forms
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from bdd_amd.instances import random_set_cover_mt, set_cover_sizes
     from bdd_amd.solver import bdd_hip_parallel_mma
