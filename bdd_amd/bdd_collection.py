@@ -33,6 +33,20 @@ class BddCollection:
         self._n = 0
         self._nb = 0
 
+    @classmethod
+    def from_arrays(cls, instr, delims) -> "BddCollection":
+        """A collection over existing storage in the reference's flat format: instr (n, 3) = {lo, hi, index} rows with absolute
+        node indices (bdd_collection.h:14-36), delims (nr_bdds + 1) = first instruction of every BDD.  The arrays are copied."""
+        instr = np.ascontiguousarray(np.asarray(instr), dtype=np.uint64).reshape(-1, 3).copy()
+        delims = np.ascontiguousarray(np.asarray(delims), dtype=np.uint64).reshape(-1).copy()
+        if delims.size == 0 or delims[0] != 0 or int(delims[-1]) != instr.shape[0] or np.any(np.diff(delims.astype(np.int64)) < 0):
+            raise ValueError("delims must start at 0, end at the number of instructions and be non-decreasing")
+        col = cls()
+        col._chunks = [instr] if instr.shape[0] else []
+        col._delims = [delims]
+        col._n, col._nb = int(instr.shape[0]), int(delims.size) - 1
+        return col
+
     # ------------------------------------------------------------------ access
     @property
     def instr(self) -> np.ndarray:

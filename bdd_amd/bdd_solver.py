@@ -112,14 +112,20 @@ class bdd_solver:
         # The solver's variables are those of the BDDs.  A variable that occurs in the objective only is free: its better value
         # contributes min(0, c) to the bound and is fixed in the primal (the reference only asserts on such costs,
         # bdd_parallel_mma_base.cpp:685-695).
+        # Such a variable may have ANY index: the LP reader numbers variables by first appearance and reads the objective first,
+        # so an objective-only variable usually lies below the last constrained one — it is recognised by its BDD
+        # count, not by its position.
         nv = bdd_col.nr_variables()
         costs = np.asarray(costs, float)
         c = np.zeros(nv)
         c[: min(nv, len(costs))] = costs[:nv]
-        self.free_ones = (costs[nv:] < 0).astype(np.int8)
-        self.free_constant = float(costs[nv:][costs[nv:] < 0].sum())
         s = bdd_hip_parallel_mma(bdd_col, c, precision="double" if precision == "double" else "float",
                                  device=int(self.config.get("device", 0)))
+        in_bdd = np.zeros(len(costs), bool)
+        in_bdd[: min(nv, len(costs))] = s.get_num_bdds_per_var()[: len(costs)] > 0
+        self.free_vars = np.flatnonzero(~in_bdd)                      # objective-only variables, any index
+        self.free_ones = (costs[self.free_vars] < 0).astype(np.int8)  # their better value
+        self.free_constant = float(costs[self.free_vars][costs[self.free_vars] < 0].sum())
         lb = None
         if name in GPU_LBFGS:
             p = self.config.get("lbfgs", {})  # :179-199
@@ -162,9 +168,8 @@ class bdd_solver:
             return []
         full = np.zeros(max(V, self.ilp.nr_variables()), np.int8)
         full[:V] = sol
-        n_free = min(len(self.free_ones), len(full) - V) if len(full) > V else 0
-        if n_free:
-            full[V:V + n_free] = self.free_ones[:n_free]   # variables of the objective only: their better value
+        keep = self.free_vars < len(full)
+        full[self.free_vars[keep]] = self.free_ones[keep]   # variables of the objective only: their better value
         self.solution = full[: self.ilp.nr_variables()].astype(int).tolist()
         obj = self.ilp.evaluate(self.solution) if self.ilp.feasible(self.solution) else float("inf")
         _log(f"[incremental primal rounding] solution objective = {obj}", self.quiet)

@@ -123,6 +123,23 @@ class bdd_hip_parallel_mma {
         for (size_t k = 0; k < L; ++k) out[var[k]].push_back({double(m0[k]), double(m1[k])});
         return out;
     }
+    // two_dim_variable_array<REAL> bdds_solution() (bdd_cuda_base.cu:1204-1233): [variable][bdd] -> 0 / 1, the argmin path of every BDD,
+    // BDDs of a variable in ascending order (primal_variable_sorting_order_, :379-391); nested vectors instead of two_dim_variable_array
+    std::vector<std::vector<REAL>> bdds_solution()
+    {
+        const size_t L = nr_layers(), V = nr_variables();
+        std::vector<char> sorted(L);
+        check(bddmma_bdds_solution(h_, 1, sorted.data(), 0));
+        std::vector<int32_t> n(V);
+        check(bddmma_num_bdds_per_var(h_, n.data()));
+        std::vector<std::vector<REAL>> out(V);
+        size_t k = 0;
+        for (size_t v = 0; v < V; ++v) {
+            out[v].resize((size_t)n[v]);
+            for (int32_t b = 0; b < n[v]; ++b, ++k) out[v][(size_t)b] = REAL(sorted[k]);
+        }
+        return out;
+    }
     std::vector<char> bdds_solution_vec_host()
     {
         std::vector<char> s(nr_layers());

@@ -74,6 +74,8 @@ struct SolverT final : SolverBase {
     RunCtl* d_run_ctl = nullptr;
     RunHost *h_run = nullptr, *d_run_host = nullptr;  // pinned + its device address
     const uint32_t* run_stop = nullptr;               // &d_run_ctl->stop while run_plain() queues iterations, nullptr otherwise
+    uint32_t run_iter = 0;                            // index of the iteration being queued by run_plain() (kernels.hpp: DevPtrs::run_iter)
+    RunGate gate() const { return RunGate{run_stop, run_iter}; }
     RunStep run_step{};                               // {partials, count, ctl, host}: what the launch that ends an iteration gets
     uint32_t* d_counts = nullptr;
     REAL *d_tmp0 = nullptr, *d_tmp1 = nullptr;        // per-layer scratch (min-marginals, sorted outputs)
@@ -366,6 +368,7 @@ struct SolverT final : SolverBase {
         d.lb_partial = d_lb_partial;
         d.mm0_out = d_tmp0; d.mm1_out = d_tmp1; d.sol_out = d_sol;
         d.stop = run_stop;
+        d.run_iter = run_iter;
         return d;
     }
     PackDev pdev(const PackBufs& b, uint32_t lb_base, uint32_t seg_off = 0) const
@@ -516,21 +519,21 @@ struct SolverT final : SolverBase {
         return BDDMMA_OK;
     }
     // compute_delta + normalize_delta + broadcast to the layers, see kernels.hpp (k_exchange_reduce)
-    void launch_bcast(const REAL* delta_var, REAL* delta_lay, const uint32_t* stop = nullptr, RunStep run = RunStep{})
+    void launch_bcast(const REAL* delta_var, REAL* delta_lay, RunGate g = RunGate{}, RunStep run = RunStep{})
     {
         hipLaunchKernelGGL((k_exchange_bcast<REAL>), dim3(cdiv(cdiv(n_layers, 4), 256)), dim3(256), 0, stream, delta_var, d_evar, delta_lay,
-                           (uint32_t)n_layers, (uint32_t)n_vars, stop, run);
+                           (uint32_t)n_layers, (uint32_t)n_vars, g, run);
     }
     // un-normalised per-variable sums of the deferred min-marginal differences (compute_delta only)
     void launch_reduce_raw(REAL* delta_var)
     {
         if (deterministic)
             hipLaunchKernelGGL((k_delta_gather<REAL, false>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr,
-                               d_vpos, delta_var, (uint32_t)n_vars, (const uint32_t*)nullptr);
+                               d_vpos, delta_var, (uint32_t)n_vars, RunGate{});
         else
             hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_RAW>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
                                d_bin_ptr, d_bvar, d_nbdds, delta_var, (REAL*)nullptr, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers,
-                               (const uint32_t*)nullptr);
+                               RunGate{});
     }
     int exchange(bool ends_iteration = false)
     {
@@ -539,17 +542,17 @@ struct SolverT final : SolverBase {
         if (entry_by_var) {
             // entries of a variable are consecutive: one thread per variable reduces, normalises and broadcasts (deterministic order)
             hipLaunchKernelGGL((k_exchange_byvar<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr, d_delta_lay,
-                               (uint32_t)n_vars, (uint32_t)n_layers, run_stop, rstep);
+                               (uint32_t)n_vars, (uint32_t)n_layers, gate(), rstep);
             delta_var_valid = false;
         } else if (deterministic) {
             hipLaunchKernelGGL((k_delta_gather<REAL, true>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr,
-                               d_vpos, d_delta_var, (uint32_t)n_vars, run_stop);
-            launch_bcast(d_delta_var, d_delta_lay, run_stop, rstep);
+                               d_vpos, d_delta_var, (uint32_t)n_vars, gate());
+            launch_bcast(d_delta_var, d_delta_lay, gate(), rstep);
             delta_var_valid = true;
         } else {
 #define LAUNCH_EX(T_, U_, N_, RUN_)                                                                                                              \
     hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, T_, U_, N_, RUN_>), dim3(n_bins), dim3(T_), exch_lds, stream, d_mm_binned, d_bin_ptr, \
-                       d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers, run_stop, rstep)
+                       d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers, gate(), rstep)
             // inside run_plain() the instantiation that honours the stop flag and runs the termination tests; otherwise the plain one
             if (exch_medium) { if (run_stop) LAUNCH_EX(EXM_THREADS, EXM_UNROLL, EXM_NPT, true); else LAUNCH_EX(EXM_THREADS, EXM_UNROLL, EXM_NPT, false); }
             else if (exch_small) { if (run_stop) LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, true); else LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false); }
@@ -666,6 +669,7 @@ struct SolverT final : SolverBase {
         if (rc) return rc;
         if (verbose) std::printf("[bdd solver] initial lower bound = %.10g, time = %.3f s\n", lb_initial, elapsed());
         RunCtl c{};
+        c.stop = RUN_NOT_STOPPED;
         c.lb_initial = lb_initial;
         c.lb_first = std::numeric_limits<double>::max();
         c.lb_post = lb_initial;
@@ -689,8 +693,13 @@ struct SolverT final : SolverBase {
             const uint64_t window = (seen && t + 4.0 * (double)WINDOW * per_iter < time_limit) ? WINDOW : 1;
             bool launched = false;
             while (queued < max_iter && queued - seen < window) {
+                run_iter = (uint32_t)std::min<uint64_t>(queued, RUN_NOT_STOPPED - 1);
                 rc = iteration(0.5);  // its last launch also reduces the bound and runs the tests (exchange(true))
-                if (rc) { run_stop = nullptr; return rc; }
+                if (rc) {  // launches of this and earlier iterations may be in flight: drain them before the gate goes away
+                    (void)hipStreamSynchronize(stream);
+                    run_stop = nullptr;
+                    return rc;
+                }
                 ++queued;
                 launched = true;
             }

@@ -118,23 +118,26 @@ void bdd_solver::construct_solver(const bdd_store& col, const std::vector<double
     if (!GPU_MMA.count(name) && !GPU_LBFGS.count(name)) throw std::runtime_error("relaxation solver " + name + " unknown");
     // NB: the reference constructs the <float> GPU solver for "double" and vice versa (:167-174); here
     // "precision" means what it says.
-    // The solver's variables are those of the BDDs.  A variable that occurs in the objective only (in no constraint, with an index
-    // past the last constrained one) is free: its better value contributes min(0, c) to the bound and is fixed in the primal.
-    // (The reference only asserts on such costs, bdd_parallel_mma_base.cpp:685-695; release builds drop them.)
+    // The solver's variables are those of the BDDs.  A variable that occurs in the objective only (in no constraint) is free: its
+    // better value contributes min(0, c) to the bound and is fixed in the primal.  Such a variable may have ANY index — the LP reader
+    // numbers variables by first appearance and reads the objective first — so it is recognised by its BDD count, not by its position
+    // (ADVICE r2).  (The reference only asserts on such costs, bdd_parallel_mma_base.cpp:685-695; release builds drop them.)
     const size_t nv = col.nr_variables();
     std::vector<double> c(nv, 0.0);
     std::copy(costs.begin(), costs.begin() + (long)std::min(nv, costs.size()), c.begin());
-    free_constant_ = 0;
-    free_ones_.assign(costs.size() > nv ? costs.size() - nv : 0, 0);
-    for (size_t v = nv; v < costs.size(); ++v)
-        if (costs[v] < 0) {
-            free_constant_ += costs[v];
-            free_ones_[v - nv] = 1;
-        }
     const int device = device_ >= 0 ? device_ : (int)config_.number_or("device", 0);
     const int rc = bddmma_create(&solver_, precision == "double" ? BDDMMA_F64 : BDDMMA_F32, device,
                                  col.instructions.data(), col.delimiters.data(), col.nr_bdds(), c.data(), c.size(), nullptr);
     if (rc != BDDMMA_OK) throw std::runtime_error(bddmma_last_error(nullptr));
+    std::vector<int32_t> nbdds(bddmma_nr_variables(solver_), 0);
+    check(bddmma_num_bdds_per_var(solver_, nbdds.data()));
+    free_constant_ = 0;
+    free_ones_.assign(costs.size(), -1);  // -1: the variable is in a BDD; 0 / 1: objective-only, its better value
+    for (size_t v = 0; v < costs.size(); ++v) {
+        if (v < nbdds.size() && nbdds[v] > 0) continue;
+        free_ones_[v] = costs[v] < 0 ? 1 : 0;
+        if (costs[v] < 0) free_constant_ += costs[v];
+    }
     if (GPU_LBFGS.count(name)) {
         const json& p = config_["lbfgs"];  // :179-199
         bddmma_lbfgs_params lp;
@@ -173,12 +176,9 @@ std::vector<char> bdd_solver::perturbation_rounding()
         log("[incremental primal rounding] No solution found");
         return {};
     }
-    if (sol.size() < ilp_.nr_variables()) {  // variables of the objective only: their better value (construct_solver)
-        const size_t nv = sol.size();
-        sol.resize(ilp_.nr_variables(), 0);
-        for (size_t v = nv; v < sol.size() && v - nv < free_ones_.size(); ++v) sol[v] = free_ones_[v - nv];
-    }
-    sol.resize(ilp_.nr_variables());  // auxiliary split variables are not part of the answer
+    sol.resize(ilp_.nr_variables(), 0);  // auxiliary split variables are not part of the answer
+    for (size_t v = 0; v < sol.size() && v < free_ones_.size(); ++v)
+        if (free_ones_[v] >= 0) sol[v] = free_ones_[v];  // variables of the objective only: their better value (construct_solver)
     solution_ = sol;
     solution_objective_ = ilp_.feasible(sol) ? ilp_.evaluate(sol) : std::numeric_limits<double>::infinity();
     std::ostringstream o;

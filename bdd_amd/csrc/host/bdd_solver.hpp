@@ -54,7 +54,7 @@ private:
     bool constructed_ = false;
     // variables that occur in the objective only (in no constraint): fixed to their better value, min(0, c) goes to the bound
     double free_constant_ = 0;
-    std::vector<char> free_ones_;
+    std::vector<signed char> free_ones_;  // per ILP variable: -1 in a BDD, 0 / 1 objective-only (its better value)
     ilp_input ilp_;
     bdd_store col_;
     bddmma_solver* solver_ = nullptr;

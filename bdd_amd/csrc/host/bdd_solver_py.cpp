@@ -42,6 +42,9 @@ void ck(int rc, const bddmma_solver* s)
 // LPMP::bdd_cuda_parallel_mma<REAL> as the Python module exposes it
 struct hip_solver {
     bddmma_solver* h = nullptr;
+    // what the solver's own bound leaves out: the ILP's constant and, for variables that occur in the objective only (any index), the
+    // better of their two values — the same terms the bdd_solver driver adds, so both report the same bound for one ILP
+    double constant = 0.0;
     hip_solver() = default;
     hip_solver(const hip_solver&) = delete;
     hip_solver& operator=(const hip_solver&) = delete;
@@ -61,6 +64,7 @@ struct hip_solver {
         std::vector<double> obj(bddilp_nr_variables(ilp));
         double constant = 0;
         bddilp_objective(ilp, obj.data(), &constant);
+        const std::vector<double> full = obj;
         obj.resize(std::min<size_t>(obj.size(), bddilp_bdds_nr_variables(col)));
         auto s = std::make_unique<hip_solver>();
         const int prec = (precision == "float" || precision == "single") ? BDDMMA_F32 : BDDMMA_F64;
@@ -69,6 +73,11 @@ struct hip_solver {
         bddilp_bdds_destroy(col);
         bddilp_destroy(ilp);
         ck(rc, nullptr);
+        std::vector<int32_t> nb(bddmma_nr_variables(s->h), 0);
+        ck(bddmma_num_bdds_per_var(s->h, nb.data()), s->h);
+        s->constant = constant;
+        for (size_t v = 0; v < full.size(); ++v)
+            if ((v >= nb.size() || nb[v] == 0) && full[v] < 0) s->constant += full[v];
         return s;
     }
     // a scratch file for the archive: memory-backed when /dev/shm exists, else under TMPDIR or /tmp
@@ -92,20 +101,41 @@ struct hip_solver {
         const char* path = path_s.c_str();
         const int rc = bddmma_save(h, path);
         std::string blob;
+        bool read_ok = false;
         if (rc == BDDMMA_OK) {
             std::ifstream f(path, std::ios::binary);
-            blob.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+            if (f) {
+                blob.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+                read_ok = !f.bad() && !blob.empty();
+            }
         }
         std::remove(path);
         ck(rc, h);
+        if (!read_ok) throw std::runtime_error("pickling: cannot read the solver archive back from " + path_s);
         return py::bytes(blob);
+    }
+    // (archive, constant, device): restored on the device it was on when that device exists in the unpickling process, else on device 0
+    py::tuple getstate() const { return py::make_tuple(dumps(), constant, bddmma_device(h)); }
+    static std::unique_ptr<hip_solver> setstate(const py::tuple& t)
+    {
+        if (t.size() != 3) throw std::runtime_error("bdd_hip_parallel_mma: invalid pickle state");
+        int device = t[2].cast<int>();
+        if (device < 0 || device >= bddmma_device_count()) device = 0;
+        auto s = loads(t[0].cast<py::bytes>(), device);
+        s->constant = t[1].cast<double>();
+        return s;
     }
     static std::unique_ptr<hip_solver> loads(const py::bytes& b, int device)
     {
         const std::string blob = b;
         const std::string path_s = scratch_file();
         const char* path = path_s.c_str();
-        { std::ofstream f(path, std::ios::binary); f.write(blob.data(), (std::streamsize)blob.size()); }
+        {
+            std::ofstream f(path, std::ios::binary);
+            f.write(blob.data(), (std::streamsize)blob.size());
+            f.flush();
+            if (!f) { std::remove(path); throw std::runtime_error("unpickling: cannot write the solver archive to " + path_s); }
+        }
         auto s = std::make_unique<hip_solver>();
         const int rc = bddmma_load(&s->h, device, path);
         std::remove(path);
@@ -154,7 +184,9 @@ PYBIND11_MODULE(bdd_solver_py, m)
     py::class_<hip_solver>(m, "bdd_hip_parallel_mma")
         .def(py::init([](const std::string& ilp_text, const std::string& precision, int device) { return hip_solver::from_ilp(ilp_text, precision, device); }),
              py::arg("ilp"), py::arg("precision") = "double", py::arg("device") = 0)
-        .def(py::pickle([](const hip_solver& s) { return s.dumps(); }, [](const py::bytes& b) { return hip_solver::loads(b, 0); }))
+        .def(py::pickle([](const hip_solver& s) { return s.getstate(); }, [](const py::tuple& t) { return hip_solver::setstate(t); }))
+        .def_readonly("constant", &hip_solver::constant)  // ILP constant + better values of objective-only variables (part of lower_bound())
+        .def("device", [](const hip_solver& s) { return bddmma_device(s.h); })
         .def("__repr__", [](const hip_solver& s) {
             return "<bdd_hip_parallel_mma>: nr_variables: " + std::to_string(bddmma_nr_variables(s.h)) + ", nr_bdds: " + std::to_string(bddmma_nr_bdds(s.h)) +
                    ", nr_layers: " + std::to_string(bddmma_nr_layers(s.h));
@@ -172,7 +204,7 @@ PYBIND11_MODULE(bdd_solver_py, m)
         .def("nr_bdds", [](const hip_solver& s) { return bddmma_nr_bdds(s.h); })
         .def("iteration", [](hip_solver& s, double omega) { ck(bddmma_iteration(s.h, omega), s.h); }, py::arg("omega") = 0.5)
         .def("iterations", [](hip_solver& s, uint64_t n, double omega) { ck(bddmma_iterations(s.h, omega, n), s.h); }, py::arg("n"), py::arg("omega") = 0.5)
-        .def("lower_bound", [](hip_solver& s) { double lb = 0; ck(bddmma_lower_bound(s.h, &lb), s.h); return lb; })
+        .def("lower_bound", [](hip_solver& s) { double lb = 0; ck(bddmma_lower_bound(s.h, &lb), s.h); return lb + s.constant; })
         // bdd_cuda_parallel_mma_py.cu:56-72: hi - lo min-marginal of every layer into a caller-owned DEVICE buffer (REAL[nr_layers])
         .def("compute_and_set_min_marginal_diff",
              [](hip_solver& s, uint64_t mm_diff_out_ptr) { ck(bddmma_min_marginal_diff(s.h, reinterpret_cast<void*>(mm_diff_out_ptr), 1), s.h); })

@@ -53,18 +53,27 @@ struct DevPtrs {
     char* sol_out;           // FWD_SOLUTION output, per layer
     // Device-resident run_solver (run_ctl_step): when the termination test of run_solver_util.h:56-73 has fired on the device, the
     // launches of the iterations the host had already queued return at once.  nullptr outside run_solver (one scalar compare of a
-    // kernel argument); otherwise one scalar load per launch.
+    // kernel argument); otherwise one scalar load per launch.  *stop = number of iterations after which the loop ended (UINT32_MAX
+    // while it runs); run_iter = index of the iteration this launch belongs to.  A launch is skipped when *stop <= run_iter, so the
+    // launch that latches the word (it belongs to iteration *stop - 1) can never skip part of its own grid — with a plain flag the
+    // workgroups dispatched after workgroup 0 had latched it returned without doing their share of the exchange.
     const uint32_t* stop;
+    uint32_t run_iter;
 };
+struct RunGate {  // the same pair for the kernels that do not take a DevPtrs
+    const uint32_t* stop = nullptr;
+    uint32_t iter = 0;
+};
+constexpr uint32_t RUN_NOT_STOPPED = 0xFFFFFFFFu;
 
-__device__ __forceinline__ bool run_stopped(const uint32_t* stop) { return stop != nullptr && *stop != 0u; }
-// The sweep kernels test the flag together with their first uniform exit: the pointer is a kernel argument, so outside run_solver
+__device__ __forceinline__ bool run_stopped(const RunGate& g) { return g.stop != nullptr && *g.stop <= g.iter; }
+// The sweep kernels test the word together with their first uniform exit: the pointer is a kernel argument, so outside run_solver
 // (nullptr) the test is one more scalar compare on values the kernel loads anyway — no extra dependent round trip at its start.
-#define BDDMMA_EXIT_IF(done_cond, stopp)                                   \
+#define BDDMMA_EXIT_IF(done_cond, dev)                                     \
     {                                                                      \
         const bool done_ = (done_cond);                                    \
-        if (done_ | ((stopp) != nullptr)) {                                \
-            if (done_ || *(stopp) != 0u) return;                           \
+        if (done_ | ((dev).stop != nullptr)) {                             \
+            if (done_ || *(dev).stop <= (dev).run_iter) return;            \
         }                                                                  \
     }
 
@@ -559,7 +568,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     auto& sAct = sAct_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
     const uint32_t quad = block_to_pack(block_id, n_quads);
-    BDDMMA_EXIT_IF(quad >= n_quads, d.stop)  // uniform for the workgroup
+    BDDMMA_EXIT_IF(quad >= n_quads, d)  // uniform for the workgroup
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;  // the last quad may be partial: such a wave only helps staging
     const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
@@ -806,7 +815,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     auto& sT = sT_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
     const uint32_t quad = block_to_pack(block_id, n_quads);
-    BDDMMA_EXIT_IF(quad >= n_quads, d.stop)
+    BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
     const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
@@ -1052,7 +1061,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
     uint32_t* sOffL = sOffL_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
     const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
-    BDDMMA_EXIT_IF(quad >= n_quads, d.stop)
+    BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
     // dynamic LDS: [staged {delta_lo, delta_hi} / mm: WPB * stage_cap pairs][per wave: words | T of every slot | {lo, hi} of every layer]
@@ -1164,7 +1173,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev p
     uint32_t* sOffL = sOffL_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
     const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
-    BDDMMA_EXIT_IF(quad >= n_quads, d.stop)
+    BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
     P2* sD = reinterpret_cast<P2*>(dyn_lds);
@@ -1288,7 +1297,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, Pack
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
     const uint32_t p = blockIdx.x;
-    BDDMMA_EXIT_IF(p >= pk.n_packs, d.stop)
+    BDDMMA_EXIT_IF(p >= pk.n_packs, d)
     WideLds<REAL> s = carve_lds<REAL>(GLOBAL ? scratch + (size_t)p * wide_lds_bytes(sizeof(REAL), ww, true) : smem, ww);
     const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
     const REAL INF = inf_v<REAL>();
@@ -1381,7 +1390,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
     __shared__ double red[WIDE_THREADS / 64];
     const uint32_t tid = threadIdx.x;
     const uint32_t p = blockIdx.x;
-    BDDMMA_EXIT_IF(p >= pk.n_packs, d.stop)
+    BDDMMA_EXIT_IF(p >= pk.n_packs, d)
     WideLds<REAL> s = carve_lds<REAL>(GLOBAL ? scratch + (size_t)p * wide_lds_bytes(sizeof(REAL), ww, true) : smem, ww);
     const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
     const REAL INF = inf_v<REAL>();
@@ -1533,7 +1542,7 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
     constexpr bool NEED_T = (MODE != FWD_PLAIN);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, T = blockDim.x;
-    BDDMMA_EXIT_IF(p >= pk.n_packs, d.stop)
+    BDDMMA_EXIT_IF(p >= pk.n_packs, d)
     const uint32_t S = ww + 2;
     // All LDS arrays are addressed as lds[offset + index] with integer offsets that rotate from hop to hop: with rotating POINTERS the
     // compiler loses the address space and emits flat loads / a flat compare-and-swap loop for the float minimum (seen in the ISA).
@@ -1726,7 +1735,7 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double red[16];
     const uint32_t tid = threadIdx.x, T = blockDim.x;
-    BDDMMA_EXIT_IF(p >= pk.n_packs, d.stop)
+    BDDMMA_EXIT_IF(p >= pk.n_packs, d)
     const uint32_t S = ww + 2;
     REAL* const lds = reinterpret_cast<REAL*>(smem);  // integer offsets instead of rotating pointers, see k_fwd_wide2
     const uint32_t oM0 = 4 * S, oM1 = 6 * S;
@@ -1966,7 +1975,7 @@ __device__ __forceinline__ void run_ctl_step(const RunStep& r)
     if (__builtin_fabs(lb_prev - lb_post) < __builtin_fabs(c.tolerance * lb_prev)) reason = 2;                // run_solver_util.h:56-61
     else if (__builtin_fabs(lb_prev - lb_post) < c.slope * __builtin_fabs(lb_initial - lb_first)) reason = 3;  // :62-67
     else if (lb_post == __builtin_huge_val()) reason = 4;                                                       // :68-73
-    if (reason) { ctl->reason = reason; ctl->stop = 1; }
+    if (reason) { ctl->reason = reason; ctl->stop = (uint32_t)(it + 1 < (uint64_t)RUN_NOT_STOPPED ? it + 1 : (uint64_t)RUN_NOT_STOPPED - 1); }  // launches of iterations >= it + 1 are skipped
     volatile RunHost* h = r.host;
     h->lb[it % RUN_RING] = lb_post;
     __threadfence_system();
@@ -2139,9 +2148,9 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
                                                                   const uint16_t* __restrict__ bvar, const int32_t* __restrict__ nbdds,
                                                                   REAL* __restrict__ delta_var, REAL* __restrict__ delta_lay,
                                                                   uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries,
-                                                                  const uint32_t* stop = nullptr, RunStep run = RunStep{})
+                                                                  RunGate gate = RunGate{}, RunStep run = RunStep{})
 {
-    if (RUN && run_stopped(stop)) return;
+    if (RUN && run_stopped(gate)) return;
     exchange_reduce_body<REAL, ACC, MODE, EX_THREADS, EX_UNROLL, NPT>(mm_binned, bin_ptr, bvar, nbdds, delta_var, delta_lay, vars_per_bin, n_vars,
                                                                        n_entries);
     if (RUN && run.ctl != nullptr && blockIdx.x == 0) {  // uniform
@@ -2159,9 +2168,9 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
 template <typename REAL>
 __global__ void __launch_bounds__(256) k_exchange_byvar(const REAL* __restrict__ mm, const uint32_t* __restrict__ var_ptr,
                                                           REAL* __restrict__ delta_lay, uint32_t n_vars, uint32_t n_entries,
-                                                          const uint32_t* stop = nullptr, RunStep run = RunStep{})
+                                                          RunGate gate = RunGate{}, RunStep run = RunStep{})
 {
-    if (run_stopped(stop)) return;
+    if (run_stopped(gate)) return;
     if (run.ctl != nullptr && blockIdx.x == 0) run_ctl_step(run);
     using P2 = typename Pair<REAL>::type;
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2200,9 +2209,9 @@ __global__ void __launch_bounds__(256) k_exchange_byvar(const REAL* __restrict__
 template <typename REAL>
 __global__ void __launch_bounds__(256) k_exchange_bcast(const REAL* __restrict__ delta_var, const uint32_t* __restrict__ evar,
                                                           REAL* __restrict__ delta_lay, uint32_t n_entries, uint32_t n_vars,
-                                                          const uint32_t* stop = nullptr, RunStep run = RunStep{})
+                                                          RunGate gate = RunGate{}, RunStep run = RunStep{})
 {
-    if (run_stopped(stop)) return;
+    if (run_stopped(gate)) return;
     // the deterministic exchange is two launches (k_delta_gather, this one): the tests latch `stop` in the LAST launch of the iteration
     if (run.ctl != nullptr && blockIdx.x == 0) run_ctl_step(run);
     using P2 = typename Pair<REAL>::type;
@@ -2243,9 +2252,9 @@ __global__ void k_normalize_delta(REAL* __restrict__ delta, const int32_t* __res
 template <typename REAL, bool NORMALIZE>
 __global__ void k_delta_gather(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ var_ptr,
                                const uint32_t* __restrict__ vpos, REAL* __restrict__ delta_var, uint32_t n_vars,
-                               const uint32_t* stop = nullptr)
+                               RunGate gate = RunGate{})
 {
-    if (run_stopped(stop)) return;
+    if (run_stopped(gate)) return;
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_vars) return;
     REAL lo = 0, hi = 0;

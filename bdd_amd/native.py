@@ -27,13 +27,12 @@ def _check(rc):
 
 def _collection_from_handle(L, h) -> BddCollection:
     n, nb = int(L.bddilp_bdds_nr_instructions(h)), int(L.bddilp_bdds_nr_bdds(h))
-    col = BddCollection()
+    instr = np.zeros((0, 3), np.uint64)
     if n:
         buf = (C.c_uint64 * (3 * n)).from_address(L.bddilp_bdds_instructions(h))
-        col._chunks = [np.frombuffer(buf, dtype=np.uint64).reshape(n, 3).copy()]
-    col._delims = [np.frombuffer((C.c_uint64 * (nb + 1)).from_address(L.bddilp_bdds_delimiters(h)), dtype=np.uint64).copy()]
-    col._n, col._nb = n, nb
-    return col
+        instr = np.frombuffer(buf, dtype=np.uint64).reshape(n, 3)
+    delims = np.frombuffer((C.c_uint64 * (nb + 1)).from_address(L.bddilp_bdds_delimiters(h)), dtype=np.uint64)
+    return BddCollection.from_arrays(instr, delims)
 
 
 def parse_lp(text: str, fmt: str = "lp") -> ILP:

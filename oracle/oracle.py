@@ -226,12 +226,7 @@ class RefCollection:
         instr = np.zeros((n, 3), np.uint64)
         delims = np.zeros(self.nr_bdds() + 1, np.uint64)
         self.R.ref_col_export(self.h, _p(instr), _p(delims))
-        out = BddCollection()
-        out._chunks = [instr]
-        out._delims = [delims]
-        out._n = n
-        out._nb = self.nr_bdds()
-        return out
+        return BddCollection.from_arrays(instr, delims)
 
 
 class RefMma:

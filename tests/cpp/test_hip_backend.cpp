@@ -97,6 +97,39 @@ static void test_costs_marginals_solution()
     CHECK(ones == 1);
 }
 
+// test/test_bdd_cuda_base_sol.cpp:30-86, both blocks: two simplex rows sharing x_4, costs set per variable, bdds_solution() as
+// [variable][bdd]; the first block's answer is unique up to the tie x_2 / x_4 in BDD 0, which the argmin rule (`cost_diff > 0 -> 0`,
+// bdd_cuda_base.cu:1121-1131) resolves towards the earlier variable
+template <typename REAL>
+static void test_bdds_solution_reference_kat()
+{
+    auto build = [](const std::vector<double>& obj) {
+        bdd_store col;
+        col.add_simplex({0, 1, 2, 3});        // x_1 + x_2 + x_3 + x_4 = 1
+        col.add_linear({1, 1, 1}, bddmma_host::ineq_t::eq, 2, {3, 4, 5});  // x_4 + x_5 + x_6 = 2
+        bdd_hip_parallel_mma<REAL> s(col);
+        for (size_t i = 0; i < obj.size(); ++i) s.set_cost(obj[i], i);
+        return s;
+    };
+    {
+        auto s = build({2, 1, 1.5, 2, 2, 3});
+        CHECK(s.nr_variables() == 6 && s.nr_bdds() == 2);
+        const auto sol = s.bdds_solution();
+        CHECK(sol.size() == 6);
+        for (size_t i = 0; i < 6; ++i) CHECK(sol[i].size() == (i == 3 ? 2u : 1u));
+        CHECK(sol[0][0] == 0); CHECK(sol[1][0] == 1); CHECK(sol[2][0] == 0); CHECK(sol[3][0] == 0);
+        CHECK(sol[3][1] == 1); CHECK(sol[4][0] == 1); CHECK(sol[5][0] == 0);
+    }
+    {
+        auto s = build({1, 1, 1, 2, 1, 1});
+        const auto sol = s.bdds_solution();
+        CHECK(sol.size() == 6);
+        for (size_t i = 0; i < 6; ++i) CHECK(sol[i].size() == (i == 3 ? 2u : 1u));
+        CHECK(sol[0][0] + sol[1][0] + sol[2][0] + sol[3][0] == 1);
+        CHECK(sol[3][1] + sol[4][0] + sol[5][0] == 2);
+    }
+}
+
 template <typename REAL>
 static void test_explicit_mm_and_distribute()
 {
@@ -289,6 +322,8 @@ int main()
         {"matching KATs <float>", test_matching_kats<float>},
         {"costs / min-marginals / solution <double>", test_costs_marginals_solution<double>},
         {"costs / min-marginals / solution <float>", test_costs_marginals_solution<float>},
+        {"bdds_solution() reference KAT (test_bdd_cuda_base_sol.cpp) <double>", test_bdds_solution_reference_kat<double>},
+        {"bdds_solution() reference KAT (test_bdd_cuda_base_sol.cpp) <float>", test_bdds_solution_reference_kat<float>},
         {"explicit forward_mm / backward_mm / distribute_delta <double>", test_explicit_mm_and_distribute<double>},
         {"explicit forward_mm / backward_mm / distribute_delta <float>", test_explicit_mm_and_distribute<float>},
         {"device-vector overloads <double>", test_device_vectors<double>},

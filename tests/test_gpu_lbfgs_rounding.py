@@ -85,8 +85,10 @@ def test_lbfgs_structured_instance_vs_oracle():
 
 
 def test_lbfgs_full_size_config4():
-    """BASELINE.json configs[3]: lbfgs parallel mma on the 10.5 M-node instance (defaults m = 5, step 1e-6, 1e-6, 0.8, 1.1)."""
-    col, costs = random_set_cover(1_000_000, 500_000, 10, seed=12345)
+    """BASELINE.json configs[3]: lbfgs parallel mma on "the same 10M-node instance" as configs[2] — the mt19937_64(12345) instance of
+    bench.py and of the full-size fixture (defaults m = 5, step 1e-6, 1e-6, 0.8, 1.1)."""
+    from bdd_amd.instances import random_set_cover_mt
+    col, costs = random_set_cover_mt(1_000_000, 500_000, 10, 12345)
     assert col.nr_bdd_nodes() == 10_500_000
     n_lbfgs, lb = run_lbfgs_pair(col, costs, "double", 20, threads=min(os.cpu_count() or 1, 32))
     assert n_lbfgs >= 10

@@ -52,6 +52,71 @@ def test_min_marginals_two_simplex():
         assert tuple(m[0]) == e
 
 
+TWO_SIMPLEX_DIFF_SIZE = "Minimize\n2 x_1 + 1 x_2 + 1.5 x_3\n+2 x_4 + 2 x_5 + 3 x_6\nSubject To\nx_1 + x_2 + x_3 + x_4 = 1\nx_4 + x_5 + x_6 = 2\nEnd\n"
+TWO_SIMPLEX_NON_UNIQUE = "Minimize\n1 x_1 + 1 x_2 + 1 x_3\n+2 x_4 + 1 x_5 + 1 x_6\nSubject To\nx_1 + x_2 + x_3 + x_4 = 1\nx_4 + x_5 + x_6 = 2\nEnd\n"
+
+
+@pytest.mark.parametrize("precision", ["float", "double"])
+def test_bdds_solution_reference_kat(precision):
+    # test/test_bdd_cuda_base_sol.cpp:30-86, both blocks: bdd_cuda_base<float>, set_cost per variable, bdds_solution() as
+    # two_dim_variable_array [variable][bdd] (bdd_cuda_base.cu:1204-1233; the sorted = 1 branch of bddmma_bdds_solution)
+    ilp = parse_lp(TWO_SIMPLEX_DIFF_SIZE)
+    s = bdd_hip_parallel_mma(to_bdd_collection(ilp), precision=precision)
+    assert s.nr_variables() == 6 and s.nr_bdds() == 2
+    for i, c in enumerate(ilp.objective):
+        s.set_cost(c, i)
+    sol = s.bdds_solution()
+    assert len(sol) == 6 and [len(x) for x in sol] == [1, 1, 1, 2, 1, 1]
+    # :48-56, exact values (BDD 0 has the tie x_2 / x_4 at cost 1: `cost_diff > 0 -> 0 else 1` takes the earlier variable)
+    assert (sol[0][0], sol[1][0], sol[2][0], sol[3][0]) == (0, 1, 0, 0)
+    assert (sol[3][1], sol[4][0], sol[5][0]) == (1, 1, 0)
+    ilp = parse_lp(TWO_SIMPLEX_NON_UNIQUE)
+    s = bdd_hip_parallel_mma(to_bdd_collection(ilp), precision=precision)
+    for i, c in enumerate(ilp.objective):
+        s.set_cost(c, i)
+    sol = s.bdds_solution()
+    assert [len(x) for x in sol] == [1, 1, 1, 2, 1, 1]
+    assert sol[0][0] + sol[1][0] + sol[2][0] + sol[3][0] == 1      # :83-84
+    assert sol[3][1] + sol[4][0] + sol[5][0] == 2
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(pack_width=64, waves_per_block=1), dict(wide_pack_width=64, pack_width=64)],
+                         ids=["default", "narrow64", "wide_and_huge"])
+def test_bdds_solution_sorted_vs_oracle(opts):
+    """bdds_solution() ([variable][bdd] order) against the oracle's bdds_solution_vec (bdd_parallel_mma_base.cpp:1197-1275) on an
+    instance where every variable sits in several BDDs, after a few iterations (non-trivial reparametrised costs)."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    col = BddCollection()
+    V = 60
+    for _ in range(40):
+        col.add_covering(np.sort(rng.choice(V, size=int(rng.integers(3, 9)), replace=False)))
+    for _ in range(25):
+        col.add_simplex(np.sort(rng.choice(V, size=int(rng.integers(3, 7)), replace=False)))
+    for _ in range(12):
+        k = int(rng.integers(8, 16))
+        co = rng.integers(1, 30, size=k)
+        col.add_linear(co, "<=", int(co.sum() // 2), np.sort(rng.choice(V, size=k, replace=False)))
+    costs = rng.normal(0, 3, col.nr_variables())
+    s = bdd_hip_parallel_mma(col, costs, precision="double", **opts)
+    o = Oracle(col, costs, "double")
+    for _ in range(4):
+        s.iteration(); o.iteration()
+    osol = o.bdds_solution_vec()
+    ovar, obdd = o.layer_info()
+    nb = s.get_num_bdds_per_var()
+    assert nb.max() >= 3
+    sol2d = s.bdds_solution()
+    assert [len(x) for x in sol2d] == list(nb)
+    # oracle layers regrouped as [variable][bdd ascending]
+    order = np.lexsort((obdd, ovar))
+    ptr = np.concatenate([[0], np.cumsum(nb)])
+    for v in range(s.nr_variables()):
+        np.testing.assert_array_equal(np.asarray(sol2d[v]), osol[order][ptr[v]:ptr[v + 1]], err_msg=f"variable {v}")
+    # and the flat vector in internal order agrees through the layer permutation
+    perm = oracle_layer_perm(s, o)
+    np.testing.assert_array_equal(s.bdds_solution_vec()[perm], osol)
+
+
 @pytest.mark.parametrize("P,kat", [(SHORT_CHAIN, 1.0), (LONG_CHAIN, -9.0), (GRID_3X3, -8.0), ("matching", -6.0)])
 def test_200_iterations_kats_and_reparametrisation(P, kat):
     # test/test_bdd_cuda_parallel_mma.cu:197-247: 200 iteration()s, distribute_delta(), final LB,

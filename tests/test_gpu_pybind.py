@@ -95,3 +95,30 @@ def test_gpu_solver_class_pickle_and_min_marginal_diff():
     _, mm0, mm1 = ref.min_marginals_cuda(get_sorted=False)
     np.testing.assert_allclose(ref.min_marginal_diff(), mm1 - mm0, atol=1e-6)
     assert abs(ref.lower_bound() - s.lower_bound()) <= 1e-5 * max(1.0, abs(s.lower_bound()))
+
+
+def test_objective_only_variables_at_any_index():
+    """a variable that occurs in the objective only is free wherever its index lies.  The LP reader numbers variables by
+    first appearance and reads the objective first, so `y` below gets index 1 — between constrained variables.  Its better value
+    enters the bound (min(0, c)) and the rounded solution (c < 0 -> 1) in both drivers and in the pybind solver class."""
+    lp = ("Minimize\nx1 - 3 y + 1.5 x2 + 2 x3 - 0.5 z + 4 w + 2 x4 - x5\nSubject To\nx1 + x2 + x3 >= 1\nx4 + x5 = 1\n"
+          "Bounds\nBinaries\nx1\ny\nx2\nx3\nz\nw\nx4\nx5\nEnd\n")
+    from bdd_amd import parse_lp
+    ilp = parse_lp(lp)
+    names = list(ilp.var_names)
+    assert names.index("y") == 1 and names.index("z") == 4 and names.index("w") == 5
+    c = cfg(lp, **{"perturbation rounding": {"initial perturbation": 0.1, "perturbation growth rate": 1.2, "inner iterations": 20,
+                                             "outer iterations": 20}})
+    want = 1.0 - 1.0 - 3.0 - 0.5   # x1 = 1, x5 = 1; y = 1, z = 1, w = 0 are free
+    for driver in (lambda: bdd_solver_py.bdd_solver(c, quiet=True).solve(), lambda: py_driver(c, quiet=True).solve()):
+        s = driver()
+        assert abs(s.lower_bound() - want) <= 1e-9
+        sol = list(s.solution)
+        assert ilp.feasible(sol) and abs(ilp.evaluate(sol) - want) <= 1e-12
+        assert sol[1] == 1 and sol[4] == 1 and sol[5] == 0
+    g = bdd_solver_py.bdd_hip_parallel_mma(lp, precision="double")
+    assert abs(g.constant - (-3.5)) <= 1e-12
+    g.iterations(20)
+    assert abs(g.lower_bound() - want) <= 1e-9
+    t = pickle.loads(pickle.dumps(g))
+    assert t.constant == g.constant and t.device() == g.device() and t.lower_bound() == g.lower_bound()

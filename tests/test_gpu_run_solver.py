@@ -122,3 +122,51 @@ def test_wide_and_mixed_pack_kinds_stop_too():
     assert (res["iterations"], res["stop_reason"], res["lb_final"]) == (its, reason, lb) and reason == 2
     for a, b in zip(s.get_solver_costs(), twin.get_solver_costs()):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("mode", ["deterministic", "by_variable", "small_bins"])
+def test_stopping_launch_completes_its_own_grid(mode):
+    """the launch that latches the stop word must not skip part of its own grid.  With thousands of exchange
+    workgroups (6 836 k_exchange_bcast / 5 469 k_exchange_byvar blocks, 21 875 bins of 64 variables) most of them are dispatched
+    after workgroup 0 has run the termination tests; a plain flag made those return without writing their delta pairs.  After
+    run_solver the deferred delta, the costs and one further iteration must equal the sequential twin's."""
+    from bdd_amd.instances import random_set_cover_mt
+    col, costs = random_set_cover_mt(1_400_000, 700_000, 10, 77)
+    opts = {"deterministic": dict(deterministic=True), "by_variable": dict(exchange_by_variable=2), "small_bins": dict(vars_per_bin=64)}[mode]
+    exact = mode != "small_bins"   # LDS-atomic accumulation order differs between two runs of the default exchange
+    twin = bdd_hip_parallel_mma(col, costs, precision="double", **opts)
+    its, lb, reason, _ = sequential_loop(twin, 200, 3e-3, 0.0)
+    assert reason == 2 and 3 <= its < 200
+    s = bdd_hip_parallel_mma(col, costs, precision="double", **opts)
+    # The race needs late dispatch, i.e. a busy GPU (the round-2 library passed this test on an idle one and failed a third of the
+    # run_solver test runs with four processes on the GPU, profiles/r03_soak_*.txt): a second solver iterates on its own stream
+    # from a second host thread while run_solver runs (ctypes releases the GIL during the calls).
+    import threading
+    other = bdd_hip_parallel_mma(col, costs, precision="float")
+    busy = threading.Event()
+
+    def load():
+        while not busy.is_set():
+            other.iterations(20)
+    t = threading.Thread(target=load)
+    t.start()
+    try:
+        res = run_solver(s, max_iter=200, tolerance=3e-3, improvement_slope=0.0, time_limit=1e9)
+    finally:
+        busy.set()
+        t.join()
+    assert (res["iterations"], res["stop_reason"]) == (its, reason)
+
+    def same(a, b):
+        if exact:
+            np.testing.assert_array_equal(a, b)
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-11)
+    assert res["lb_final"] == lb if exact else abs(res["lb_final"] - lb) <= 1e-11 * abs(lb)
+    same(s.get_delta(), twin.get_delta())
+    for a, b in zip(s.get_solver_costs(), twin.get_solver_costs()):
+        same(a, b)
+    s.iteration(); twin.iteration()
+    a, b = s.lower_bound(), twin.lower_bound()
+    assert a == b if exact else abs(a - b) <= 1e-11 * abs(b)
+    same(s.get_delta(), twin.get_delta())

@@ -276,7 +276,7 @@ def test_layout_rejects_bad_input():
     col.add_simplex([0, 1, 2])
     ins = col.instr.copy()
     ins[0, 0] = 3  # root lo -> node of layer 2: skips a layer
-    bad = BddCollection(); bad._chunks = [ins]; bad._delims = [col.delims]; bad._n = col._n; bad._nb = 1
+    bad = BddCollection.from_arrays(ins, col.delims)
     with pytest.raises(capi.BddMmaError, match="QBDD"):
         Layout(bad)
     with pytest.raises(capi.BddMmaError):

@@ -14,22 +14,12 @@ SPLIT_GOLDEN = [n for n in _ALL if n.startswith("split_")]      # split_qbdd inp
 
 
 def collection_from_arrays(instr, delims):
-    col = BddCollection()
-    col._chunks = [np.asarray(instr).astype(np.uint64)]
-    col._delims = [np.asarray(delims).astype(np.uint64)]
-    col._n = int(instr.shape[0])
-    col._nb = int(delims.shape[0]) - 1
-    return col
+    return BddCollection.from_arrays(instr, delims)
 
 
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
-    col = BddCollection()
-    col._chunks = [z["instr"].astype(np.uint64)]
-    col._delims = [z["delims"].astype(np.uint64)]
-    col._n = int(z["instr"].shape[0])
-    col._nb = int(z["delims"].shape[0]) - 1
-    return col, z
+    return BddCollection.from_arrays(z["instr"], z["delims"]), z
 
 
 def pad_costs(costs, n):

@@ -19,8 +19,11 @@ for r in range(reps):
             fails += 1
             msg = str(e).splitlines()
             print(f"FAIL rep {r} seed {s}: " + " | ".join(m.strip() for m in msg[:12])[:900], flush=True)
-        except Exception as e:
+        except KeyboardInterrupt:
+            raise
+        except BaseException as e:  # pytest.skip raises a BaseException
             if "skip" in type(e).__name__.lower():
                 continue
+            fails += 1
             traceback.print_exc()
 print(f"pid {os.getpid()}: {fails} failures in {reps * len(seeds)} runs")
