@@ -555,6 +555,23 @@ struct SolverT final : SolverBase {
                        d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers, gate(), rstep)
             // inside run_plain() the instantiation that honours the stop flag and runs the termination tests; otherwise the plain one
             if (exch_medium) { if (run_stop) LAUNCH_EX(EXM_THREADS, EXM_UNROLL, EXM_NPT, true); else LAUNCH_EX(EXM_THREADS, EXM_UNROLL, EXM_NPT, false); }
+            else if (exch_small && !run_stop && (opts_variant & 0x38u)) {
+                // the shelved round-2 rewrite's ingredients, one instantiation per combination that the bisection uses (kernels.hpp: EXV_*)
+#define LAUNCH_EXV(V_)                                                                                                                          \
+    hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, EXS_THREADS, EXS_UNROLL, EXS_NPT, false, V_>), dim3(n_bins), dim3(EXS_THREADS), \
+                       exch_lds, stream, d_mm_binned, d_bin_ptr, d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars,  \
+                       (uint32_t)n_layers, RunGate{}, RunStep{})
+                switch ((opts_variant >> 3) & 7u) {
+                    case 1: LAUNCH_EXV(1); break;
+                    case 2: LAUNCH_EXV(2); break;
+                    case 3: LAUNCH_EXV(3); break;
+                    case 4: LAUNCH_EXV(4); break;
+                    case 5: LAUNCH_EXV(5); break;
+                    case 6: LAUNCH_EXV(6); break;
+                    default: LAUNCH_EXV(7); break;
+                }
+#undef LAUNCH_EXV
+            }
             else if (exch_small) { if (run_stop) LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, true); else LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false); }
             else { if (run_stop) LAUNCH_EX(EX_THREADS, EX_UNROLL, EX_NPT, true); else LAUNCH_EX(EX_THREADS, EX_UNROLL, EX_NPT, false); }
 #undef LAUNCH_EX

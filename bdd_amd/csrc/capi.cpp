@@ -351,16 +351,50 @@ int bddmma_incremental_mm_agreement_rounding(bddmma_solver* s, bddmma_lbfgs* lbf
 // File: magic, header {precision, #arrays, sizeof(LayoutScalars), sizeof(bddmma_options)}, LayoutScalars, options, the layout arrays
 // as {id, element size, count, data} records (layout.hpp: visit_layout_arrays), then lo / hi / deferred mm / delta.  Loading
 // uploads the arrays as they are: build_layout does not run again.
-static const char kMagic[8] = {'B', 'D', 'D', 'M', 'M', 'A', '0', '4'};  // 04: narrow node words carry the layer index (layout.hpp)
+static const char kMagic[8] = {'B', 'D', 'D', 'M', 'M', 'A', '0', '5'};  // 05: checksum of the layout section behind the arrays; 04: narrow node words carry the layer index
 
 namespace {
 struct FileCloser {
     FILE* f;
     ~FileCloser() { if (f) std::fclose(f); }
 };
-// Consistency of a layout read from a file: the offsets every kernel trusts must be monotone and end where the sizes say.
+// Checksum of the layout section: four independent multiply-rotate lanes over 8-byte words, so that a 240 MB section costs
+// ~20 ms; byte order is the host's (little endian on every target of this library), a foreign-endian file fails the magic / header test.
+struct Checksum {
+    uint64_t lane[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+    uint64_t n = 0;
+    static uint64_t mix(uint64_t h, uint64_t w)
+    {
+        h ^= w * 0x9FB21C651E98DF25ull;
+        h = (h << 27) | (h >> 37);
+        return h * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    }
+    void add(const void* p, size_t bytes)
+    {
+        const unsigned char* c = static_cast<const unsigned char*>(p);
+        n += bytes;
+        size_t i = 0;
+        for (; i + 32 <= bytes; i += 32) {
+            uint64_t w[4];
+            std::memcpy(w, c + i, 32);
+            for (int k = 0; k < 4; ++k) lane[k] = mix(lane[k], w[k]);
+        }
+        for (int k = 0; i < bytes; i += 8, ++k) {
+            uint64_t w = 0;
+            std::memcpy(&w, c + i, std::min<size_t>(8, bytes - i));
+            lane[k & 3] = mix(lane[k & 3], w ^ 0xA5A5A5A5A5A5A5A5ull);
+        }
+    }
+    uint64_t value() const { return mix(mix(mix(mix(n, lane[0]), lane[1]), lane[2]), lane[3]); }
+};
+
+// Consistency of a layout read from a file.  The arrays go to kernels that index LDS and global memory with them, and to host code
+// that copies them into caller buffers, so everything that is used as an index, an offset or a size is checked against its target
+// before a solver is built from it (one linear pass per array).  Tables that are functions of other tables (the resident
+// headers) are recomputed and compared.
 bool layout_plausible(const HostLayout& L, std::string& why)
 {
+    auto fail = [&](const std::string& m) { why = m; return false; };
     auto mono_to = [&](const auto& v, uint64_t first, uint64_t last, const char* name) {
         if (v.empty()) { why = std::string(name) + " is empty"; return false; }
         if (v.front() != first || v.back() != last) { why = std::string(name) + " does not span its range"; return false; }
@@ -368,40 +402,121 @@ bool layout_plausible(const HostLayout& L, std::string& why)
             if (v[i] < v[i - 1]) { why = std::string(name) + " is not monotone"; return false; }
         return true;
     };
-    if (L.n_layers == 0 || L.n_vars == 0 || L.n_bdds == 0) { why = "empty layout"; return false; }
+    auto all_below = [&](const auto& v, uint64_t bound, const char* name) {
+        for (auto x : v)
+            if ((uint64_t)x >= bound) { why = std::string(name) + " out of range"; return false; }
+        return true;
+    };
+    const Exchange& X = L.ex;
+    if (L.n_layers == 0 || L.n_vars == 0 || L.n_bdds == 0) return fail("empty layout");
+    // ---- scalars the launch configuration and the LDS carving are computed from
+    if (L.pack_width != 64 && L.pack_width != 128 && L.pack_width != 256) return fail("pack_width");
+    if (X.waves_per_block != 1 && X.waves_per_block != 2 && X.waves_per_block != 4 && X.waves_per_block != 8) return fail("waves_per_block");
+    if (X.stage_cap == 0 || X.stage_cap > 640) return fail("stage_cap");  // kernels.hpp: stage_cap <= 64 * STAGE_ITERS
+    if (L.wide_pack_width > 4096) return fail("wide_pack_width");
+    if (X.vars_per_bin == 0 || X.vars_per_bin > 65536 || (uint64_t)X.n_bins != (L.n_vars + X.vars_per_bin - 1) / X.vars_per_bin) return fail("vars_per_bin / n_bins");
+    if (L.n_slots >= (1ull << 32) || L.n_layers >= (1ull << 31) || L.n_vars >= (1ull << 31) || L.narrow_slots > L.n_slots) return fail("sizes");
+    // ---- array sizes
     if (L.layer_var.size() != L.n_layers || L.layer_bdd.size() != L.n_layers || L.var_layers.size() != L.n_layers ||
-        L.ex.lpos.size() != L.n_layers || L.ex.evar.size() != L.n_layers || L.ex.bvar.size() != L.n_layers || L.ex.vpos.size() != L.n_layers ||
+        X.lpos.size() != L.n_layers || X.evar.size() != L.n_layers || X.bvar.size() != L.n_layers || X.vpos.size() != L.n_layers ||
         L.num_bdds_per_var.size() != L.n_vars || L.var_ptr.size() != L.n_vars + 1 || L.bdd_root_slot.size() != L.n_bdds ||
-        L.ex.bin_ptr.size() != (size_t)L.ex.n_bins + 1) { why = "array sizes do not match the header"; return false; }
-    if (!mono_to(L.var_ptr, 0, L.n_layers, "var_ptr") || !mono_to(L.ex.bin_ptr, 0, L.n_layers, "bin_ptr")) return false;
+        X.bin_ptr.size() != (size_t)X.n_bins + 1) return fail("array sizes do not match the header");
+    if (L.nodes_per_hop.size() != L.n_hops || L.layers_per_hop.size() != L.n_hops) return fail("per-hop statistics do not have n_hops entries");
+    if (!mono_to(L.var_ptr, 0, L.n_layers, "var_ptr") || !mono_to(X.bin_ptr, 0, L.n_layers, "bin_ptr")) return false;
+    // ---- packs: offsets monotone and contiguous over the three sets, hops no wider than the set's pack width
     uint64_t slots = 0, layers = 0;
+    const uint32_t widths[3] = {L.pack_width, L.wide_pack_width, L.huge_pack_width};
+    int set = 0;
     for (const PackSet* ps : {&L.narrow, &L.wide, &L.huge}) {
-        const uint32_t P = ps->n_packs();
-        if (P == 0) continue;
-        if (ps->pack_steps.size() != P) { why = "pack_steps size"; return false; }
-        if (!mono_to(ps->pack_hop_ptr, 0, ps->hop_node_off.size() - 1, "pack_hop_ptr")) return false;
-        if (ps->hop_layer_off.size() != ps->hop_node_off.size()) { why = "hop offset sizes"; return false; }
+        const uint32_t P = ps->n_packs(), maxw = widths[set++];
+        if (P == 0) {
+            if (!ps->hop_node_off.empty() && ps->hop_node_off.size() != 1) return fail("hop records without packs");
+            continue;
+        }
+        if (ps->pack_steps.size() != P) return fail("pack_steps size");
+        if (ps->hop_node_off.empty() || !mono_to(ps->pack_hop_ptr, 0, ps->hop_node_off.size() - 1, "pack_hop_ptr")) return fail("pack_hop_ptr");
+        if (ps->hop_layer_off.size() != ps->hop_node_off.size()) return fail("hop offset sizes");
         if (!mono_to(ps->hop_node_off, slots, ps->hop_node_off.back(), "hop_node_off") ||
             !mono_to(ps->hop_layer_off, layers, ps->hop_layer_off.back(), "hop_layer_off")) return false;
+        for (size_t q = 0; q + 1 < ps->hop_node_off.size(); ++q)
+            if (ps->hop_node_off[q + 1] - ps->hop_node_off[q] > maxw || ps->hop_layer_off[q + 1] - ps->hop_layer_off[q] > maxw) return fail("hop wider than its pack");
         slots = ps->hop_node_off.back();
         layers = ps->hop_layer_off.back();
     }
-    if (slots != L.n_slots || layers != L.n_layers) { why = "pack offsets do not cover the slots / layers"; return false; }
-    for (uint32_t e : L.ex.lpos) if (e >= L.n_layers) { why = "lpos out of range"; return false; }
-    for (int32_t v : L.layer_var) if (v < 0 || (uint64_t)v >= L.n_vars) { why = "layer variable out of range"; return false; }
+    if (slots != L.n_slots || layers != L.n_layers) return fail("pack offsets do not cover the slots / layers");
+    if (L.narrow.n_packs() ? L.narrow.hop_node_off.back() != L.narrow_slots : L.narrow_slots != 0) return fail("narrow_slots");
+    // ---- per-layer / per-variable / per-entry index arrays
+    if (!all_below(X.lpos, L.n_layers, "lpos") || !all_below(X.vpos, L.n_layers, "vpos") || !all_below(L.var_layers, L.n_layers, "var_layers") ||
+        !all_below(X.evar, L.n_vars, "evar") || !all_below(X.bvar, X.vars_per_bin, "bvar") || !all_below(L.bdd_root_slot, L.n_slots, "bdd_root_slot")) return false;
+    for (int32_t v : L.layer_var) if (v < 0 || (uint64_t)v >= L.n_vars) return fail("layer variable out of range");
+    for (int32_t b : L.layer_bdd) if (b < 0 || (uint64_t)b >= L.n_bdds) return fail("layer BDD out of range");
+    for (int32_t c : L.num_bdds_per_var) if (c < 0) return fail("negative BDD count");
+    for (uint32_t b = 0; b < X.n_bins; ++b)  // an entry's variable lies in the bin that holds the entry
+        for (uint32_t e = X.bin_ptr[b]; e < X.bin_ptr[b + 1]; ++e)
+            if (X.evar[e] / X.vars_per_bin != b || X.evar[e] % X.vars_per_bin != X.bvar[e]) return fail("entry outside its variable's bin");
+    // ---- narrow packs: words, stage groups, cooperative staging, resident headers
     const uint32_t Pn = L.narrow.n_packs();
     if (Pn) {
-        if (L.narrow_word_off.size() != Pn || L.ex.pack_group_ptr.size() != (size_t)Pn + 1 || L.res.pack_hdr.size() != (size_t)Pn * 8) { why = "narrow pack tables"; return false; }
-        const uint32_t nl = L.narrow.hop_layer_off.back();
-        if (L.ex.cs_entry.size() != nl || L.ex.cs_slot.size() != nl) { why = "staging tables"; return false; }
-        if (!mono_to(L.ex.cs_ptr, 0, nl, "cs_ptr") || !mono_to(L.ex.quad_round_ptr, 0, L.ex.cs_ptr.size() - 1, "quad_round_ptr")) return false;
-        for (uint32_t e : L.ex.cs_entry) if (e >= L.n_layers) { why = "cs_entry out of range"; return false; }
+        const PackSet& N = L.narrow;
+        const uint32_t nl = N.hop_layer_off.back(), n_rec = (uint32_t)N.hop_node_off.size() - 1;
+        const uint32_t WPB = X.waves_per_block, n_quads = (Pn + WPB - 1) / WPB;
+        if (L.narrow_word_off.size() != Pn || X.pack_group_ptr.size() != (size_t)Pn + 1 || L.res.pack_hdr.size() != (size_t)Pn * 8 ||
+            L.res.quad_hdr.size() != (size_t)n_quads * 4 || X.quad_round_ptr.size() != (size_t)n_quads + 1) return fail("narrow pack tables");
+        if (X.cs_entry.size() != nl || X.cs_slot.size() != nl) return fail("staging tables");
+        if (X.cs_ptr.empty() || !mono_to(X.cs_ptr, 0, nl, "cs_ptr") || !mono_to(X.quad_round_ptr, 0, X.cs_ptr.size() - 1, "quad_round_ptr")) return fail("staging pointers");
+        for (size_t r = 0; r + 1 < X.cs_ptr.size(); ++r)
+            if (X.cs_ptr[r + 1] - X.cs_ptr[r] > 64u * WPB * 10u) return fail("staging round larger than a workgroup can hold");
+        if (!all_below(X.cs_entry, L.n_layers, "cs_entry") || !all_below(X.cs_slot, (uint64_t)WPB * X.stage_cap, "cs_slot")) return false;
+        const size_t G = X.grp_hop_end.size();
+        if (X.grp_layer_off.size() != G + 1 || !mono_to(X.pack_group_ptr, 0, G, "pack_group_ptr") || !mono_to(X.grp_layer_off, 0, nl, "grp_layer_off")) return fail("stage groups");
+        for (size_t g = 0; g < G; ++g)
+            if (X.grp_hop_end[g] > n_rec || X.grp_layer_off[g + 1] - X.grp_layer_off[g] > X.stage_cap) return fail("stage group out of range");
         for (uint32_t p = 0; p < Pn; ++p) {
-            const uint32_t s0 = L.narrow.hop_node_off[L.narrow.pack_hop_ptr[p]], s1 = L.narrow.hop_node_off[L.narrow.pack_hop_ptr[p + 1]];
-            if ((uint64_t)L.narrow_word_off[p] + (s1 - s0) > L.narrow_words_unique.size()) { why = "word offsets out of range"; return false; }
+            const uint32_t s0 = N.hop_node_off[N.pack_hop_ptr[p]], s1 = N.hop_node_off[N.pack_hop_ptr[p + 1]];
+            if ((uint64_t)L.narrow_word_off[p] + (s1 - s0) > L.narrow_words_unique.size()) return fail("word offsets out of range");
+            for (uint32_t g = X.pack_group_ptr[p]; g < X.pack_group_ptr[p + 1]; ++g)  // a pack's groups end inside the pack, in order
+                if (X.grp_hop_end[g] <= N.pack_hop_ptr[p] || X.grp_hop_end[g] > N.pack_hop_ptr[p + 1] || (g > X.pack_group_ptr[p] && X.grp_hop_end[g] < X.grp_hop_end[g - 1]))
+                    return fail("stage group outside its pack");
+        }
+        for (uint32_t w : L.narrow_words_unique)  // children index the W + 2 entries of the LDS frontier arrays
+            if ((w & NW_CHILD_MASK) > L.pack_width + 1 || ((w >> NW_CHILD_BITS) & NW_CHILD_MASK) > L.pack_width + 1) return fail("narrow node word: child out of range");
+        // the resident headers are functions of the tables above (layout.cpp): recompute and compare
+        uint32_t max_slots = 0, max_layers = 0;
+        for (uint32_t p = 0; p < Pn; ++p) {
+            const uint32_t q0 = N.pack_hop_ptr[p], q1 = N.pack_hop_ptr[p + 1];
+            const uint32_t want[8] = {N.hop_node_off[q0], N.hop_node_off[q1] - N.hop_node_off[q0], N.hop_layer_off[q0], N.hop_layer_off[q1] - N.hop_layer_off[q0], q0,
+                                      (q1 - q0) | ((uint32_t)N.pack_steps[p] << 16), L.narrow_word_off[p], 0};
+            if (q1 - q0 > 0xFFFFu || std::memcmp(want, &L.res.pack_hdr[(size_t)p * 8], sizeof(want)) != 0) return fail("resident pack header");
+            max_slots = std::max(max_slots, want[1]);
+            max_layers = std::max(max_layers, want[3]);
+            if (L.res.ok && (q1 - q0 > 63 || X.pack_group_ptr[p + 1] - X.pack_group_ptr[p] != 1)) return fail("resident sweeps flagged for a pack they cannot hold");
+        }
+        if (L.res.max_slots != max_slots || L.res.max_layers != max_layers) return fail("resident sizes");
+        for (uint32_t Q = 0; Q < n_quads; ++Q) {
+            const uint32_t r0 = X.quad_round_ptr[Q], r1 = X.quad_round_ptr[Q + 1];
+            const uint32_t want[4] = {r1 > r0 ? X.cs_ptr[r0] : 0, r1 > r0 ? X.cs_ptr[r0 + 1] - X.cs_ptr[r0] : 0, r1 - r0, 0};
+            if (std::memcmp(want, &L.res.quad_hdr[(size_t)Q * 4], sizeof(want)) != 0) return fail("resident workgroup header");
+            if (L.res.ok && r1 - r0 != 1) return fail("resident sweeps flagged for a workgroup with several rounds");
+        }
+    } else if (L.res.ok || !L.narrow_words_unique.empty()) {
+        return fail("narrow tables without narrow packs");
+    }
+    // ---- wide / huge packs: children and layer fields index arrays of the pack's width (+ 2 sink entries)
+    if (L.wide_words.size() != L.n_slots - L.narrow_slots) return fail("wide words");
+    {
+        size_t w0 = 0;
+        int k = 1;
+        for (const PackSet* ps : {&L.wide, &L.huge}) {
+            const uint32_t maxw = widths[k++];
+            if (ps->n_packs() == 0) continue;
+            const size_t w1 = w0 + (ps->hop_node_off.back() - ps->hop_node_off.front());
+            for (size_t i = w0; i < w1; ++i) {
+                const uint64_t w = L.wide_words[i], lo = w & WW_CHILD_MASK, hi = (w >> WW_CHILD_BITS) & WW_CHILD_MASK, ly = (w >> (2 * WW_CHILD_BITS)) & WW_CHILD_MASK;
+                if ((lo < WW_TOP && lo >= maxw) || (hi < WW_TOP && hi >= maxw) || ly >= maxw) return fail("wide node word out of range");
+            }
+            w0 = w1;
         }
     }
-    if (L.wide_words.size() != L.n_slots - L.narrow_slots) { why = "wide words"; return false; }
     return true;
 }
 }  // namespace
@@ -427,11 +542,18 @@ int bddmma_save(const bddmma_solver* s, const char* path)
         const uint64_t hdr[4] = {(uint64_t)b->precision, n_arrays, sizeof(LayoutScalars), sizeof(bddmma_options)};
         const LayoutScalars sc = layout_scalars(H);
         w(kMagic, 8); w(hdr, sizeof(hdr)); w(&sc, sizeof(sc)); w(&b->saved_opts, sizeof(bddmma_options));
+        Checksum cs;
+        cs.add(&sc, sizeof(sc));
+        cs.add(&b->saved_opts, sizeof(bddmma_options));
         visit_layout_arrays(H, [&](int id, auto& vec) {
             const uint64_t rec[3] = {(uint64_t)id, sizeof(vec[0]), vec.size()};
             w(rec, sizeof(rec));
             w(vec.data(), vec.size() * sizeof(vec[0]));
+            cs.add(rec, sizeof(rec));
+            cs.add(vec.data(), vec.size() * sizeof(vec[0]));
         });
+        const uint64_t sum = cs.value();
+        w(&sum, sizeof(sum));
         w(lo.data(), lo.size()); w(hi.data(), hi.size()); w(mm.data(), mm.size()); w(delta.data(), delta.size());
         fc.f = nullptr;
         ok = (std::fclose(f) == 0) && ok;
@@ -468,10 +590,14 @@ int bddmma_load(bddmma_solver** out, int device, const char* path)
         HostLayout H;
         set_layout_scalars(H, sc);
         bool bad = false;
+        Checksum cs;
+        cs.add(&sc, sizeof(sc));
+        cs.add(&opts, sizeof(opts));
         for (uint64_t a = 0; a < hdr[1] && ok && !bad; ++a) {
             uint64_t rec[3] = {0, 0, 0};
             r(rec, sizeof(rec));
             if (!ok) break;
+            cs.add(rec, sizeof(rec));
             // a count the rest of the file cannot hold means a truncated or corrupt record: refuse before allocating
             if (rec[1] == 0 || rec[1] > 8 || rec[2] > (file_size - (uint64_t)std::ftell(f)) / rec[1]) { bad = true; break; }
             bool found = false;
@@ -481,13 +607,23 @@ int bddmma_load(bddmma_solver** out, int device, const char* path)
                 if (sizeof(vec[0]) != rec[1]) { bad = true; return; }
                 vec.resize(rec[2]);
                 r(vec.data(), rec[2] * rec[1]);
+                if (ok) cs.add(vec.data(), rec[2] * rec[1]);
             });
             if (!found) bad = true;
         }
         std::string why;
+        if (ok && !bad) {
+            uint64_t sum = 0;
+            r(&sum, sizeof(sum));
+            if (ok && sum != cs.value()) { bad = true; why = "layout checksum mismatch"; }
+        }
         if (!ok || bad || !layout_plausible(H, why)) {
             g_err = "corrupt or truncated checkpoint" + (why.empty() ? std::string() : " (" + why + ")");
             return BDDMMA_ERR_IO;
+        }
+        {   // the cost section must be complete before a device is touched
+            const uint64_t Rb = hdr[0] == (uint64_t)BDDMMA_F64 ? 8 : 4, need = (3 * H.n_layers + 2 * H.n_vars) * Rb;
+            if (file_size - (uint64_t)std::ftell(f) < need) { g_err = "corrupt or truncated checkpoint (cost section incomplete)"; return BDDMMA_ERR_IO; }
         }
         int rc = create_solver(&impl, (int)hdr[0], device, H, &opts, g_err);
         if (rc) return rc;

@@ -2015,12 +2015,39 @@ constexpr int EXM_UNROLL = 12;
 constexpr int EXM_NPT = 8;
 constexpr uint32_t EXM_MAX_VARS_PER_BIN = EXM_THREADS * EXM_NPT / 2;
 
-// (A version of this kernel with scalar-offset entry addressing — descriptors ending at the bin's last entry, no per-lane offset
-// selects — and one predicated atomic per entry was 4-16 % faster on small instances and passed every serial test, but with several
-// processes sharing the GPU (pytest -n 4) about 1 % of the differential fuzz runs came out with 1e-7 errors; the cause was not found
-// (buffer range checks with the scalar offset at or beyond the descriptor's end are reliable in isolation and under the same load,
-// tools/rangestress.hip), so the kernel stays as it was.)
-template <typename REAL, typename ACC, int MODE, int EX_THREADS, int EX_UNROLL, int NPT>
+// (Round 2 shelved a version of this kernel with scalar-offset entry addressing and one predicated atomic per entry because about 1 % of the
+// differential fuzz runs came out with 1e-7 errors when several processes shared the GPU.  Root cause, found in round 3 by bisecting the
+// rewrite's three ingredients (EXV_* below) under that load: a hardware write-data hazard of 16-byte buffer stores with an SGPR soffset that
+// the compiler does not guard — see hop_store(double2) and profiles/r03_exchange_variant_rootcause.txt.  The entry LOADS by scalar offset,
+// the idiom the narrow sweeps use, were never involved.)
+// pair stores with the chunk's first entry in the scalar offset (EXV_SOFF_STORES below)
+__device__ __forceinline__ void hop_store(float2 v, rsrc_t rh, uint32_t voff, uint32_t soff)
+{
+    using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(rh, 0, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rh, voff, soff, BDDMMA_ST_AUX);
+}
+// 16-byte store with an SGPR soffset: on gfx950 a VMEM store of more than 64 bits needs one wait state before a VALU instruction
+// overwrites its data registers — also when soffset is an SGPR, which the ISA manuals exempt and the compiler therefore does not pad
+// (LLVM GCNHazardRecognizer::createsVALUHazard).  Without the s_nop 1.1 % of such pairs store the overwritten first dword
+// (tools/store_hazard.hip, profiles/r03_exchange_variant_rootcause.txt): this was the round-2 exchange rewrite's "rare 1e-7 error".
+// -DBDDMMA_REPRODUCE_STORE_HAZARD builds without it (tools/build_variant.sh), for the record only; tests/test_isa_lint.py checks the
+// built library for unpadded pairs.
+__device__ __forceinline__ void hop_store(double2 v, rsrc_t rh, uint32_t voff, uint32_t soff)
+{
+    using u4 = decltype(__builtin_amdgcn_raw_buffer_load_b128(rh, 0, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rh, voff, soff, 0);
+#ifndef BDDMMA_REPRODUCE_STORE_HAZARD
+    asm volatile("s_nop 0" ::: "memory");
+#endif
+}
+// VAR: the three ingredients of the round-2 rewrite that was shelved (see the note above), separately switchable so that the rare
+// multi-process discrepancy can be bisected (bddmma_options.variant_flags bits 3-5, 256-thread instantiation only; profiles/r03_exchange_variant_soak.txt):
+enum : int {
+    EXV_SOFF_LOADS = 1,    // entry loads: lane offset tid * size, chunk start in the scalar offset, descriptor ends at the bin's last entry
+    EXV_SOFF_STORES = 2,   // the pair broadcast addressed the same way
+    EXV_ONE_ATOMIC = 4,    // one predicated LDS atomic per entry (slot 2 v + [mm > 0], value |mm|) instead of two branches around two atomics
+};
+template <typename REAL, typename ACC, int MODE, int EX_THREADS, int EX_UNROLL, int NPT, int VAR = 0>
 __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
                                                      const uint16_t* __restrict__ bvar, const int32_t* __restrict__ nbdds,
                                                      REAL* __restrict__ delta_var, REAL* __restrict__ delta_lay,
@@ -2033,17 +2060,25 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
     const uint32_t v0 = b * vars_per_bin;
     const uint32_t nv = min(vars_per_bin, n_vars - v0);
     const uint32_t e0 = bin_ptr[b], e1 = bin_ptr[b + 1];
-    const rsrc_t rmm = make_rsrc(mm_binned, n_entries), rev = make_rsrc(bvar, n_entries);
+    constexpr bool SOFF_L = (VAR & EXV_SOFF_LOADS) != 0, SOFF_S = (VAR & EXV_SOFF_STORES) != 0, ONE_ATOMIC = (VAR & EXV_ONE_ATOMIC) != 0;
+    const rsrc_t rmm = make_rsrc(mm_binned, SOFF_L ? e1 : n_entries), rev = make_rsrc(bvar, SOFF_L ? e1 : n_entries);
     const rsrc_t rnb = make_rsrc(nbdds, n_vars);
+    const uint32_t vo_m = tid * (uint32_t)sizeof(REAL), vo_v = tid * 2u, vo_p = tid * (uint32_t)sizeof(P2);
     const bool one_chunk = (e1 - e0) <= EX_THREADS * EX_UNROLL;
     // first chunk: every load of the workgroup is issued before anything is consumed
     REAL m[EX_UNROLL];
     uint32_t lv[EX_UNROLL];
 #pragma unroll
     for (int u = 0; u < EX_UNROLL; ++u) {
-        const uint32_t e = e0 + tid + u * EX_THREADS;
-        bload(m[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);  // out of range: 0 -> no contribution
-        lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
+        if (SOFF_L) {
+            const uint32_t es = e0 + u * EX_THREADS;  // uniform
+            hop_load(m[u], rmm, vo_m, es * (uint32_t)sizeof(REAL));  // past the bin: 0 -> no contribution
+            lv[u] = __builtin_amdgcn_raw_buffer_load_b16(rev, vo_v, es * 2u, 0);
+        } else {
+            const uint32_t e = e0 + tid + u * EX_THREADS;
+            bload(m[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);  // out of range: 0 -> no contribution
+            lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
+        }
     }
     // number of BDDs of the variables this thread normalises (needed only after the accumulation)
     int nb[NPT];
@@ -2061,16 +2096,28 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
     auto load_chunk = [&](REAL (&mm_)[EX_UNROLL], uint32_t (&lv_)[EX_UNROLL], uint32_t start) {
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
-            const uint32_t e = start + tid + u * EX_THREADS;
-            bload(mm_[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
-            lv_[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
+            if (SOFF_L) {
+                const uint32_t es = start + u * EX_THREADS;
+                hop_load(mm_[u], rmm, vo_m, es * (uint32_t)sizeof(REAL));
+                lv_[u] = __builtin_amdgcn_raw_buffer_load_b16(rev, vo_v, es * 2u, 0);
+            } else {
+                const uint32_t e = start + tid + u * EX_THREADS;
+                bload(mm_[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
+                lv_[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
+            }
         }
     };
     auto accumulate = [&](const REAL (&mm_)[EX_UNROLL], const uint32_t (&lv_)[EX_UNROLL]) {
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
-            if (mm_[u] > 0) lds_add(&tile[2 * lv_[u] + 1], ACC(mm_[u]));
-            else if (mm_[u] < 0) lds_add(&tile[2 * lv_[u]], ACC(-mm_[u]));
+            if (ONE_ATOMIC) {
+                const REAL mv = mm_[u];
+                const uint32_t slot = 2 * lv_[u] + (mv > 0 ? 1u : 0u);
+                if (mv != 0) lds_add(&tile[slot], ACC(mv > 0 ? mv : -mv));
+            } else {
+                if (mm_[u] > 0) lds_add(&tile[2 * lv_[u] + 1], ACC(mm_[u]));
+                else if (mm_[u] < 0) lds_add(&tile[2 * lv_[u]], ACC(-mm_[u]));
+            }
         }
     };
     {
@@ -2110,22 +2157,24 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
     }
     if (MODE != EX_ITER) return;
     __syncthreads();
-    const rsrc_t rdl = make_rsrc(delta_lay, 2ull * n_entries);
+    const rsrc_t rdl = make_rsrc(delta_lay, 2ull * (SOFF_S ? e1 : n_entries));
 #pragma unroll
     for (int u = 0; u < EX_UNROLL; ++u) {  // first chunk: the local variable indices are still in registers
         const uint32_t e = e0 + tid + u * EX_THREADS;
         P2 pr;
         pr.x = REAL(tile[2 * lv[u]]);
         pr.y = REAL(tile[2 * lv[u] + 1]);
-        bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
+        if (SOFF_S) hop_store(pr, rdl, vo_p, (e0 + u * EX_THREADS) * (uint32_t)sizeof(P2));
+        else bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
     }
     if (one_chunk) return;
-    for (uint32_t base = e0 + EX_THREADS * EX_UNROLL + tid; base < e1; base += EX_THREADS * EX_UNROLL) {
+    for (uint32_t base = e0 + EX_THREADS * EX_UNROLL + tid; (SOFF_L || SOFF_S) ? base - tid < e1 : base < e1; base += EX_THREADS * EX_UNROLL) {
         uint32_t lv2[EX_UNROLL];
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
             const uint32_t e = base + u * EX_THREADS;
-            lv2[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
+            if (SOFF_L) lv2[u] = __builtin_amdgcn_raw_buffer_load_b16(rev, vo_v, (e - tid) * 2u, 0);
+            else lv2[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
         }
 #pragma unroll
         for (int u = 0; u < EX_UNROLL; ++u) {
@@ -2133,7 +2182,8 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
             P2 pr;
             pr.x = REAL(tile[2 * lv2[u]]);
             pr.y = REAL(tile[2 * lv2[u] + 1]);
-            bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
+            if (SOFF_S) hop_store(pr, rdl, vo_p, (e - tid) * (uint32_t)sizeof(P2));
+            else bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
         }
     }
 }
@@ -2143,7 +2193,7 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
 // behind the body, where no register of the exchange is live any more (the 1024-thread double instantiation sits at its 128-VGPR limit).
 // RUN = false is the kernel every other caller launches: `stop` and `run` are not looked at, the code is the body alone.
 template <typename REAL, typename ACC, int MODE, int EX_THREADS = bddmma::EX_THREADS, int EX_UNROLL = bddmma::EX_UNROLL, int NPT = bddmma::EX_NPT,
-          bool RUN = false>
+          bool RUN = false, int VAR = 0>
 __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
                                                                   const uint16_t* __restrict__ bvar, const int32_t* __restrict__ nbdds,
                                                                   REAL* __restrict__ delta_var, REAL* __restrict__ delta_lay,
@@ -2151,8 +2201,8 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
                                                                   RunGate gate = RunGate{}, RunStep run = RunStep{})
 {
     if (RUN && run_stopped(gate)) return;
-    exchange_reduce_body<REAL, ACC, MODE, EX_THREADS, EX_UNROLL, NPT>(mm_binned, bin_ptr, bvar, nbdds, delta_var, delta_lay, vars_per_bin, n_vars,
-                                                                       n_entries);
+    exchange_reduce_body<REAL, ACC, MODE, EX_THREADS, EX_UNROLL, NPT, VAR>(mm_binned, bin_ptr, bvar, nbdds, delta_var, delta_lay, vars_per_bin, n_vars,
+                                                                            n_entries);
     if (RUN && run.ctl != nullptr && blockIdx.x == 0) {  // uniform
         __syncthreads();
         run_ctl_step(run);

@@ -16,7 +16,7 @@ from bdd_amd.instances import GRID_3X3, LONG_CHAIN, SHORT_CHAIN, assignment_ilp,
 from bdd_amd.solver import bdd_hip_lbfgs, bdd_hip_parallel_mma, run_solver
 from oracle.oracle import Oracle
 from test_oracle_kat import SIMPLEX_KATS
-from util import FULLSIZE, GOLDEN, load_golden, pad_costs, suffix
+from util import FULLSIZE, GOLDEN, load_golden, pad_costs, suffix, Checksum as _Checksum, parse_checkpoint as _parse_checkpoint, write_checkpoint as _write_checkpoint, CHECKPOINT_ARRAY_IDS
 
 pytestmark = pytest.mark.gpu
 
@@ -381,6 +381,70 @@ def test_checkpoint_holds_the_layout_and_rejects_corrupt_files():
                 assert np.isfinite(u.lower_bound()) or True
 
 
+def test_checkpoint_index_arrays_are_validated_not_only_checksummed():
+    """a file with a matching header must not reach the kernels (or the host-side copies) with indices, offsets or sizes
+    outside their targets.  Every case below carries a CORRECT checksum, so it is the index validation that has to refuse it."""
+    from bdd_amd import capi
+    col, costs = random_set_cover(600, 500, 6, seed=4)
+    s = bdd_hip_parallel_mma(col, costs, precision="double", waves_per_block=2)
+    s.iterations(3)
+    ids = CHECKPOINT_ARRAY_IDS
+    with tempfile.TemporaryDirectory() as td:
+        path, bad = os.path.join(td, "solver.bin"), os.path.join(td, "bad.bin")
+        s.save(path)
+        raw = open(path, "rb").read()
+        head, sc, opts, recs, stored, tail = _parse_checkpoint(raw)
+        cs = _Checksum(); cs.add(sc); cs.add(opts)
+        for i, es, cnt, data in recs:
+            cs.add(i.to_bytes(8, "little") + es.to_bytes(8, "little") + cnt.to_bytes(8, "little")); cs.add(data)
+        assert cs.value() == stored                                     # the Python restatement of the checksum matches the library's
+        _write_checkpoint(bad, head, sc, opts, recs, tail)              # ... and a rewritten, unmodified file loads
+        assert bdd_hip_parallel_mma.load(bad).lower_bound() == s.lower_bound()
+        # a flipped byte anywhere in the layout section is caught by the checksum
+        b2 = bytearray(raw); b2[len(raw) // 3] ^= 0x40
+        open(bad, "wb").write(bytes(b2))
+        with pytest.raises(capi.BddMmaError, match="checksum|corrupt"):
+            bdd_hip_parallel_mma.load(bad)
+
+        def poke(name, index, value, dtype):
+            out = []
+            for i, es, cnt, data in recs:
+                if i == ids[name]:
+                    a = np.frombuffer(data, dtype=dtype).copy()
+                    a[index] = value
+                    data = a.tobytes()
+                out.append([i, es, cnt, data])
+            return out
+        n_layers, n_vars = s.nr_layers(), s.nr_variables()
+        cases = [
+            poke("evar", 7, n_vars + 3, np.uint32), poke("bvar", 5, 60000, np.uint16), poke("lpos", 0, n_layers, np.uint32),
+            poke("vpos", 3, 2**31, np.uint32), poke("var_layers", 9, n_layers + 1, np.uint32), poke("layer_var", 2, -1, np.int32),
+            poke("bdd_root_slot", 1, 2**32 - 1, np.uint32), poke("cs_entry", 4, n_layers, np.uint32), poke("cs_slot", 4, 65000, np.uint16),
+            poke("pack_hdr", 1, 10**6, np.uint32), poke("pack_hdr", 6, 2**31, np.uint32), poke("quad_hdr", 1, 10**6, np.uint32),
+            poke("grp_hop_end", 0, 2**30, np.uint32), poke("grp_layer_off", 1, 2**30, np.uint32), poke("num_bdds_per_var", 0, -5, np.int32),
+            poke("narrow_words", 0, 0x1FF | (0x1FF << 9), np.uint32),       # children 511: outside the LDS frontier of a 128-slot pack
+        ]
+        # per-hop statistics one entry short: bddmma_layers_per_hop copies size() elements into a caller buffer of n_hops
+        short = []
+        for i, es, cnt, data in recs:
+            if i == ids["layers_per_hop"]:
+                cnt, data = cnt - 1, data[:-8]
+            short.append([i, es, cnt, data])
+        cases.append(short)
+        # scalars: pack_width 100, waves_per_block 3, stage_cap 0
+        sc_cases = []
+        for off, val in ((56, 100), (56 + 16 + 12, 3), (56 + 16 + 8, 0)):
+            b = bytearray(sc); b[off:off + 4] = int(val).to_bytes(4, "little"); sc_cases.append(bytes(b))
+        for k, r in enumerate(cases):
+            _write_checkpoint(bad, head, sc, opts, r, tail)
+            with pytest.raises(capi.BddMmaError, match="corrupt"):
+                bdd_hip_parallel_mma.load(bad)
+        for b in sc_cases:
+            _write_checkpoint(bad, head, b, opts, recs, tail)
+            with pytest.raises(capi.BddMmaError, match="corrupt"):
+                bdd_hip_parallel_mma.load(bad)
+
+
 def test_run_solver_and_lbfgs():
     col, costs = random_set_cover(3000, 2500, 8, seed=13)
     s = bdd_hip_parallel_mma(col, costs, precision="double")
@@ -671,7 +735,8 @@ def test_randomised_instances_and_layout_options_vs_oracle(seed):
     opts = dict(pack_width=pw, waves_per_block=wpb, stage_cap=max(cap, pw), vars_per_bin=int(rng.choice([0, 64, 256])),
                 wide_pack_width=int(rng.choice([0, 64])), keep_bdd_order=bool(rng.integers(0, 2)),
                 resident_sweeps=int(rng.choice([0, 1, 2])), exchange_by_variable=int(rng.choice([0, 0, 2])),
-                variant_flags=int(rng.choice([0, 0, 1, 2, 3])), pack_fill=int(rng.choice([0, 0, pw // 2, 16])))
+                variant_flags=int(rng.choice([0, 0, 1, 2, 3])) | int(os.environ.get("BDDMMA_FUZZ_VARIANT_OR", "0")),  # the env: tools/soak.sh bisections
+                pack_fill=int(rng.choice([0, 0, pw // 2, 16])))
     s = bdd_hip_parallel_mma(col, costs, precision="double", **opts)
     o = Oracle(col, costs, "double")
     assert abs(s.lower_bound() - o.lower_bound()) <= 1e-9 * max(1.0, abs(o.lower_bound())), opts
