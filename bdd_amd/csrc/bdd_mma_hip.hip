@@ -77,6 +77,8 @@ struct SolverT final : SolverBase {
     uint32_t run_iter = 0;                            // index of the iteration being queued by run_plain() (kernels.hpp: DevPtrs::run_iter)
     RunGate gate() const { return RunGate{run_stop, run_iter}; }
     RunStep run_step{};                               // {partials, count, ctl, host}: what the launch that ends an iteration gets
+    REAL* d_mm_layer = nullptr;   // deferred min-marginal differences in layer order, written by the backward solve sweeps once an L-BFGS wrapper uses them
+    bool mm_layer_valid = false;  // equal to d_mm_binned (permuted): true after a backward solve sweep, false after anything else that writes the deferred values
     uint32_t* d_counts = nullptr;
     REAL *d_tmp0 = nullptr, *d_tmp1 = nullptr;        // per-layer scratch (min-marginals, sorted outputs)
     char* d_sol = nullptr;
@@ -367,6 +369,7 @@ struct SolverT final : SolverBase {
         d.n_slots = (uint32_t)n_slots; d.n_layers = (uint32_t)n_layers; d.n_narrow_layers = n_narrow_layers;
         d.lb_partial = d_lb_partial;
         d.mm0_out = d_tmp0; d.mm1_out = d_tmp1; d.sol_out = d_sol;
+        d.mm_layer = d_mm_layer;  // nullptr until an L-BFGS wrapper asks for it (lbfgs_views)
         d.stop = run_stop;
         d.run_iter = run_iter;
         return d;
@@ -638,6 +641,7 @@ struct SolverT final : SolverBase {
         int rc;
         if (!bwd_valid && (rc = backward_run())) return rc;  // bdd_cuda_parallel_mma.cu:211-212
         rc = launch_fwd<FWD_SOLVE>(delta_lay, omega, BDDMMA_K_FORWARD_MM);
+        mm_layer_valid = false;  // the forward sweep rewrites the deferred values by entry only
         if (rc) return rc;
         fwd_valid = true;
         bwd_valid = false;
@@ -651,6 +655,7 @@ struct SolverT final : SolverBase {
         }
         int rc = launch_bwd<BWD_SOLVE>(delta_lay, omega, BDDMMA_K_BACKWARD_MM);
         if (rc) return rc;
+        mm_layer_valid = d_mm_layer != nullptr;
         fwd_valid = false;
         bwd_valid = true;
         return BDDMMA_OK;
@@ -811,6 +816,7 @@ struct SolverT final : SolverBase {
     {
         HIPCHK(hipSetDevice(device));
         hipLaunchKernelGGL((k_distribute_delta<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lo, d_hi, d_mm_binned, d_lpos, (uint32_t)n_layers);
+        mm_layer_valid = false;
         HIPCHK(hipMemsetAsync(d_delta_var, 0, 2 * n_vars * sizeof(REAL), stream));  // bdd_cuda_base.cu:1428
         HIPCHK(hipMemsetAsync(d_delta_lay, 0, 2 * n_layers * sizeof(REAL), stream));
         delta_var_valid = true;
@@ -924,6 +930,7 @@ struct SolverT final : SolverBase {
             hipLaunchKernelGGL((k_strided_copy<REAL>), g, b, 0, stream, d_hi, 2u, (const REAL*)d_tmp0, 1u, (uint32_t)n_layers);
         }
         if (mm) {
+            mm_layer_valid = false;
             HIPCHK(hipMemcpyAsync(d_tmp0, mm, n_layers * sizeof(REAL), k, stream));
             hipLaunchKernelGGL((k_layers_to_entries<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_tmp0, d_lpos, d_mm_binned, (uint32_t)n_layers);
         }
@@ -1008,6 +1015,33 @@ struct SolverT final : SolverBase {
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         (void)hipFree(s);
         HIPCHK(e);
+        return BDDMMA_OK;
+    }
+    int bdds_solution_async(char* dev_out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        int rc;
+        if ((rc = backward_run())) return rc;
+        HIPCHK(hipMemsetAsync(dev_out, 0, n_layers, stream));
+        char* const own = d_sol;
+        d_sol = dev_out;  // ptrs() hands d_sol to the sweep
+        rc = launch_fwd<FWD_SOLUTION>(nullptr, REAL(0), BDDMMA_K_OTHER);
+        d_sol = own;
+        if (rc) return rc;
+        fwd_valid = true;
+        return BDDMMA_OK;
+    }
+    int lbfgs_views(LbfgsViews* out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        int rc;
+        if (!d_mm_layer && (rc = dalloc(&d_mm_layer, n_layers))) return rc;
+        if (!mm_layer_valid) {
+            hipLaunchKernelGGL((k_entries_to_layers<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_mm_binned, d_lpos, d_mm_layer, (uint32_t)n_layers);
+            HIPCHK(hipGetLastError());
+            mm_layer_valid = true;
+        }
+        *out = LbfgsViews{d_lohi, d_mm_layer};
         return BDDMMA_OK;
     }
     int net_solver_costs(void* out, int on_device) override
@@ -1150,6 +1184,7 @@ struct SolverT final : SolverBase {
         HIPCHK(hipEventElapsedTime(&f, ev_t0, ev_t1));
         *ms = f;
         fwd_valid = bwd_valid = false;
+        mm_layer_valid = false;
         return BDDMMA_OK;
     }
 };

@@ -48,6 +48,7 @@ struct DevPtrs {
     uint32_t n_layers;
     uint32_t n_narrow_layers;
     double* lb_partial;      // per pack (narrow packs first, then wide)
+    REAL* mm_layer;          // BWD_SOLVE: the min-marginal differences also in layer order (nullptr: not wanted; SolverT::lbfgs_views)
     REAL* mm0_out;           // BWD_MARGINALS outputs, per layer
     REAL* mm1_out;
     char* sol_out;           // FWD_SOLUTION output, per layer
@@ -985,6 +986,16 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
         if (MODE == BWD_SOLVE) {
             if (WPB > 1) __syncthreads(); else wave_sync();
             stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
+            if (d.mm_layer != nullptr && k < ng) {  // uniform per wave: this wave's group occupies the layers [gl0, next group) and its own LDS slots
+                const uint32_t nlay = pk.grp_layer_off[g0 + k + 1] - gl0;
+                const rsrc_t rml = make_rsrc(d.mm_layer, d.n_layers);
+#pragma unroll
+                for (int u = 0; u < STAGE_ITERS; ++u) {  // straight-line: the LDS reads and the stores of all slices are independent
+                    const uint32_t j = lane + 64u * u;
+                    const REAL mv = sDw[j < nlay ? j : 0].x;
+                    bstore(mv, rml, j < nlay ? (gl0 + j) * (uint32_t)sizeof(REAL) : OOB);
+                }
+            }
             if (WPB > 1) __syncthreads();
         }
     }
@@ -1244,6 +1255,8 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev p
     if (WPB > 1) __syncthreads(); else wave_sync();
     stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
     if (!has_pack) return;
+    if (d.mm_layer != nullptr)
+        for (uint32_t j = lane; j < nlayers; j += 64) d.mm_layer[layer0 + j] = sDw[j].x;
     // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251)
     const uint32_t n0 = __builtin_amdgcn_readfirstlane(sOffN[1]);
     double sum = 0.0;
@@ -1444,6 +1457,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
                     d.lohi[2 * (size_t)(lbase + l)] = nlo;
                     d.lohi[2 * (size_t)(lbase + l) + 1] = nhi;
                     d.mm_binned[e] = mm;
+                    if (d.mm_layer != nullptr) d.mm_layer[lbase + l] = mm;
                 }
             } else {
                 t = rmin(th + s.hc[l], tl + s.lc[l]);
@@ -1851,6 +1865,7 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
                 nc.y = nhi;
                 bstore(nc, rs.lohi, head ? (lb + l) * (uint32_t)sizeof(P2) : OOB);
                 bstore(mm, rs.mm, head ? E0[i] * (uint32_t)sizeof(REAL) : OOB);
+                if (d.mm_layer != nullptr && head) d.mm_layer[lb + l] = mm;
             } else {
                 t = rmin(th[i] + C0[i].y, tl[i] + C0[i].x);  // backward_step, bdd_cuda_base.cu:646-667
                 if (MODE == BWD_MARGINALS && head) {

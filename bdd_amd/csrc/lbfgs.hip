@@ -12,8 +12,11 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/bdd_mma.h"
@@ -250,6 +253,396 @@ static __global__ void k_store_iterate(const REAL* __restrict__ cur_x, REAL* __r
     }
 }
 
+
+// =================================================================================================================================
+// Gram-matrix ("vector-free") form of compute_update_direction (round 3; Chen et al., "Large-scale L-BFGS using MapReduce", 2014)
+// =================================================================================================================================
+// The direction of lbfgs_impl.h:226-316 is always  q = g + sum_p cy[p] y_p + sum_p cs[p] s_p , so the two loops can run on the
+// COEFFICIENTS once the dot products among {s_p, y_p, g} are known:  <s_i, q> = Sg[i] + sum cy[r] SY[i][r] + sum cs[r] SS[i][r]  etc.
+// The two-loop recursion as vector passes is 2 m dependent (dot -> coefficient -> axpy) launches over nr_layers-sized vectors (13
+// launches, ~325 us of a ~580 us iteration at 10.5 M nodes); here an iteration makes TWO passes over the history:
+//   k_lb_store_gram : store_iterate (x = hi - lo + deferred mm formed in place — the mm in layer order come from the backward sweep itself,
+//                     SolverT::lbfgs_views —, s = x - x_prev, y = g_prev - g, prev <- cur) fused
+//                     with every dot product the new pair and the new g add to the Gram matrices (6 per kept pair + 5);
+//   k_lb_finalize   : one workgroup: sums the partial dots in a fixed order (deterministic), applies the curvature filter
+//                     rho_inv > 1e-8 (:112) and the ring update ON THE DEVICE (no host round trip for rho_inv), runs the two loops
+//                     on the coefficients;
+//   k_lb_direction  : q = g + sum cy y + sum cs s in one pass (accumulated in double, rounded to REAL once).
+// The Gram entries between kept pairs are computed once, when a pair is stored, and stay valid while both are kept.
+// Physical slots: LB_P = LB_MAXS + 1 (one spare that receives the new pair); `order` lists the kept slots, oldest first.
+constexpr int LB_MAXS = 8;           // history sizes of the fused path (larger ones take the two-loop path below)
+constexpr int LB_P = LB_MAXS + 1;
+constexpr int LB_BLOCKS = 768;       // workgroups of the store pass = partial sums per dot product (3 per CU: all resident at once, one epilogue each)
+struct LbDev {                       // device memory
+    double SS[LB_P][LB_P], SY[LB_P][LB_P], YY[LB_P][LB_P];  // SY[a][b] = <s_a, y_b>; SY[a][a] = rho_inv of pair a
+    double Sg[LB_P], Yg[LB_P];                                // products with the current subgradient
+    double cy[LB_P], cs[LB_P];                                // coefficients of the direction, by physical slot
+    double rho_inv_new;
+    uint32_t order[LB_P];
+    uint32_t count, free_slot, prev_stored, accepted, have_dir, pad_;
+};
+struct LbHost {                      // pinned host memory: what the host reads (only while the history fills up, and for diagnostics)
+    double rho_inv_new;
+    uint32_t count, prev_stored, accepted, have_dir;
+    uint64_t seq;
+};
+__host__ __device__ constexpr int lb_ndots(int ns) { return 6 * ns + 5; }
+
+// Four consecutive elements per thread and trip: 16-byte loads of the REAL vectors, 4-byte loads of the char vectors (one byte per
+// lane and instruction made the char streams — y of every kept pair, g, g_prev — cost as many load instructions as the REAL ones for a
+// quarter of the bytes).  `slot` = elements between two slots of S / Y (a multiple of 64, so every slot is 16-byte aligned).
+template <typename T>
+__device__ __forceinline__ void ld4(T (&v)[4], const T* p)
+{
+    if (sizeof(T) == 4) {
+        const uint4 x = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(T, (typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type)w[i]);
+    } else {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(p), b2 = *(reinterpret_cast<const ulonglong2*>(p) + 1);
+        const uint64_t w[4] = {a.x, a.y, b2.x, b2.y};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(T, (typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type)w[i]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void st4(T* p, const T (&v)[4])
+{
+    if (sizeof(T) == 4) {
+        uint4 x;
+        x.x = __builtin_bit_cast(uint32_t, (typename std::conditional<sizeof(T) == 4, T, float>::type)v[0]);
+        x.y = __builtin_bit_cast(uint32_t, (typename std::conditional<sizeof(T) == 4, T, float>::type)v[1]);
+        x.z = __builtin_bit_cast(uint32_t, (typename std::conditional<sizeof(T) == 4, T, float>::type)v[2]);
+        x.w = __builtin_bit_cast(uint32_t, (typename std::conditional<sizeof(T) == 4, T, float>::type)v[3]);
+        *reinterpret_cast<uint4*>(p) = x;
+    } else {
+        ulonglong2 a, b2;
+        a.x = __builtin_bit_cast(uint64_t, (typename std::conditional<sizeof(T) == 8, T, double>::type)v[0]);
+        a.y = __builtin_bit_cast(uint64_t, (typename std::conditional<sizeof(T) == 8, T, double>::type)v[1]);
+        b2.x = __builtin_bit_cast(uint64_t, (typename std::conditional<sizeof(T) == 8, T, double>::type)v[2]);
+        b2.y = __builtin_bit_cast(uint64_t, (typename std::conditional<sizeof(T) == 8, T, double>::type)v[3]);
+        *reinterpret_cast<ulonglong2*>(p) = a;
+        *(reinterpret_cast<ulonglong2*>(p) + 1) = b2;
+    }
+}
+__device__ __forceinline__ void ldc4(char (&v)[4], const char* p)
+{
+    const uint32_t x = *reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (char)(signed char)((x >> (8 * i)) & 0xFFu);
+}
+__device__ __forceinline__ void stc4(char* p, const char (&v)[4])
+{
+    uint32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x |= (uint32_t)(unsigned char)v[i] << (8 * i);
+    *reinterpret_cast<uint32_t*>(p) = x;
+}
+
+template <typename REAL, int NS>
+static __global__ void __launch_bounds__(256) k_lb_store_gram(const REAL* __restrict__ lohi, const REAL* __restrict__ mm_layer,
+                                                              REAL* __restrict__ prev_x, const char* __restrict__ cur_g, char* __restrict__ prev_g,
+                                                              REAL* __restrict__ S, char* __restrict__ Y, size_t slot, const LbDev* __restrict__ st,
+                                                              double* __restrict__ partial, uint32_t n)
+{
+    constexpr int ND = lb_ndots(NS);
+    constexpr int NK = NS > 0 ? NS : 1;
+    __shared__ double red[ND][4];
+    const bool have_prev = st->prev_stored != 0;   // uniform
+    const uint32_t w = st->free_slot;
+    REAL* const sw = S + (size_t)w * slot;
+    char* const yw = Y + (size_t)w * slot;
+    const REAL* sk[NK];
+    const char* yk[NK];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const uint32_t p = st->order[k];
+        sk[k] = S + (size_t)p * slot;
+        yk[k] = Y + (size_t)p * slot;
+    }
+    double acc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) acc[d] = 0.0;
+    // one element: x = hi - lo + mm (k_net_costs), s = x - x_prev, y = g_prev - g (lbfgs_impl.h:81,100), and the products
+    auto element = [&](const REAL lo, const REAL hi, const REAL mmv, const char g, const REAL xp, const char gp, const REAL (&sv_)[NK], const char (&yv_)[NK],
+                       REAL& x_out, REAL& s_out, char& y_out) {
+        const REAL x = (hi - lo) + mmv;
+        const REAL sv = REAL(x - xp);
+        const char yv = (char)(gp - g);
+        x_out = x; s_out = sv; y_out = yv;
+        const double ds = have_prev ? (double)sv : 0.0, dy = have_prev ? (double)yv : 0.0, dg = (double)g;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const double a = (double)sv_[k], b = (double)yv_[k];
+            acc[6 * k + 0] += ds * a;
+            acc[6 * k + 1] += ds * b;
+            acc[6 * k + 2] += a * dy;
+            acc[6 * k + 3] += dy * b;
+            acc[6 * k + 4] += a * dg;
+            acc[6 * k + 5] += b * dg;
+        }
+        acc[6 * NS + 0] += ds * ds;
+        acc[6 * NS + 1] += ds * dy;
+        acc[6 * NS + 2] += dy * dy;
+        acc[6 * NS + 3] += ds * dg;
+        acc[6 * NS + 4] += dy * dg;
+    };
+    const uint64_t n4 = n / 4, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n4; c += stride) {
+        const uint64_t j = 4 * c;
+        REAL c0[4], c1[4], mmv[4], xp[4] = {REAL(0), REAL(0), REAL(0), REAL(0)}, sv_[NK][4];
+        char g[4], gp[4] = {0, 0, 0, 0}, yv_[NK][4];
+        ld4(c0, lohi + 2 * j);        // {lo, hi} of elements j, j + 1
+        ld4(c1, lohi + 2 * j + 4);    // ... j + 2, j + 3
+        ld4(mmv, mm_layer + j);
+        ldc4(g, cur_g + j);
+        if (have_prev) {
+            ld4(xp, prev_x + j);
+            ldc4(gp, prev_g + j);
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            ld4(sv_[k], sk[k] + j);
+            ldc4(yv_[k], yk[k] + j);
+        }
+        REAL x4[4], s4[4];
+        char y4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            REAL se[NK];
+            char ye[NK];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) { se[k] = sv_[k][e]; ye[k] = yv_[k][e]; }
+            const REAL lo = e < 2 ? c0[2 * e] : c1[2 * (e - 2)], hi = e < 2 ? c0[2 * e + 1] : c1[2 * (e - 2) + 1];
+            element(lo, hi, mmv[e], g[e], xp[e], gp[e], se, ye, x4[e], s4[e], y4[e]);
+        }
+        if (have_prev) {
+            st4(sw + j, s4);
+            stc4(yw + j, y4);
+        }
+        st4(prev_x + j, x4);
+        stc4(prev_g + j, g);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) {  // the last n % 4 elements
+        const uint64_t i = 4 * n4 + threadIdx.x;
+        REAL se[NK];
+        char ye[NK];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { se[k] = sk[k][i]; ye[k] = yk[k][i]; }
+        REAL x, sv;
+        char yv;
+        element(lohi[2 * i], lohi[2 * i + 1], mm_layer[i], cur_g[i], have_prev ? prev_x[i] : REAL(0), have_prev ? prev_g[i] : (char)0, se, ye, x, sv, yv);
+        if (have_prev) { sw[i] = sv; yw[i] = yv; }
+        prev_x[i] = x;
+        prev_g[i] = cur_g[i];
+    }
+    // per-block partial sums, layout [dot][block]: in-wave trees for all dots, ONE barrier, then thread d adds the four waves' values
+    // (a barrier pair per dot cost ~4 us per workgroup for the 35 dots of a history of five)
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        double a = acc[d];
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+        if ((threadIdx.x & 63) == 0) red[d][threadIdx.x >> 6] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < ND) partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// One workgroup of 1024: fixed-order sums of the partial dots, curvature filter + ring update, two loops on the coefficients.
+// m = history size; want_dir: the host will run the L-BFGS branch if the history is full after this store.
+// The state is copied to LDS first and written back at the end: thread 0's recursion is ~400 dependent accesses, which took 30 us
+// against global memory (one L2 round trip each) and takes ~2 us against LDS.
+static __global__ void __launch_bounds__(1024) k_lb_finalize(const double* __restrict__ partial, uint32_t nb, int ns, int m, int want_dir, LbDev* __restrict__ st,
+                                                             LbHost* __restrict__ host)
+{
+    __shared__ double dots[lb_ndots(LB_MAXS)];
+    __shared__ LbDev T;
+    static_assert(sizeof(LbDev) % 8 == 0, "LbDev is copied as 8-byte words");
+    constexpr uint32_t WORDS = sizeof(LbDev) / 8;
+    {
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(st);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(&T);
+        for (uint32_t i = threadIdx.x; i < WORDS; i += blockDim.x) dst[i] = src[i];
+    }
+    const int nd = lb_ndots(ns);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = (int)wave; d < nd; d += 16) {
+        // nb <= LB_BLOCKS = 12 x 64: the lane's partial sums in one batch of loads, added in the order of the plain loop
+        double pp[LB_BLOCKS / 64];
+#pragma unroll
+        for (int u = 0; u < LB_BLOCKS / 64; ++u) {
+            const uint32_t b = lane + 64u * u;
+            pp[u] = b < nb ? partial[(size_t)d * nb + b] : 0.0;
+        }
+        double a = 0.0;
+#pragma unroll
+        for (int u = 0; u < LB_BLOCKS / 64; ++u)
+            if (lane + 64u * u < nb) a += pp[u];
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+        if (lane == 0) dots[d] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t w = T.free_slot;
+        uint32_t count = T.count;
+        for (int k = 0; k < ns; ++k) {
+            const uint32_t p = T.order[k];
+            T.Sg[p] = dots[6 * k + 4];
+            T.Yg[p] = dots[6 * k + 5];
+        }
+        uint32_t accepted = 0;
+        if (T.prev_stored) {
+            const double rho_inv = dots[6 * ns + 1];
+            T.rho_inv_new = rho_inv;
+            if (rho_inv > 1e-8) {  // lbfgs_impl.h:112
+                for (int k = 0; k < ns; ++k) {
+                    const uint32_t p = T.order[k];
+                    T.SS[w][p] = T.SS[p][w] = dots[6 * k + 0];
+                    T.SY[w][p] = dots[6 * k + 1];
+                    T.SY[p][w] = dots[6 * k + 2];
+                    T.YY[w][p] = T.YY[p][w] = dots[6 * k + 3];
+                }
+                T.SS[w][w] = dots[6 * ns + 0];
+                T.SY[w][w] = rho_inv;
+                T.YY[w][w] = dots[6 * ns + 2];
+                T.Sg[w] = dots[6 * ns + 3];
+                T.Yg[w] = dots[6 * ns + 4];
+                uint32_t next_free;
+                if ((int)count == m) {  // the oldest pair leaves
+                    next_free = T.order[0];
+                    for (int k = 0; k + 1 < m; ++k) T.order[k] = T.order[k + 1];
+                    T.order[m - 1] = w;
+                } else {
+                    T.order[count++] = w;
+                    uint32_t used = 0;
+                    for (uint32_t k = 0; k < count; ++k) used |= 1u << T.order[k];
+                    next_free = 0;
+                    while (used & (1u << next_free)) ++next_free;
+                }
+                T.free_slot = next_free;
+                T.count = count;
+                accepted = 1;
+            } else {
+                T.prev_stored = 0;  // :118-121: the next call only records the state
+            }
+        } else {
+            T.prev_stored = 1;
+        }
+        T.accepted = accepted;
+        T.have_dir = (want_dir && (int)count == m) ? 1u : 0u;
+    }
+    __syncthreads();
+    // compute_update_direction (:226-316) on the coefficients, by wavefront 0: lane r holds the coefficients of the pair with logical
+    // index r (physical slot order[r]); every step's dot product is one LDS read per lane and a butterfly sum, so the 2 m dependent
+    // steps cost ~0.2 us each instead of ~2 us as a scalar loop over LDS.  The sum runs over the lanes in a fixed order: deterministic.
+    if (wave == 0 && T.have_dir) {
+        const int r = (int)lane;
+        const bool act = r < m;
+        const uint32_t pr = act ? T.order[r] : 0u;
+        double cy = 0.0, cs = 0.0, alpha_mine = 0.0;
+        auto wave_sum = [&](double v) {
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            return v;
+        };
+        for (int i = m - 1; i >= 0; --i) {
+            const uint32_t p = T.order[i];
+            const double part = act ? cy * T.SY[p][pr] + cs * T.SS[p][pr] : 0.0;
+            const double dot = T.Sg[p] + wave_sum(part);
+            const double al = dot / T.SY[p][p];
+            if (r == i) { alpha_mine = al; cy -= al; }
+        }
+        const uint32_t pl = T.order[m - 1];
+        const double h_diag = T.SY[pl][pl] / (1e-8 + T.YY[pl][pl]);  // :291
+        for (int i = 0; i < m; ++i) {
+            const uint32_t p = T.order[i];
+            double rho = 1.0 / T.SY[p][p];
+            if (i == 0) rho *= h_diag;
+            const double part = act ? cy * T.YY[p][pr] + cs * T.SY[pr][p] : 0.0;
+            const double dot = T.Yg[p] + wave_sum(part);
+            if (r == i) cs += alpha_mine - rho * dot;
+        }
+        if (lane < LB_P) { T.cy[lane] = 0.0; T.cs[lane] = 0.0; }
+        __builtin_amdgcn_wave_barrier();
+        if (act) { T.cy[pr] = cy; T.cs[pr] = cs; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        volatile LbHost* h = host;
+        h->rho_inv_new = T.rho_inv_new;
+        h->count = T.count;
+        h->prev_stored = T.prev_stored;
+        h->accepted = T.accepted;
+        h->have_dir = T.have_dir;
+        __threadfence_system();
+        h->seq = ++T.pad_;
+    }
+    __syncthreads();
+    {
+        uint64_t* dst = reinterpret_cast<uint64_t*>(st);
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(&T);
+        for (uint32_t i = threadIdx.x; i < WORDS; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+// q = g + sum_k cy[order[k]] y_k + sum_k cs[order[k]] s_k  (oldest first; accumulated in double, rounded to REAL once)
+template <typename REAL, int NS>
+static __global__ void __launch_bounds__(256) k_lb_direction(REAL* __restrict__ dir, const char* __restrict__ cur_g, const REAL* __restrict__ S, const char* __restrict__ Y,
+                                                             size_t slot, const LbDev* __restrict__ st, uint32_t n)
+{
+    const REAL* sk[NS];
+    const char* yk[NS];
+    double cy[NS], cs[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const uint32_t p = st->order[k];
+        sk[k] = S + (size_t)p * slot;
+        yk[k] = Y + (size_t)p * slot;
+        cy[k] = st->cy[p];
+        cs[k] = st->cs[p];
+    }
+    const uint64_t n4 = n / 4, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n4; c += stride) {  // four consecutive elements, see k_lb_store_gram
+        const uint64_t j = 4 * c;
+        char g[4], yv[NS][4];
+        REAL sv[NS][4];
+        ldc4(g, cur_g + j);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            ldc4(yv[k], yk[k] + j);
+            ld4(sv[k], sk[k] + j);
+        }
+        REAL out[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double q = (double)g[e];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) q += cy[k] * (double)yv[k][e];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) q += cs[k] * (double)sv[k][e];
+            out[e] = REAL(q);
+        }
+        st4(dir + j, out);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) {
+        const uint64_t i = 4 * n4 + threadIdx.x;
+        double q = (double)cur_g[i];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) q += cy[k] * (double)yk[k][i];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) q += cs[k] * (double)sk[k][i];
+        dir[i] = REAL(q);
+    }
+}
+static __global__ void k_lb_reset(LbDev* st)
+{
+    st->count = 0;
+    st->free_slot = 0;
+    st->prev_stored = 0;
+    st->accepted = 0;
+    st->have_dir = 0;
+}
+
 template <typename REAL>
 struct Lbfgs final : bddmma_lbfgs {
     struct Hist {
@@ -273,12 +666,22 @@ struct Lbfgs final : bddmma_lbfgs {
     uint64_t mma_iterations = 0, lbfgs_iterations = 0;
     uint32_t n = 0;
     hipStream_t st = nullptr;
+    // Gram-matrix path (history sizes <= LB_MAXS; BDDMMA_LBFGS_TWO_LOOP=1 keeps the two-loop passes for A/B runs)
+    bool gram = false;
+    REAL* S = nullptr;       // LB_P slots of n entries
+    char* Y = nullptr;
+    LbDev* d_lb = nullptr;
+    LbHost *h_lb = nullptr, *d_lb_host = nullptr;  // pinned + its device address
+    double* d_gpartial = nullptr;
+    size_t slot = 0;         // elements between two slots of S / Y (n rounded up to 64: 16-byte aligned slots for the vector loads)
+    int h_count = 0;         // pairs kept: read back while the history fills up, constant (= history_size) afterwards
 
     int device = 0;  // cached: the wrapped solver may already be gone when the wrapper is destroyed
     ~Lbfgs() override
     {
         (void)hipSetDevice(device);
         for (void* q : allocs) (void)hipFree(q);
+        if (h_lb) (void)hipHostFree(h_lb);
     }
     template <typename T>
     int alloc(T** q, size_t cnt)
@@ -296,10 +699,22 @@ struct Lbfgs final : bddmma_lbfgs {
         st = (hipStream_t)b->stream_handle();
         step_size = p.init_step_size;
         int rc;
-        if ((rc = alloc(&prev_x, n)) || (rc = alloc(&cur_x, n)) || (rc = alloc(&dir, n)) || (rc = alloc(&prev_g, n)) ||
-            (rc = alloc(&cur_g, n)) || (rc = alloc(&d_partial, 2048)) || (rc = alloc(&d_scalar, SC_COUNT)))
-            return rc;
         if (p.history_size >= SC_DOT) { err = "history size must be < 32"; return BDDMMA_ERR_INVALID_ARGUMENT; }
+        const char* two_loop = std::getenv("BDDMMA_LBFGS_TWO_LOOP");
+        gram = p.history_size <= LB_MAXS && !(two_loop && two_loop[0] == '1');
+        if ((rc = alloc(&prev_x, n)) || (rc = alloc(&dir, n)) || (rc = alloc(&prev_g, n)) || (rc = alloc(&cur_g, n))) return rc;
+        if (gram) {
+            slot = ((size_t)n + 63) & ~(size_t)63;
+            if ((rc = alloc(&S, (size_t)(p.history_size + 1) * slot)) || (rc = alloc(&Y, (size_t)(p.history_size + 1) * slot)) ||
+                (rc = alloc(&d_gpartial, (size_t)lb_ndots(LB_MAXS) * LB_BLOCKS)) || (rc = alloc(&d_lb, 1)))
+                return rc;
+            LHIP(hipHostMalloc((void**)&h_lb, sizeof(LbHost), hipHostMallocMapped));
+            LHIP(hipHostGetDevicePointer((void**)&d_lb_host, h_lb, 0));
+            std::memset((void*)h_lb, 0, sizeof(LbHost));
+            LHIP(hipMemsetAsync(d_lb, 0, sizeof(LbDev), st));
+            return 0;
+        }
+        if ((rc = alloc(&cur_x, n)) || (rc = alloc(&d_partial, 2048)) || (rc = alloc(&d_scalar, SC_COUNT))) return rc;
         for (int i = 0; i < p.history_size + 1; ++i) {
             Hist h;
             if ((rc = alloc(&h.s, n)) || (rc = alloc(&h.y, n))) return rc;
@@ -310,7 +725,7 @@ struct Lbfgs final : bddmma_lbfgs {
     void get_state(bddmma_lbfgs_state* out) const override
     {
         out->step_size = step_size;
-        out->history_entries = (int32_t)history.size();
+        out->history_entries = gram ? h_count : (int32_t)history.size();
         out->num_unsuccessful_updates = unsuccessful;
         out->last_kind = last_kind;
         out->last_trials = last_trials;
@@ -321,9 +736,64 @@ struct Lbfgs final : bddmma_lbfgs {
     void flush() override  // flush_lbfgs_states, lbfgs_impl.h:318-326
     {
         unsuccessful = 0;
+        if (gram) {
+            (void)hipSetDevice(device);
+            hipLaunchKernelGGL(k_lb_reset, dim3(1), dim3(1), 0, st, d_lb);
+            h_count = 0;
+            return;
+        }
         for (auto& h : history) free_slots.push_back(h);
         history.clear();
         prev_stored = false;
+    }
+    // store_iterate (lbfgs_impl.h:45-135) + the Gram updates, on the device; the host reads the number of kept pairs back only while
+    // the history fills up (afterwards it is history_size whatever the curvature filter decides: a rejected pair replaces nothing)
+    int store_iterate_gram(int want_dir)
+    {
+        SolverBase* b = s->impl;
+        SolverBase::LbfgsViews v;
+        int rcv = b->lbfgs_views(&v);
+        if (rcv) { err = b->err; return rcv; }
+        const uint32_t nb = std::min<uint32_t>(LB_BLOCKS, std::max<uint32_t>(1, (n / 4 + 255) / 256));
+#define LB_STORE(NS_)                                                                                                                      \
+    hipLaunchKernelGGL((k_lb_store_gram<REAL, NS_>), dim3(nb), dim3(256), 0, st, (const REAL*)v.lohi, (const REAL*)v.mm_layer, prev_x,            \
+                       (const char*)cur_g, prev_g, S, Y, slot, (const LbDev*)d_lb, d_gpartial, n)
+        switch (h_count) {
+            case 0: LB_STORE(0); break;
+            case 1: LB_STORE(1); break;
+            case 2: LB_STORE(2); break;
+            case 3: LB_STORE(3); break;
+            case 4: LB_STORE(4); break;
+            case 5: LB_STORE(5); break;
+            case 6: LB_STORE(6); break;
+            case 7: LB_STORE(7); break;
+            default: LB_STORE(8); break;
+        }
+#undef LB_STORE
+        hipLaunchKernelGGL(k_lb_finalize, dim3(1), dim3(1024), 0, st, (const double*)d_gpartial, nb, h_count, p.history_size, want_dir, d_lb, d_lb_host);
+        LHIP(hipGetLastError());
+        if (h_count < p.history_size) {
+            LHIP(hipStreamSynchronize(st));
+            h_count = (int)((volatile LbHost*)h_lb)->count;
+        }
+        return 0;
+    }
+    int direction_gram()
+    {
+        const dim3 g(std::min<uint32_t>(4096, std::max<uint32_t>(1, (n / 4 + 255) / 256))), b(256);
+#define LB_DIR(NS_) hipLaunchKernelGGL((k_lb_direction<REAL, NS_>), g, b, 0, st, dir, (const char*)cur_g, (const REAL*)S, (const char*)Y, slot, (const LbDev*)d_lb, n)
+        switch (p.history_size) {
+            case 2: LB_DIR(2); break;
+            case 3: LB_DIR(3); break;
+            case 4: LB_DIR(4); break;
+            case 5: LB_DIR(5); break;
+            case 6: LB_DIR(6); break;
+            case 7: LB_DIR(7); break;
+            default: LB_DIR(8); break;
+        }
+#undef LB_DIR
+        LHIP(hipGetLastError());
+        return 0;
     }
     template <typename TA, typename TB>
     int dot(const TA* a, const TB* b, double* out)
@@ -484,10 +954,21 @@ struct Lbfgs final : bddmma_lbfgs {
             if ((rc = lower_bound(&lb))) return rc;
             lb_history.push_back(lb);
         }
-        if ((rc = b->bdds_solution(0, cur_g, 1))) { err = b->err; return rc; }
-        if ((rc = store_iterate())) return rc;
-        if (update_possible() && (int)lb_history.size() >= p.history_size) {  // choose_solver, :409-417
-            if ((rc = compute_direction())) return rc;
+        bool lbfgs_step;
+        if (gram) {
+            if ((rc = b->bdds_solution_async(cur_g))) { err = b->err; return rc; }
+            // the branch is taken when the history is full AFTER this store: it may complete it
+            const bool may = unsuccessful <= 5 && (int)lb_history.size() >= p.history_size && h_count + 1 >= p.history_size;
+            if ((rc = store_iterate_gram(may ? 1 : 0))) return rc;
+            lbfgs_step = may && h_count >= p.history_size;
+            if (lbfgs_step && (rc = direction_gram())) return rc;
+        } else {
+            if ((rc = b->bdds_solution(0, cur_g, 1))) { err = b->err; return rc; }
+            if ((rc = store_iterate())) return rc;
+            lbfgs_step = update_possible() && (int)lb_history.size() >= p.history_size;  // choose_solver, :409-417
+            if (lbfgs_step && (rc = compute_direction())) return rc;
+        }
+        if (lbfgs_step) {
             if ((rc = b->projection_means(dir))) { err = b->err; return rc; }  // make_dual_feasible(direction), applied inside the steps
             if ((rc = search_step_size_and_apply())) return rc;
             last_kind = 1;

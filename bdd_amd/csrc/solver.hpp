@@ -68,6 +68,18 @@ struct SolverBase {
     virtual int projection_means(const void* g_dev) = 0;                       // per-variable means of a device vector, kept inside the solver
     virtual int gradient_step_projected(const void* g_dev, double step) = 0;   // costs += step * (g - its per-variable mean)
     virtual void* stream_handle() = 0;
+    // L-BFGS wrapper (lbfgs.hip): the argmin paths straight into a device buffer with nothing but stream order (bdds_solution() also
+    // copies and synchronises), and the arrays net_solver_costs() is made of, so that x = hi - lo + deferred mm is formed inside the
+    // wrapper's own pass instead of being written and read back
+    struct LbfgsViews {
+        const void* lohi;          // {lo, hi} per layer, REAL
+        const void* mm_layer;      // deferred min-marginal differences per layer, REAL (the sweeps keep them by entry; see lbfgs_views)
+    };
+    virtual int bdds_solution_async(char* dev_out) = 0;
+    // From the first call on the backward solve sweeps also write their min-marginal differences in layer order (one coalesced 4-8 byte
+    // store per layer), so that the wrapper reads x without the 5 M random gathers of net_solver_costs(); rebuilt by a gather when
+    // something else changed the deferred values since the last backward sweep.
+    virtual int lbfgs_views(LbfgsViews* out) = 0;
     virtual int time_kernel(int kind, uint64_t reps, double* ms) = 0;
     // one round of perturb_primal_costs (incremental_mm_agreement_rounding_cuda.cu:262-331); counts = #one,#zero,#equal,#inconsistent
     // `applied` = 0 when the solution was read off (all variables one / zero) and the costs were left alone; c0_host / c1_host

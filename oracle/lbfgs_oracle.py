@@ -89,8 +89,53 @@ class LbfgsOracle:
     def update_possible(self):
         return len(self.history) >= self.m and self.num_unsuccessful <= 5
 
-    # :226-316
+    # :226-316 in the form lbfgs.hip computes it (round 3): the direction is always g + sum a_p y_p + sum b_p s_p, so the two loops
+    # run on the coefficients with the dot products <s_i, q>, <y_i, q> expanded over the Gram matrices SS, SY, YY and the products
+    # with g ("vector-free L-BFGS", Chen et al. 2014) — 2 passes over the history instead of 2 m dependent ones; the values are
+    # those of compute_update_direction_two_loop up to rounding (float: q is not rounded to REAL after every axpy but once at the end).
     def compute_update_direction(self, cur_g):
+        dtype = self.s.dtype
+        f8 = np.float64
+        S = [h[0].astype(f8) for h in self.history]
+        Y = [h[1].astype(f8) for h in self.history]
+        g = cur_g.astype(f8)
+        m = len(S)
+        SS = np.array([[np.dot(S[i], S[j]) for j in range(m)] for i in range(m)])
+        SY = np.array([[np.dot(S[i], Y[j]) for j in range(m)] for i in range(m)])   # SY[i][j] = <s_i, y_j>; the diagonal is rho_inv
+        YY = np.array([[np.dot(Y[i], Y[j]) for j in range(m)] for i in range(m)])
+        Sg = np.array([np.dot(S[i], g) for i in range(m)])
+        Yg = np.array([np.dot(Y[i], g) for i in range(m)])
+        rho_inv = [h[2] for h in self.history]                                       # as stored (== SY[i][i] up to summation order)
+        cy, cs = np.zeros(m), np.zeros(m)
+        alphas = np.zeros(m)
+        for i in range(m - 1, -1, -1):
+            dot = Sg[i]
+            for r in range(m):
+                dot += cy[r] * SY[i][r]
+            for r in range(m):
+                dot += cs[r] * SS[i][r]
+            alphas[i] = dot / rho_inv[i]
+            cy[i] -= alphas[i]
+        h_diag = rho_inv[m - 1] / (1e-8 + YY[m - 1][m - 1])                           # :291
+        for i in range(m):
+            rho = 1.0 / rho_inv[i]
+            if i == 0:
+                rho *= h_diag
+            dot = Yg[i]
+            for r in range(m):
+                dot += cy[r] * YY[i][r]
+            for r in range(m):
+                dot += cs[r] * SY[r][i]
+            cs[i] += alphas[i] - rho * dot
+        d = g.copy()
+        for i in range(m):
+            d = d + cy[i] * Y[i]
+        for i in range(m):
+            d = d + cs[i] * S[i]
+        return np.ascontiguousarray(d.astype(dtype))
+
+    # the literal two-loop recursion (what rounds 1-2 implemented; kept as the cross-check of the form above, tests/test_lbfgs_oracle_forms.py)
+    def compute_update_direction_two_loop(self, cur_g):
         dtype = self.s.dtype
         d = cur_g.astype(dtype)
         alphas = []
