@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -558,24 +559,32 @@ struct SolverT final : SolverBase {
                        d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers, gate(), rstep)
             // inside run_plain() the instantiation that honours the stop flag and runs the termination tests; otherwise the plain one
             if (exch_medium) { if (run_stop) LAUNCH_EX(EXM_THREADS, EXM_UNROLL, EXM_NPT, true); else LAUNCH_EX(EXM_THREADS, EXM_UNROLL, EXM_NPT, false); }
-            else if (exch_small && !run_stop && (opts_variant & 0x38u)) {
-                // the shelved round-2 rewrite's ingredients, one instantiation per combination that the bisection uses (kernels.hpp: EXV_*)
-#define LAUNCH_EXV(V_)                                                                                                                          \
-    hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, EXS_THREADS, EXS_UNROLL, EXS_NPT, false, V_>), dim3(n_bins), dim3(EXS_THREADS), \
+            else if (exch_small) {
+                // 256-thread exchange (small instances).  Default since round 3: scalar-offset entry addressing + one predicated atomic per
+                // entry (kernels.hpp: EXV_*, all three = 7) — the round-2 rewrite, correct now that the 16-byte store hazard is guarded
+                // (hop_store(double2)); 4.7 -> 4.4 us per launch at 1.05 M nodes.  variant_flags bits 3-5 select another combination
+                // (the bisection of profiles/r03_exchange_variant_rootcause.txt), bit 6 the round-2 kernel.
+#define LAUNCH_EXV(V_, RUN_)                                                                                                                    \
+    hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, EXS_THREADS, EXS_UNROLL, EXS_NPT, RUN_, V_>), dim3(n_bins), dim3(EXS_THREADS), \
                        exch_lds, stream, d_mm_binned, d_bin_ptr, d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars,  \
-                       (uint32_t)n_layers, RunGate{}, RunStep{})
-                switch ((opts_variant >> 3) & 7u) {
-                    case 1: LAUNCH_EXV(1); break;
-                    case 2: LAUNCH_EXV(2); break;
-                    case 3: LAUNCH_EXV(3); break;
-                    case 4: LAUNCH_EXV(4); break;
-                    case 5: LAUNCH_EXV(5); break;
-                    case 6: LAUNCH_EXV(6); break;
-                    default: LAUNCH_EXV(7); break;
+                       (uint32_t)n_layers, gate(), rstep)
+                const uint32_t var = (opts_variant & 0x40u) ? 0u : (((opts_variant >> 3) & 7u) ? ((opts_variant >> 3) & 7u) : 7u);
+                if (run_stop) {
+                    if (var == 0) LAUNCH_EXV(0, true); else LAUNCH_EXV(7, true);
+                } else {
+                    switch (var) {
+                        case 0: LAUNCH_EXV(0, false); break;
+                        case 1: LAUNCH_EXV(1, false); break;
+                        case 2: LAUNCH_EXV(2, false); break;
+                        case 3: LAUNCH_EXV(3, false); break;
+                        case 4: LAUNCH_EXV(4, false); break;
+                        case 5: LAUNCH_EXV(5, false); break;
+                        case 6: LAUNCH_EXV(6, false); break;
+                        default: LAUNCH_EXV(7, false); break;
+                    }
                 }
 #undef LAUNCH_EXV
             }
-            else if (exch_small) { if (run_stop) LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, true); else LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false); }
             else { if (run_stop) LAUNCH_EX(EX_THREADS, EX_UNROLL, EX_NPT, true); else LAUNCH_EX(EX_THREADS, EX_UNROLL, EX_NPT, false); }
 #undef LAUNCH_EX
             delta_var_valid = false;
@@ -1185,6 +1194,30 @@ struct SolverT final : SolverBase {
         *ms = f;
         fwd_valid = bwd_valid = false;
         mm_layer_valid = false;
+#ifdef BDDMMA_STAMPS
+        if (const char* path = std::getenv("BDDMMA_STAMPS_FILE")) {  // one more launch with per-wave phase stamps (kernels.hpp: BDDMMA_STAMP)
+            const size_t slots = 0x100000u + 65536u * 16u;
+            unsigned long long* d_st = nullptr;
+            HIPCHK(hipMalloc((void**)&d_st, slots * 8 * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(d_st, 0, slots * 8 * sizeof(unsigned long long)));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_bddmma_stamps), &d_st, sizeof(d_st)));
+            HIPCHK(hipStreamSynchronize(stream));
+            rc = once();
+            HIPCHK(hipStreamSynchronize(stream));
+            unsigned long long* null_ = nullptr;
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_bddmma_stamps), &null_, sizeof(null_)));
+            std::vector<unsigned long long> h(slots * 8);
+            HIPCHK(hipMemcpy(h.data(), d_st, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            (void)hipFree(d_st);
+            if (FILE* f2 = std::fopen((std::string(path) + "." + std::to_string(kind)).c_str(), "w")) {
+                for (size_t sl = 0; sl < slots; ++sl)
+                    if (h[sl * 8] != 0)
+                        std::fprintf(f2, "%zu %llu %llu %llu %llu %llu\n", sl, h[sl * 8], h[sl * 8 + 1], h[sl * 8 + 2], h[sl * 8 + 3], h[sl * 8 + 4]);
+                std::fclose(f2);
+            }
+            if (rc) return rc;
+        }
+#endif
         return BDDMMA_OK;
     }
 };

@@ -96,6 +96,23 @@ struct PackDev {
     uint32_t nt_potentials;  // streaming narrow sweeps, double: store F / T non-temporally (see hop_store)
 };
 
+// -DBDDMMA_STAMPS (tools/build_variant.sh): per-wave s_memrealtime stamps at the phase boundaries of the small-instance kernels, for
+// the latency budget of profiles/r03_1m_latency.txt.  Stamp i of slot s is taken after everything issued before it has arrived
+// (s_waitcnt 0), so the differences are the phases' durations on that wave.  Not compiled into the shipped library.
+#ifdef BDDMMA_STAMPS
+__device__ unsigned long long* g_bddmma_stamps = nullptr;
+#define BDDMMA_STAMP(slot, idx)                                                                              \
+    do {                                                                                                     \
+        if (g_bddmma_stamps != nullptr) {                                                                    \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
+            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); /* 100 MHz */                     \
+            if ((threadIdx.x & 63) == 0) g_bddmma_stamps[(size_t)(slot) * 8 + (idx)] = t_;                   \
+        }                                                                                                    \
+    } while (0)
+#else
+#define BDDMMA_STAMP(slot, idx) do { } while (0)
+#endif
+
 template <typename REAL> struct Pair;
 template <> struct Pair<float> { using type = float2; };
 template <> struct Pair<double> { using type = double2; };
@@ -1075,6 +1092,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
     BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
+    BDDMMA_STAMP(p, 0);
     // dynamic LDS: [staged {delta_lo, delta_hi} / mm: WPB * stage_cap pairs][per wave: words | T of every slot | {lo, hi} of every layer]
     P2* sD = reinterpret_cast<P2*>(dyn_lds);
     P2* sDw = sD + (size_t)wave * pk.stage_cap;
@@ -1090,6 +1108,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
     const uint32_t c0 = rd.quad_hdr[4 * (size_t)quad], cnt = rd.quad_hdr[4 * (size_t)quad + 1];
     const REAL INF = inf_v<REAL>();
     const NarrowRs<REAL> rs(d);
+    BDDMMA_STAMP(p, 1);
     // ---- round trip 2: the whole pack -> LDS, hop offsets, staging tables; round trip 3 (inside stage_load): the delta pairs
     wave_copy_to_lds(d.nwords + woff, sW, nslots * 4u, lane);
     wave_copy_to_lds(d.T + slot0, sTa, nslots * (uint32_t)sizeof(REAL), lane);
@@ -1112,6 +1131,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
         sF[0][j] = (j < ne) ? REAL(0) : INF;  // every slot of hop 0 is a root (flush_costs_from_root)
     }
     if (WPB > 1) __syncthreads(); else wave_sync();
+    BDDMMA_STAMP(p, 2);
     int cur = 0;
     for (uint32_t h = 0; h < nh; ++h) {
         const uint32_t ne2 = __builtin_amdgcn_readfirstlane(sOffN[min(h + 2, nh)]);
@@ -1161,8 +1181,10 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
         nb = ne;
         ne = ne2;
     }
+    BDDMMA_STAMP(p, 3);
     if (WPB > 1) __syncthreads(); else wave_sync();
     stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);  // min-marginal differences -> entry array
+    BDDMMA_STAMP(p, 4);
 }
 
 template <typename REAL, int R, int WPB>
@@ -1187,6 +1209,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev p
     BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
+    BDDMMA_STAMP(p, 0);
     P2* sD = reinterpret_cast<P2*>(dyn_lds);
     P2* sDw = sD + (size_t)wave * pk.stage_cap;
     const uint32_t wave_off = WPB * pk.stage_cap * (uint32_t)sizeof(P2) + (uint32_t)wave * res_wave_bytes(sizeof(REAL), rd.ns, rd.nl);
@@ -1200,6 +1223,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev p
     const uint32_t c0 = rd.quad_hdr[4 * (size_t)quad], cnt = rd.quad_hdr[4 * (size_t)quad + 1];
     const REAL INF = inf_v<REAL>();
     const NarrowRs<REAL> rs(d);
+    BDDMMA_STAMP(p, 1);
     wave_copy_to_lds(d.nwords + woff, sW, nslots * 4u, lane);
     wave_copy_to_lds(d.F + slot0, sFa, nslots * (uint32_t)sizeof(REAL), lane);
     wave_copy_to_lds(d.lohi + 2 * (size_t)layer0, sC, nlayers * (uint32_t)sizeof(P2), lane);
@@ -1214,6 +1238,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane < 4) sT[lane >> 1][W + (lane & 1)] = (lane & 1) ? INF : REAL(0);
     if (WPB > 1) __syncthreads(); else wave_sync();
+    BDDMMA_STAMP(p, 2);
     int cur = 0;
     for (uint32_t h = nh; h-- > 0;) {
         const uint32_t nb = __builtin_amdgcn_readfirstlane(sOffN[h]), ne = __builtin_amdgcn_readfirstlane(sOffN[h + 1]);
@@ -1252,8 +1277,10 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev p
         wave_sync();
         cur ^= 1;
     }
+    BDDMMA_STAMP(p, 3);
     if (WPB > 1) __syncthreads(); else wave_sync();
     stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
+    BDDMMA_STAMP(p, 4);
     if (!has_pack) return;
     if (d.mm_layer != nullptr)
         for (uint32_t j = lane; j < nlayers; j += 64) d.mm_layer[layer0 + j] = sDw[j].x;
@@ -2075,6 +2102,7 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
     const uint32_t v0 = b * vars_per_bin;
     const uint32_t nv = min(vars_per_bin, n_vars - v0);
     const uint32_t e0 = bin_ptr[b], e1 = bin_ptr[b + 1];
+    BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 0);
     constexpr bool SOFF_L = (VAR & EXV_SOFF_LOADS) != 0, SOFF_S = (VAR & EXV_SOFF_STORES) != 0, ONE_ATOMIC = (VAR & EXV_ONE_ATOMIC) != 0;
     const rsrc_t rmm = make_rsrc(mm_binned, SOFF_L ? e1 : n_entries), rev = make_rsrc(bvar, SOFF_L ? e1 : n_entries);
     const rsrc_t rnb = make_rsrc(nbdds, n_vars);
@@ -2095,6 +2123,7 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
             lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
         }
     }
+    BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 1);  // (waits for the first chunk here: the kernel itself does not)
     // number of BDDs of the variables this thread normalises (needed only after the accumulation)
     int nb[NPT];
     if (MODE == EX_ITER) {
@@ -2156,6 +2185,7 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
         }
     }
     __syncthreads();
+    BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 2);
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
         const uint32_t i = tid + k * EX_THREADS;
@@ -2172,6 +2202,7 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
     }
     if (MODE != EX_ITER) return;
     __syncthreads();
+    BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 3);
     const rsrc_t rdl = make_rsrc(delta_lay, 2ull * (SOFF_S ? e1 : n_entries));
 #pragma unroll
     for (int u = 0; u < EX_UNROLL; ++u) {  // first chunk: the local variable indices are still in registers
@@ -2182,6 +2213,7 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
         if (SOFF_S) hop_store(pr, rdl, vo_p, (e0 + u * EX_THREADS) * (uint32_t)sizeof(P2));
         else bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
     }
+    BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 4);
     if (one_chunk) return;
     for (uint32_t base = e0 + EX_THREADS * EX_UNROLL + tid; (SOFF_L || SOFF_S) ? base - tid < e1 : base < e1; base += EX_THREADS * EX_UNROLL) {
         uint32_t lv2[EX_UNROLL];

@@ -83,7 +83,10 @@ typedef struct bddmma_options {
     uint32_t variant_flags;    /* switches between equivalent code paths, for A/B measurements and the differential tests (default 0):
                                   bit 0: narrow and wide backward sweeps as two launches (default: one, k_bwd_mixed)
                                   bit 1: narrow and wide forward sweeps as two launches (default: one, k_fwd_mixed)
-                                  bit 2: no non-temporal stores of the potentials (default: on for double instances above 640 MB) */
+                                  bit 2: no non-temporal stores of the potentials (default: on for double instances above 640 MB)
+                                  bits 3-5: 256-thread exchange kernel with this combination of {1: scalar-offset entry loads, 2: scalar-offset
+                                            pair stores, 4: one predicated LDS atomic per entry} instead of all three (the default)
+                                  bit 6: the round-2 256-thread exchange kernel (none of the three) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
                                   instance (the sweeps are bound by instructions issued, not by latency), kept for experiments */

@@ -1,0 +1,39 @@
+"""Per-wave phase timeline of the small-instance kernels from a -DBDDMMA_STAMPS build (tools/build_variant.sh stamps -DBDDMMA_STAMPS):
+    BDDMMA_LIB=build/libstamps.so BDDMMA_STAMPS_FILE=gpurun_out/stamps python tools/stamps.py [--vars V --rows B | --matching N]
+Prints, per kernel class, when the phases start and end relative to the first wave's entry (s_memtime ticks -> us at 100 MHz)."""
+import argparse, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bdd_amd import capi
+capi.LIB_PATH = os.path.abspath(os.environ["BDDMMA_LIB"])
+from bdd_amd.instances import random_set_cover_mt, assignment_ilp
+from bdd_amd import to_bdd_collection
+from bdd_amd.solver import bdd_hip_parallel_mma
+ap = argparse.ArgumentParser()
+ap.add_argument("--vars", type=int, default=100_000)
+ap.add_argument("--rows", type=int, default=50_000)
+ap.add_argument("--matching", type=int, default=0)
+ap.add_argument("--precision", default="float")
+a = ap.parse_args()
+if a.matching:
+    ilp = assignment_ilp(a.matching)
+    col, costs = to_bdd_collection(ilp), np.asarray(ilp.objective, float)
+else:
+    col, costs = random_set_cover_mt(a.vars, a.rows, 10, 12345)
+s = bdd_hip_parallel_mma(col, costs, precision=a.precision)
+s.iterations(20)
+base = os.environ["BDDMMA_STAMPS_FILE"]
+names = {2: "fwd_solve", 3: "bwd_solve", 4: "exchange"}
+labels = {2: ["entry", "headers", "pack + pairs in LDS", "hop loop done", "flushed"], 4: ["entry", "first chunk arrived", "accumulated", "normalised", "pairs stored"]}
+labels[3] = labels[2]
+for kind in (2, 3, 4):
+    ms = s.time_kernel(kind, 50)
+    z = np.loadtxt(f"{base}.{kind}", dtype=np.float64, ndmin=2)
+    t = z[:, 1:]
+    t0 = t[:, 0].min()
+    tick_us = 0.01   # s_memtime: 100 MHz constant clock
+    print(f"{names[kind]}: {ms * 1e3:.2f} us per launch (50 launches back to back), {t.shape[0]} waves stamped")
+    for i, lab in enumerate(labels[kind]):
+        c = (t[:, i][t[:, i] > 0] - t0) * tick_us
+        if c.size:
+            print(f"   {lab:24s} first {c.min():6.2f}  median {np.median(c):6.2f}  last {c.max():6.2f} us after the first wave's entry")
