@@ -24,7 +24,7 @@ class Options(C.Structure):
     _fields_ = [("pack_width", C.c_uint32), ("wide_pack_width", C.c_uint32), ("deterministic", C.c_uint32),
                 ("vars_per_bin", C.c_uint32), ("stage_cap", C.c_uint32), ("waves_per_block", C.c_uint32),
                 ("keep_bdd_order", C.c_uint32), ("resident_sweeps", C.c_uint32), ("exchange_by_variable", C.c_uint32),
-                ("variant_flags", C.c_uint32), ("pack_fill", C.c_uint32), ("reserved", C.c_uint32 * 1)]
+                ("variant_flags", C.c_uint32), ("pack_fill", C.c_uint32), ("pack_stagger", C.c_uint32)]
 
 
 class LbfgsParams(C.Structure):

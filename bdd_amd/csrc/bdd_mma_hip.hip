@@ -86,6 +86,7 @@ struct SolverT final : SolverBase {
     struct PackBufs {
         uint32_t *pack_hop_ptr = nullptr, *hop_node_off = nullptr, *hop_layer_off = nullptr;
         uint8_t* pack_steps = nullptr;
+        uint16_t* hop_root = nullptr;  // narrow packs only (layout.hpp: PackSet::hop_root)
         uint32_t n_packs = 0;
     } nb_, wb_, hb_;  // narrow, wide, huge packs
     uint32_t wide_lds = 0, wide_threads = 256, wide_npt = 1;
@@ -207,6 +208,11 @@ struct SolverT final : SolverBase {
         if ((rc = upload(&d_var_layers, L.var_layers, 8))) return rc;
         if ((rc = upload(&d_root_slot, L.bdd_root_slot, 9))) return rc;
         if ((rc = upload_packs(nb_, L.narrow, 10))) return rc;
+        if (L.narrow.hop_root.size() + 1 != L.narrow.hop_node_off.size() && !L.narrow.hop_node_off.empty()) {
+            err = "narrow hop_root table does not match the hop records";
+            return BDDMMA_ERR_INVALID_ARGUMENT;
+        }
+        if ((rc = upload(&nb_.hop_root, L.narrow.hop_root, 38))) return rc;
         if ((rc = upload_packs(wb_, L.wide, 14))) return rc;
         if ((rc = upload_packs(hb_, L.huge, 18))) return rc;
         huge_pack_width = L.huge_pack_width;
@@ -234,6 +240,21 @@ struct SolverT final : SolverBase {
         if ((rc = upload(&d_cs_slot, L.ex.cs_slot, 33))) return rc;
         wpb = L.ex.waves_per_block;
         entry_by_var = L.ex.entry_by_var;
+        {   // balance of the narrow packs' hop counts over contiguous eighths of the pack sequence (see xcd_chunk)
+            const uint32_t P = L.narrow.n_packs();
+            if (P >= 64) {
+                uint64_t part[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0;
+                const uint32_t per = (P + 7) / 8;
+                for (uint32_t p = 0; p < P; ++p) {
+                    const uint32_t h = L.narrow.pack_hop_ptr[p + 1] - L.narrow.pack_hop_ptr[p];
+                    part[std::min<uint32_t>(7, p / per)] += h;
+                    total += h;
+                }
+                uint64_t mx = 0;
+                for (uint64_t v : part) mx = std::max(mx, v);
+                if (mx * 8 * 10 > total * 11) xcd_chunk_auto = 32;
+            }
+        }
         for (uint8_t st : L.narrow.pack_steps) narrow_seg = narrow_seg || st >= 2;
         vars_per_bin = L.ex.vars_per_bin; n_bins = L.ex.n_bins; stage_cap = L.ex.stage_cap;
         n_narrow_layers = L.ex.grp_layer_off.empty() ? 0 : L.ex.grp_layer_off.back();
@@ -377,13 +398,24 @@ struct SolverT final : SolverBase {
     }
     PackDev pdev(const PackBufs& b, uint32_t lb_base, uint32_t seg_off = 0) const
     {
-        return PackDev{b.pack_hop_ptr, b.hop_node_off, b.hop_layer_off, b.pack_steps, d_pack_word_off,
+        return PackDev{b.pack_hop_ptr, b.hop_node_off, b.hop_layer_off, b.pack_steps, b.hop_root, d_pack_word_off,
                        d_pack_group_ptr, d_grp_layer_off, d_grp_hop_end, d_quad_round_ptr, d_cs_ptr, stage_cap, seg_off, b.n_packs, lb_base,
-                       nt_potentials};
+                       nt_potentials, xcd_chunk()};
     }
     // dynamic LDS of a narrow launch with `w` waves per workgroup: `base` bytes of the kernel's own use, then (only when some pack has
     // layers wider than two nodes) the seg_min2 scratch, 128 REALs per wave
     uint32_t seg_bytes(uint32_t w) const { return narrow_seg ? w * 128 * (uint32_t)sizeof(REAL) : 0; }
+    // block -> pack map of the narrow launches (kernels.hpp: block_to_pack): chunks of 32 workgroups interleaved over the XCDs
+    // — chosen when contiguous eighths would be unbalanced (init: hop counts per eighth differ by more than 10 %: instances that mix
+    // constraint families); homogeneous instances keep the contiguous map, which measured 1-3 % faster there (neighbouring packs share
+    // more L2 lines).  variant_flags bit 7 forces the contiguous map, bit 8 the interleaved one.
+    uint32_t xcd_chunk_auto = 0;
+    uint32_t xcd_chunk() const { return (opts_variant & 0x80u) ? 0u : ((opts_variant & 0x100u) ? 32u : xcd_chunk_auto); }
+    uint32_t narrow_grid(uint32_t n_quads) const
+    {
+        const uint32_t c = xcd_chunk();
+        return c ? 8 * c * cdiv(n_quads, 8 * c) : 8 * cdiv(n_quads, 8);
+    }
 
     template <int MODE>
     int launch_fwd(const REAL* delta_lay, REAL omega, int kclass)
@@ -394,7 +426,7 @@ struct SolverT final : SolverBase {
         if (mixed && mixed_fwd && MODE == FWD_SOLVE) {
             const PackDev pkw = pdev(wb_, nb_.n_packs), pkn = pdev(nb_, 0, stage_lds);
             const uint32_t nw8 = (wb_.n_packs + 7u) & ~7u;
-            const dim3 grid(nw8 + 8 * cdiv(cdiv(nb_.n_packs, wpb), 8)), block(64 * wpb);
+            const dim3 grid(nw8 + narrow_grid(cdiv(nb_.n_packs, wpb))), block(64 * wpb);
 #define LAUNCH_M(R_, W_)                                                                                                                                   \
     switch (mixed_npt) {                                                                                                                                   \
         case 1: hipLaunchKernelGGL((k_fwd_mixed<REAL, R_, W_, 1>), grid, block, mixed_lds, stream, d, pkn, pkw, omega, wide_pack_width); break;            \
@@ -428,7 +460,7 @@ struct SolverT final : SolverBase {
             const uint32_t base_lds = res ? res_lds : ((MODE == FWD_SOLVE) ? stage_lds : 0);
             const uint32_t dyn = base_lds + seg_bytes(w);
             const PackDev pk = pdev(nb_, 0, base_lds);
-            const dim3 grid(8 * cdiv(cdiv(nb_.n_packs, w), 8)), block(64 * w);
+            const dim3 grid(narrow_grid(cdiv(nb_.n_packs, w))), block(64 * w);
             const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
 #define LAUNCH_N(R_, W_)                                                                                                      \
     if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, d, pk, rd, omega);                           \
@@ -463,7 +495,7 @@ struct SolverT final : SolverBase {
         if (mixed && MODE == BWD_SOLVE) {
             const PackDev pkw = pdev(wb_, nb_.n_packs), pkn = pdev(nb_, 0, stage_lds);
             const uint32_t nw8 = (wb_.n_packs + 7u) & ~7u;
-            const dim3 grid(nw8 + 8 * cdiv(cdiv(nb_.n_packs, wpb), 8)), block(64 * wpb);
+            const dim3 grid(nw8 + narrow_grid(cdiv(nb_.n_packs, wpb))), block(64 * wpb);
 #define LAUNCH_M(R_, W_)                                                                                                                                   \
     switch (mixed_npt) {                                                                                                                                   \
         case 1: hipLaunchKernelGGL((k_bwd_mixed<REAL, R_, W_, 1>), grid, block, mixed_lds, stream, d, pkn, pkw, omega, wide_pack_width); break;            \
@@ -497,7 +529,7 @@ struct SolverT final : SolverBase {
             const uint32_t base_lds = res ? res_lds : ((MODE == BWD_SOLVE) ? stage_lds : 0);
             const uint32_t dyn = base_lds + seg_bytes(w);
             const PackDev pk = pdev(nb_, 0, base_lds);
-            const dim3 grid(8 * cdiv(cdiv(nb_.n_packs, w), 8)), block(64 * w);
+            const dim3 grid(narrow_grid(cdiv(nb_.n_packs, w))), block(64 * w);
             const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
 #define LAUNCH_N(R_, W_)                                                                                                      \
     if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, d, pk, rd, omega);                           \

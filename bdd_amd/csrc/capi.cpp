@@ -351,7 +351,7 @@ int bddmma_incremental_mm_agreement_rounding(bddmma_solver* s, bddmma_lbfgs* lbf
 // File: magic, header {precision, #arrays, sizeof(LayoutScalars), sizeof(bddmma_options)}, LayoutScalars, options, the layout arrays
 // as {id, element size, count, data} records (layout.hpp: visit_layout_arrays), then lo / hi / deferred mm / delta.  Loading
 // uploads the arrays as they are: build_layout does not run again.
-static const char kMagic[8] = {'B', 'D', 'D', 'M', 'M', 'A', '0', '5'};  // 05: checksum of the layout section behind the arrays; 04: narrow node words carry the layer index
+static const char kMagic[8] = {'B', 'D', 'D', 'M', 'M', 'A', '0', '6'};  // 06: hop_root (staggered packs); 05: checksum of the layout section; 04: narrow node words carry the layer index
 
 namespace {
 struct FileCloser {
@@ -463,6 +463,14 @@ bool layout_plausible(const HostLayout& L, std::string& why)
         if (L.narrow_word_off.size() != Pn || X.pack_group_ptr.size() != (size_t)Pn + 1 || L.res.pack_hdr.size() != (size_t)Pn * 8 ||
             L.res.quad_hdr.size() != (size_t)n_quads * 4 || X.quad_round_ptr.size() != (size_t)n_quads + 1) return fail("narrow pack tables");
         if (X.cs_entry.size() != nl || X.cs_slot.size() != nl) return fail("staging tables");
+        if (N.hop_root.size() != n_rec) return fail("hop_root size");
+        for (uint32_t p = 0; p < Pn; ++p)
+            for (uint32_t q = N.pack_hop_ptr[p]; q < N.pack_hop_ptr[p + 1]; ++q) {
+                const uint16_t r = N.hop_root[q];
+                if (r == NO_ROOT) continue;
+                if (q == N.pack_hop_ptr[p] || r >= N.hop_node_off[q + 1] - N.hop_node_off[q]) return fail("hop_root out of range");
+                if (L.res.ok) return fail("resident sweeps flagged for a staggered pack");
+            }
         if (X.cs_ptr.empty() || !mono_to(X.cs_ptr, 0, nl, "cs_ptr") || !mono_to(X.quad_round_ptr, 0, X.cs_ptr.size() - 1, "quad_round_ptr")) return fail("staging pointers");
         for (size_t r = 0; r + 1 < X.cs_ptr.size(); ++r)
             if (X.cs_ptr[r + 1] - X.cs_ptr[r] > 64u * WPB * 10u) return fail("staging round larger than a workgroup can hold");

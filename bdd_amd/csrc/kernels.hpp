@@ -83,6 +83,7 @@ struct PackDev {
     const uint32_t* hop_node_off;
     const uint32_t* hop_layer_off;
     const uint8_t* pack_steps;
+    const uint16_t* hop_root;        // narrow packs: per (pack, hop) record the local slot of a BDD root below the pack's first hop, or NO_ROOT (layout.hpp)
     const uint32_t* pack_word_off;   // narrow packs: first word of the pack's (shared) word sequence
     const uint32_t* pack_group_ptr;  // narrow packs: stage groups
     const uint32_t* grp_layer_off;
@@ -94,6 +95,7 @@ struct PackDev {
     uint32_t n_packs;
     uint32_t lb_base;  // index of this set's first pack in lb_partial
     uint32_t nt_potentials;  // streaming narrow sweeps, double: store F / T non-temporally (see hop_store)
+    uint32_t xcd_chunk;      // block_to_pack: workgroups per chunk of the XCD-interleaved map (0: contiguous eighths)
 };
 
 // -DBDDMMA_STAMPS (tools/build_variant.sh): per-wave s_memrealtime stamps at the phase boundaries of the small-instance kernels, for
@@ -177,13 +179,20 @@ __device__ __forceinline__ REAL frontier_load(const REAL* p)
     return *p;
 }
 
-// XCD-aware block -> pack map: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md),
-// so giving XCD x the contiguous pack range [x*per, (x+1)*per) keeps neighbouring packs — which
-// share variables in structured problems — behind the same 4 MiB L2.
-__device__ __forceinline__ uint32_t block_to_pack(uint32_t bid, uint32_t n_packs)
+// XCD-aware block -> pack map: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md).  XCD x gets chunks of `chunk`
+// consecutive workgroups' packs — chunk x, x + 8, x + 16, ... — so that neighbouring packs, which share variables in structured
+// problems, sit behind the same 4 MiB L2, while every XCD sees every part of the pack sequence: instances that mix constraint
+// families (cheap 10-hop covering packs, expensive 30-hop knapsack packs; packs are ordered by family) had all their expensive packs
+// on one or two XCDs when each XCD owned one contiguous eighth (chunk = 0: that map, kept for A/B runs, variant_flags bit 7).
+// The grid is a multiple of 8 * chunk workgroups (the launcher rounds up; surplus workgroups exit at once).
+__device__ __forceinline__ uint32_t block_to_pack(uint32_t bid, uint32_t n_packs, uint32_t chunk)
 {
-    const uint32_t per = (n_packs + 7u) >> 3;
-    return (bid & 7u) * per + (bid >> 3);
+    if (chunk == 0) {
+        const uint32_t per = (n_packs + 7u) >> 3;
+        return (bid & 7u) * per + (bid >> 3);
+    }
+    const uint32_t x = bid & 7u, i = bid >> 3;
+    return ((i / chunk) * 8u + x) * chunk + i % chunk;
 }
 
 // ---- per-layer min across the lanes of a layer ---------------------------------------------------
@@ -274,6 +283,10 @@ __device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, uint32_t po
         seg_pair_min(a, b, pos, len);
         return;
     }
+#ifdef BDDMMA_EXP_NOSEG  // timing experiment only (wrong results): what the LDS segmented minimum costs
+    seg_pair_min(a, b, pos, len);
+    return;
+#endif
     const REAL INF = inf_v<REAL>();
     const uint32_t head = (uint32_t)lane - pos;
     sM[lane] = INF;
@@ -422,6 +435,7 @@ constexpr int HOP_UNROLL = BDDMMA_HOP_UNROLL;  // hops per trip of the narrow ke
 struct HopWindow {
     uint32_t* node;   // LDS [HOP_WIN]
     uint32_t* layer;  // LDS [HOP_WIN]
+    uint32_t* root;   // LDS [HOP_WIN]: PackDev::hop_root of the record (NO_ROOT past the pack's last hop)
     uint32_t base;    // record index of window slot 0
     uint32_t q1;      // one past the pack's last hop record (offsets clamp there)
     __device__ __forceinline__ void fill(const PackDev& pk, uint32_t new_base, int lane)
@@ -430,7 +444,13 @@ struct HopWindow {
         const uint32_t q = min(new_base + (uint32_t)lane, q1);
         node[lane] = pk.hop_node_off[q];
         layer[lane] = pk.hop_layer_off[q];
+        root[lane] = new_base + (uint32_t)lane < q1 ? (uint32_t)pk.hop_root[q] : (uint32_t)NO_ROOT;
         wave_sync();
+    }
+    // root slot of hop q (below the pack's first hop), NO_ROOT if no BDD starts there
+    __device__ __forceinline__ uint32_t root_of(uint32_t q) const
+    {
+        return __builtin_amdgcn_readfirstlane(root[min(q, q1) - base]);
     }
     __device__ __forceinline__ uint32_t node_off(uint32_t q) const
     {
@@ -574,7 +594,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     __shared__ REAL sF_[WPB][2][W + 2];
     __shared__ REAL sT_[WPB][2][W + 2];  // costs-from-terminal of the next hop, written one hop ahead (double buffer)
     __shared__ unsigned char sAct_[WPB][2][MODE == FWD_SOLUTION ? W + 2 : 1];
-    __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN];
+    __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN], sOffR_[WPB][HOP_WIN];
     const uint32_t tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int lane = tid & 63;
@@ -585,7 +605,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     auto& sT = sT_[wave];
     auto& sAct = sAct_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(block_id, n_quads);
+    const uint32_t quad = block_to_pack(block_id, n_quads, pk.xcd_chunk);
     BDDMMA_EXIT_IF(quad >= n_quads, d)  // uniform for the workgroup
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;  // the last quad may be partial: such a wave only helps staging
@@ -595,7 +615,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     const NarrowRs<REAL> rs(d);
     // hop_node_off / hop_layer_off have one entry past the last hop of the last pack, so index q1 is
     // always readable; offsets beyond q1 are clamped (those hops have no nodes for this pack)
-    HopWindow hw{sOffN_[wave], sOffL_[wave], q0, q1};
+    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1};
     auto off = [&](uint32_t q) { return hw.node_off(q); };
     // word address of slot s of this pack = s + wd (the pack's words live in a sequence shared by all packs of its structure)
     const uint32_t wd = has_pack ? pk.pack_word_off[p] - pk.hop_node_off[q0] : 0;
@@ -648,6 +668,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     }
     int cur = 0;
     uint32_t q = q0;
+    uint32_t rt = NO_ROOT;  // root slot of hop q when a BDD starts there (staggered packs); the first hop's roots are set up above
     const uint32_t g0 = (MODE == FWD_SOLVE && has_pack) ? pk.pack_group_ptr[p] : 0;
     const uint32_t ng = (MODE == FWD_SOLVE && has_pack) ? pk.pack_group_ptr[p + 1] - g0 : 0;
     const uint32_t r0 = (MODE == FWD_SOLVE) ? pk.quad_round_ptr[quad] : 0;
@@ -698,15 +719,17 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                 const bool act = !(w & NW_PAD);
                 const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
                 f[r] = sF[cur][j];
+                if (j == rt) f[r] = REAL(0);  // a BDD that starts at this hop: its root has no parents (flush_costs_from_root)
                 if (NEED_T) {
                     tl[r] = sT[cur][lo_i];  // sinks: [W] = 0, [W+1] = +inf
                     th[r] = sT[cur][hi_i];
                 }
                 if (MODE == FWD_SOLVE) dd[r] = sDw[act ? La.lg[r] - gl0 : 0];  // staging index: position of the layer inside its group
-                if (MODE == FWD_SOLUTION) on_path[r] = act && sAct[cur][j];
+                if (MODE == FWD_SOLUTION) on_path[r] = act && (sAct[cur][j] || j == rt);
             }
             const uint32_t o_new = off(q + 2 * D + 3);
             const uint32_t l_next = hw.layer_off(q + D + 1);
+            const uint32_t rt_next = hw.root_of(q + 1);
             // ---- set-up of the next hop's buffers (nothing above depends on it)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -781,6 +804,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             for (int i = 0; i < 2 * D + 2; ++i) o[i] = o[i + 1];
             o[2 * D + 2] = o_new;
             lcur = l_next;
+            rt = rt_next;
 #pragma unroll
             for (int i = 0; i < 2 * D; ++i)
 #pragma unroll
@@ -823,7 +847,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     P2* sD = reinterpret_cast<P2*>(dyn_lds);
     __shared__ REAL sT_[WPB][2][W + 2];  // per wave; +2: sink entries TOP = W (0) and BOT = W + 1 (+inf)
-    __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN];
+    __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN], sOffR_[WPB][HOP_WIN];
     const uint32_t tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int lane = tid & 63;
@@ -832,7 +856,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
     auto& sT = sT_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(block_id, n_quads);
+    const uint32_t quad = block_to_pack(block_id, n_quads, pk.xcd_chunk);
     BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
@@ -840,7 +864,8 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     const int steps = SEG ? (has_pack ? pk.pack_steps[p] : 0) : 1;
     const REAL INF = inf_v<REAL>();
     const NarrowRs<REAL> rs(d);
-    HopWindow hw{sOffN_[wave], sOffL_[wave], q0, q1};
+    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1};
+    double lb_stag = 0.0;  // costs-to-terminal of the roots below the pack's first hop (staggered packs), for the lower bound
     // node range of hop q; hops below q0 (pipeline run-off) are empty
     auto nb_of = [&](uint32_t q) { return hw.node_off(q); };
     const uint32_t wd = has_pack ? pk.pack_word_off[p] - pk.hop_node_off[q0] : 0;  // see k_fwd_narrow
@@ -925,6 +950,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             }
             const uint32_t o_new = (q >= q0 + 2 * D + 1) ? nb_of(q - 1 - 2 * D) : o[2 * D + 1];
             const uint32_t l_next = hw.layer_off(q >= q0 + D + 1 ? q - 1 - D : q0);
+            const uint32_t rt = q > q0 ? hw.root_of(q) : (uint32_t)NO_ROOT;  // the first hop's roots are summed behind the loop
             // ---- arithmetic
             REAL t[R], nlo[R], nhi[R], mmv[R], lp[R], hp[R];
 #pragma unroll
@@ -974,6 +1000,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                     }
                 }
                 if (act) sT[cur ^ 1][j] = t[r];
+                if (j == rt) lb_stag += (double)t[r];
             }
             store_vals<R>(t, d.T, nb, o[0] - o[1], lane, pk.nt_potentials);
             wave_sync();
@@ -1019,7 +1046,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     if (!has_pack) return;
     // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251)
     const uint32_t n0 = nb_of(q0 + 1) - nb_of(q0);
-    double s = 0.0;
+    double s = lb_stag;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t j = lane + 64 * r;
@@ -1088,7 +1115,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(DevPtrs<REAL> d, PackDev p
     uint32_t* sOffN = sOffN_[wave];
     uint32_t* sOffL = sOffL_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
+    const uint32_t quad = block_to_pack(blockIdx.x, n_quads, pk.xcd_chunk);
     BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
@@ -1205,7 +1232,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(DevPtrs<REAL> d, PackDev p
     uint32_t* sOffN = sOffN_[wave];
     uint32_t* sOffL = sOffL_[wave];
     const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(blockIdx.x, n_quads);
+    const uint32_t quad = block_to_pack(blockIdx.x, n_quads, pk.xcd_chunk);
     BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;

@@ -70,11 +70,17 @@ struct PackBuilder {
     std::vector<uint32_t> nlayers;  // layers per hop in the open pack
     uint32_t maxw = 0;
     bool open = false;
+    // Staggered packing (bddmma_options.pack_stagger): a BDD that does not fit the open pack from hop 0 may start `d` hops further down,
+    // where the BDDs already placed have become narrow again, as long as the pack stays within `max_hops` hops and no other BDD starts
+    // at that hop (the kernels know one root slot per hop below the first).  0: every BDD starts at hop 0.
+    uint32_t max_hops = 0;
+    std::vector<uint16_t> root;     // per hop of the open pack: local slot of the BDD that starts there (hops > 0), or NO_ROOT
 
     // closed packs
     std::vector<uint32_t> pack_first_bdd;      // index into `order`
     std::vector<uint32_t> pack_hop_ptr;        // into flat_used / flat_nlayers
     std::vector<uint32_t> flat_used, flat_nlayers;
+    std::vector<uint16_t> flat_root;
     std::vector<uint8_t> pack_steps;
 
     static uint8_t steps_for(uint32_t w)
@@ -89,9 +95,12 @@ struct PackBuilder {
         pack_hop_ptr.push_back((uint32_t)flat_used.size());
         flat_used.insert(flat_used.end(), used.begin(), used.end());
         flat_nlayers.insert(flat_nlayers.end(), nlayers.begin(), nlayers.end());
+        root.resize(used.size(), NO_ROOT);
+        flat_root.insert(flat_root.end(), root.begin(), root.end());
         pack_steps.push_back(steps_for(maxw));
         used.clear();
         nlayers.clear();
+        root.clear();
         maxw = 0;
         open = false;
     }
@@ -100,32 +109,50 @@ struct PackBuilder {
         if (group && (u % group) + w > group) u = (u + group - 1) / group * group;
         return u;
     }
-    // widths[0..n) = layer widths of the BDD.  Writes the slot position of every layer to pos[].
-    void add(uint32_t order_idx, const uint32_t* widths, uint32_t n, uint32_t* pos)
+    bool fits_at(uint32_t d, const uint32_t* widths, uint32_t n) const
     {
+        for (uint32_t h = 0; h < n; ++h) {
+            const uint32_t u = d + h < used.size() ? used[d + h] : 0;
+            if (place(u, widths[h]) + widths[h] > (fill ? fill : width)) return false;
+        }
+        return true;
+    }
+    // widths[0..n) = layer widths of the BDD.  Writes the slot position of every layer to pos[]; returns the hop of the pack at which
+    // the BDD starts.
+    uint32_t add(uint32_t order_idx, const uint32_t* widths, uint32_t n, uint32_t* pos)
+    {
+        uint32_t d = 0;
         if (open) {
-            bool fits = true;
-            for (uint32_t h = 0; h < n && fits; ++h) {
-                const uint32_t u = h < used.size() ? used[h] : 0;
-                if (place(u, widths[h]) + widths[h] > (fill ? fill : width)) fits = false;
+            bool fits = fits_at(0, widths, n);
+            if (!fits && max_hops > n) {
+                for (uint32_t dd = 1; dd + n <= max_hops && dd <= used.size() && !fits; ++dd) {
+                    if (dd < root.size() && root[dd] != NO_ROOT) continue;  // one BDD may start per hop
+                    if (fits_at(dd, widths, n)) { fits = true; d = dd; }
+                }
             }
             if (!fits) close();
         }
         if (!open) {
             open = true;
+            d = 0;
             pack_first_bdd.push_back(order_idx);
         }
-        if (used.size() < n) {
-            used.resize(n, 0);
-            nlayers.resize(n, 0);
+        if (used.size() < d + n) {
+            used.resize(d + n, 0);
+            nlayers.resize(d + n, 0);
         }
         for (uint32_t h = 0; h < n; ++h) {
-            const uint32_t p = place(used[h], widths[h]);
+            const uint32_t p = place(used[d + h], widths[h]);
             pos[h] = p;
-            used[h] = p + widths[h];
-            nlayers[h]++;
+            used[d + h] = p + widths[h];
+            nlayers[d + h]++;
             maxw = std::max(maxw, widths[h]);
         }
+        if (d > 0) {
+            root.resize(std::max<size_t>(root.size(), d + 1), NO_ROOT);
+            root[d] = (uint16_t)pos[0];
+        }
+        return d;
     }
     void finish(uint32_t n_order)
     {
@@ -369,6 +396,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         order_n.swap(grouped);
     }
     std::vector<uint32_t> lay_pos(Lin);  // slot position of every input layer inside its (pack,hop)
+    std::vector<uint32_t> bdd_hop0(n_bdds, 0);  // hop of its pack at which a BDD starts (> 0: staggered narrow packs)
     // Wide packs are swept by one workgroup each, two barriers per hop whatever the width, so for a given amount of wide BDDs
     // narrower packs mean more workgroups in flight.  The pack width adapts: aim at >= 1024 packs (4 workgroups per CU), but a
     // pack must hold the widest of these BDDs; wide_pack_width (the option) stays the upper limit.
@@ -394,7 +422,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
             const uint32_t l0 = bdd_lay_ptr[b], n = bdd_lay_ptr[b + 1] - l0;
             widths.resize(n);
             for (uint32_t h = 0; h < n; ++h) widths[h] = (uint32_t)(layer_end(b, l0 + h) - lay_first[l0 + h]);
-            pb.add(k, widths.data(), n, &lay_pos[l0]);
+            bdd_hop0[b] = pb.add(k, widths.data(), n, &lay_pos[l0]);
         }
         pb.finish((uint32_t)order.size());
     };
@@ -437,7 +465,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
                     const uint32_t l0 = bdd_lay_ptr[b], nn = bdd_lay_ptr[b + 1] - l0;
                     widths.resize(nn);
                     for (uint32_t h = 0; h < nn; ++h) widths[h] = (uint32_t)(layer_end(b, l0 + h) - lay_first[l0 + h]);
-                    pb.add(kk, widths.data(), nn, &lay_pos[l0]);
+                    bdd_hop0[b] = pb.add(kk, widths.data(), nn, &lay_pos[l0]);
                 }
                 k = k1;
                 continue;
@@ -468,6 +496,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
                 for (uint32_t h = 0; h < n; ++h) {
                     pb.flat_used.push_back(pos[cnt - 1][h] + rep_w[h]);
                     pb.flat_nlayers.push_back(cnt);
+                    pb.flat_root.push_back(NO_ROOT);
                 }
                 pb.pack_steps.push_back(PackBuilder::steps_for(maxw));
             }
@@ -482,6 +511,21 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         }
         pb.finish(n_order);
     };
+    {   // staggered narrow packs: explicit limit, or automatic when the instance is large enough that the longer (hence fewer) packs
+        // still fill the GPU — below ~4096 packs a sweep is bound by the length of one pack's hop chain, not by lane utilisation
+        uint64_t narrow_nodes = 0;
+        uint32_t longest = 0;
+        for (uint32_t b : order_n) {
+            narrow_nodes += (delims[b + 1] - delims[b]) - 2;
+            longest = std::max(longest, bdd_lay_ptr[b + 1] - bdd_lay_ptr[b]);
+        }
+        const uint32_t opt = opts ? opts->pack_stagger : 0;
+        if (opt >= 2) pn.max_hops = opt;
+        else if (opt == 0) {
+            const uint64_t hops_for_4096_packs = narrow_nodes / ((uint64_t)W * 4096 * 6 / 10 + 1);
+            pn.max_hops = hops_for_4096_packs >= longest + 2 ? (uint32_t)std::min<uint64_t>(hops_for_4096_packs, 3ull * longest) : 0;
+        }
+    }
     form_narrow();
     form(pw, order_w);
     form(ph, order_h);
@@ -515,6 +559,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         const uint32_t P = pb.n_packs();
         ps.pack_hop_ptr.resize(P + 1);
         ps.pack_steps = pb.pack_steps;
+        if (!wide) ps.hop_root = pb.flat_root;
         // offsets of every (pack, hop) record first (a running sum), then the packs are emitted independently
         const uint32_t n_rec = P ? pb.pack_hop_ptr[P] : 0;
         ps.hop_node_off.resize((size_t)n_rec + 1);
@@ -540,8 +585,10 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
                 for (uint32_t k = pb.pack_first_bdd[p]; k < pb.pack_first_bdd[p + 1]; ++k) {
                     const uint64_t b = order[k];
                     const uint32_t l0 = bdd_lay_ptr[b], n = bdd_lay_ptr[b + 1] - l0;
-                    for (uint32_t h = 0; h < n; ++h) {
-                        const uint32_t l = l0 + h;
+                    const uint32_t d0 = bdd_hop0[b];  // hop of the pack at which this BDD starts
+                    for (uint32_t hb = 0; hb < n; ++hb) {
+                        const uint32_t h = d0 + hb;   // hop of the pack; hb = depth inside the BDD
+                        const uint32_t l = l0 + hb;
                         const uint64_t f = lay_first[l], e = layer_end(b, l);
                         const uint32_t lloc = lcount[h]++;
                         // index of the layer inside its 64-lane group of the hop (the BDDs of a pack are placed left to right)
@@ -554,15 +601,15 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
                         in_layer_to_internal[l] = lg;
                         L.layer_var[lg] = (int32_t)instr[f].index;
                         L.layer_bdd[lg] = (int32_t)b;
-                        t_nodes[t][h] += e - f;
-                        t_layers[t][h] += 1;
-                        const bool last = (h + 1 == n);
+                        t_nodes[t][hb] += e - f;   // per-hop statistics count by depth inside the BDD, as the reference's hops do
+                        t_layers[t][hb] += 1;
+                        const bool last = (hb + 1 == n);
                         const uint64_t nf = last ? 0 : lay_first[l + 1];
                         const uint32_t npos = last ? 0 : lay_pos[l + 1];
                         for (uint64_t i = f; i < e; ++i) {
                             const uint32_t j = lay_pos[l] + (uint32_t)(i - f);
                             const uint32_t slot = ps.hop_node_off[base_q + h] + j;
-                            if (h == 0) L.bdd_root_slot[b] = slot;
+                            if (hb == 0) L.bdd_root_slot[b] = slot;
                             if (keep_debug_maps) L.slot_to_instr[slot] = i;
                             uint64_t ch[2];
                             for (int side = 0; side < 2; ++side) {
@@ -850,6 +897,8 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
                 Rz.max_slots = std::max(Rz.max_slots, s1 - s0);
                 Rz.max_layers = std::max(Rz.max_layers, l1 - l0);
                 if (q1 - q0 > 63 || X.pack_group_ptr[p + 1] - X.pack_group_ptr[p] != 1) Rz.ok = false;
+                for (uint32_t q = q0; q < q1; ++q)
+                    if (N.hop_root[q] != NO_ROOT) Rz.ok = false;  // the resident sweeps know roots at a pack's first hop only
             }
             for (uint32_t Q = 0; Q < n_quads; ++Q) {
                 const uint32_t r0 = X.quad_round_ptr[Q], r1 = X.quad_round_ptr[Q + 1];

@@ -44,6 +44,7 @@ constexpr uint32_t nw_pad_word(uint32_t pack_width)
 }
 constexpr uint32_t NARROW_MAX_LAYER_WIDTH = 64;  // a layer never straddles a 64-lane group
 constexpr uint32_t NARROW_MAX_PACK_WIDTH = 256;  // 64 * R, R <= 4
+constexpr uint16_t NO_ROOT = 0xFFFFu;            // PackSet::hop_root
 
 // ---- wide node word (uint64) ---------------------------------------------------------------
 //  bits  0..20  lo child (local index in next hop) or WW_BOT / WW_TOP
@@ -64,6 +65,10 @@ struct PackSet {
     std::vector<uint32_t> hop_layer_off;
     // per pack: number of shuffle-halving steps a segmented min needs = ceil(log2(max layer width))
     std::vector<uint8_t> pack_steps;
+    // one entry per (pack,hop): local slot of the root of a BDD that STARTS at this hop of its pack, or NO_ROOT.  Every slot of a
+    // pack's first hop is a root (the BDDs placed side by side from hop 0); further down at most one BDD starts per hop (staggered
+    // packing, bddmma_options.pack_stagger).  Narrow packs only; empty for the other sets.
+    std::vector<uint16_t> hop_root;
     uint32_t n_packs() const { return pack_hop_ptr.empty() ? 0 : (uint32_t)pack_hop_ptr.size() - 1; }
 };
 
@@ -199,8 +204,9 @@ void visit_layout_arrays(LAYOUT& L, V&& v)
     v(30, L.ex.quad_round_ptr); v(31, L.ex.cs_ptr); v(32, L.ex.cs_entry); v(33, L.ex.cs_slot);
     v(34, L.res.pack_hdr); v(35, L.res.quad_hdr);
     v(36, L.nodes_per_hop); v(37, L.layers_per_hop);
+    v(38, L.narrow.hop_root);
 }
-constexpr int LAYOUT_ARRAY_IDS = 38;
+constexpr int LAYOUT_ARRAY_IDS = 39;
 
 // Returns BDDMMA_OK or an error code; `err` receives the message.
 int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,

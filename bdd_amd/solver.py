@@ -39,7 +39,7 @@ class bdd_hip_parallel_mma:
     def __init__(self, bdd_col: BddCollection, costs_hi=None, precision: str = "double", device: int = 0,
                  pack_width: int = 0, wide_pack_width: int = 0, deterministic: bool = False,
                  vars_per_bin: int = 0, stage_cap: int = 0, waves_per_block: int = 0, keep_bdd_order: bool = False,
-                 resident_sweeps: int = 0, exchange_by_variable: int = 0, variant_flags: int = 0, pack_fill: int = 0, _handle=None):
+                 resident_sweeps: int = 0, exchange_by_variable: int = 0, variant_flags: int = 0, pack_fill: int = 0, pack_stagger: int = 0, _handle=None):
         self._L = capi.lib()
         self.value_type = {"double": np.float64, "float": np.float32, "single": np.float32}[precision]
         self._prec = capi.F64 if self.value_type == np.float64 else capi.F32
@@ -53,6 +53,7 @@ class bdd_hip_parallel_mma:
         opts.resident_sweeps = int(resident_sweeps)         # 0 automatic, 1 off, 2 on
         opts.exchange_by_variable = int(exchange_by_variable)             # 2: entries by (variable, bdd)
         opts.pack_fill = int(pack_fill)
+        opts.pack_stagger = int(pack_stagger)
         opts.variant_flags = int(variant_flags)             # bit 0 / 1: backward / forward narrow + wide sweeps as two launches
         h = C.c_void_p()
         costs = None if costs_hi is None else np.ascontiguousarray(costs_hi, dtype=np.float64)

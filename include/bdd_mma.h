@@ -86,11 +86,17 @@ typedef struct bddmma_options {
                                   bit 2: no non-temporal stores of the potentials (default: on for double instances above 640 MB)
                                   bits 3-5: 256-thread exchange kernel with this combination of {1: scalar-offset entry loads, 2: scalar-offset
                                             pair stores, 4: one predicated LDS atomic per entry} instead of all three (the default)
-                                  bit 6: the round-2 256-thread exchange kernel (none of the three) */
+                                  bit 6: the round-2 256-thread exchange kernel (none of the three)
+                                  bit 7 / bit 8: narrow workgroups mapped to XCDs in contiguous eighths / in interleaved chunks of 32
+                                                 (default: interleaved when the eighths' hop counts differ by more than 10 %) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
                                   instance (the sweeps are bound by instructions issued, not by latency), kept for experiments */
-    uint32_t reserved[1];
+    uint32_t pack_stagger;     /* narrow packs whose BDDs start at different hops ("staggered"): a BDD that no longer fits next to the ones
+                                  of the open pack hop by hop is tried a few hops further down, where those have become narrow again — BDDs
+                                  of general linear rows are narrow at both ends and wide in the middle, and side by side from hop 0 they
+                                  fill ~30 % of a pack's lanes.  Value = most hops a pack may have; 0: automatic (on when the instance is
+                                  large enough to keep >= 4096 packs), 1: off. */
 } bddmma_options;
 
 /* ---- construction ------------------------------------------------------- */

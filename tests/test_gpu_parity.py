@@ -736,7 +736,7 @@ def test_randomised_instances_and_layout_options_vs_oracle(seed):
                 wide_pack_width=int(rng.choice([0, 64])), keep_bdd_order=bool(rng.integers(0, 2)),
                 resident_sweeps=int(rng.choice([0, 1, 2])), exchange_by_variable=int(rng.choice([0, 0, 2])),
                 variant_flags=int(rng.choice([0, 0, 1, 2, 3])) | int(os.environ.get("BDDMMA_FUZZ_VARIANT_OR", "0")),  # the env: tools/soak.sh bisections
-                pack_fill=int(rng.choice([0, 0, pw // 2, 16])))
+                pack_fill=int(rng.choice([0, 0, pw // 2, 16])), pack_stagger=int(rng.choice([0, 1, 24, 60, 200])))
     s = bdd_hip_parallel_mma(col, costs, precision="double", **opts)
     o = Oracle(col, costs, "double")
     assert abs(s.lower_bound() - o.lower_bound()) <= 1e-9 * max(1.0, abs(o.lower_bound())), opts

@@ -11,7 +11,7 @@ for _ in range(3):
     co = rng.integers(1, 40, size=14)
     col.add_linear(co, "<=", int(co.sum() // 2), np.sort(rng.choice(120, size=14, replace=False)))
 costs = np.concatenate([costs, np.zeros(col.nr_variables() - len(costs))])
-s = bdd_hip_parallel_mma(col, costs, precision="double", waves_per_block=2, pack_width=64)
+s = bdd_hip_parallel_mma(col, costs, precision="double", waves_per_block=2, pack_width=64, pack_stagger=30)
 s.iterations(3)
-s.save("gpurun_out/checkpoint_small_v05.bin")
-print(os.path.getsize("gpurun_out/checkpoint_small_v05.bin"), s.lower_bound(), s.nr_packs())
+s.save("gpurun_out/checkpoint_small_v06.bin")
+print(os.path.getsize("gpurun_out/checkpoint_small_v06.bin"), s.lower_bound(), s.nr_packs())
