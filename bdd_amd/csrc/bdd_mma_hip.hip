@@ -80,6 +80,8 @@ struct SolverT final : SolverBase {
     RunStep run_step{};                               // {partials, count, ctl, host}: what the launch that ends an iteration gets
     REAL* d_mm_layer = nullptr;   // deferred min-marginal differences in layer order, written by the backward solve sweeps once an L-BFGS wrapper uses them
     bool mm_layer_valid = false;  // equal to d_mm_binned (permuted): true after a backward solve sweep, false after anything else that writes the deferred values
+    CostQuot* d_cost_q = nullptr;      // update_costs: per-variable quotients (kernels.hpp: k_cost_quotients)
+    uint8_t* d_cost_flags = nullptr;
     uint32_t* d_counts = nullptr;
     REAL *d_tmp0 = nullptr, *d_tmp1 = nullptr;        // per-layer scratch (min-marginals, sorted outputs)
     char* d_sol = nullptr;
@@ -904,8 +906,14 @@ struct SolverT final : SolverBase {
             dlo = tmp;
             dhi = tmp + n_lo;
         }
-        hipLaunchKernelGGL((k_update_costs<REAL, TIN>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lohi, d_var, d_nbdds, dlo, n_lo, dhi, n_hi,
-                           (uint32_t)n_layers);
+        if (!d_cost_q) {
+            int rc;
+            if ((rc = dalloc(&d_cost_q, n_vars)) || (rc = dalloc(&d_cost_flags, n_vars))) { if (tmp) (void)hipFree(tmp); return rc; }
+        }
+        hipLaunchKernelGGL((k_cost_quotients<TIN>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_cost_q, d_cost_flags, d_nbdds, dlo, n_lo, dhi, n_hi,
+                           (uint32_t)n_vars);
+        hipLaunchKernelGGL((k_update_costs<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lohi, d_var, (const CostQuot*)d_cost_q,
+                           (const uint8_t*)d_cost_flags, (uint32_t)(n_lo != 0), (uint32_t)(n_hi != 0), (uint32_t)n_layers);
         if (tmp) { HIPCHK(hipStreamSynchronize(stream)); (void)hipFree(tmp); }
         return BDDMMA_OK;
     }
@@ -1180,7 +1188,7 @@ struct SolverT final : SolverBase {
         HIPCHK(hipMalloc(&c, BDDMMA_TRIAD_BYTES));
         HIPCHK(hipMemsetAsync(b, 0, BDDMMA_TRIAD_BYTES, stream));
         HIPCHK(hipMemsetAsync(c, 0, BDDMMA_TRIAD_BYTES, stream));
-        const unsigned grid = 16384;
+        const unsigned grid = (unsigned)((n4 + 255) / 256);  // one vector per thread (kernels.hpp: k_stream)
         auto once = [&]() {
             if (copy) k_stream<true><<<grid, 256, 0, stream>>>(a, b, c, 3.0f, n4);
             else k_stream<false><<<grid, 256, 0, stream>>>(a, b, c, 3.0f, n4);

@@ -95,6 +95,12 @@ int bddmma_create(bddmma_solver** out, int precision, int device, const bddmma_i
 }
 
 int bddmma_device_count(void) { return device_count(); }
+int bddmma_set_layout_threads(int n)
+{
+    if (n < 0) return BDDMMA_ERR_INVALID_ARGUMENT;
+    set_layout_threads((unsigned)n);
+    return BDDMMA_OK;
+}
 
 void bddmma_destroy(bddmma_solver* s)
 {

@@ -244,6 +244,13 @@ std::vector<std::vector<std::array<double, 2>>> bdd_solver::min_marginals()
 }
 
 // ---------------------------------------------------------------------------------------------- batch farm
+// one layout build per device slot at a time: each gets its share of the host cores (8 slots x 32 builder threads would oversubscribe them)
+static void share_layout_threads(size_t slots)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    bddmma_set_layout_threads((int)std::max<size_t>(1, std::min<size_t>(32, (hw ? hw : 1) / std::max<size_t>(1, slots))));
+}
+
 std::vector<batch_result> solve_batch(const std::vector<std::string>& configs, const std::vector<int>& devices, bool quiet)
 {
     std::vector<batch_result> out(configs.size());
@@ -271,9 +278,11 @@ std::vector<batch_result> solve_batch(const std::vector<std::string>& configs, c
             r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
     };
+    share_layout_threads(devices.size());
     std::vector<std::thread> th;
     for (int d : devices) th.emplace_back(worker, d);
     for (auto& t : th) t.join();
+    bddmma_set_layout_threads(0);
     return out;
 }
 
@@ -332,9 +341,11 @@ std::vector<bench_result> bench_set_cover(uint64_t n_vars, uint64_t n_rows, uint
         }
         if (s) bddmma_destroy(s);
     };
+    share_layout_threads(seeds.size());
     std::vector<std::thread> th;
     for (size_t i = 0; i < seeds.size(); ++i) th.emplace_back(worker, i);
     for (auto& t : th) t.join();
+    bddmma_set_layout_threads(0);
     if (aggregate) {
         double worst = 0;
         size_t n_ok = 0;

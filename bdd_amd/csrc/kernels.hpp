@@ -2425,19 +2425,39 @@ __global__ void k_layers_to_entries(const REAL* __restrict__ in, const uint32_t*
 
 // set_vars_costs_func (bdd_cuda_base.cu:457-474).  Quotient and sum are formed in double and rounded
 // once to REAL, as the reference CPU solver does (bdd_parallel_mma_base.cpp:640,651,674-677).
-template <typename REAL, typename TIN>
-__global__ void k_update_costs(REAL* __restrict__ lohi, const int32_t* __restrict__ var, const int32_t* __restrict__ nbdds,
-                               const TIN* __restrict__ c_lo, uint64_t n_lo, const TIN* __restrict__ c_hi, uint64_t n_hi, uint32_t n_layers)
+// Two steps.  As one kernel every layer gathered its variable's BDD count and both cost entries itself: three random reads per layer
+// over 4-8 MB arrays, 935 MB of sector traffic for 5 M layers (126 us).  Now k_cost_quotients reads the caller's
+// vectors once, coalesced, and leaves {c_lo / n, c_hi / n} per variable as one 16-byte record; the per-layer pass makes ONE gather.
+// Flags per record: bit 0 / 1 = the side is SET to 0 (variable past the end of a shorter vector, :465-469).
+struct CostQuot {
+    double lo, hi;
+};
+template <typename TIN>
+__global__ void k_cost_quotients(CostQuot* __restrict__ q, uint8_t* __restrict__ flags, const int32_t* __restrict__ nbdds, const TIN* __restrict__ c_lo, uint64_t n_lo,
+                                 const TIN* __restrict__ c_hi, uint64_t n_hi, uint32_t n_vars)
 {
-    // both sides in one pass over the interleaved {lo, hi} array: one read of the layer's variable and BDD count, one 2 x REAL read-modify-write
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vars) return;
+    const double nb = (double)nbdds[v];
+    CostQuot r;
+    r.lo = (n_lo && v < n_lo) ? (double)c_lo[v] / nb : 0.0;
+    r.hi = (n_hi && v < n_hi) ? (double)c_hi[v] / nb : 0.0;
+    q[v] = r;
+    flags[v] = (uint8_t)(((n_lo && v >= n_lo) ? 1 : 0) | ((n_hi && v >= n_hi) ? 2 : 0));
+}
+template <typename REAL>
+__global__ void k_update_costs(REAL* __restrict__ lohi, const int32_t* __restrict__ var, const CostQuot* __restrict__ q, const uint8_t* __restrict__ flags,
+                               uint32_t do_lo, uint32_t do_hi, uint32_t n_layers)
+{
     using P2 = typename Pair<REAL>::type;
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= n_layers) return;
     const int v = var[l];
+    const CostQuot d = q[v];
+    const uint32_t f = flags[v];
     P2 c = reinterpret_cast<P2*>(lohi)[l];
-    const double nb = (double)nbdds[v];
-    if (n_lo) c.x = (uint64_t)v >= n_lo ? REAL(0) : REAL((double)c.x + (double)c_lo[v] / nb);  // :465-469: past the vector's end the cost is SET to 0
-    if (n_hi) c.y = (uint64_t)v >= n_hi ? REAL(0) : REAL((double)c.y + (double)c_hi[v] / nb);
+    if (do_lo) c.x = (f & 1u) ? REAL(0) : REAL((double)c.x + d.lo);
+    if (do_hi) c.y = (f & 2u) ? REAL(0) : REAL((double)c.y + d.hi);
     reinterpret_cast<P2*>(lohi)[l] = c;
 }
 
@@ -2662,28 +2682,21 @@ __global__ void k_fill(T* __restrict__ p, T v, uint64_t n)
     if (i < n) p[i] = v;
 }
 
-// STREAM triad a = b + s*c (COPY: a = b): 16-byte non-temporal accesses, 4 independent vectors per thread and
-// trip — the fastest of the variants tried on MI355X (profiles/r01_stream_ceiling.txt).  The measured HBM
-// ceilings bench.py quotes the sweep against.
+// STREAM triad a = b + s*c (COPY: a = b): the measured HBM ceilings bench.py quotes next to the sweeps.  One 16-byte vector per
+// thread, no loop: a one-shot grid keeps every CU's memory queue full for the whole launch and reaches the 6.3-6.7 TB/s of
+// MI355X_MICROARCH.md, where the persistent grid-stride version of rounds 1-2 (4 vectors per thread and trip, non-temporal) stayed at
+// 5.1-5.3 TB/s — below what the solver's own sweeps sustain, i.e. not a ceiling (VERDICT r2 #4b).  profiles/r01_stream_ceiling.txt has
+// the variants.
 typedef float stream_v4 __attribute__((ext_vector_type(4)));
 template <bool COPY>
 static __global__ void __launch_bounds__(256) k_stream(stream_v4* __restrict__ a, const stream_v4* __restrict__ b,
                                                        const stream_v4* __restrict__ c, float s, uint64_t n4)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 3 * stride < n4; i += 4 * stride) {
-        stream_v4 x[4], y[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = __builtin_nontemporal_load(&b[i + k * stride]);
-        if (!COPY) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) y[k] = __builtin_nontemporal_load(&c[i + k * stride]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] += s * y[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(x[k], &a[i + k * stride]);
-    }
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    stream_v4 x = b[i];
+    if (!COPY) x += s * c[i];
+    a[i] = x;
 }
 
 // L-BFGS vector helpers (lbfgs_impl.h two-loop recursion; thrust::inner_product / transform there)

@@ -2,6 +2,7 @@
 #include "layout.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -17,13 +18,15 @@ namespace {
 
 // Host threads for the layout build (std::thread: no OpenMP runtime to link).  The reference builds its layout with ~10 device
 // sorts (bdd_cuda_base.cu:146-391); here it is host work, spread over the cores: f(begin, end, thread) over contiguous chunks.
+std::atomic<unsigned> g_layout_threads{0};  // bddmma_set_layout_threads: 0 = BDDMMA_THREADS, else min(cores, 32)
 struct Par {
     unsigned nt = 1;
     Par()
     {
         const char* e = std::getenv("BDDMMA_THREADS");
         const unsigned hw = std::thread::hardware_concurrency();
-        nt = e ? (unsigned)std::atoi(e) : std::min(hw ? hw : 1u, 32u);
+        const unsigned set = g_layout_threads.load(std::memory_order_relaxed);
+        nt = set ? set : (e ? (unsigned)std::atoi(e) : std::min(hw ? hw : 1u, 32u));
         if (nt < 1) nt = 1;
     }
     template <typename F>
@@ -913,5 +916,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     lap("vpos + resident headers");
     return BDDMMA_OK;
 }
+
+void set_layout_threads(unsigned n) { g_layout_threads.store(n, std::memory_order_relaxed); }
 
 }  // namespace bddmma

@@ -208,6 +208,10 @@ void visit_layout_arrays(LAYOUT& L, V&& v)
 }
 constexpr int LAYOUT_ARRAY_IDS = 39;
 
+// Host threads of the layout build: 0 = automatic (BDDMMA_THREADS, else min(cores, 32)).  Processes that build several layouts at once
+// (one per device slot: bddmma_host::solve_batch / bench_set_cover) share the cores through this.
+void set_layout_threads(unsigned n);
+
 // Returns BDDMMA_OK or an error code; `err` receives the message.
 int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
                  const bddmma_options* opts, HostLayout& out, std::string& err, bool keep_debug_maps,

@@ -98,6 +98,8 @@ def main():
         # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (the ranks then share devices: the numbers mean nothing)
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    if world > 1:   # the layout of every rank's instance is built on the host cores: each rank takes its share (default: up to 32 threads)
+        os.environ.setdefault("BDDMMA_THREADS", str(max(1, min(32, (os.cpu_count() or 1) // world))))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -167,7 +169,7 @@ def main():
     second = None
     if not args.no_second_precision:
         s2, dt2, prof2, lb2 = run(other)
-        second = (dt2, prof2, lb2)
+        second = (dt2, prof2, lb2, s2.device_bytes())
         s2.close()
     solver, dt, prof, lb = run(args.precision)
 
@@ -222,19 +224,19 @@ def main():
                 "hbm_resident_bytes": resident,
                 "event_stride": stride,
             },
-            "roofline": roofline(prof, sizes, R, its / world, args, sfx, triad_gbs, copy_gbs),
+            "roofline": roofline(prof, sizes, R, its / world, args, sfx, triad_gbs, copy_gbs, resident),
             "value_with_lower_bound_every_iteration": lb_rate,
             "value_with_lower_bound_every_iteration_host_loop": lb_rate_host_loop,
             "lower_bound_after": {"iterations": pre_iterations.get("n", 0) + args.warmup + 2 * args.steps, "value": lb},
             "clock_warm_iterations": pre_iterations.get("n", 0),
         }
         if second is not None:
-            dt2, prof2, lb2 = second
+            dt2, prof2, lb2, _res2 = second
             R2, sfx2 = (8, "f64") if other == "double" else (4, "f32")
             its2 = aggregate_rate(world, args.steps, dt2)
             out["value_" + sfx2] = its2
             out["ms_per_step_" + sfx2] = dt2 / args.steps * 1e3
-            out["roofline_" + sfx2] = roofline(prof2, sizes, R2, its2 / world, args, sfx2, triad_gbs, copy_gbs)
+            out["roofline_" + sfx2] = roofline(prof2, sizes, R2, its2 / world, args, sfx2, triad_gbs, copy_gbs, second[3])
             out["lower_bound_after_" + sfx2] = {"iterations": pre_iterations.get("n", 0) + args.warmup + 2 * args.steps, "value": lb2,
                                                "rel_diff_to_" + sfx: abs(lb2 - lb) / max(abs(lb), 1e-300)}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
@@ -245,31 +247,47 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(prof, sizes, R, its_per_gpu, args, sfx, triad_gbs, copy_gbs):
-    """`achieved` = algorithmic bytes the named (slower) sweep launch processes / its average duration, from hipEvent pairs recorded on
-    the solver's stream inside the timed region; `frac_whole_iteration` prices the whole iteration (4 launches + gaps) on the
-    driver's clock against B_iter; `traffic` = counter-measured HBM bytes per launch of the same kernel (committed rocprofv3 PMC
-    passes; null when the kernel sources changed since they were taken)."""
+INFINITY_CACHE_BYTES = 256 << 20  # MI355X_MICROARCH.md "Infinity Cache (L3)"
+
+
+def roofline(prof, sizes, R, its_per_gpu, args, sfx, triad_gbs, copy_gbs, resident):
+    """Dominant kernel = the slower of the two sweep launches; durations from hipEvent pairs recorded on the solver's stream inside
+    a second pass of the same K steps.
+      achieved / frac_algorithmic : SURVEY §8(d)'s ALGORITHMIC bytes of one sweep launch / its average duration (the contract figure).
+                                    The layout moves fewer bytes than that (4-byte shared node words instead of 12 B of indices, no
+                                    terminals), so this rate can exceed what HBM delivers — it is a work rate, not a bandwidth.
+      traffic / frac             : bytes the launch really moves, from the committed rocprofv3 PMC passes of this command
+                                    ((2 FETCH_SIZE + WRITE_SIZE) x 1024, profiles/<tag>/traffic.json, valid while the kernel sources
+                                    hash to what they were taken on) / the same duration / 8 TB/s.  `frac` falls back to the
+                                    algorithmic figure (and says so in frac_basis) when no matching counters are committed.
+      frac_whole_iteration       : B_iter x value / 8 TB/s on the driver's clock (4 launches + gaps)."""
     names = ["forward_mm", "backward_mm", "finish_delta", "other"]
     avg_ms = [prof["total_ms"][i] / max(prof["launches"][i], 1) for i in range(4)]
     dom = 0 if avg_ms[0] >= avg_ms[1] else 1
     b_sweep, b_exch, b_iter = sweep_bytes(sizes, R), exchange_bytes(sizes, R), iteration_bytes(sizes, R)
     achieved = b_sweep / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
-    traffic = measured_traffic(names[dom], args, sfx)
+    traffic, traffic_exch, traffic_src = measured_traffic(names[dom], args, sfx)
+    counter_gbs = traffic / (avg_ms[dom] * 1e-3) / 1e9 if traffic and avg_ms[dom] > 0 else None
     whole = b_iter * its_per_gpu / 1e9
+    hbm_only = hbm_only_fractions()
     return {
         "bound": "hbm",
         "kernel": names[dom],
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS,
+        "frac": (counter_gbs if counter_gbs is not None else achieved) / HBM_PEAK_GBS,
+        "frac_basis": (f"counter bytes of the launch ({traffic_src}) / hipEvent duration" if counter_gbs is not None
+                       else "algorithmic bytes (no committed PMC passes match these kernel sources / this workload)"),
+        "frac_algorithmic": achieved / HBM_PEAK_GBS,
         "traffic": traffic,
-        "frac_counter_bytes": (traffic / (avg_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms[dom] > 0 else None,
+        "achieved_counter_GBs": counter_gbs,
         "algorithmic_bytes_per_launch": b_sweep,
         "algorithmic_bytes_exchange_launch": b_exch,
         "algorithmic_bytes_per_iteration": b_iter,
         "frac_exchange_launch": (b_exch / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_ms[2] > 0 else None,
+        "traffic_exchange_launch": traffic_exch,
+        "frac_exchange_launch_counter_bytes": (traffic_exch / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_exch and avg_ms[2] > 0 else None,
         "whole_iteration_GBs": whole,
         "frac_whole_iteration": whole / HBM_PEAK_GBS,
         "avg_launch_ms": {names[i]: avg_ms[i] for i in range(3)},
@@ -277,7 +295,27 @@ def roofline(prof, sizes, R, its_per_gpu, args, sfx, triad_gbs, copy_gbs):
         "timed_launches": {names[i]: prof["launches"][i] for i in range(3)},
         "stream_triad_GBs": triad_gbs,
         "stream_copy_GBs": copy_gbs,
+        "infinity_cache_note": {
+            "resident_bytes": resident,
+            "infinity_cache_bytes": INFINITY_CACHE_BYTES,
+            "resident_over_cache": resident / INFINITY_CACHE_BYTES,
+            "note": "FETCH_SIZE / WRITE_SIZE count the L2's fabric requests, Infinity-Cache hits included: with the working set within a few "
+                    "times the 256 MiB cache part of `traffic` is served on-die, so `frac` is an L2<->fabric rate; the HBM-only figure is "
+                    "the whole-iteration fraction of an instance ten times the size (4.5 GB resident), hbm_only_frac_whole_iteration",
+            "hbm_only_frac_whole_iteration": hbm_only,
+        },
     }
+
+
+def hbm_only_fractions():
+    """frac_whole_iteration of the 105 M-node instance (V = 10 M, B = 5 M, k = 10: 4.5 / 7.2 GB resident, no Infinity-Cache help), measured
+    with tools/kbench.py and committed in profiles/ (None if the file is missing)."""
+    for name in ("r03_hbm_only_105m.json", "r02_hbm_only_105m.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            return {"f32": d.get("f32"), "f64": d.get("f64"), "source": "profiles/" + name}
+    return None
 
 
 def timed_region(run_steps, device_sync, dist):
@@ -309,29 +347,35 @@ def aggregate_rate(world, steps, dt):
 
 
 def measured_traffic(kernel, args, sfx):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/<tag>/traffic.json, produced by tools/profile.sh + tools/collect_profiles.py: separate --pmc runs,
-    bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md §HBM).  The file is stamped with the hash of the
-    kernel sources it was measured on; None when no profile matches the workload or the sources changed since."""
+    """(HBM bytes per launch of the dominant sweep kernel, of the exchange kernel, source) from the committed rocprofv3 PMC passes of
+    this same command (profiles/<tag>/traffic.json, produced by tools/profile.sh + tools/collect_profiles.py: separate --pmc runs,
+    bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md §HBM).  The file is stamped with the hash of the kernel
+    sources it was measured on; (None, None, None) when no profile matches the workload or the sources changed since."""
     tag = {(1_000_000, 500_000, 10): "10m", (100_000, 50_000, 10): "1m"}.get((args.vars, args.rows, args.k))
     if tag is None or args.deterministic or args.pack_width or args.wpb or args.vars_per_bin or args.stage_cap:
-        return None
-    for rnd in ("r02",):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_{sfx}", "traffic.json")
+        return None, None, None
+    for rnd in ("r03", "r02"):
+        rel = os.path.join("profiles", f"{rnd}_{tag}_{sfx}", "traffic.json")
+        path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
         d = json.load(open(path))
         if d.get("_source_hash") != source_hash():
-            return None
+            continue
         want = "k_fwd_narrow" if kernel == "forward_mm" else "k_bwd_narrow"
+        sweep = None
         for name, v in d.items():
             m = re.search(want + r"<\w+, \d+, (\d+), \d+(?:, \w+)?>", name)   # <REAL, R, MODE, waves per block[, SEG]>; MODE 1 = solve
             if m and m.group(1) == "1":
-                return v["hbm_bytes"]
-        for name, v in d.items():   # small instances: the resident sweeps
-            if re.search(want.replace("_narrow", "_res") + r"<", name):
-                return v["hbm_bytes"]
-    return None
+                sweep = v["hbm_bytes"]
+        if sweep is None:
+            for name, v in d.items():   # small instances: the resident sweeps
+                if re.search(want.replace("_narrow", "_res") + r"<", name):
+                    sweep = v["hbm_bytes"]
+        exch = next((v["hbm_bytes"] for name, v in d.items() if "k_exchange_reduce" in name and isinstance(v, dict)), None)
+        if sweep is not None:
+            return sweep, exch, rel
+    return None, None, None
 
 
 def cpu_baseline(col, costs, args, sizes):

@@ -115,6 +115,10 @@ void bddmma_destroy(bddmma_solver* s);
 /* Number of HIP devices visible to the process (0 when there is none / no driver).  One host thread per device, each with its own
  * handles, is the multi-GPU model: independent instances, no collective (reference: device 0 hard-coded, include/cuda_utils.h:111-114). */
 int bddmma_device_count(void);
+/* Host threads one layout build (bddmma_create) may use: 0 = automatic (environment BDDMMA_THREADS, else min(cores, 32)).  A process that
+ * builds one instance per GPU at the same time gives every build cores / #GPUs (the reference builds its layout on the device,
+ * bdd_cuda_base.cu:146-391; here it is host work). */
+int bddmma_set_layout_threads(int n);
 /* Error text of the last failed call on `s`; with s == NULL the last failed bddmma_create. */
 const char* bddmma_last_error(const bddmma_solver* s);
 

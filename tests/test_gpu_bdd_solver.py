@@ -169,3 +169,34 @@ def test_batch_farm_command_line(tmp_path):
     ref = bdd_hip_parallel_mma(col, costs, precision="double")
     ref.iterations(50)
     assert abs(rows[1]["lower_bound"] - ref.lower_bound()) <= 1e-9 * abs(ref.lower_bound())
+
+
+def test_eight_slot_rehearsal_on_one_gpu(tmp_path):
+    """BASELINE.json configs[4] (8 instances, one per GPU) cannot be run here: both N = 8 paths are rehearsed with all eight slots on the
+    one GPU of this box — the line shapes, the per-rank work and the host-thread budget are what an 8-GPU node would see, the
+    numbers are not.  (1) bench.py under torch.distributed.run, 8 ranks, gloo barrier, max over ranks, ONE JSON line from rank 0;
+    (2) bdd_solver_cl --bench-set-cover with --devices 0,0,0,0,0,0,0,0: eight host threads, each builds and times its own instance."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BDDMMA_BENCH_SHARE_GPUS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", "29741", os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--vars", "100000",
+                          "--rows", "50000", "--no-second-precision", "--clock-warm", "0.05"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    one = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+    assert one <= set(d) and d["n_gpus"] == 8 and d["steps"] == 20 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 8 * 20 / (d["ms_per_step"] * 20e-3)) <= 1e-6 * d["value"]       # whole-job rate = all ranks' steps / max time
+    assert "cpu_baseline" not in d                                                          # the CPU leg is timed at N = 1 only
+    exe = os.path.join(root, "bdd_amd", "csrc", "bdd_solver_cl")
+    out = subprocess.run([exe, "--bench-set-cover", "100000", "50000", "10", "--iterations", "200", "--warmup", "20", "--seeds", "12345-12352",
+                          "--devices", "0,0,0,0,0,0,0,0", "--precision", "float"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 9 and rows[8]["instances"] == 8 and rows[8]["aggregate_iterations_per_second"] > 0
+    assert sorted(r["seed"] for r in rows[:8]) == list(range(12345, 12353)) and all(r["ok"] for r in rows[:8])
+    # equal work per slot: the eight bounds are those of eight DIFFERENT instances (no slot ran another one's seed twice)
+    assert len({round(r["lower_bound"], 6) for r in rows[:8]}) == 8
