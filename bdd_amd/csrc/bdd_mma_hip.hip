@@ -308,6 +308,8 @@ struct SolverT final : SolverBase {
         SET_DYN((k_exchange_reduce<REAL, double, EX_ITER>), exch_lds);
         SET_DYN((k_exchange_reduce<REAL, double, EX_RAW>), exch_lds);
         SET_DYN((k_exchange_reduce<REAL, double, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, true>), exch_lds);  // run_plain()'s instantiation
+        SET_DYN((k_exchange_reduce<REAL, double, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, false, 7>), exch_lds);
+        SET_DYN((k_exchange_reduce<REAL, double, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, true, 7>), exch_lds);
         opts_variant = opts ? opts->variant_flags : 0u;
         mixed_fwd = (opts_variant & 2u) == 0;
         // measured in double: 7.1 M nodes (490 MB resident) lose 12 % with non-temporal potentials, 10.5 M (720 MB) gain 4 %
@@ -588,38 +590,36 @@ struct SolverT final : SolverBase {
             launch_bcast(d_delta_var, d_delta_lay, gate(), rstep);
             delta_var_valid = true;
         } else {
-#define LAUNCH_EX(T_, U_, N_, RUN_)                                                                                                              \
-    hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, T_, U_, N_, RUN_>), dim3(n_bins), dim3(T_), exch_lds, stream, d_mm_binned, d_bin_ptr, \
+            // All three sizes run the lean form since round 3 (kernels.hpp: EXV_* = 7: scalar-offset entry addressing, one predicated atomic per
+            // entry; its 16-byte store hazard is guarded): 10.5 M nodes 124.1 -> 122.1 us per iteration (float), 236.0 -> 232.4 (double);
+            // 1.05 M nodes 4.7 -> 4.4 us per launch.  variant_flags bit 6 selects the round-2 form (0), bits 3-5 any combination for the
+            // 256-thread kernel (the bisection of profiles/r03_exchange_variant_rootcause.txt).
+#define LAUNCH_EX(T_, U_, N_, RUN_, V_)                                                                                                              \
+    hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, T_, U_, N_, RUN_, V_>), dim3(n_bins), dim3(T_), exch_lds, stream, d_mm_binned, d_bin_ptr, \
                        d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers, gate(), rstep)
-            // inside run_plain() the instantiation that honours the stop flag and runs the termination tests; otherwise the plain one
-            if (exch_medium) { if (run_stop) LAUNCH_EX(EXM_THREADS, EXM_UNROLL, EXM_NPT, true); else LAUNCH_EX(EXM_THREADS, EXM_UNROLL, EXM_NPT, false); }
-            else if (exch_small) {
-                // 256-thread exchange (small instances).  Default since round 3: scalar-offset entry addressing + one predicated atomic per
-                // entry (kernels.hpp: EXV_*, all three = 7) — the round-2 rewrite, correct now that the 16-byte store hazard is guarded
-                // (hop_store(double2)); 4.7 -> 4.4 us per launch at 1.05 M nodes.  variant_flags bits 3-5 select another combination
-                // (the bisection of profiles/r03_exchange_variant_rootcause.txt), bit 6 the round-2 kernel.
-#define LAUNCH_EXV(V_, RUN_)                                                                                                                    \
-    hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, EXS_THREADS, EXS_UNROLL, EXS_NPT, RUN_, V_>), dim3(n_bins), dim3(EXS_THREADS), \
-                       exch_lds, stream, d_mm_binned, d_bin_ptr, d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars,  \
-                       (uint32_t)n_layers, gate(), rstep)
-                const uint32_t var = (opts_variant & 0x40u) ? 0u : (((opts_variant >> 3) & 7u) ? ((opts_variant >> 3) & 7u) : 7u);
-                if (run_stop) {
-                    if (var == 0) LAUNCH_EXV(0, true); else LAUNCH_EXV(7, true);
-                } else {
-                    switch (var) {
-                        case 0: LAUNCH_EXV(0, false); break;
-                        case 1: LAUNCH_EXV(1, false); break;
-                        case 2: LAUNCH_EXV(2, false); break;
-                        case 3: LAUNCH_EXV(3, false); break;
-                        case 4: LAUNCH_EXV(4, false); break;
-                        case 5: LAUNCH_EXV(5, false); break;
-                        case 6: LAUNCH_EXV(6, false); break;
-                        default: LAUNCH_EXV(7, false); break;
-                    }
+#define LAUNCH_EX_RV(T_, U_, N_)                                                                        \
+    do {                                                                                                \
+        if (opts_variant & 0x40u) {                                                                     \
+            if (run_stop) LAUNCH_EX(T_, U_, N_, true, 0); else LAUNCH_EX(T_, U_, N_, false, 0);         \
+        } else {                                                                                        \
+            if (run_stop) LAUNCH_EX(T_, U_, N_, true, 7); else LAUNCH_EX(T_, U_, N_, false, 7);         \
+        }                                                                                               \
+    } while (0)
+            if (exch_medium) LAUNCH_EX_RV(EXM_THREADS, EXM_UNROLL, EXM_NPT);
+            else if (exch_small && !run_stop && !(opts_variant & 0x40u) && ((opts_variant >> 3) & 7u)) {
+                switch ((opts_variant >> 3) & 7u) {
+                    case 1: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 1); break;
+                    case 2: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 2); break;
+                    case 3: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 3); break;
+                    case 4: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 4); break;
+                    case 5: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 5); break;
+                    case 6: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 6); break;
+                    default: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 7); break;
                 }
-#undef LAUNCH_EXV
             }
-            else { if (run_stop) LAUNCH_EX(EX_THREADS, EX_UNROLL, EX_NPT, true); else LAUNCH_EX(EX_THREADS, EX_UNROLL, EX_NPT, false); }
+            else if (exch_small) LAUNCH_EX_RV(EXS_THREADS, EXS_UNROLL, EXS_NPT);
+            else LAUNCH_EX_RV(EX_THREADS, EX_UNROLL, EX_NPT);
+#undef LAUNCH_EX_RV
 #undef LAUNCH_EX
             delta_var_valid = false;
         }

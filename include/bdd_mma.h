@@ -86,7 +86,7 @@ typedef struct bddmma_options {
                                   bit 2: no non-temporal stores of the potentials (default: on for double instances above 640 MB)
                                   bits 3-5: 256-thread exchange kernel with this combination of {1: scalar-offset entry loads, 2: scalar-offset
                                             pair stores, 4: one predicated LDS atomic per entry} instead of all three (the default)
-                                  bit 6: the round-2 256-thread exchange kernel (none of the three)
+                                  bit 6: the round-2 exchange kernels (none of the three), every bin size
                                   bit 7 / bit 8: narrow workgroups mapped to XCDs in contiguous eighths / in interleaved chunks of 32
                                                  (default: interleaved when the eighths' hop counts differ by more than 10 %) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
