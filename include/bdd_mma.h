@@ -91,7 +91,7 @@ typedef struct bddmma_options {
                                                  (default: interleaved when the eighths' hop counts differ by more than 10 %) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
-                                  instance (the sweeps are bound by instructions issued, not by latency), kept for experiments */
+                                  instance (NOTES.md section 6: the sweeps are bound by instructions issued, not by latency), kept for experiments */
     uint32_t pack_stagger;     /* narrow packs whose BDDs start at different hops ("staggered"): a BDD that no longer fits next to the ones
                                   of the open pack hop by hop is tried a few hops further down, where those have become narrow again — BDDs
                                   of general linear rows are narrow at both ends and wide in the middle, and side by side from hop 0 they
