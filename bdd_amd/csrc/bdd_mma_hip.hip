@@ -14,6 +14,7 @@
 #include <limits>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bdd_mma.h"
@@ -740,22 +741,24 @@ struct SolverT final : SolverBase {
         c.lb_post = lb_initial;
         c.tolerance = tolerance;
         c.slope = slope;
+        c.time_limit = time_limit;
         std::memset((void*)h_run, 0, sizeof(RunHost));
         run_step = RunStep{d_lb_partial, nb_.n_packs + wb_.n_packs + hb_.n_packs, d_run_ctl, d_run_host};
         HIPCHK(hipMemcpyAsync(d_run_ctl, &c, sizeof(RunCtl), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_run_begin, dim3(1), dim3(1), 0, stream, d_run_ctl, (uint64_t)(elapsed() * RUN_TICKS_PER_SECOND));
         HIPCHK(hipStreamSynchronize(stream));  // c is a stack object
         constexpr uint64_t WINDOW = 6;  // iterations queued ahead of the last bound seen (< RUN_RING)
         volatile RunHost* hr = h_run;
         uint64_t queued = 0, seen = 0;
         uint32_t idle_spins = 0;
+        double idle_since = 0.0;
         int reason = 0;
         double lb_post = lb_initial;
         run_stop = &d_run_ctl->stop;
         while (true) {
-            // near the time limit: one iteration at a time, so that none is queued which the sequential loop would not run
-            const double t = elapsed();
-            const double per_iter = seen ? t / (double)seen : 0.0;
-            const uint64_t window = (seen && t + 4.0 * (double)WINDOW * per_iter < time_limit) ? WINDOW : 1;
+            // (the wall-clock limit is tested on the device with the other criteria, run_ctl_step: iterations queued behind the one that
+            // crossed it return at once like those behind any other stop)
+            const uint64_t window = WINDOW;
             bool launched = false;
             while (queued < max_iter && queued - seen < window) {
                 run_iter = (uint32_t)std::min<uint64_t>(queued, RUN_NOT_STOPPED - 1);
@@ -775,19 +778,20 @@ struct SolverT final : SolverBase {
             bool stop = false;
             for (; seen < done && !stop; ++seen) {
                 lb_post = hr->lb[seen % RUN_RING];
-                const double ts = elapsed();
-                if (verbose) std::printf("[bdd solver] iteration %llu, lower bound = %.10g, time = %.3f s\n", (unsigned long long)seen, lb_post, ts);
-                if (ts > time_limit) { reason = 1; stop = true; }  // run_solver_util.h:50-55 (tested before the bound's criteria)
+                if (verbose) std::printf("[bdd solver] iteration %llu, lower bound = %.10g, time = %.3f s\n", (unsigned long long)seen, lb_post, elapsed());
             }
             if (stop) break;
             if (dev_reason && seen == done) { reason = dev_reason; break; }
             if (seen == max_iter) break;
             if (!launched && done == seen) {
-                // nothing new.  After ~0.2 s without a published bound make sure the device is still alive: a blocking wait for the
-                // stream (harmless if an iteration is simply that long) — still nothing then means the queued launches were lost,
-                // which the checks behind the loop report.  (hipStreamQuery is not used for this: it was seen to report an idle
-                // stream with launches still queued, which ended runs early.)
-                if (++idle_spins > 2000000u) {
+                // nothing new: spin for the first millisecond (an iteration is 20-250 us), then poll every 50 us without holding a core.
+                // After 0.2 s without a published bound make sure the device is still alive: a blocking wait for the stream (harmless
+                // if an iteration is simply that long) — still nothing then means the queued launches were lost, which the checks
+                // behind the loop report.  (hipStreamQuery is not used for this: it was seen to report an idle stream with launches
+                // still queued, which ended runs early.)
+                const double now = elapsed();
+                if (idle_spins++ == 0) idle_since = now;
+                if (now - idle_since > 0.2) {
                     const hipError_t e = hipStreamSynchronize(stream);
                     if (e != hipSuccess) {
                         run_stop = nullptr;
@@ -796,8 +800,11 @@ struct SolverT final : SolverBase {
                     }
                     if ((hr->state & ((1ull << 56) - 1)) == seen) break;
                     idle_spins = 0;
+                } else if (now - idle_since > 1e-3) {
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+                } else {
+                    __builtin_ia32_pause();
                 }
-                __builtin_ia32_pause();
             } else {
                 idle_spins = 0;
             }

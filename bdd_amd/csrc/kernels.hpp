@@ -2000,9 +2000,16 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_mixed(DevPtrs<REAL> d, PackDev
 constexpr uint32_t RUN_RING = 64;
 struct RunCtl {  // device memory
     double lb_initial, lb_first, lb_post, tolerance, slope;
+    double time_limit;   // seconds since the start of run_solver (run_solver_util.h:45-55); tested on the device's constant 100 MHz clock
+    uint64_t t0;         // s_memrealtime at the start of the run (minus what the host had already spent), set by k_run_begin
     uint64_t iter;
     uint32_t stop, reason;
 };
+constexpr double RUN_TICKS_PER_SECOND = 1e8;  // s_memrealtime
+static __global__ void k_run_begin(RunCtl* ctl, uint64_t host_ticks_so_far)
+{
+    ctl->t0 = __builtin_amdgcn_s_memrealtime() - host_ticks_so_far;
+}
 struct RunHost {  // pinned host memory, written by the device
     uint64_t state;       // (iterations whose bound has been published) | (stop reason << 56): one word, so the host never sees half an update
     double lb[RUN_RING];  // bound after iteration i at [i % RUN_RING]
@@ -2041,7 +2048,11 @@ __device__ __forceinline__ void run_ctl_step(const RunStep& r)
     ctl->lb_post = lb_post;
     ctl->iter = it + 1;
     uint32_t reason = 0;
-    if (__builtin_fabs(lb_prev - lb_post) < __builtin_fabs(c.tolerance * lb_prev)) reason = 2;                // run_solver_util.h:56-61
+    // the wall-clock limit first, as the reference tests it (:45-55) — on the device, so that no iteration queued behind the one that crossed
+    // the limit runs (the host-side test let up to window - 1 more iterations execute)
+    const double time_spent = (double)(__builtin_amdgcn_s_memrealtime() - c.t0) / RUN_TICKS_PER_SECOND;
+    if (time_spent > c.time_limit) reason = 1;
+    else if (__builtin_fabs(lb_prev - lb_post) < __builtin_fabs(c.tolerance * lb_prev)) reason = 2;           // run_solver_util.h:56-61
     else if (__builtin_fabs(lb_prev - lb_post) < c.slope * __builtin_fabs(lb_initial - lb_first)) reason = 3;  // :62-67
     else if (lb_post == __builtin_huge_val()) reason = 4;                                                       // :68-73
     if (reason) { ctl->reason = reason; ctl->stop = (uint32_t)(it + 1 < (uint64_t)RUN_NOT_STOPPED ? it + 1 : (uint64_t)RUN_NOT_STOPPED - 1); }  // launches of iterations >= it + 1 are skipped

@@ -94,6 +94,16 @@ def test_time_limit_and_degenerate_limits():
     res = run_solver(s, max_iter=10**7, tolerance=0.0, improvement_slope=0.0, time_limit=0.05)
     assert res["stop_reason"] == 1 and 1 <= res["iterations"] < 10**7 and 0.05 <= res["seconds"] < 2.0
     assert s.lower_bound() == res["lb_final"]
+    # the clock is tested on the device with the other criteria (run_ctl_step): the iterations queued behind the one that crossed the limit
+    # did not run — the state is the one after exactly `iterations` iterations (the host-side test let up to five more execute)
+    a = bdd_hip_parallel_mma(col, costs, precision="double", deterministic=True)
+    b = bdd_hip_parallel_mma(col, costs, precision="double", deterministic=True)
+    res = run_solver(a, max_iter=10**7, tolerance=0.0, improvement_slope=0.0, time_limit=0.03)
+    assert res["stop_reason"] == 1 and res["iterations"] > 10
+    b.iterations(res["iterations"])
+    assert a.lower_bound() == b.lower_bound() == res["lb_final"]
+    for x, y in zip(a.get_solver_costs(), b.get_solver_costs()):
+        np.testing.assert_array_equal(x, y)
     # and the solver is reusable afterwards (the stop flag of one run does not leak into the next calls)
     before = s.lower_bound()
     s.iterations(3)
