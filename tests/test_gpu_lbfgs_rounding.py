@@ -84,6 +84,23 @@ def test_lbfgs_structured_instance_vs_oracle():
     run_lbfgs_pair(col, np.asarray(ilp.objective, float), "double", 40)
 
 
+@pytest.mark.parametrize("precision,tol", [("double", 1e-9), ("float", 2e-3)])
+def test_applied_direction_is_dual_feasible(precision, tol):
+    """make_dual_feasible(direction) (bdd_cuda_base.cu:1261-1303) keeps the cost of every variable: sum over its layers of hi - lo (with the
+    deferred min-marginal differences distributed) stays the objective coefficient — after many L-BFGS steps the primal objective vector
+    must still be the input costs."""
+    col, costs = random_set_cover(3000, 2500, 8, seed=13)
+    s = bdd_hip_parallel_mma(col, costs, precision=precision)
+    l = bdd_hip_lbfgs(s)
+    steps = 0
+    for _ in range(80):
+        l.iteration()
+        steps += l.state()["last_kind"]
+    assert steps >= 40                      # most iterations did apply an L-BFGS step
+    s.distribute_delta()
+    np.testing.assert_allclose(s.get_primal_objective_vector_host(), costs, rtol=0, atol=tol)
+
+
 def test_lbfgs_full_size_config4():
     """BASELINE.json configs[3]: lbfgs parallel mma on "the same 10M-node instance" as configs[2] — the mt19937_64(12345) instance of
     bench.py and of the full-size fixture (defaults m = 5, step 1e-6, 1e-6, 0.8, 1.1)."""
