@@ -1,14 +1,14 @@
 """Which draw order did the survey's driver use for the mt19937_64(12345) set-cover instance of BASELINE.md §2?
 
 BASELINE.md quotes LB(20 iterations, 1.05 M nodes, double) = 24594.218672 from the unmodified reference, but the driver that
-drew the rows was not kept.  This script builds the instance in the draw orders of tools/instance_order_search.cpp (rows before /
+drew the rows was not kept.  This script builds the instance in the draw orders of tests/tools/instance_order_search.cpp (rows before /
 after the costs, per-element vs per-row rejection of duplicates, uniform_int_distribution vs modulo vs scaled doubles, the cost
 engine shared / re-seeded / seed + 1 / 32-bit, a 32-bit row engine) and runs the CPU oracle for 20 iterations on each.  Result
 (DESIGN.md §4): no order reproduces the value; the closest is 24597.052681 (rows first, per-element rejection, costs afterwards),
 which is the order bdd_amd/csrc/host/instances.cpp documents as the benchmark instance.
 
-    g++ -O2 -std=c++17 -shared -fPIC -o build/libinstance_order_search.so tools/instance_order_search.cpp
-    python tools/instance_order_search.py
+    g++ -O2 -std=c++17 -shared -fPIC -o build/libinstance_order_search.so tests/tools/instance_order_search.cpp
+    python tests/tools/instance_order_search.py
 """
 import ctypes as C
 import itertools
@@ -17,11 +17,11 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bdd_amd.bdd_collection import BddCollection  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
 
-L = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "libinstance_order_search.so"))
+L = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "build", "libinstance_order_search.so"))
 V, B, k, target = 100_000, 50_000, 10, 24594.218672
 for r32, crng, drawm, dup, order in itertools.product([0, 1], [0, 1, 2, 3], [0, 1, 2], [0, 1], [0, 1]):
     if r32 and drawm == 2:

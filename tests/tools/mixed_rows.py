@@ -1,4 +1,4 @@
-import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bdd_amd.instances import random_set_cover_mixed, random_set_cover
 from bdd_amd.solver import bdd_hip_parallel_mma
 from oracle.oracle import Oracle

@@ -1,8 +1,8 @@
 """Race hunt: run the differential fuzz test for a few seeds over and over (launch several copies at once on one GPU):
-    python tools/stress_fuzz.py REPEATS SEED [SEED ...]"""
+    python tests/tools/stress_fuzz.py REPEATS SEED [SEED ...]"""
 import os, sys, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 from bdd_amd import capi
 if os.environ.get("BDDMMA_LIB"):
     capi.LIB_PATH = os.path.abspath(os.environ["BDDMMA_LIB"])

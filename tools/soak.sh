@@ -1,6 +1,6 @@
 #!/bin/bash
 # Soak of the shipped kernels with several processes sharing the one GPU (VERDICT r2 #1b): P copies of the differential fuzz
-# (tools/stress_fuzz.py) and P copies of tests/test_gpu_run_solver.py in a loop, all at once.
+# (tests/tools/stress_fuzz.py) and P copies of tests/test_gpu_run_solver.py in a loop, all at once.
 #   tools/soak.sh TAG [P=4] [FUZZ_REPEATS=25] [RUN_SOLVER_LOOPS=8] [ENV=VALUE ...]
 # Summary -> gpurun_out/soak_TAG/summary.txt (copy to profiles/).
 set -u
@@ -13,7 +13,7 @@ SEEDS=$(seq 0 39)
 t0=$(date +%s)
 pids=()
 for p in $(seq 1 "$P"); do
-    python tools/stress_fuzz.py "$REPS" $SEEDS > "$OUT/fuzz_$p.txt" 2>&1 &
+    python tests/tools/stress_fuzz.py "$REPS" $SEEDS > "$OUT/fuzz_$p.txt" 2>&1 &
     pids+=($!)
     (for i in $(seq 1 "$LOOPS"); do python -m pytest tests/test_gpu_run_solver.py -q -x -rf -p no:cacheprovider 2>&1 | grep -E "^(FAILED|E  )|passed|failed" | cut -c1-300; done) > "$OUT/runsolver_$p.txt" 2>&1 &
     pids+=($!)

@@ -2,7 +2,7 @@
 with set-cover rows.  Prints sizes, pack statistics, kernel times, iterations/s and the SURVEY §8(d) roofline fraction of the whole
 iteration (B_iter = 2 [12 N' + 2R N + (5R+4) L' + (8R+4) V]).
 
-    python tools/widebench.py [--rows 4000] [--vars 20000] [--k 14] [--cover-rows 0] [--cover-k 10] [--precision float,double] [--oracle 1]
+    python tools/widebench.py [--rows 4000] [--vars 20000] [--k 14] [--cover-rows 0] [--cover-k 10] [--precision float,double]
                               [--pack-width 0] [--variant 0] [--wpb 0] [--vars-per-bin 0] [--iters 200]
     4 000 rows = 1 M nodes (the round-1/2 benchmark), 40 000 rows = 10 M nodes."""
 import argparse, os, sys, time
@@ -21,7 +21,6 @@ ap.add_argument("--k", type=int, default=14)
 ap.add_argument("--cover-rows", type=int, default=0)
 ap.add_argument("--cover-k", type=int, default=10)
 ap.add_argument("--precision", default="float,double")
-ap.add_argument("--oracle", type=int, default=0, help="1: compare the bound after 5 iterations with the CPU oracle")
 ap.add_argument("--pack-width", type=int, default=0)
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--wpb", type=int, default=0)
@@ -64,12 +63,6 @@ for prec in a.precision.split(","):
     b_iter = 2 * (12 * Nt + 2 * R * N + (5 * R + 4) * L + (8 * R + 4) * Vs)
     s.iterations(5)
     line = f"{prec}: packs {s.nr_packs()}, hops {s.nr_hops()}, layers {L}, variables {Vs}, lb {s.lower_bound():.6f}"
-    if a.oracle:
-        from oracle.oracle import Oracle
-        o = Oracle(col, costs, prec, threads=16)
-        for _ in range(5):
-            o.iteration()
-        line += f" (oracle {o.lower_bound():.6f})"
     print(line)
     names = ["fwd_plain", "bwd_plain", "fwd_solve", "bwd_solve", "exchange"]
     print("   " + "  ".join(f"{n}={s.time_kernel(i, 20) * 1e3:.1f}us" for i, n in enumerate(names)))
