@@ -363,16 +363,17 @@ def measured_traffic(kernel, args, sfx):
         if d.get("_source_hash") != source_hash():
             continue
         want = "k_fwd_narrow" if kernel == "forward_mm" else "k_bwd_narrow"
+        real = "float" if sfx == "f32" else "double"   # one profile holds both precisions: the default bench run times both
         sweep = None
         for name, v in d.items():
-            m = re.search(want + r"<\w+, \d+, (\d+), \d+(?:, \w+)?>", name)   # <REAL, R, MODE, waves per block[, SEG]>; MODE 1 = solve
+            m = re.search(want + "<" + real + r", \d+, (\d+), \d+(?:, \w+)?>", name)   # <REAL, R, MODE, waves per block[, SEG]>; MODE 1 = solve
             if m and m.group(1) == "1":
                 sweep = v["hbm_bytes"]
         if sweep is None:
             for name, v in d.items():   # small instances: the resident sweeps
-                if re.search(want.replace("_narrow", "_res") + r"<", name):
+                if re.search(want.replace("_narrow", "_res") + "<" + real + ",", name):
                     sweep = v["hbm_bytes"]
-        exch = next((v["hbm_bytes"] for name, v in d.items() if "k_exchange_reduce" in name and isinstance(v, dict)), None)
+        exch = next((v["hbm_bytes"] for name, v in d.items() if "k_exchange_reduce<" + real + "," in name and isinstance(v, dict)), None)
         if sweep is not None:
             return sweep, exch, rel
     return None, None, None

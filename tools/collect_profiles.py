@@ -13,10 +13,12 @@ dst = f"profiles/{tag}"
 os.makedirs(dst, exist_ok=True)
 shutil.copy(f"{src}/trace/trace_kernel_stats.csv", f"{dst}/kernel_stats.csv")
 shutil.copy(f"{src}/bench_under_trace.json", f"{dst}/bench_under_trace.json")
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob(f"{src}/pmc_*/pmc_counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# [sum, count] of a counter over the dispatches of one kernel (tools/profile.sh aggregates on the GPU box)
+agg = collections.defaultdict(dict)
+for f in sorted(glob.glob(f"{src}/pmc_*.agg.json")):
+    for k, d in json.load(open(f)).items():
+        for c, (s, n) in d.items():
+            agg[k][c] = [s / n] * int(n)   # the mean, repeated: the code below only takes means and counts
 with open(f"{dst}/pmc_summary.txt", "w") as out:
     out.write("# rocprofv3 --pmc, one pass per counter group (tools/profile.sh); mean per dispatch of `python bench.py --steps 10`\n")
     for k, d in sorted(agg.items()):

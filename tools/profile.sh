@@ -11,6 +11,18 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- p
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
   name=$(echo $pmc | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $pmc --output-format csv -d $out/pmc_$name -o pmc -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > /dev/null 2> $out/pmc_$name.err
+  # per-dispatch rows -> per-kernel sums on the box (the raw CSVs of three workloads exceed the 64 MiB that travel back)
+  python - $out/pmc_$name <<'PY'
+import collections, csv, glob, json, shutil, sys
+d = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        a = agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+shutil.rmtree(d)
+json.dump(agg, open(d + ".agg.json", "w"))
+PY
 done
 # the per-dispatch trace is not needed for the summaries and would push gpurun_out/ over the 64 MiB that travel back
 find $out -name "*kernel_trace.csv" -delete
