@@ -468,7 +468,7 @@ struct SolverT final : SolverBase {
             const dim3 grid(narrow_grid(cdiv(nb_.n_packs, w))), block(64 * w);
             const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
 #define LAUNCH_N(R_, W_)                                                                                                      \
-    if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, d, pk, rd, omega);                           \
+    if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d, pk, omega);                           \
     else if (two_node) hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_, MODE != FWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
     else hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
@@ -537,7 +537,7 @@ struct SolverT final : SolverBase {
             const dim3 grid(narrow_grid(cdiv(nb_.n_packs, w))), block(64 * w);
             const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
 #define LAUNCH_N(R_, W_)                                                                                                      \
-    if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, d, pk, rd, omega);                           \
+    if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d, pk, omega);                           \
     else if (two_node) hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_, MODE != BWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
     else hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
