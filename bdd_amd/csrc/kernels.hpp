@@ -216,6 +216,23 @@ __device__ __forceinline__ double dpp_from_next(double v)
     const unsigned int h2 = (unsigned int)__builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
     return __builtin_bit_cast(double, ((unsigned long long)h2 << 32) | l2);
 }
+template <typename REAL>
+constexpr int SEG_FOLD_STEPS = sizeof(REAL) == 4 ? 2 : 1;  // see seg_min2
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v)  // DPP move with control CTRL (row_shl:n = 0x100 + n); lanes without a source keep their value
+{
+    const int x = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double v)
+{
+    const long long x = __builtin_bit_cast(long long, v);
+    const int lo = (int)x, hi = (int)(x >> 32);
+    const unsigned int l2 = (unsigned int)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    const unsigned int h2 = (unsigned int)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)h2 << 32) | l2);
+}
 __device__ __forceinline__ double dpp_from_prev(double v)
 {
     const long long x = __builtin_bit_cast(long long, v);
@@ -276,6 +293,27 @@ __device__ __forceinline__ void seg_pair_min(float& a, float& b, uint32_t pos, u
     a = pos == 1 ? ta : a;
     b = pos == 1 ? tb : b;
 }
+// The same fold for the wide packs, whose lanes know their layer's index in the hop (`key`: equal for the consecutive lanes of a layer;
+// inactive lanes pass a key no layer has) instead of a position: returns true in the lanes that must issue the LDS atomics.
+template <typename REAL>
+__device__ __forceinline__ bool seg_fold_by_key(REAL& a, REAL& b, uint32_t key, int lane)
+{
+    constexpr int K = SEG_FOLD_STEPS<REAL>;
+    constexpr uint32_t G = 1u << K;
+#define BDDMMA_SEG_STEP(SH)                                                                                                \
+    {                                                                                                                      \
+        const uint32_t kn = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x100 + SH, 0xF, 0xF, false);      \
+        const bool same = kn == key;   /* past the row: kn = ~key */                                                       \
+        const REAL an = dpp_row<0x100 + SH>(a), bn = dpp_row<0x100 + SH>(b);                                               \
+        a = same ? rmin(a, an) : a;                                                                                        \
+        b = same ? rmin(b, bn) : b;                                                                                        \
+    }
+    BDDMMA_SEG_STEP(1)
+    if (K >= 2) BDDMMA_SEG_STEP(2)
+#undef BDDMMA_SEG_STEP
+    const uint32_t kp = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x111, 0xF, 0xF, false);  // row_shr:1: lane i <- lane i - 1
+    return ((uint32_t)lane & (G - 1u)) == 0u || kp != key;
+}
 template <typename REAL>
 __device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, uint32_t pos, uint32_t len, int steps, REAL* sM)
 {
@@ -292,8 +330,31 @@ __device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, uint32_t po
     sM[lane] = INF;
     sM[64 + lane] = INF;
     seg_fence();
-    __hip_atomic_fetch_min(&sM[head], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_min(&sM[64 + head], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // Before LDS: the lanes of a layer fold their values with K DPP steps (row_shl 1, 2: lane i takes lane i + 2^j of its 16-lane row if
+    // that lane belongs to the same layer, i.e. its position is pos + 2^j), so lane i holds the minimum over the next 2^K lanes of its
+    // layer and row, and only every 2^K-th lane of a layer plus the first lane of each row issue the atomics.  All lanes of a layer hit ONE
+    // address, which LDS serialises: at 10 M knapsack nodes the solve sweeps were LDS-bound (57 % busy, half of it these conflicts).
+    // Measured there (it/s float / double): K = 0: 3 730 / 2 940, 1: 4 140 / 3 230, 2: 4 220 / 3 170, 3: 4 050 / 3 080, 4: 3 830 / 2 950
+    // (each step costs ~7 VALU in float and ~11 in double, and the sweeps are VALU-bound next) -> K = 2 in float, 1 in double.
+    {
+        constexpr int K = SEG_FOLD_STEPS<REAL>;
+        constexpr uint32_t G = 1u << K;
+#define BDDMMA_SEG_STEP(SH)                                                                                               \
+    {                                                                                                                     \
+        const uint32_t pn = (uint32_t)__builtin_amdgcn_update_dpp((int)pos, (int)pos, 0x100 + SH, 0xF, 0xF, false);    \
+        const bool same = pn == pos + SH;   /* past the row: pn = pos */                                                  \
+        const REAL an = dpp_row<0x100 + SH>(a), bn = dpp_row<0x100 + SH>(b);                                              \
+        a = same ? rmin(a, an) : a;                                                                                       \
+        b = same ? rmin(b, bn) : b;                                                                                       \
+    }
+        BDDMMA_SEG_STEP(1)
+        if (K >= 2) BDDMMA_SEG_STEP(2)
+#undef BDDMMA_SEG_STEP
+        if ((pos & (G - 1u)) == 0u || ((uint32_t)lane & 15u) == 0u) {
+            __hip_atomic_fetch_min(&sM[head], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_min(&sM[64 + head], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
     seg_fence();
     a = sM[head];
     b = sM[64 + head];
@@ -1721,9 +1782,11 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
             }
             if (MODE == FWD_SOLVE) {
                 const uint32_t l = ww_layer(W0[i]);
-                if (act) {  // inactive lanes have nothing to contribute (and would all hit one address)
-                    lds_min(&lds[oMa + l], (f[i] + C0[i].x) + tl[i]);
-                    lds_min(&lds[oMb + l], (f[i] + C0[i].y) + th[i]);
+                REAL a = (f[i] + C0[i].x) + tl[i], b = (f[i] + C0[i].y) + th[i];
+                const bool lead = seg_fold_by_key(a, b, act ? l : 0xFFFFFFFFu, (int)(tid & 63u));
+                if (act && lead) {  // inactive lanes have nothing to contribute (and would all hit one address)
+                    lds_min(&lds[oMa + l], a);
+                    lds_min(&lds[oMb + l], b);
                 }
             }
         }
@@ -1899,7 +1962,8 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
                     a = F0[i] + (tl[i] + C0[i].x);
                     b = F0[i] + (th[i] + C0[i].y);
                 }
-                if (act) {
+                const bool lead = seg_fold_by_key(a, b, act ? l : 0xFFFFFFFFu, (int)(tid & 63u));
+                if (act && lead) {
                     lds_min(&lds[oMa + l], a);
                     lds_min(&lds[oMb + l], b);
                 }
