@@ -216,8 +216,11 @@ __device__ __forceinline__ double dpp_from_next(double v)
     const unsigned int h2 = (unsigned int)__builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
     return __builtin_bit_cast(double, ((unsigned long long)h2 << 32) | l2);
 }
+#ifndef BDDMMA_SEG_FOLD_F32
+#define BDDMMA_SEG_FOLD_F32 2
+#endif
 template <typename REAL>
-constexpr int SEG_FOLD_STEPS = sizeof(REAL) == 4 ? 2 : 1;  // see seg_min2
+constexpr int SEG_FOLD_STEPS = sizeof(REAL) == 4 ? BDDMMA_SEG_FOLD_F32 : 1;  // see seg_min2
 template <int CTRL>
 __device__ __forceinline__ float dpp_row(float v)  // DPP move with control CTRL (row_shl:n = 0x100 + n); lanes without a source keep their value
 {
@@ -293,6 +296,35 @@ __device__ __forceinline__ void seg_pair_min(float& a, float& b, uint32_t pos, u
     a = pos == 1 ? ta : a;
     b = pos == 1 ? tb : b;
 }
+// One fold step: a, b <- min with the values SH lanes up the row where `same` holds.  float: v_min_f32_dpp takes the shifted operand
+// directly (through the builtins the compiler emits v_mov, v_mov_dpp, two v_max canonicalisations and v_min per value: 14 instead of 5
+// VALU per step); s_nop 1: a DPP operand written by the preceding VALU instruction needs two wait states (see seg_pair_min).  Lanes
+// without a source lane keep an undefined destination, which `same` (false there) never selects.
+template <int SH>
+__device__ __forceinline__ void seg_fold_step(float& a, float& b, bool same)
+{
+    float ta, tb;
+#define BDDMMA_FOLD_ASM(N)                                                        \
+    asm("s_nop 1\n\t"                                                             \
+        "v_min_f32_dpp %0, %2, %2 row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+        "v_min_f32_dpp %1, %3, %3 row_shl:" #N " row_mask:0xf bank_mask:0xf"       \
+        : "=&v"(ta), "=&v"(tb)                                                     \
+        : "v"(a), "v"(b))
+    static_assert(SH == 1 || SH == 2 || SH == 4, "row_shl:1 / 2 / 4");
+    if (SH == 1) BDDMMA_FOLD_ASM(1);
+    else if (SH == 2) BDDMMA_FOLD_ASM(2);
+    else BDDMMA_FOLD_ASM(4);
+#undef BDDMMA_FOLD_ASM
+    a = same ? ta : a;
+    b = same ? tb : b;
+}
+template <int SH>
+__device__ __forceinline__ void seg_fold_step(double& a, double& b, bool same)
+{
+    const double an = dpp_row<0x100 + SH>(a), bn = dpp_row<0x100 + SH>(b);
+    a = same ? rmin(a, an) : a;
+    b = same ? rmin(b, bn) : b;
+}
 // The same fold for the wide packs, whose lanes know their layer's index in the hop (`key`: equal for the consecutive lanes of a layer;
 // inactive lanes pass a key no layer has) instead of a position: returns true in the lanes that must issue the LDS atomics.
 template <typename REAL>
@@ -303,13 +335,11 @@ __device__ __forceinline__ bool seg_fold_by_key(REAL& a, REAL& b, uint32_t key, 
 #define BDDMMA_SEG_STEP(SH)                                                                                                \
     {                                                                                                                      \
         const uint32_t kn = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x100 + SH, 0xF, 0xF, false);      \
-        const bool same = kn == key;   /* past the row: kn = ~key */                                                       \
-        const REAL an = dpp_row<0x100 + SH>(a), bn = dpp_row<0x100 + SH>(b);                                               \
-        a = same ? rmin(a, an) : a;                                                                                        \
-        b = same ? rmin(b, bn) : b;                                                                                        \
+        seg_fold_step<SH>(a, b, kn == key);   /* past the row: kn = ~key */                                                \
     }
     BDDMMA_SEG_STEP(1)
     if (K >= 2) BDDMMA_SEG_STEP(2)
+    if (K >= 3) BDDMMA_SEG_STEP(4)
 #undef BDDMMA_SEG_STEP
     const uint32_t kp = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x111, 0xF, 0xF, false);  // row_shr:1: lane i <- lane i - 1
     return ((uint32_t)lane & (G - 1u)) == 0u || kp != key;
@@ -335,20 +365,18 @@ __device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, uint32_t po
     // layer and row, and only every 2^K-th lane of a layer plus the first lane of each row issue the atomics.  All lanes of a layer hit ONE
     // address, which LDS serialises: at 10 M knapsack nodes the solve sweeps were LDS-bound (57 % busy, half of it these conflicts).
     // Measured there (it/s float / double): K = 0: 3 730 / 2 940, 1: 4 140 / 3 230, 2: 4 220 / 3 170, 3: 4 050 / 3 080, 4: 3 830 / 2 950
-    // (each step costs ~7 VALU in float and ~11 in double, and the sweeps are VALU-bound next) -> K = 2 in float, 1 in double.
+    // (measured with the builtin form of the step, ~14 VALU in float; the sweeps are VALU-bound next) -> K = 2 in float, 1 in double.
     {
         constexpr int K = SEG_FOLD_STEPS<REAL>;
         constexpr uint32_t G = 1u << K;
 #define BDDMMA_SEG_STEP(SH)                                                                                               \
     {                                                                                                                     \
         const uint32_t pn = (uint32_t)__builtin_amdgcn_update_dpp((int)pos, (int)pos, 0x100 + SH, 0xF, 0xF, false);    \
-        const bool same = pn == pos + SH;   /* past the row: pn = pos */                                                  \
-        const REAL an = dpp_row<0x100 + SH>(a), bn = dpp_row<0x100 + SH>(b);                                              \
-        a = same ? rmin(a, an) : a;                                                                                       \
-        b = same ? rmin(b, bn) : b;                                                                                       \
+        seg_fold_step<SH>(a, b, pn == pos + SH);   /* past the row: pn = pos */                                           \
     }
         BDDMMA_SEG_STEP(1)
         if (K >= 2) BDDMMA_SEG_STEP(2)
+        if (K >= 3) BDDMMA_SEG_STEP(4)
 #undef BDDMMA_SEG_STEP
         if ((pos & (G - 1u)) == 0u || ((uint32_t)lane & 15u) == 0u) {
             __hip_atomic_fetch_min(&sM[head], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
