@@ -1,11 +1,15 @@
-"""L-BFGS iterations on the 10.5 M-node instance for a profiler run:  python tools/lbfgs_prof.py [float|double] [iters]"""
+"""L-BFGS iterations on the 10.5 M-node instance (or V variables, V / 2 rows) for a profiler run:  python tools/lbfgs_prof.py [float|double] [iters] [V]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bdd_amd import capi
+if os.environ.get("BDDMMA_LIB"):
+    capi.LIB_PATH = os.path.abspath(os.environ["BDDMMA_LIB"])   # experimental builds under build/
 from bdd_amd.instances import random_set_cover_mt
 from bdd_amd.solver import bdd_hip_lbfgs, bdd_hip_parallel_mma
 prec = sys.argv[1] if len(sys.argv) > 1 else "float"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-col, costs = random_set_cover_mt(1_000_000, 500_000, 10, 12345)
+V = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+col, costs = random_set_cover_mt(V, V // 2, 10, 12345)
 s = bdd_hip_parallel_mma(col, costs, precision=prec)
 l = bdd_hip_lbfgs(s)
 for _ in range(20):
