@@ -72,6 +72,10 @@ struct SolverT final : SolverBase {
     // sweep in between (L-BFGS reads the bound at the end of an iteration and again before its step search) costs nothing
     bool lb_cached = false;
     double lb_cache = 0.0;
+    double *h_lb_slot = nullptr, *d_lb_slot = nullptr;  // lower_bound_enqueue / _fetch: two pinned doubles
+    bool lb_slot_known[2] = {false, false};
+    double lb_slot_value[2] = {0.0, 0.0};
+    uint64_t lb_gen = 0, lb_slot_gen[2] = {0, 0};       // lb_gen counts the backward launches: a fetched slot of the current generation is the cached bound
     // device-resident run_solver (kernels.hpp: run_ctl_step)
     RunCtl* d_run_ctl = nullptr;
     RunHost *h_run = nullptr, *d_run_host = nullptr;  // pinned + its device address
@@ -116,6 +120,7 @@ struct SolverT final : SolverBase {
         if (device >= 0) (void)hipSetDevice(device);
         for (void* p : allocs) (void)hipFree(p);
         if (h_lb) (void)hipHostFree(h_lb);
+        if (h_lb_slot) (void)hipHostFree(h_lb_slot);
         if (h_run) (void)hipHostFree(h_run);
         if (d_run_ctl) (void)hipFree(d_run_ctl);
         for (auto& e : ev_pool) {
@@ -494,6 +499,7 @@ struct SolverT final : SolverBase {
     int launch_bwd(const REAL* delta_lay, REAL omega, int kclass)
     {
         lb_cached = false;
+        ++lb_gen;
         DevPtrs<REAL> d = ptrs(delta_lay);
         prof_begin(kclass);
         hipStream_t sw = stream;
@@ -661,6 +667,42 @@ struct SolverT final : SolverBase {
         HIPCHK(hipStreamSynchronize(stream));
         *lb = lb_cache = *(volatile double*)h_lb;
         lb_cached = true;
+        return BDDMMA_OK;
+    }
+    int lower_bound_enqueue(int slot) override
+    {
+        if (slot < 0 || slot > 1) { err = "lower_bound_enqueue: slot must be 0 or 1"; return BDDMMA_ERR_INVALID_ARGUMENT; }
+        int rc = backward_run();
+        if (rc) return rc;
+        lb_slot_gen[slot] = lb_gen;
+        if (lb_cached) {
+            lb_slot_known[slot] = true;
+            lb_slot_value[slot] = lb_cache;
+            return BDDMMA_OK;
+        }
+        if (!h_lb_slot) {
+            HIPCHK(hipHostMalloc((void**)&h_lb_slot, 2 * sizeof(double), hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer((void**)&d_lb_slot, h_lb_slot, 0));
+        }
+        hipLaunchKernelGGL(k_lb_reduce, dim3(1), dim3(1024), 0, stream, d_lb_partial, nb_.n_packs + wb_.n_packs + hb_.n_packs, d_lb_slot + slot);
+        HIPCHK(hipGetLastError());
+        lb_slot_known[slot] = false;
+        return BDDMMA_OK;
+    }
+    int lower_bound_fetch(int slot, double* lb) override
+    {
+        if (slot < 0 || slot > 1) { err = "lower_bound_fetch: slot must be 0 or 1"; return BDDMMA_ERR_INVALID_ARGUMENT; }
+        if (!lb_slot_known[slot]) {
+            if (!h_lb_slot) { err = "lower_bound_fetch without lower_bound_enqueue"; return BDDMMA_ERR_STATE; }
+            HIPCHK(hipStreamSynchronize(stream));
+            lb_slot_value[slot] = ((volatile double*)h_lb_slot)[slot];
+            lb_slot_known[slot] = true;
+        }
+        *lb = lb_slot_value[slot];
+        if (lb_slot_gen[slot] == lb_gen && bwd_valid) {  // no backward launch since: this is the bound of the current costs
+            lb_cache = *lb;
+            lb_cached = true;
+        }
         return BDDMMA_OK;
     }
     int lower_bound_per_bdd(void* out, int on_device) override

@@ -660,6 +660,10 @@ struct Lbfgs final : bddmma_lbfgs {
     char *prev_g = nullptr, *cur_g = nullptr;
     double *d_partial = nullptr, *d_scalar = nullptr;
     std::deque<double> lb_history;
+    // The bound after an iteration is only ENQUEUED (SolverBase::lower_bound_enqueue, slot 0); its value is fetched together with the
+    // first trial step's bound of the next iteration (slot 1), so the steady L-BFGS iteration has one host wait instead of two.  While
+    // it is pending, lb_history's last entry is a placeholder.
+    bool lb_pending = false;
     double step_size = 0;
     int unsuccessful = 0;
     bool prev_stored = false;
@@ -817,6 +821,16 @@ struct Lbfgs final : bddmma_lbfgs {
     }
     dim3 grid() const { return dim3((n + 255) / 256 ? (n + 255) / 256 : 1); }
 
+    int resolve_pending()
+    {
+        if (!lb_pending) return 0;
+        double lb;
+        int rc = s->impl->lower_bound_fetch(0, &lb);
+        if (rc) { err = s->impl->err; return rc; }
+        lb_history.back() = lb;
+        lb_pending = false;
+        return 0;
+    }
     int lower_bound(double* lb)
     {
         int rc = s->impl->lower_bound(lb);
@@ -896,14 +910,22 @@ struct Lbfgs final : bddmma_lbfgs {
     int search_step_size_and_apply()
     {
         SolverBase* b = s->impl;
-        double lb_pre;
+        double lb_pre = 0.0;
         int rc;
-        if ((rc = lower_bound(&lb_pre))) return rc;
+        // the bound before the step is the one enqueued at the end of the previous iteration (nothing has touched the costs since);
+        // it is fetched with the first trial's bound
+        const bool pre_pending = lb_pending;
+        if (!pre_pending && (rc = lower_bound(&lb_pre))) return rc;
         const int m = p.history_size;
         auto rel_change = [&](double* out) -> int {
             double lb;
-            int r = lower_bound(&lb);
-            if (r) return r;
+            int r;
+            if (lb_pending) {
+                if ((r = b->lower_bound_enqueue(1))) { err = b->err; return r; }
+                if ((r = resolve_pending())) return r;
+                lb_pre = lb_history.back();
+                if ((r = b->lower_bound_fetch(1, &lb))) { err = b->err; return r; }
+            } else if ((r = lower_bound(&lb))) return r;
             const double cur_inc = lb - lb_pre;
             const double past_inc = *(lb_history.rbegin() + m - 2) - *(lb_history.rbegin() + m - 1);
             *out = cur_inc / (1e-9 + past_inc);
@@ -983,8 +1005,15 @@ struct Lbfgs final : bddmma_lbfgs {
             ++mma_iterations;
         }
         if ((rc = b->iteration(0.5))) { err = b->err; return rc; }
-        if ((rc = lower_bound(&lb))) return rc;
-        lb_history.push_back(lb);
+        if ((rc = resolve_pending())) return rc;   // (only after an iteration without an L-BFGS step: the search fetches it otherwise)
+        if (gram) {
+            if ((rc = b->lower_bound_enqueue(0))) { err = b->err; return rc; }
+            lb_history.push_back(0.0);
+            lb_pending = true;
+        } else {
+            if ((rc = lower_bound(&lb))) return rc;
+            lb_history.push_back(lb);
+        }
         if (lb_history.size() > (size_t)std::max(64, p.history_size + 2)) lb_history.pop_front();
         return 0;
     }

@@ -44,6 +44,10 @@ struct SolverBase {
     virtual int forward_run() = 0;
     virtual int backward_run() = 0;
     virtual int lower_bound(double* lb) = 0;
+    // The same bound without the host waiting for it: enqueue the backward run + reduction into one of two pinned slots, fetch it
+    // later (the fetch waits for the stream).  The value is the bound of the costs at enqueue time, whatever was enqueued behind it.
+    virtual int lower_bound_enqueue(int slot) = 0;
+    virtual int lower_bound_fetch(int slot, double* lb) = 0;
     virtual int lower_bound_per_bdd(void* out, int on_device) = 0;
     virtual int iteration(double omega) = 0;
     // run_solver (include/run_solver_util.h:10-77) around iteration(): termination tests on the device, see bdd_mma_hip.hip
