@@ -473,7 +473,7 @@ struct SolverT final : SolverBase {
             const dim3 grid(narrow_grid(cdiv(nb_.n_packs, w))), block(64 * w);
             const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
 #define LAUNCH_N(R_, W_)                                                                                                      \
-    if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d, pk, omega);                           \
+    if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
     else if (two_node) hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_, MODE != FWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
     else hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
@@ -543,7 +543,7 @@ struct SolverT final : SolverBase {
             const dim3 grid(narrow_grid(cdiv(nb_.n_packs, w))), block(64 * w);
             const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
 #define LAUNCH_N(R_, W_)                                                                                                      \
-    if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d, pk, omega);                           \
+    if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
     else if (two_node) hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_, MODE != BWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
     else hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
@@ -579,8 +579,8 @@ struct SolverT final : SolverBase {
                                d_vpos, delta_var, (uint32_t)n_vars, RunGate{});
         else
             hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_RAW>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
-                               d_bin_ptr, d_bvar, d_nbdds, delta_var, (REAL*)nullptr, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers,
-                               RunGate{});
+                               d_bin_ptr, d_bvar, (const uint32_t*)nullptr, 0u, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers, d_nbdds, delta_var,
+                               (REAL*)nullptr, RunStep{});
     }
     int exchange(bool ends_iteration = false)
     {
@@ -602,8 +602,8 @@ struct SolverT final : SolverBase {
             // 1.05 M nodes 4.7 -> 4.4 us per launch.  variant_flags bit 6 selects the round-2 form (0), bits 3-5 any combination for the
             // 256-thread kernel (the bisection of profiles/r03_exchange_variant_rootcause.txt).
 #define LAUNCH_EX(T_, U_, N_, RUN_, V_)                                                                                                              \
-    hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, T_, U_, N_, RUN_, V_>), dim3(n_bins), dim3(T_), exch_lds, stream, d_mm_binned, d_bin_ptr, \
-                       d_bvar, d_nbdds, (REAL*)nullptr, d_delta_lay, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers, gate(), rstep)
+    hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, T_, U_, N_, RUN_, V_>), dim3(n_bins + ((RUN_) && rstep.ctl != nullptr ? 1u : 0u)), dim3(T_), exch_lds, stream, d_mm_binned, d_bin_ptr, \
+                       d_bvar, gate().stop, gate().iter, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers, d_nbdds, (REAL*)nullptr, d_delta_lay, rstep)
 #define LAUNCH_EX_RV(T_, U_, N_)                                                                        \
     do {                                                                                                \
         if (opts_variant & 0x40u) {                                                                     \

@@ -1171,8 +1171,10 @@ struct ResDev {
 // What a resident sweep needs for its FIRST loads comes as leading plain kernel arguments: with -mllvm -amdgpu-kernarg-preload-count the
 // command processor hands the first 16 dwords of plain (non-struct) arguments over in SGPRs at wave launch, so the header loads do not wait
 // for the kernarg segment's own round trip (measured on the exchange, whose arguments are all plain: 4.4 -> 4.15 us at 1.05 M nodes).
+// The stop word of the device-resident run_solver is among them: its load is issued at once and tested when the headers have arrived (no
+// side effect happens before), instead of a dependent round trip in front of everything else.
 #define RES_LEADING_ARGS const uint32_t* __restrict__ res_pack_hdr, const uint32_t* __restrict__ res_quad_hdr, uint32_t res_ns, uint32_t res_nl, \
-                         uint32_t res_n_packs, uint32_t res_xcd_chunk
+                         uint32_t res_n_packs, uint32_t res_xcd_chunk, const uint32_t* res_stop, uint32_t res_run_iter
 typedef __attribute__((address_space(3))) void* lds_vptr_t;
 typedef __attribute__((address_space(1))) const void* glb_vptr_t;
 
@@ -1211,7 +1213,8 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(RES_LEADING_ARGS, DevPtrs<
     uint32_t* sOffL = sOffL_[wave];
     const uint32_t n_quads = (res_n_packs + WPB - 1) / WPB;
     const uint32_t quad = block_to_pack(blockIdx.x, n_quads, res_xcd_chunk);
-    BDDMMA_EXIT_IF(quad >= n_quads, d)
+    if (quad >= n_quads) return;
+    const uint32_t stop_word = res_stop != nullptr ? *res_stop : RUN_NOT_STOPPED;  // tested below, with the headers
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < res_n_packs;
     BDDMMA_STAMP(p, 0);
@@ -1228,6 +1231,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fwd_res(RES_LEADING_ARGS, DevPtrs<
     const uint32_t nslots = has_pack ? hp[1] : 0, nlayers = has_pack ? hp[3] : 0, nh = has_pack ? (hp[5] & 0xFFFFu) : 0;
     const int steps = (int)(hp[5] >> 16);
     const uint32_t c0 = rd.quad_hdr[4 * (size_t)quad], cnt = rd.quad_hdr[4 * (size_t)quad + 1];
+    if (stop_word <= res_run_iter) return;  // run_solver has stopped (uniform for the grid): nothing has been written yet
     const REAL INF = inf_v<REAL>();
     const NarrowRs<REAL> rs(d);
     BDDMMA_STAMP(p, 1);
@@ -1329,7 +1333,8 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(RES_LEADING_ARGS, DevPtrs<
     uint32_t* sOffL = sOffL_[wave];
     const uint32_t n_quads = (res_n_packs + WPB - 1) / WPB;
     const uint32_t quad = block_to_pack(blockIdx.x, n_quads, res_xcd_chunk);
-    BDDMMA_EXIT_IF(quad >= n_quads, d)
+    if (quad >= n_quads) return;
+    const uint32_t stop_word = res_stop != nullptr ? *res_stop : RUN_NOT_STOPPED;  // tested below, with the headers
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < res_n_packs;
     BDDMMA_STAMP(p, 0);
@@ -1344,6 +1349,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(RES_LEADING_ARGS, DevPtrs<
     const uint32_t nslots = has_pack ? hp[1] : 0, nlayers = has_pack ? hp[3] : 0, nh = has_pack ? (hp[5] & 0xFFFFu) : 0;
     const int steps = (int)(hp[5] >> 16);
     const uint32_t c0 = rd.quad_hdr[4 * (size_t)quad], cnt = rd.quad_hdr[4 * (size_t)quad + 1];
+    if (stop_word <= res_run_iter) return;  // run_solver has stopped (uniform for the grid): nothing has been written yet
     const REAL INF = inf_v<REAL>();
     const NarrowRs<REAL> rs(d);
     BDDMMA_STAMP(p, 1);
@@ -2227,10 +2233,11 @@ enum : int {
     EXV_ONE_ATOMIC = 4,    // one predicated LDS atomic per entry (slot 2 v + [mm > 0], value |mm|) instead of two branches around two atomics
 };
 template <typename REAL, typename ACC, int MODE, int EX_THREADS, int EX_UNROLL, int NPT, int VAR = 0>
-__device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
+__device__ __forceinline__ bool exchange_reduce_body(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
                                                      const uint16_t* __restrict__ bvar, const int32_t* __restrict__ nbdds,
                                                      REAL* __restrict__ delta_var, REAL* __restrict__ delta_lay,
-                                                     uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries)
+                                                     uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries,
+                                                     uint32_t stop_word = RUN_NOT_STOPPED, uint32_t run_iter = 0)  // false: run_solver has stopped
 {
     using P2 = typename Pair<REAL>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
@@ -2261,6 +2268,7 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
         }
     }
     BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 1);  // (waits for the first chunk here: the kernel itself does not)
+    if (stop_word <= run_iter) return false;  // uniform for the grid; nothing has been written yet
     // number of BDDs of the variables this thread normalises (needed only after the accumulation)
     int nb[NPT];
     if (MODE == EX_ITER) {
@@ -2337,7 +2345,7 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
             if (MODE != EX_ITER || delta_var) delta_var[2 * (size_t)v0 + i] = x;
         }
     }
-    if (MODE != EX_ITER) return;
+    if (MODE != EX_ITER) return true;
     __syncthreads();
     BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 3);
     const rsrc_t rdl = make_rsrc(delta_lay, 2ull * (SOFF_S ? e1 : n_entries));
@@ -2351,7 +2359,7 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
         else bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
     }
     BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 4);
-    if (one_chunk) return;
+    if (one_chunk) return true;
     for (uint32_t base = e0 + EX_THREADS * EX_UNROLL + tid; (SOFF_L || SOFF_S) ? base - tid < e1 : base < e1; base += EX_THREADS * EX_UNROLL) {
         uint32_t lv2[EX_UNROLL];
 #pragma unroll
@@ -2370,6 +2378,7 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
             else bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
         }
     }
+    return true;
 }
 
 // The launch: `stop` (device-resident run_solver, DevPtrs::stop) makes it return at once when the termination test has fired; `run`
@@ -2379,18 +2388,26 @@ __device__ __forceinline__ void exchange_reduce_body(const REAL* __restrict__ mm
 template <typename REAL, typename ACC, int MODE, int EX_THREADS = bddmma::EX_THREADS, int EX_UNROLL = bddmma::EX_UNROLL, int NPT = bddmma::EX_NPT,
           bool RUN = false, int VAR = 0>
 __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
-                                                                  const uint16_t* __restrict__ bvar, const int32_t* __restrict__ nbdds,
-                                                                  REAL* __restrict__ delta_var, REAL* __restrict__ delta_lay,
+                                                                  const uint16_t* __restrict__ bvar, const uint32_t* stop, uint32_t run_iter,
                                                                   uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries,
-                                                                  RunGate gate = RunGate{}, RunStep run = RunStep{})
+                                                                  const int32_t* __restrict__ nbdds, REAL* __restrict__ delta_var,
+                                                                  REAL* __restrict__ delta_lay, RunStep run = RunStep{})
 {
-    if (RUN && run_stopped(gate)) return;
-    exchange_reduce_body<REAL, ACC, MODE, EX_THREADS, EX_UNROLL, NPT, VAR>(mm_binned, bin_ptr, bvar, nbdds, delta_var, delta_lay, vars_per_bin, n_vars,
-                                                                            n_entries);
-    if (RUN && run.ctl != nullptr && blockIdx.x == 0) {  // uniform
-        __syncthreads();
+    // argument order: what the first loads need comes first (the first 16 dwords of plain arguments are preloaded into SGPRs, see
+    // RES_LEADING_ARGS); the stop word's load is issued at once and tested inside the body when the first chunk's loads are in flight
+    const uint32_t stop_word = (RUN && stop != nullptr) ? *stop : RUN_NOT_STOPPED;
+    // The launch that ends an iteration of run_solver has one workgroup more than bins: it adds up the per-pack bounds the backward sweep
+    // has left and runs the termination tests while the others work on their bins (as the tail of workgroup 0, behind its bin, the
+    // reduction's dependent round trips were the end of the launch: run_solver at 1.05 M nodes 36.3 -> 35.6 us per iteration with the stop
+    // word's load overlapped, -> 33.3 us with the extra workgroup, the plain loop being 32.0; 10.5 M nodes 125.1 -> 122.3 us).
+    if (RUN && run.ctl != nullptr && blockIdx.x == gridDim.x - 1) {  // uniform
+        if (stop_word <= run_iter) return;
         run_ctl_step(run);
+        return;
     }
+    if (!exchange_reduce_body<REAL, ACC, MODE, EX_THREADS, EX_UNROLL, NPT, VAR>(mm_binned, bin_ptr, bvar, nbdds, delta_var, delta_lay, vars_per_bin,
+                                                                                 n_vars, n_entries, stop_word, RUN ? run_iter : 0u))
+        return;
 }
 
 // Exchange for entry arrays ordered by (variable, bdd) (layout.hpp: Exchange::entry_by_var): the entries of variable v are
