@@ -1171,14 +1171,64 @@ struct SolverT final : SolverBase {
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
-    // make_dual_feasible + gradient_step for a device vector that is only applied, never read back (lbfgs.hip): the means once ...
+    // make_dual_feasible + gradient_step for a device vector that is only applied, never read back (lbfgs.hip).
+    // Large instances (>= 500 k layers; variant_flags bit 9 forces it, bit 10 forbids it): the vector goes through the staging tables
+    // to entry order, is projected per bin in LDS and comes back to layer order together with the first step (kernels.hpp:
+    // k_stage_transpose / k_project_entries) — then every further step is a plain stream.  Small ones: the per-variable means by gather ...
     REAL* d_proj_q = nullptr;
+    REAL* d_proj_dir = nullptr;     // the projected vector in layer order (staged path)
+    REAL* d_proj_ent = nullptr;     // ... and in entry order
+    bool proj_staged = false;       // the last projection_means took the staged path
+    bool proj_pending = false;      // ... and its way back to layer order is still to be done (with the first step)
+    bool proj_attr_set = false;
+    bool use_staged_projection() const
+    {
+        if (opts_variant & 0x400u) return false;
+        if (n_narrow_layers == 0) return false;
+        return (opts_variant & 0x200u) != 0 || n_layers >= 500000;
+    }
+    template <int TO_LAYERS>
+    void launch_stage_transpose(const REAL* in, REAL* out, REAL* lohi, REAL step)
+    {
+        const PackDev pk = pdev(nb_, 0);
+        const uint32_t n_quads = (uint32_t)cdiv(nb_.n_packs, wpb);
+        const uint32_t lds = wpb * stage_cap * (uint32_t)sizeof(REAL);
+#define LAUNCH_T(W_) hipLaunchKernelGGL((k_stage_transpose<REAL, W_, TO_LAYERS>), dim3(n_quads), dim3(64 * W_), lds, stream, in, out, pk, (const uint32_t*)d_cs_entry, \
+                                        (const uint16_t*)d_cs_slot, n_narrow_layers, (uint32_t)n_layers, lohi, step)
+        switch (wpb) { case 1: LAUNCH_T(1); break; case 2: LAUNCH_T(2); break; case 4: LAUNCH_T(4); break; default: LAUNCH_T(8); break; }
+#undef LAUNCH_T
+    }
     int projection_means(const void* g) override
     {
         HIPCHK(hipSetDevice(device));
         int rc;
-        if (!d_proj_q && (rc = dalloc(&d_proj_q, n_vars))) return rc;
-        hipLaunchKernelGGL((k_projection_means<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, (const REAL*)g, d_var_ptr, d_var_layers, d_proj_q, (uint32_t)n_vars);
+        proj_staged = use_staged_projection();
+        proj_pending = false;
+        if (!proj_staged) {
+            if (!d_proj_q && (rc = dalloc(&d_proj_q, n_vars))) return rc;
+            hipLaunchKernelGGL((k_projection_means<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, (const REAL*)g, d_var_ptr, d_var_layers, d_proj_q, (uint32_t)n_vars);
+            HIPCHK(hipGetLastError());
+            return BDDMMA_OK;
+        }
+        if (!d_proj_dir && (rc = dalloc(&d_proj_dir, n_layers))) return rc;
+        if (!d_proj_ent && (rc = dalloc(&d_proj_ent, n_layers))) return rc;
+        const uint32_t plds = vars_per_bin * (uint32_t)sizeof(double);
+        if (!proj_attr_set) {
+            if (plds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_entries<REAL, EX_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+            proj_attr_set = true;
+        }
+        // layers -> entries 
+        launch_stage_transpose<0>((const REAL*)g, d_proj_ent, (REAL*)nullptr, REAL(0));
+        if (n_layers > n_narrow_layers)
+            hipLaunchKernelGGL((k_layers_to_entries<REAL>), dim3(cdiv(n_layers - n_narrow_layers, 256)), dim3(256), 0, stream, (const REAL*)g + n_narrow_layers,
+                               d_lpos + n_narrow_layers, d_proj_ent, (uint32_t)(n_layers - n_narrow_layers));
+        // x_e -= mean over the entries of its variable
+#define LAUNCH_P(T_) hipLaunchKernelGGL((k_project_entries<REAL, T_>), dim3(n_bins), dim3(T_), plds, stream, d_proj_ent, d_bin_ptr, d_bvar, d_nbdds, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers)
+        if (exch_small) LAUNCH_P(EXS_THREADS);
+        else if (exch_medium) LAUNCH_P(EXM_THREADS);
+        else LAUNCH_P(EX_THREADS);
+#undef LAUNCH_P
+        proj_pending = true;
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
@@ -1186,6 +1236,25 @@ struct SolverT final : SolverBase {
     int gradient_step_projected(const void* g, double step) override
     {
         HIPCHK(hipSetDevice(device));
+        if (proj_staged) {
+            if (proj_pending) {
+                // entries -> layers, with this step applied on the way
+                launch_stage_transpose<1>((const REAL*)d_proj_ent, d_proj_dir, d_lohi, REAL(step));
+                if (n_layers > n_narrow_layers) {
+                    const uint32_t nw = (uint32_t)(n_layers - n_narrow_layers);
+                    hipLaunchKernelGGL((k_entries_to_layers<REAL>), dim3(cdiv(nw, 256)), dim3(256), 0, stream, (const REAL*)d_proj_ent, d_lpos + n_narrow_layers,
+                                       d_proj_dir + n_narrow_layers, nw);
+                    hipLaunchKernelGGL((k_gradient_step<REAL>), dim3(cdiv(nw, 256)), dim3(256), 0, stream, d_hi + 2 * (size_t)n_narrow_layers,
+                                       (const REAL*)d_proj_dir + n_narrow_layers, REAL(step), nw);
+                }
+                proj_pending = false;
+            } else {
+                hipLaunchKernelGGL((k_gradient_step<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_hi, (const REAL*)d_proj_dir, REAL(step), (uint32_t)n_layers);
+            }
+            fwd_valid = bwd_valid = false;
+            HIPCHK(hipGetLastError());
+            return BDDMMA_OK;
+        }
         if (!d_proj_q) { err = "gradient_step_projected without projection_means"; return BDDMMA_ERR_INVALID_ARGUMENT; }
         hipLaunchKernelGGL((k_gradient_step_projected<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_hi, (const REAL*)g, d_proj_q, (const uint32_t*)d_var, REAL(step), (uint32_t)n_layers);
         fwd_valid = bwd_valid = false;

@@ -2712,6 +2712,163 @@ __global__ void k_gradient_step_projected(REAL* __restrict__ hi, const REAL* __r
     hi[2 * (size_t)l] = hi[2 * (size_t)l] + step * gp;
 }
 
+// ---- make_dual_feasible of a device vector through the staging tables (the L-BFGS direction at large sizes) ------------------------
+// As gathers (k_projection_means + k_gradient_step_projected) the layer <-> variable coupling costs a random access per layer in
+// each direction: 63 us for the means and 44 us per trial step at 5 M layers (profiles/r03_lbfgs_time_to_bound.txt), ~30 us of each
+// being the gather.  The sweeps do the same coupling through the (entry, slot) staging tables in runs of consecutive entries, and the
+// exchange reduces per variable in LDS.  The same three steps for any layer-ordered vector:
+//   k_stage_transpose<.., 0> : layers -> entries   (a quad's waves copy their stage group to LDS, the items stream it out by entry)
+//   k_project_entries        : per bin: sums per variable in LDS (double accumulators), x_e -= sum / nr_bdds(var), in place
+//   k_stage_transpose<.., 1> : entries -> layers   (the reverse), optionally applying the first gradient step on the way
+// after which every trial step is the plain streaming k_gradient_step.  Layers of wide / huge packs have no staging tables: they go
+// through lpos (k_layers_to_entries / k_entries_to_layers on their range).
+template <typename REAL, int WPB, int TO_LAYERS>
+__global__ void __launch_bounds__(64 * WPB) k_stage_transpose(const REAL* __restrict__ in, REAL* __restrict__ out, PackDev pk,
+                                                               const uint32_t* __restrict__ cs_entry, const uint16_t* __restrict__ cs_slot,
+                                                               uint32_t n_narrow_layers, uint32_t n_layers, REAL* __restrict__ lohi, REAL step)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    REAL* sD = reinterpret_cast<REAL*>(dyn_lds);
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t quad = blockIdx.x;
+    const uint32_t p = quad * WPB + wave;
+    const bool has_pack = p < pk.n_packs;
+    const uint32_t g0 = has_pack ? pk.pack_group_ptr[p] : 0;
+    const uint32_t ng = has_pack ? pk.pack_group_ptr[p + 1] - g0 : 0;
+    const uint32_t r0 = pk.quad_round_ptr[quad], n_rounds = pk.quad_round_ptr[quad + 1] - r0;
+    const rsrc_t rse = make_rsrc(cs_entry, n_narrow_layers), rss = make_rsrc(cs_slot, n_narrow_layers);
+    const rsrc_t rin = make_rsrc(in, n_layers), rout = make_rsrc(out, n_layers), rlh = make_rsrc(lohi, 2ull * n_layers);
+    REAL* sDw = sD + (size_t)wave * pk.stage_cap;
+    for (uint32_t k = 0; k < n_rounds; ++k) {
+        const uint32_t c0 = pk.cs_ptr[r0 + k], cnt = pk.cs_ptr[r0 + k + 1] - c0;
+        uint32_t gl0 = 0, gn = 0;
+        if (k < ng) {
+            gl0 = pk.grp_layer_off[g0 + k];
+            gn = pk.grp_layer_off[g0 + k + 1] - gl0;
+        }
+        uint32_t e[STAGE_ITERS], sl[STAGE_ITERS];
+#pragma unroll
+        for (int u = 0; u < STAGE_ITERS; ++u) {
+            const uint32_t i = 64 * WPB * u + tid;
+            e[u] = bload_u32(rse, i < cnt ? (c0 + i) * 4u : OOB);
+            sl[u] = bload_u16(rss, i < cnt ? (c0 + i) * 2u : OOB);
+        }
+        if (!TO_LAYERS) {
+            REAL x[STAGE_ITERS];
+#pragma unroll
+            for (int u = 0; u < STAGE_ITERS; ++u) {
+                const uint32_t i = lane + 64 * u;
+                bload(x[u], rin, i < gn ? (gl0 + i) * (uint32_t)sizeof(REAL) : OOB);
+            }
+#pragma unroll
+            for (int u = 0; u < STAGE_ITERS; ++u) {
+                const uint32_t i = lane + 64 * u;
+                if (i < gn) sDw[i] = x[u];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < STAGE_ITERS; ++u) {
+                const uint32_t i = 64 * WPB * u + tid;
+                const REAL v = sD[i < cnt ? sl[u] : 0];
+                bstore(v, rout, i < cnt ? e[u] * (uint32_t)sizeof(REAL) : OOB);
+            }
+            __syncthreads();  // the next round overwrites the staging area
+        } else {
+            REAL v[STAGE_ITERS];
+#pragma unroll
+            for (int u = 0; u < STAGE_ITERS; ++u) {
+                const uint32_t i = 64 * WPB * u + tid;
+                bload(v[u], rin, i < cnt ? e[u] * (uint32_t)sizeof(REAL) : OOB);
+            }
+#pragma unroll
+            for (int u = 0; u < STAGE_ITERS; ++u) {
+                const uint32_t i = 64 * WPB * u + tid;
+                if (i < cnt) sD[sl[u]] = v[u];
+            }
+            __syncthreads();
+            // the group's layers are contiguous: values out, and hi += step * x on whole {lo, hi} pairs (lo rewritten unchanged: full-width
+            // stores instead of every other word), all loads of the group in flight together
+            using P2 = typename Pair<REAL>::type;
+            P2 c[STAGE_ITERS];
+            if (lohi != nullptr) {
+#pragma unroll
+                for (int u = 0; u < STAGE_ITERS; ++u) {
+                    const uint32_t i = lane + 64 * u;
+                    bload(c[u], rlh, i < gn ? (gl0 + i) * (uint32_t)sizeof(P2) : OOB);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < STAGE_ITERS; ++u) {
+                const uint32_t i = lane + 64 * u;
+                const REAL x = sDw[i < gn ? i : 0];
+                bstore(x, rout, i < gn ? (gl0 + i) * (uint32_t)sizeof(REAL) : OOB);
+                if (lohi != nullptr) {
+                    c[u].y = c[u].y + step * x;   // k_gradient_step
+                    bstore(c[u], rlh, i < gn ? (gl0 + i) * (uint32_t)sizeof(P2) : OOB);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// One workgroup per bin of variables (the exchange's bins and its u16 local variable indices): x_e -= (sum over the entries of the
+// variable) / nr_bdds(variable).  The sum is accumulated in double by LDS atomics and rounded to REAL once, then divided in REAL as
+// k_make_dual_feasible does.
+template <typename REAL, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_project_entries(REAL* __restrict__ x, const uint32_t* __restrict__ bin_ptr, const uint16_t* __restrict__ bvar,
+                                                               const int32_t* __restrict__ nbdds, uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    double* tile = reinterpret_cast<double*>(dyn_lds);
+    constexpr int U = 8;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t v0 = b * vars_per_bin;
+    const uint32_t nv = min(vars_per_bin, n_vars - v0);
+    const uint32_t e0 = bin_ptr[b], e1 = bin_ptr[b + 1];
+    const rsrc_t rx = make_rsrc(x, n_entries), rv = make_rsrc(bvar, n_entries);
+    for (uint32_t i = tid; i < nv; i += THREADS) tile[i] = 0.0;
+    __syncthreads();
+    for (uint32_t base = e0; base < e1; base += THREADS * U) {
+        REAL m[U];
+        uint32_t lv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = base + tid + u * THREADS;
+            bload(m[u], rx, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
+            lv[u] = bload_u16(rv, e < e1 ? e * 2u : OOB);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = base + tid + u * THREADS;
+            if (e < e1) lds_add(&tile[lv[u]], (double)m[u]);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nv; i += THREADS) {
+        const int nb = nbdds[v0 + i];
+        const REAL s = REAL(tile[i]);
+        tile[i] = nb > 0 ? (double)(s / REAL(nb)) : 0.0;
+    }
+    __syncthreads();
+    for (uint32_t base = e0; base < e1; base += THREADS * U) {
+        REAL m[U];
+        uint32_t lv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = base + tid + u * THREADS;
+            bload(m[u], rx, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
+            lv[u] = bload_u16(rv, e < e1 ? e * 2u : OOB);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = base + tid + u * THREADS;
+            bstore(m[u] - REAL(tile[lv[u]]), rx, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
+        }
+    }
+}
+
 // compute_primal_objective_vec (bdd_cuda_base.cu:1352-1362)
 template <typename REAL>
 __global__ void k_primal_objective(const REAL* __restrict__ lo, const REAL* __restrict__ hi, const uint32_t* __restrict__ var_ptr,

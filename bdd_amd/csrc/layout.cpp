@@ -525,8 +525,11 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         const uint32_t opt = opts ? opts->pack_stagger : 0;
         if (opt >= 2) pn.max_hops = opt;
         else if (opt == 0) {
-            const uint64_t hops_for_4096_packs = narrow_nodes / ((uint64_t)W * 4096 * 6 / 10 + 1);
-            pn.max_hops = hops_for_4096_packs >= longest + 2 ? (uint32_t)std::min<uint64_t>(hops_for_4096_packs, 3ull * longest) : 0;
+            // (the pack count to keep was 4096 until the segmented minimum got its DPP folds; on those kernels 10 M knapsack nodes run at
+            // 4 320 / 4 223 / 4 674 / 4 377 / 4 446 it/s with at most 28 / 36 / 42 / 48 / 56 hops per pack (6 724 ... 2 552 packs), the mixed
+            // instance at 5 255 / 5 394 / 5 451 / 5 101 with 28 / 36 / 42 / 48: three BDD lengths, ~3 600 packs = 3.5 waves per SIMD)
+            const uint64_t hops_for_packs = narrow_nodes / ((uint64_t)W * 2730 * 6 / 10 + 1);
+            pn.max_hops = hops_for_packs >= longest + 2 ? (uint32_t)std::min<uint64_t>(hops_for_packs, 3ull * longest) : 0;
         }
     }
     form_narrow();
@@ -706,6 +709,10 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         // up to 1024 variables per bin the exchange runs its 256-thread variant (kernels.hpp: EXS_*), which is also the better choice
         // a little beyond (V = 300-400 k: 1024 per bin 9.1-9.7 us, the 1024-thread kernel on 1216-1600 per bin 10.8-11.2 us)
         if (auto_vb > 1024 && auto_vb <= 2048) auto_vb = 1024;
+        // double, large V: bins of 2048 (512-thread exchange workgroups, two per CU, whose load / accumulate / store phases overlap) instead of
+        // ~256 bins of one 1024-thread workgroup per CU: the exchange 25.9 -> 22.3 us while the sweeps lose 2-5 us to shorter runs in the entry
+        // arrays: 10.5 M nodes 4 165 / 4 263 -> 4 315 / 4 334 it/s (two alternating runs on one box).  Float loses 1 % with the same change.
+        if (real_size == 8 && auto_vb > 2048) auto_vb = 2048;
         X.vars_per_bin = opts && opts->vars_per_bin ? opts->vars_per_bin : auto_vb;
         // stage groups hold <= stage_cap layers of one pack; the default is the largest pack's layer count (one group per pack) up to
         // 640, so that small packs do not reserve LDS staging space they never use
@@ -799,7 +806,6 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         // cooperative staging tables
         // default: 4 packs per workgroup (measured after the node words became shared: 4 beats 8 in float by 5-8 %:
         // 28 KB of LDS per workgroup instead of 57 KB, i.e. 5 instead of 4 waves per SIMD)
-        (void)real_size;
         X.waves_per_block = opts && opts->waves_per_block ? opts->waves_per_block : 4;
         // small instances: keep at least ~512 workgroups so that every CU has work
         if (!(opts && opts->waves_per_block))

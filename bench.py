@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--wpb", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-precision", action="store_true")
+    ap.add_argument("--no-lbfgs", action="store_true", dest="no_lbfgs", help="skip the L-BFGS leg (BASELINE.json configs[3]) after the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--deterministic", action="store_true")
     ap.add_argument("--event-stride", type=int, default=0, help="hipEvent pairs around every n-th iteration's launches (0: steps // 16)")
@@ -194,6 +195,9 @@ def main():
         copy_gbs = 2 * (1 << 30) / (solver.time_kernel(7, 20) * 1e-3) / 1e9
     packs, hops, resident = solver.nr_packs(), solver.nr_hops(), solver.device_bytes()
     solver.close()
+    lbfgs = None
+    if rank == 0 and not args.no_lbfgs:
+        lbfgs = {p: lbfgs_rate(col, costs, p, local_rank, args) for p in ([args.precision] if args.no_second_precision else [args.precision, other])}
 
     if rank == 0:
         its = aggregate_rate(world, args.steps, dt)
@@ -239,12 +243,39 @@ def main():
             out["roofline_" + sfx2] = roofline(prof2, sizes, R2, its2 / world, args, sfx2, triad_gbs, copy_gbs, second[3])
             out["lower_bound_after_" + sfx2] = {"iterations": pre_iterations.get("n", 0) + args.warmup + 2 * args.steps, "value": lb2,
                                                "rel_diff_to_" + sfx: abs(lb2 - lb) / max(abs(lb), 1e-300)}
+        if lbfgs is not None:
+            out["lbfgs"] = {"what": "BASELINE.json configs[3]: L-BFGS around the same solver on the same instance (history 5, the reference's default "
+                                    "parameters), fresh solver, 20 untimed iterations that fill the history, then the timed ones; outside the timed "
+                                    "region of `value`", **lbfgs}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(col, costs, args, sizes)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def lbfgs_rate(col, costs, precision, device, args, iters=100):
+    from bdd_amd.solver import bdd_hip_lbfgs, bdd_hip_parallel_mma
+    s = bdd_hip_parallel_mma(col, costs, precision=precision, device=device, pack_width=args.pack_width, deterministic=args.deterministic,
+                             vars_per_bin=args.vars_per_bin, stage_cap=args.stage_cap, waves_per_block=args.wpb)
+    l = bdd_hip_lbfgs(s)
+    for _ in range(20):
+        l.iteration()
+    s.lower_bound()
+    t0 = time.perf_counter()
+    trials = steps = 0
+    for _ in range(iters):
+        l.iteration()
+        st = l.state()
+        trials += st["last_trials"]
+        steps += st["last_kind"]
+    lb = s.lower_bound()
+    dt = time.perf_counter() - t0
+    l.close()
+    s.close()
+    return {"value": iters / dt, "unit": "iterations/s", "ms_per_iteration": dt / iters * 1e3, "iterations": iters, "lbfgs_steps": steps,
+            "trial_steps_per_iteration": trials / iters, "lower_bound_after": {"iterations": 20 + iters, "value": lb}}
 
 
 INFINITY_CACHE_BYTES = 256 << 20  # MI355X_MICROARCH.md "Infinity Cache (L3)"

@@ -88,7 +88,9 @@ typedef struct bddmma_options {
                                             pair stores, 4: one predicated LDS atomic per entry} instead of all three (the default)
                                   bit 6: the round-2 exchange kernels (none of the three), every bin size
                                   bit 7 / bit 8: narrow workgroups mapped to XCDs in contiguous eighths / in interleaved chunks of 32
-                                                 (default: interleaved when the eighths' hop counts differ by more than 10 %) */
+                                                 (default: interleaved when the eighths' hop counts differ by more than 10 %)
+                                  bit 9 / bit 10: make_dual_feasible of the L-BFGS direction through the staging tables / by gathers
+                                                  (default: staged from 500 000 layers on) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
                                   instance (NOTES.md section 6: the sweeps are bound by instructions issued, not by latency), kept for experiments */
@@ -96,7 +98,7 @@ typedef struct bddmma_options {
                                   of the open pack hop by hop is tried a few hops further down, where those have become narrow again — BDDs
                                   of general linear rows are narrow at both ends and wide in the middle, and side by side from hop 0 they
                                   fill ~30 % of a pack's lanes.  Value = most hops a pack may have; 0: automatic (on when the instance is
-                                  large enough to keep >= 4096 packs), 1: off. */
+                                  large enough to keep ~2 700 packs of three BDD lengths), 1: off. */
 } bddmma_options;
 
 /* ---- construction ------------------------------------------------------- */

@@ -23,8 +23,8 @@ from oracle.oracle import Oracle
 pytestmark = pytest.mark.gpu
 
 
-def run_lbfgs_pair(col, costs, precision, iters, threads=1, **params):
-    s = bdd_hip_parallel_mma(col, costs, precision=precision)
+def run_lbfgs_pair(col, costs, precision, iters, threads=1, solver_options=None, **params):
+    s = bdd_hip_parallel_mma(col, costs, precision=precision, **(solver_options or {}))
     l = bdd_hip_lbfgs(s, **params)
     o = LbfgsOracle(Oracle(col, costs, precision, threads=threads), **params)
     # In double everything is compared, to 1e-9, for all iterations.  Float: the subgradient (an argmin path per BDD) is
@@ -84,13 +84,48 @@ def test_lbfgs_structured_instance_vs_oracle():
     run_lbfgs_pair(col, np.asarray(ilp.objective, float), "double", 40)
 
 
+STAGED, GATHER = 0x200, 0x400   # bddmma_options.variant_flags bits 9 / 10: make_dual_feasible(direction) through the staging tables / by gathers
+
+
+@pytest.mark.parametrize("precision", ["double", "float"])
+@pytest.mark.parametrize("options", [dict(), dict(waves_per_block=1, pack_width=64), dict(waves_per_block=8, stage_cap=128, vars_per_bin=64),
+                                     dict(waves_per_block=2, vars_per_bin=2048), dict(vars_per_bin=4096), dict(exchange_by_variable=2)])
+def test_lbfgs_staged_projection_vs_oracle(precision, options):
+    """The projection of the direction as the large instances do it (k_stage_transpose / k_project_entries: layers -> entries through the
+    sweeps' staging tables, per-variable means in LDS per exchange bin, back with the first step applied), forced on a small instance
+    for every shape of the tables: 1 / 2 / 4 / 8 packs per workgroup, 256- / 512- / 1024-thread bins, several rounds per quad."""
+    col, costs = random_set_cover(3000 if options.get("vars_per_bin", 0) < 2048 else 20000, 2500, 8, seed=5)
+    n_lbfgs, _ = run_lbfgs_pair(col, costs, precision, 40, solver_options=dict(variant_flags=STAGED, **options))
+    assert n_lbfgs >= 10
+
+
+def test_lbfgs_staged_projection_with_wide_and_long_packs():
+    """Layers of wide packs have no staging tables (they go through lpos); long BDDs have several stage groups per pack."""
+    from bdd_amd import BddCollection
+    rng = np.random.Generator(np.random.PCG64(5))
+    V = 400
+    col = BddCollection()
+    for _ in range(8):
+        k = int(rng.integers(16, 22))
+        vs = np.sort(rng.choice(V, size=k, replace=False))
+        co = rng.integers(1, 40, size=k)
+        col.add_linear(co, "<=", int(co.sum() // 2), vs)
+    col.add_covering(np.sort(rng.choice(V, size=200, replace=False)))
+    for _ in range(300):
+        col.add_covering(np.sort(rng.choice(V, size=6, replace=False)))
+    costs = rng.uniform(0.5, 3, col.nr_variables()).round(3)
+    for flags in (STAGED, GATHER):
+        run_lbfgs_pair(col, costs, "double", 40, solver_options=dict(variant_flags=flags, pack_width=64, wide_pack_width=512, stage_cap=64))
+
+
+@pytest.mark.parametrize("flags", [0, STAGED])
 @pytest.mark.parametrize("precision,tol", [("double", 1e-9), ("float", 2e-3)])
-def test_applied_direction_is_dual_feasible(precision, tol):
+def test_applied_direction_is_dual_feasible(precision, tol, flags):
     """make_dual_feasible(direction) (bdd_cuda_base.cu:1261-1303) keeps the cost of every variable: sum over its layers of hi - lo (with the
     deferred min-marginal differences distributed) stays the objective coefficient — after many L-BFGS steps the primal objective vector
     must still be the input costs."""
     col, costs = random_set_cover(3000, 2500, 8, seed=13)
-    s = bdd_hip_parallel_mma(col, costs, precision=precision)
+    s = bdd_hip_parallel_mma(col, costs, precision=precision, variant_flags=flags)
     l = bdd_hip_lbfgs(s)
     steps = 0
     for _ in range(80):
