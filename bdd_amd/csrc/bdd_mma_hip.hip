@@ -1099,7 +1099,7 @@ struct SolverT final : SolverBase {
         if ((rc = backward_run())) return rc;
         HIPCHK(hipMemsetAsync(d_sol, 0, n_layers, stream));
         if ((rc = launch_fwd<FWD_SOLUTION>(nullptr, REAL(0), BDDMMA_K_OTHER))) return rc;
-        fwd_valid = true;  // the solution sweep recomputes and stores cost-from-root
+        // (fwd_valid stays what it was: the solution sweep recomputes the costs-from-root on the fly and does not store them)
         const hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
         if (!sorted) {
             HIPCHK(hipMemcpyAsync(sol, d_sol, n_layers, k, stream));
@@ -1126,7 +1126,6 @@ struct SolverT final : SolverBase {
         rc = launch_fwd<FWD_SOLUTION>(nullptr, REAL(0), BDDMMA_K_OTHER);
         d_sol = own;
         if (rc) return rc;
-        fwd_valid = true;
         return BDDMMA_OK;
     }
     int lbfgs_views(LbfgsViews* out) override

@@ -885,7 +885,9 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                 lds_min(&sF[cur ^ 1][plo ? lo_i : j], plo ? f[r] + nlo[r] : INF);
                 lds_min(&sF[cur ^ 1][phi ? hi_i : j], phi ? f[r] + nhi[r] : INF);
             }
-            store_vals<R>(f, d.F, nb, o[1] - o[0], lane, pk.nt_potentials);
+            // (the argmin-path sweep leaves the stored costs-from-root alone: nothing reads them after it, and it is 38 MB of the ~120 MB the
+            // sweep moves at 10.5 M nodes)
+            if (MODE != FWD_SOLUTION) store_vals<R>(f, d.F, nb, o[1] - o[0], lane, pk.nt_potentials);
             wave_sync();
             cur ^= 1;
             // ---- rotate the pipeline registers
@@ -1858,7 +1860,7 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
                 lds_min(&lds[oFn + (plo ? lo_i : j)], plo ? f[i] + nlo : INF);
                 lds_min(&lds[oFn + (phi ? hi_i : j)], phi ? f[i] + nhi : INF);
             }
-            bstore(f[i], rs.F, act ? (nv[0] + j) * (uint32_t)sizeof(REAL) : OOB);
+            if (MODE != FWD_SOLUTION) bstore(f[i], rs.F, act ? (nv[0] + j) * (uint32_t)sizeof(REAL) : OOB);
         }
         // set-up of later hops: the frontier after next is cleared, T of hop q+2 goes to LDS (phase A of the next hop reads it),
         // the minima of hop q+1 are reset
