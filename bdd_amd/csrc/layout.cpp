@@ -822,6 +822,19 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
                 X.waves_per_block = std::min(X.waves_per_block, fit);
             }
         }
+        // Staggered packs: one pack per workgroup.  The waves of a workgroup share its LDS and meet at the barriers of the staging rounds, and
+        // staggered packs differ in length and in what their hops cost (BDDs start and end anywhere inside them), so a workgroup of four lives as
+        // long as its slowest pack; uniform packs finish together.  Measured on the round-3 kernels, 10 M nodes, 4 -> 1 packs per workgroup, it/s
+        // float / double: 20 k knapsack + 250 k covering rows 5 458 -> 6 110 / 2 862 -> 3 293, 10 k + 400 k 5 641 -> 6 886 / 2 961 -> 3 512, 30 k +
+        // 100 k 5 342 -> 5 234 / 3 152 -> 3 418, 40 k knapsack rows of 14 variables 4 734 -> 4 890 / 3 300 -> 3 740, of 10 variables 11 595 ->
+        // 12 972 / 9 885 -> 10 173.  Not staggered: random set cover keeps 4 (8 127 vs 7 717 / 4 351 vs 3 926 with one), the 1 M-node knapsack
+        // instance its 2 (19 189 vs 18 475).  (The hop counts alone do not tell: grouping staggered packs by four pads them by < 10 %.)
+        if (!(opts && opts->waves_per_block) && X.waves_per_block > 1) {
+            bool staggered = false;
+            for (uint16_t r : N.hop_root)
+                if (r != NO_ROOT) { staggered = true; break; }
+            if (staggered) X.waves_per_block = 1;
+        }
         if (X.waves_per_block != 1 && X.waves_per_block != 2 && X.waves_per_block != 4 && X.waves_per_block != 8) {
             err = "waves_per_block must be 1, 2, 4 or 8";
             return BDDMMA_ERR_INVALID_ARGUMENT;
