@@ -179,7 +179,15 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
     // hop chain, so prefer more, narrower packs.  Only when the caller left pack_width open.
     // (threshold measured on random set cover: 2.1 M nodes = 1 563 packs of 128: 64-wide 18.5 / 19.1 us per sweep vs 19.7 / 18.3; 4.2 M nodes =
     // 3 125 packs: 29.4 / 29.6 vs 27.3 / 25.5 — so 128 stays from ~2 000 packs on)
-    if (rc == BDDMMA_OK && !(opts && opts->pack_width) && L.narrow.n_packs() < 2048 && L.narrow.n_packs() > 0) {
+    // Longer packs need more of them: 161 538 rows of 32 variables (10.5 M nodes) are 2 524 packs of 128 with 32 hops and run at 6 455 it/s, as
+    // 64-wide packs at 7 319 (float); 40 000 knapsack rows in staggered packs of 42 hops: 3 767 packs of 128 4 901 / 3 790 it/s (float / double),
+    // 6 048 of 64 5 333 / 4 015.  So the pack count below which 64-wide packs are tried grows with the hops of the longest pack (x hops / 16,
+    // between 1 and 3).
+    uint32_t longest_pack = 0;
+    if (rc == BDDMMA_OK)
+        for (uint32_t p = 0; p < L.narrow.n_packs(); ++p) longest_pack = std::max(longest_pack, L.narrow.pack_hop_ptr[p + 1] - L.narrow.pack_hop_ptr[p]);
+    const uint32_t few_packs = 2048u * std::min(48u, std::max(16u, longest_pack)) / 16u;
+    if (rc == BDDMMA_OK && !(opts && opts->pack_width) && L.narrow.n_packs() < few_packs && L.narrow.n_packs() > 0) {
         bddmma_options o = opts ? *opts : bddmma_options{};
         o.pack_width = 64;
         HostLayout L2;
