@@ -541,6 +541,25 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         }
     }
     form_narrow();
+    // Staggered narrow packs get one pack per workgroup (see waves_per_block below), and the wide packs of the same launch then have one
+    // wavefront each: narrower wide packs (two hop slots per lane, ~one BDD per pack) keep more of them in flight.  With 128 instead of the
+    // 256-512 the rule above picks (10 M nodes, it/s float / double): 30 k knapsack + 100 k covering rows 5 892 -> 6 012 / 3 530 -> 3 911, 20 k +
+    // 250 k 6 084 -> 6 209 / 3 256 -> 3 438, 40 k knapsack rows 5 344 -> 5 295 / 3 881 -> 3 835.
+    if (!order_w.empty() && !(opts && (opts->wide_pack_width || opts->waves_per_block))) {
+        bool staggered = false;
+        for (uint16_t r : pn.flat_root)
+            if (r != NO_ROOT) { staggered = true; break; }
+        if (staggered) {
+            uint32_t max_w = 0;
+            for (uint32_t b : order_w) max_w = std::max(max_w, bdd_maxw[b]);
+            const uint32_t narrow_ww = std::max(128u, (max_w + 63u) / 64u * 64u);
+            if (narrow_ww < WWe) {
+                WWe = narrow_ww;
+                L.wide_pack_width = WWe;
+                pw.width = WWe;
+            }
+        }
+    }
     form(pw, order_w);
     form(ph, order_h);
 
