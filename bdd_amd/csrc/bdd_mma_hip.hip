@@ -358,7 +358,14 @@ struct SolverT final : SolverBase {
         }
         if (wb_.n_packs) {
             // one workgroup per wide pack, thread t owns the nodes t + i * wide_threads of a hop (kernels.hpp: k_fwd_wide2)
-            wide_threads = std::min<uint32_t>(1024, (wide_pack_width + 63) / 64 * 64);
+            // two nodes of a hop per thread: half the wavefronts at the hop's two barriers and two independent chains per lane.  Wide-only
+            // instance (25 000 rows of 18 variables, 15 M nodes): packs of 512 / 1024 slots with one node per thread 1 823 / 1 662 it/s, with
+            // two 2 158 / 2 205, with four (1024 slots) 1 936
+            wide_threads = std::min<uint32_t>(1024, std::max<uint32_t>(64, ((wide_pack_width + 1) / 2 + 63) / 64 * 64));
+            if (const char* e = std::getenv("BDDMMA_WIDE_THREADS")) {  // experiments: another workgroup size (<= 4 nodes per thread)
+                const uint32_t t = (uint32_t)std::atoi(e) / 64 * 64;
+                if (t >= 64 && t <= 1024 && (wide_pack_width + t - 1) / t <= 4) wide_threads = t;
+            }
             wide_npt = (wide_pack_width + wide_threads - 1) / wide_threads;
             wide_npt = wide_npt <= 1 ? 1 : (wide_npt <= 2 ? 2 : 4);
             wide_lds = (uint32_t)wide2_lds_bytes(sizeof(REAL), wide_pack_width, true);
