@@ -93,7 +93,7 @@ struct SolverT final : SolverBase {
     struct PackBufs {
         uint32_t *pack_hop_ptr = nullptr, *hop_node_off = nullptr, *hop_layer_off = nullptr;
         uint8_t* pack_steps = nullptr;
-        uint16_t* hop_root = nullptr;  // narrow packs only (layout.hpp: PackSet::hop_root)
+        uint16_t* hop_root = nullptr;  // narrow and wide packs (layout.hpp: PackSet::hop_root)
         uint32_t n_packs = 0;
     } nb_, wb_, hb_;  // narrow, wide, huge packs
     uint32_t wide_lds = 0, wide_threads = 256, wide_npt = 1;
@@ -222,6 +222,11 @@ struct SolverT final : SolverBase {
         }
         if ((rc = upload(&nb_.hop_root, L.narrow.hop_root, 38))) return rc;
         if ((rc = upload_packs(wb_, L.wide, 14))) return rc;
+        if (L.wide.hop_root.size() + 1 != L.wide.hop_node_off.size() && !L.wide.hop_node_off.empty()) {
+            err = "wide hop_root table does not match the hop records";
+            return BDDMMA_ERR_INVALID_ARGUMENT;
+        }
+        if ((rc = upload(&wb_.hop_root, L.wide.hop_root, 39))) return rc;
         if ((rc = upload_packs(hb_, L.huge, 18))) return rc;
         huge_pack_width = L.huge_pack_width;
         if (hb_.n_packs && (rc = dalloc(&d_huge_scratch, (size_t)hb_.n_packs * wide_lds_bytes(sizeof(REAL), huge_pack_width, true)))) return rc;

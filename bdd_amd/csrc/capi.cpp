@@ -357,7 +357,7 @@ int bddmma_incremental_mm_agreement_rounding(bddmma_solver* s, bddmma_lbfgs* lbf
 // File: magic, header {precision, #arrays, sizeof(LayoutScalars), sizeof(bddmma_options)}, LayoutScalars, options, the layout arrays
 // as {id, element size, count, data} records (layout.hpp: visit_layout_arrays), then lo / hi / deferred mm / delta.  Loading
 // uploads the arrays as they are: build_layout does not run again.
-static const char kMagic[8] = {'B', 'D', 'D', 'M', 'M', 'A', '0', '6'};  // 06: hop_root (staggered packs); 05: checksum of the layout section; 04: narrow node words carry the layer index
+static const char kMagic[8] = {'B', 'D', 'D', 'M', 'M', 'A', '0', '7'};  // 07: hop_root of the wide packs too; 06: hop_root (staggered packs); 05: checksum of the layout section; 04: narrow node words carry the layer index
 
 namespace {
 struct FileCloser {
@@ -522,6 +522,16 @@ bool layout_plausible(const HostLayout& L, std::string& why)
         int k = 1;
         for (const PackSet* ps : {&L.wide, &L.huge}) {
             const uint32_t maxw = widths[k++];
+            // staggered wide packs (format 07): a root below a pack's first hop is a slot of that hop; huge packs have no such table
+            if (ps == &L.wide) {
+                if (ps->hop_root.size() + 1 != ps->hop_node_off.size() && !(ps->hop_node_off.empty() && ps->hop_root.empty())) return fail("wide hop_root size");
+                for (uint32_t p = 0; p < ps->n_packs(); ++p)
+                    for (uint32_t q = ps->pack_hop_ptr[p]; q < ps->pack_hop_ptr[p + 1]; ++q) {
+                        const uint16_t r = ps->hop_root[q];
+                        if (r == NO_ROOT) continue;
+                        if (q == ps->pack_hop_ptr[p] || r >= ps->hop_node_off[q + 1] - ps->hop_node_off[q]) return fail("wide hop_root out of range");
+                    }
+            }
             if (ps->n_packs() == 0) continue;
             const size_t w1 = w0 + (ps->hop_node_off.back() - ps->hop_node_off.front());
             for (size_t i = w0; i < w1; ++i) {

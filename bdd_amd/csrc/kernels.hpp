@@ -1781,7 +1781,11 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
     }
     __syncthreads();
     uint32_t fc = 0, cur = 0;  // frontier buffer fc: current, (fc+1)%3: next, (fc+2)%3: being cleared for the hop after
+    // staggered wide packs: slot of the BDD that starts at hop q (below the pack's first hop), read two hops ahead like the offsets
+    auto root_at = [&](uint32_t q) -> uint32_t { return (q > q0 && q < q1) ? (uint32_t)pk.hop_root[q] : (uint32_t)NO_ROOT; };
+    uint32_t rt0 = NO_ROOT, rt1 = root_at(q0 + 1);
     for (uint32_t q = q0; q < q1; ++q) {
+        const uint32_t rt2 = root_at(q + 2);
         const uint32_t n = nv[1] - nv[0];
         const uint32_t oFc = fc * S, oFn = (fc == 2 ? 0 : fc + 1) * S, oFx = (fc == 0 ? 2 : fc - 1) * S;
         const uint32_t oT = cur ? oT1 : oT0, oTn = cur ? oT0 : oT1;
@@ -1812,6 +1816,7 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
             const uint32_t j = tid + i * T;
             const bool act = j < n;
             f[i] = act ? lds[oFc + j] : INF;
+            if (j == rt0) f[i] = REAL(0);  // a BDD that starts at this hop: its root has no parents (flush_costs_from_root)
             if (NEED_T) {
                 tl[i] = lds[oT + ww_lo(W0[i], ww)];
                 th[i] = lds[oT + ww_hi(W0[i], ww)];
@@ -1847,7 +1852,7 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
                 bstore(nc, rs.lohi, head ? (lv[0] + l) * (uint32_t)sizeof(P2) : OOB);
                 bstore(mm, rs.mm, head ? E0[i] * (uint32_t)sizeof(REAL) : OOB);
             } else if (MODE == FWD_SOLUTION) {
-                if (act && ldsA[oFc + j]) {
+                if (act && (ldsA[oFc + j] || j == rt0)) {
                     const REAL hi_path = f[i] + (th[i] + nhi);  // backward_step_with_path_costs, bdd_cuda_base.cu:633-640
                     const REAL lo_path = f[i] + (tl[i] + nlo);
                     const bool take_lo = (hi_path - lo_path) > 0;
@@ -1891,6 +1896,7 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
         }
         nv[0] = nv[1]; nv[1] = nv[2]; nv[2] = nv[3]; nv[3] = nv[4]; nv[4] = nv5;
         lv[0] = lv[1]; lv[1] = lv[2]; lv[2] = lv[3]; lv[3] = lv4;
+        rt0 = rt1; rt1 = rt2;
     }
 }
 
@@ -1957,7 +1963,12 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
     if (tid < 4) lds[(tid >> 1) * S + ww + (tid & 1)] = (tid & 1) ? INF : REAL(0);
     __syncthreads();
     uint32_t tc = 0, cur = 0;  // T buffer tc: hop q+1 (children), tc^1: hop q (being written)
+    // staggered wide packs: the root that sits at hop q below the pack's first hop contributes its cost-to-terminal to the lower bound
+    auto root_at = [&](int64_t h) -> uint32_t { return h > (int64_t)q0 ? (uint32_t)pk.hop_root[h] : (uint32_t)NO_ROOT; };
+    uint32_t rt0 = root_at(q), rt1 = root_at(q - 1);
+    double lb_stag = 0.0;
     for (; q >= (int64_t)q0; --q) {
+        const uint32_t rt2 = root_at(q - 2);
         const uint32_t n = cnt_of(q), nb = nb_of(q), lb = lb_of(q);
         const uint32_t oTc = tc * S, oTn = (tc ^ 1) * S;
         const uint32_t oMa = oM0 + cur * S, oMb = oM1 + cur * S, oMa_n = oM0 + (cur ^ 1) * S, oMb_n = oM1 + (cur ^ 1) * S;
@@ -2035,6 +2046,7 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
                 }
             }
             if (act) lds[oTn + j] = t;
+            if (j == rt0) lb_stag += (double)t;
             bstore(t, rs.T, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
         }
         if (NEED_M) {
@@ -2052,10 +2064,11 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
             C0[i] = C1[i];
             if (MODE == BWD_SOLVE) D0[i] = D1[i];
         }
+        rt0 = rt1; rt1 = rt2;
     }
     // lower bound contribution of this pack (bdd_cuda_base.cu:1243-1251)
     const uint32_t n0 = pk.hop_node_off[q0 + 1] - pk.hop_node_off[q0];
-    double acc = 0.0;
+    double acc = lb_stag;
     for (uint32_t j = tid; j < n0; j += T) acc += (double)lds[tc * S + j];
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((tid & 63) == 0) red[tid >> 6] = acc;

@@ -563,6 +563,37 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
             }
         }
     }
+    {   // staggered wide packs: BDDs of general linear rows are diamond-shaped (mean layer width ~ a third of the widest), so side by side from
+        // hop 0 a wide pack fills a third of its slots.  Staggered, a pack is ONE BDD wide and chains them — the next one starts where the
+        // previous one narrows — over up to three BDD lengths, while >= ~500 packs remain.  25 000 rows of 18 variables (15 M nodes, layers up
+        // to ~510 nodes), it/s float: packs of 512 / 640 / 768 / 1024 slots side by side 2 136 / 1 898 / 1 851 / 2 194; staggered over 36 hops
+        // 2 628 / 2 264 / 2 149 / 2 089, over 54 (three lengths) 2 844 / 2 865 / 2 603 / 2 205, over 90 2 371 / 2 161 / 1 995 / 1 787.
+        uint64_t wide_nodes = 0;
+        uint32_t longest = 0, max_w = 0;
+        for (uint32_t b : order_w) {
+            wide_nodes += (delims[b + 1] - delims[b]) - 2;
+            longest = std::max(longest, bdd_lay_ptr[b + 1] - bdd_lay_ptr[b]);
+            max_w = std::max(max_w, bdd_maxw[b]);
+        }
+        const uint32_t opt = opts ? opts->pack_stagger : 0;
+        if (opt >= 2) pw.max_hops = opt;
+        else if (opt == 0 && !order_w.empty()) {
+            const uint32_t one_wide = std::min(WW, std::max(128u, (max_w + 63u) / 64u * 64u));
+            const uint32_t w_st = opts && opts->wide_pack_width ? pw.width : std::max(one_wide, max_w);
+            // packs to keep: ~500, and enough wavefronts for the chip when the narrow packs of the launch do not provide them (a wide pack has
+            // w_st / 128 wavefronts: 4 000 such rows = 2.5 M nodes are 994 packs side by side, 7 747 it/s, and 582 chained ones, 6 315)
+            const uint64_t waves_per_pack = std::max<uint64_t>(1, w_st / 128);
+            const uint64_t narrow_waves = pn.n_packs();
+            const uint64_t keep = std::max<uint64_t>(512, narrow_waves < 2048 ? (2048 - narrow_waves) / waves_per_pack : 0);
+            const uint64_t hops_for_packs = wide_nodes / ((uint64_t)w_st * keep * 6 / 10 + 1);
+            if (hops_for_packs >= longest + 2) {
+                pw.max_hops = (uint32_t)std::min<uint64_t>(hops_for_packs, 3ull * longest);
+                pw.width = w_st;
+                WWe = w_st;
+                L.wide_pack_width = WWe;
+            }
+        }
+    }
     form(pw, order_w);
     form(ph, order_h);
 
@@ -595,7 +626,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         const uint32_t P = pb.n_packs();
         ps.pack_hop_ptr.resize(P + 1);
         ps.pack_steps = pb.pack_steps;
-        if (!wide) ps.hop_root = pb.flat_root;
+        ps.hop_root = pb.flat_root;  // wide packs: staggered too (k_*_wide2); huge packs: all NO_ROOT
         // offsets of every (pack, hop) record first (a running sum), then the packs are emitted independently
         const uint32_t n_rec = P ? pb.pack_hop_ptr[P] : 0;
         ps.hop_node_off.resize((size_t)n_rec + 1);

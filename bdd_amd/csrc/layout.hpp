@@ -204,9 +204,9 @@ void visit_layout_arrays(LAYOUT& L, V&& v)
     v(30, L.ex.quad_round_ptr); v(31, L.ex.cs_ptr); v(32, L.ex.cs_entry); v(33, L.ex.cs_slot);
     v(34, L.res.pack_hdr); v(35, L.res.quad_hdr);
     v(36, L.nodes_per_hop); v(37, L.layers_per_hop);
-    v(38, L.narrow.hop_root);
+    v(38, L.narrow.hop_root); v(39, L.wide.hop_root);
 }
-constexpr int LAYOUT_ARRAY_IDS = 39;
+constexpr int LAYOUT_ARRAY_IDS = 40;
 
 // Host threads of the layout build: 0 = automatic (BDDMMA_THREADS, else min(cores, 32)).  Processes that build several layouts at once
 // (one per device slot: bddmma_host::solve_batch / bench_set_cover) share the cores through this.

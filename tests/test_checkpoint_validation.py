@@ -1,6 +1,6 @@
 """Checkpoint validation without a GPU (capi.cpp: bddmma_load).  A file is checked — magic, record sizes, checksum of the layout
 section, every index / offset / size array against its target — BEFORE a device is touched, so on a box without a GPU a good file
-gets as far as "no HIP device" and a bad one is refused as corrupt.  tests/golden/checkpoint_small_v06.bin was written by
+gets as far as "no HIP device" and a bad one is refused as corrupt.  tests/golden/checkpoint_small_v07.bin was written by
 tools/make_checkpoint_fixture.py on an MI355X (120 variables, 93 BDDs, narrow + wide packs, 39 KB)."""
 import os
 
@@ -11,7 +11,7 @@ from bdd_amd import capi
 from bdd_amd.solver import bdd_hip_parallel_mma
 from util import CHECKPOINT_ARRAY_IDS as IDS, GOLDEN_DIR, Checksum, parse_checkpoint, write_checkpoint
 
-FIXTURE = os.path.join(GOLDEN_DIR, "checkpoint_small_v06.bin")
+FIXTURE = os.path.join(GOLDEN_DIR, "checkpoint_small_v07.bin")
 
 
 def load_error(path):

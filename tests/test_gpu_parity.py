@@ -284,6 +284,70 @@ def test_wide_packs_vs_oracle(precision):
         assert col.evaluate(b, x)
 
 
+@pytest.mark.parametrize("precision", ["double", "float"])
+@pytest.mark.parametrize("variant", [0, 3])   # narrow + wide sweeps in one launch / as separate launches
+def test_staggered_wide_packs_vs_oracle(precision, variant):
+    """Wide packs that chain their BDDs (hop_root of the wide packs, k_*_wide2): a pack is one BDD wide and the next BDD starts where the
+    previous one narrows.  Forced here by pack_stagger on a handful of wide BDDs; the large instances take it automatically."""
+    import ctypes as C
+    from bdd_amd import capi
+    rng = np.random.Generator(np.random.PCG64(77))
+    col = BddCollection()
+    V = 60
+    for _ in range(14):
+        k = int(rng.integers(15, 20))
+        vs = np.sort(rng.choice(V, size=k, replace=False))
+        co = rng.integers(1, 40, size=k)
+        col.add_linear(co, "<=", int(co.sum() // 2), vs)
+    for _ in range(40):
+        col.add_covering(np.sort(rng.choice(V, size=5, replace=False)))
+    costs = rng.normal(0, 3, col.nr_variables()).round(3)
+    # the widest layer decides the pack width: one BDD per hop, so every further BDD of a pack has to start below the first hop
+    widest = max(np.bincount(col.instr[int(col.delims[b]):int(col.delims[b + 1]) - 2, 2].astype(np.int64)).max() for b in range(14))
+    wpw = int(-(-widest // 64) * 64)
+    opts = dict(pack_width=64, wide_pack_width=wpw, pack_stagger=60, variant_flags=variant)
+    # the layout really is staggered: fewer wide packs than wide BDDs
+    h = C.c_void_p()
+    o_ = capi.Options(64, wpw, 0, 0, 0, 0); o_.pack_stagger = 60
+    L = capi.lib()
+    capi.check(L.bddmma_layout_create(C.byref(h), np.ascontiguousarray(col.instr).ctypes.data_as(C.c_void_p),
+                                      np.ascontiguousarray(col.delims).ctypes.data_as(C.c_void_p), col.nr_bdds(), C.byref(o_)), None)
+    n_wide_packs = int(L.bddmma_layout_size(h, 4))
+    L.bddmma_layout_destroy(h)
+    n_wide_bdds = sum(1 for b in range(14) if np.bincount(col.instr[int(col.delims[b]):int(col.delims[b + 1]) - 2, 2].astype(np.int64)).max() > 64)
+    assert 0 < n_wide_packs < n_wide_bdds, (n_wide_packs, n_wide_bdds)
+    s = bdd_hip_parallel_mma(col, costs, precision=precision, **opts)
+    o = Oracle(col, costs, precision)
+    assert close(s.lower_bound(), o.lower_bound(), precision, 100)
+    np.testing.assert_allclose(s.lower_bound_per_bdd(), o.lower_bound_per_bdd(), rtol=TOL[precision]["rel"], atol=100 * TOL[precision]["abs"])
+    for _ in range(12):
+        s.iteration(); o.iteration()
+        assert close(s.lower_bound(), o.lower_bound(), precision, 100)
+    np.testing.assert_allclose(s.lower_bound_per_bdd(), o.lower_bound_per_bdd(), rtol=TOL[precision]["rel"], atol=100 * TOL[precision]["abs"])
+    perm = oracle_layer_perm(s, o)
+    if precision == "double":
+        lo, hi, _ = s.get_solver_costs()
+        olo, ohi = o.get_costs()
+        np.testing.assert_allclose(lo[perm], olo, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(hi[perm], ohi, rtol=1e-9, atol=1e-9)
+    # plain min-marginals and the argmin paths on a fresh solver (MARGINALS / SOLUTION modes of the wide kernels)
+    s2 = bdd_hip_parallel_mma(col, costs, precision=precision, **opts)
+    o2 = Oracle(col, costs, precision)
+    _, a0, a1 = s2.min_marginals_cuda(False)
+    om = o2.min_marginals()
+    p2 = oracle_layer_perm(s2, o2)
+    np.testing.assert_allclose(a0[p2], om[:, 0], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(a1[p2], om[:, 1], rtol=1e-5, atol=1e-4)
+    sol = s2.bdds_solution_vec()
+    lo, hi, _ = s2.get_solver_costs()
+    lbs = s2.lower_bound_per_bdd()
+    for b in range(col.nr_bdds()):
+        m = s2.get_bdd_index() == b
+        x = np.zeros(col.nr_variables()); x[s2.get_primal_variable_index()[m]] = sol[m]
+        assert col.evaluate(b, x)
+        assert abs(np.where(sol[m] == 1, hi[m], lo[m]).sum() - lbs[b]) < (1e-9 if precision == "double" else 1e-3)
+
+
 def test_deterministic_mode_is_bit_reproducible_and_agrees():
     col, costs = random_set_cover(3000, 2500, 8, seed=9)
     runs = []

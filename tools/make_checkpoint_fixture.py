@@ -13,5 +13,5 @@ for _ in range(3):
 costs = np.concatenate([costs, np.zeros(col.nr_variables() - len(costs))])
 s = bdd_hip_parallel_mma(col, costs, precision="double", waves_per_block=2, pack_width=64, pack_stagger=30)
 s.iterations(3)
-s.save("gpurun_out/checkpoint_small_v06.bin")
-print(os.path.getsize("gpurun_out/checkpoint_small_v06.bin"), s.lower_bound(), s.nr_packs())
+s.save("gpurun_out/checkpoint_small_v07.bin")
+print(os.path.getsize("gpurun_out/checkpoint_small_v07.bin"), s.lower_bound(), s.nr_packs())
