@@ -826,8 +826,9 @@ def test_randomised_instances_and_layout_options_vs_oracle(seed):
         else:
             co = rng.integers(1, 9, size=k)
             rows.append((co, vs, ">=", int(rng.integers(1, co.sum() - co.max() + 1))))  # every variable may still be 0
-    if seed % 2 == 1:      # a few rows with layers wider than a wavefront: workgroup-per-pack (and, with wide_pack_width 64, huge) packs
-        for _ in range(int(rng.integers(1, 4))):
+    if seed % 2 == 1:      # a few rows with layers wider than a wavefront: workgroup-per-pack (and, with wide_pack_width 64, huge) packs;
+        # up to eight of them, so that pack_stagger also chains wide BDDs (hop_root of the wide packs)
+        for _ in range(int(rng.integers(1, 9))):
             k = int(rng.integers(12, min(V, 20) + 1))
             co = rng.integers(1, 60, size=k)
             rows.append((co, np.sort(rng.choice(V, size=k, replace=False)), "<=", int(rng.integers(co.max(), co.sum()))))
@@ -840,7 +841,7 @@ def test_randomised_instances_and_layout_options_vs_oracle(seed):
     wpb = int(rng.choice([1, 2, 4, 8]))
     cap = int(rng.choice([pw, 256, 640])) if wpb < 8 else 256
     opts = dict(pack_width=pw, waves_per_block=wpb, stage_cap=max(cap, pw), vars_per_bin=int(rng.choice([0, 64, 256])),
-                wide_pack_width=int(rng.choice([0, 64])), keep_bdd_order=bool(rng.integers(0, 2)),
+                wide_pack_width=int(rng.choice([0, 64, 128, 256])), keep_bdd_order=bool(rng.integers(0, 2)),
                 resident_sweeps=int(rng.choice([0, 1, 2])), exchange_by_variable=int(rng.choice([0, 0, 2])),
                 variant_flags=int(rng.choice([0, 0, 1, 2, 3])) | int(os.environ.get("BDDMMA_FUZZ_VARIANT_OR", "0")),  # the env: tools/soak.sh bisections
                 pack_fill=int(rng.choice([0, 0, pw // 2, 16])), pack_stagger=int(rng.choice([0, 1, 24, 60, 200])))
