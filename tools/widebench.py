@@ -24,6 +24,7 @@ ap.add_argument("--precision", default="float,double")
 ap.add_argument("--pack-width", type=int, default=0)
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--wide-pack-width", type=int, default=0, dest="wpw")
+ap.add_argument("--res", type=int, default=0, help="resident sweeps: 0 auto, 1 off, 2 on")
 ap.add_argument("--wpb", type=int, default=0)
 ap.add_argument("--vars-per-bin", type=int, default=0)
 ap.add_argument("--iters", type=int, default=200)
@@ -59,7 +60,7 @@ print(f"layout: {sz(3)} narrow packs of width {sz(16)} over {sz(7)} (pack, hop) 
 Lh.bddmma_layout_destroy(h)
 for prec in a.precision.split(","):
     R = 4 if prec == "float" else 8
-    s = bdd_hip_parallel_mma(col, costs, precision=prec, pack_width=a.pack_width, wide_pack_width=a.wpw, variant_flags=a.variant, waves_per_block=a.wpb, vars_per_bin=a.vars_per_bin, pack_stagger=a.stagger)
+    s = bdd_hip_parallel_mma(col, costs, precision=prec, pack_width=a.pack_width, wide_pack_width=a.wpw, variant_flags=a.variant, resident_sweeps=a.res, waves_per_block=a.wpb, vars_per_bin=a.vars_per_bin, pack_stagger=a.stagger)
     L, Vs = s.nr_layers(), s.nr_variables()
     b_iter = 2 * (12 * Nt + 2 * R * N + (5 * R + 4) * L + (8 * R + 4) * Vs)
     s.iterations(5)
