@@ -1192,6 +1192,7 @@ struct SolverT final : SolverBase {
     bool proj_staged = false;       // the last projection_means took the staged path
     bool proj_pending = false;      // ... and its way back to layer order is still to be done (with the first step)
     bool proj_attr_set = false;
+    const void* proj_of = nullptr;  // the vector the last projection_means was called on
     bool use_staged_projection() const
     {
         if (opts_variant & 0x400u) return false;
@@ -1215,6 +1216,7 @@ struct SolverT final : SolverBase {
         int rc;
         proj_staged = use_staged_projection();
         proj_pending = false;
+        proj_of = g;
         if (!proj_staged) {
             if (!d_proj_q && (rc = dalloc(&d_proj_q, n_vars))) return rc;
             hipLaunchKernelGGL((k_projection_means<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, (const REAL*)g, d_var_ptr, d_var_layers, d_proj_q, (uint32_t)n_vars);
@@ -1247,6 +1249,7 @@ struct SolverT final : SolverBase {
     int gradient_step_projected(const void* g, double step) override
     {
         HIPCHK(hipSetDevice(device));
+        if (g != proj_of) { err = "gradient_step_projected: not the vector projection_means was called on"; return BDDMMA_ERR_INVALID_ARGUMENT; }
         if (proj_staged) {
             if (proj_pending) {
                 // entries -> layers, with this step applied on the way
