@@ -348,6 +348,47 @@ def test_staggered_wide_packs_vs_oracle(precision, variant):
         assert abs(np.where(sol[m] == 1, hi[m], lo[m]).sum() - lbs[b]) < (1e-9 if precision == "double" else 1e-3)
 
 
+@pytest.mark.parametrize("seed,stagger,wpw", [(1, 50, 0), (2, 36, 128), (3, 0, 0), (4, 90, 256)])
+def test_medium_general_rows_chained_packs_vs_oracle(seed, stagger, wpw):
+    """A few thousand general linear rows of 10-20 variables with random coefficients (layers of 30-140 nodes: narrow and wide packs, both chained
+    over several BDD lengths), random cover rows in between: bound, arc costs and per-BDD bounds against the CPU oracle after 8 iterations."""
+    from bdd_amd import native
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    V = 6000
+    rows = []
+    for _ in range(2500):
+        k = int(rng.integers(10, 21))
+        vs = np.sort(rng.choice(V, size=k, replace=False))
+        co = rng.integers(1, 30, size=k)
+        rows.append((co, vs, "<=" if rng.random() < 0.7 else ">=", int(co.sum() // 2)))
+    for _ in range(4000):
+        rows.append((np.ones(6, int), np.sort(rng.choice(V, size=6, replace=False)), ">=", 1))
+    col = native.rows_to_bdd_collection(rows)
+    costs = rng.uniform(-5, 5, col.nr_variables()).round(3)
+    s = bdd_hip_parallel_mma(col, costs, precision="double", pack_stagger=stagger, wide_pack_width=wpw)
+    f = bdd_hip_parallel_mma(col, costs, precision="float", pack_stagger=stagger, wide_pack_width=wpw)
+    o = Oracle(col, costs, "double", threads=min(os.cpu_count() or 1, 16))
+    assert abs(s.lower_bound() - o.lower_bound()) <= 1e-9 * abs(o.lower_bound())
+    for _ in range(8):
+        s.iteration(); f.iteration(); o.iteration()
+        ref = o.lower_bound()
+        assert abs(s.lower_bound() - ref) <= 1e-9 * abs(ref)
+        assert abs(f.lower_bound() - ref) <= 1e-5 * abs(ref)
+    perm = oracle_layer_perm(s, o)
+    lo, hi, _ = s.get_solver_costs()
+    olo, ohi = o.get_costs()
+    np.testing.assert_allclose(lo[perm], olo, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(hi[perm], ohi, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(s.lower_bound_per_bdd(), o.lower_bound_per_bdd(), rtol=1e-9, atol=1e-9)
+    sol = s.bdds_solution_vec()
+    lbs = s.lower_bound_per_bdd()
+    bdd = s.get_bdd_index()
+    order = np.argsort(bdd, kind="stable")
+    picked = np.where(sol == 1, hi, lo)[order]
+    starts = np.searchsorted(bdd[order], np.arange(col.nr_bdds()))
+    np.testing.assert_allclose(np.add.reduceat(picked, starts), lbs, rtol=1e-9, atol=1e-8)   # every argmin path attains its BDD's bound
+
+
 def test_deterministic_mode_is_bit_reproducible_and_agrees():
     col, costs = random_set_cover(3000, 2500, 8, seed=9)
     runs = []
