@@ -17,7 +17,7 @@ BOT = np.uint64(2**64 - 2)
 
 
 class Layout:
-    def __init__(self, col, pack_width=0, wide_pack_width=0, vars_per_bin=0, stage_cap=0, waves_per_block=0, exchange_by_variable=0, pack_fill=0):
+    def __init__(self, col, pack_width=0, wide_pack_width=0, vars_per_bin=0, stage_cap=0, waves_per_block=0, exchange_by_variable=0, pack_fill=0, pack_stagger=0):
         L = capi.lib()
         instr = np.ascontiguousarray(col.instr, dtype=np.uint64)
         delims = np.ascontiguousarray(col.delims, dtype=np.uint64)
@@ -25,10 +25,12 @@ class Layout:
         opts = capi.Options(pack_width, wide_pack_width, 0, vars_per_bin, stage_cap, waves_per_block)
         opts.exchange_by_variable = exchange_by_variable
         opts.pack_fill = pack_fill
+        opts.pack_stagger = pack_stagger
         rc = L.bddmma_layout_create(C.byref(h), instr.ctypes.data_as(C.c_void_p), delims.ctypes.data_as(C.c_void_p),
                                     col.nr_bdds(), C.byref(opts))
         capi.check(rc, None)
         self.L, self.h = L, h
+        self.pack_stagger = pack_stagger
         sz = lambda w: int(L.bddmma_layout_size(h, w))
         self.pack_width = sz(16)
         self.n_slots, self.narrow_slots, self.n_layers = sz(0), sz(1), sz(2)
@@ -188,7 +190,10 @@ def check_exchange(lay):
             assert (int(lay.quad_hdr[Q][0]), int(lay.quad_hdr[Q][1])) == (int(lay.cs_ptr[r0]), int(lay.cs_ptr[r0 + 1] - lay.cs_ptr[r0]))
     one_group = all(int(lay.pack_group_ptr[p + 1] - lay.pack_group_ptr[p]) == 1 for p in range(lay.np_n))
     short = all(int(lay.pack_hdr[p][5]) & 0xFFFF <= 63 for p in range(lay.np_n))
-    assert lay.res_ok == (lay.np_n > 0 and one_group and short)
+    if lay.pack_stagger >= 2 and not lay.res_ok:
+        pass   # a pack with a BDD that starts below its first hop rules the resident sweeps out (they know roots at the first hop only)
+    else:
+        assert lay.res_ok == (lay.np_n > 0 and one_group and short)
 
 
 def check_roundtrip(col, **kw):
@@ -268,6 +273,29 @@ def test_roundtrip_many_packs_and_wide():
     col2.add_covering([0, 5, 9])
     lay2 = check_roundtrip(col2, pack_width=64)
     assert lay2.np_w == 1 and lay2.np_n == 1
+
+
+@pytest.mark.parametrize("pack_width,wide_pack_width", [(64, 192), (128, 256), (64, 0)])
+def test_roundtrip_chained_packs(pack_width, wide_pack_width):
+    """pack_stagger: BDDs of a pack may start below its first hop, in narrow and in wide packs (hop_root); every node, child, layer and root
+    still decodes to the input."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    col = BddCollection()
+    V = 60
+    for _ in range(14):                      # layers of 59-135 nodes: wide packs (and narrow ones at pack width 128)
+        k = int(rng.integers(15, 20))
+        co = rng.integers(1, 40, size=k)
+        col.add_linear(co, "<=", int(co.sum() // 2), np.sort(rng.choice(V, size=k, replace=False)))
+    for _ in range(30):                      # layers of up to ~40 nodes: narrow packs
+        k = int(rng.integers(8, 13))
+        co = rng.integers(1, 12, size=k)
+        col.add_linear(co, "<=", int(co.sum() // 2), np.sort(rng.choice(V, size=k, replace=False)))
+    for _ in range(40):
+        col.add_covering(np.sort(rng.choice(V, size=5, replace=False)))
+    side_by_side = Layout(col, pack_width=pack_width, wide_pack_width=wide_pack_width, pack_stagger=1)
+    chained = check_roundtrip(col, pack_width=pack_width, wide_pack_width=wide_pack_width, pack_stagger=60)
+    assert chained.np_w < side_by_side.np_w and chained.np_n < side_by_side.np_n      # fewer, longer packs of both kinds
+    assert chained.n_slots <= side_by_side.n_slots + 64 * chained.n_layers             # same nodes (narrow slots may differ by group padding)
 
 
 def test_layout_rejects_bad_input():
