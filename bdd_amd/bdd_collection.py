@@ -249,6 +249,94 @@ class BddCollection:
         return self.add_linear([1] * len(variables), "=", k, variables)
 
     # ---------------------------------------------------------------- splitting
+    # ---- text exports ("export bdd lp" / "export bdd graph" of the driver; reference include/bdd_collection/bdd_collection.h:731-830, :663-729)
+    def write_bdd_lp(self, costs) -> str:
+        """The network-flow LP over the arcs of all BDDs, linked by the original variables; same rows, names and order as the reference's."""
+        ins, d = self.instr, self.delims
+        out = ["Minimize\n"]
+        for i, c in enumerate(costs):
+            out.append(f"{'-' if c < 0 else '+'}{abs(float(c)):g} x_{i}\n")
+        out.append("Subject To\n")
+        is_bot = lambda k: ins[k, 2] == BOTSINK
+        is_sink = lambda k: ins[k, 2] >= BOTSINK
+        arc = lambda b, k, v: f"arc_{b}_{k - int(d[b])}_{v}"
+        for b in range(self.nr_bdds()):
+            d0, d1 = int(d[b]), int(d[b + 1])
+            lo, hi = int(ins[d0, 0]), int(ins[d0, 1])
+            row = f"R_{b}: "
+            if not is_bot(lo):
+                row += arc(b, d0, 0)
+            if not is_bot(hi):
+                row += " + " + arc(b, d0, 1)
+            out.append(row + " = 1\n")
+            incoming = [[] for _ in range(d1 - d0)]
+            if not is_sink(lo):
+                incoming[lo - d0].append((d0, 0))
+            if not is_sink(hi):
+                incoming[hi - d0].append((d0, 1))
+            for i in range(d0 + 1, d1 - 2):
+                lo, hi = int(ins[i, 0]), int(ins[i, 1])
+                row = f"FC_{b}_{i - d0}: "
+                if not is_bot(lo):
+                    row += arc(b, i, 0)
+                if not is_bot(hi):
+                    row += " + " + arc(b, i, 1)
+                for n, v in incoming[i - d0]:
+                    row += " - " + arc(b, n, v)
+                out.append(row + " = 0\n")
+                if not is_sink(lo):
+                    incoming[lo - d0].append((i, 0))
+                if not is_sink(hi):
+                    incoming[hi - d0].append((i, 1))
+        for b in range(self.nr_bdds()):
+            d0, d1 = int(d[b]), int(d[b + 1])
+            cur = int(ins[d0, 2])
+            row = ""
+            for i in range(d0, d1 - 2):
+                if int(ins[i, 2]) != cur:
+                    out.append(row + f" - x_{cur} = 0\n")
+                    row = ""
+                    cur = int(ins[i, 2])
+                if not is_bot(int(ins[i, 1])):
+                    row += " + " + arc(b, i, 1)
+            out.append(row + f" - x_{cur} = 0\n")
+        out.append("Bounds\nBinaries\n")
+        for b in range(self.nr_bdds()):
+            for i in range(int(d[b]), int(d[b + 1]) - 2):
+                if not is_bot(int(ins[i, 0])):
+                    out.append(arc(b, i, 0) + "\n")
+                if not is_bot(int(ins[i, 1])):
+                    out.append(arc(b, i, 1) + "\n")
+        out.append("End\n")
+        return "".join(out)
+
+    def export_graphviz(self, b: int) -> str:
+        """BDD b as a Graphviz digraph, one cluster per variable (the reference iterates an unordered_map over the clusters: their order in
+        the file carries no meaning; here they come in variable order, the sinks first)."""
+        ins, d = self.instr, self.delims
+        d0, d1 = int(d[b]), int(d[b + 1])
+        clusters, last_node = {}, {}
+        for i in range(d0, d1):
+            idx = ins[i, 2]
+            if idx >= BOTSINK:
+                clusters.setdefault(2**64 - 1, []).append(f'{i - d0} [label="{"top" if idx == TOPSINK else "bot"}"];\n')
+            else:
+                clusters.setdefault(int(idx), []).append(f'{i - d0} [label="{int(idx)}"];\n')
+                last_node[int(idx)] = i - d0
+        out = ["digraph BDD\n{\n"]
+        for key in sorted(clusters, key=lambda k: (k != 2**64 - 1, k)):
+            out.append(f"subgraph cluster_{key} {{\n" + "".join(clusters[key]) + "color = blue\n}\n")
+        order = [last_node[v] for v in sorted(last_node)]
+        for a, c in zip(order, order[1:]):
+            out.append(f"{a} -> {c} [style=invis];\n")
+        for i in range(d0, d1):
+            if ins[i, 2] >= BOTSINK:
+                continue
+            out.append(f"{i - d0} -> {int(ins[i, 1]) - d0};\n")
+            out.append(f'{i - d0} -> {int(ins[i, 0]) - d0}[style="dashed"];\n')
+        out.append("}\n")
+        return "".join(out)
+
     def layer_widths(self, b: int) -> list:
         """#nodes per variable layer of BDD b (bdd_collection::layer_widths, bdd_collection.h:195)."""
         d = self.delims

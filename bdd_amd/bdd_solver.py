@@ -184,9 +184,14 @@ class bdd_solver:
             self.export_lp()
             self.bdd_col = self.transform_to_BDDs(self.ilp)
             self.print_statistics()
-            for key in ("export bdd lp", "export bdd graph"):
-                if key in self.config:
-                    raise RuntimeError(f"'{key}' is not available in this backend")
+            if "export bdd lp" in self.config:          # bdd_solver.cpp:400-410
+                with open(self.config["export bdd lp"], "w") as f:
+                    f.write(self.bdd_col.write_bdd_lp(self.ilp.objective))
+            if "export bdd graph" in self.config:       # :432-462: <name>_<bdd>.dot per BDD (the reference also shells out to `dot -Tpng`)
+                stem = os.path.splitext(self.config["export bdd graph"])[0]
+                for b in range(self.bdd_col.nr_bdds()):
+                    with open(f"{stem}_{b}.dot", "w") as f:
+                        f.write(self.bdd_col.export_graphviz(b))
             self.solver, self.lbfgs = self.construct_solver(self.bdd_col, self.ilp.objective)
             _log(f"[bdd solver] set-up time = {time.time() - t0:.3f} s", self.quiet)
         self.solve_dual()

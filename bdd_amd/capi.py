@@ -140,6 +140,8 @@ ILP_SIGNATURES = {
     "bddilp_bdds_nr_variables": (_U64, [_V]),
     "bddilp_bdds_instructions": (_V, [_V]),
     "bddilp_bdds_delimiters": (_V, [_V]),
+    "bddilp_write_bdd_lp": (_I, [_V, _V, _U64, _V, _U64, C.c_char_p]),
+    "bddilp_export_graphviz": (_I, [_V, _V, _U64, _U64, C.c_char_p]),
     "bddilp_random_set_cover": (_I, [_U64, _U64, _U64, _U64, _V, _V]),
 }
 

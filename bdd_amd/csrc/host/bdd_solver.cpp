@@ -211,8 +211,19 @@ void bdd_solver::solve()
                       << "\n[print_statistics] maximum num. constraints per var = " << mx << "\n[print_statistics] mean num. constraints per var = "
                       << (per_var.empty() ? 0.0 : (double)sum / (double)per_var.size()) << std::endl;
         }
-        for (const char* key : {"export bdd lp", "export bdd graph"})
-            if (config_.contains(key)) throw std::runtime_error(std::string("'") + key + "' is not available in this backend");
+        if (config_.contains("export bdd lp")) {   // bdd_solver.cpp:400-410
+            std::ofstream f(config_["export bdd lp"].str);
+            col_.write_bdd_lp(f, ilp_.objective);
+        }
+        if (config_.contains("export bdd graph")) {   // :432-462: <name>_<bdd>.dot per BDD (the reference also shells out to `dot -Tpng`; not done here)
+            const std::string file = config_["export bdd graph"].str;
+            const size_t dot = file.rfind('.');
+            const std::string stem = dot != std::string::npos ? file.substr(0, dot) : file;
+            for (size_t b = 0; b < col_.nr_bdds(); ++b) {
+                std::ofstream f(stem + "_" + std::to_string(b) + ".dot");
+                col_.export_graphviz(b, f);
+            }
+        }
         construct_solver(col_, ilp_.objective);
         char buf[64];
         std::snprintf(buf, sizeof buf, "%.3f", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());

@@ -1,5 +1,10 @@
 // bdd_store.cpp — see bdd_store.hpp.  Host-only C++17.
 #include "bdd_store.hpp"
+#include <cmath>
+#include <string>
+#include <limits>
+#include <array>
+#include <unordered_map>
 
 #include <algorithm>
 #include <cassert>
@@ -509,6 +514,108 @@ std::pair<size_t, size_t> bdd_store::split_long_bdds(size_t nr_vars, size_t spli
     const size_t n = removed.size();
     remove(std::move(removed));
     return {n, next};
+}
+
+
+// ---- text exports ---------------------------------------------------------------------------------------------------------------
+// Both follow the reference's emitters statement by statement (the files are meant to be read by the same downstream tools): the same
+// identifiers, the same order of rows, the same quirks (a row whose lo arc goes to the bot sink starts with " + ").
+namespace {
+inline bool top_sink(const bddmma_instruction& i) { return i.index == BDDMMA_TOPSINK; }
+inline bool bot_sink(const bddmma_instruction& i) { return i.index == BDDMMA_BOTSINK; }
+inline bool sink(const bddmma_instruction& i) { return top_sink(i) || bot_sink(i); }
+}  // namespace
+
+void bdd_store::write_bdd_lp(std::ostream& s, const std::vector<double>& costs) const
+{
+    auto arc = [&](size_t b, size_t idx, size_t value) {
+        return std::string("arc_") + std::to_string(b) + "_" + std::to_string(idx - delimiters[b]) + "_" + std::to_string(value);
+    };
+    auto var = [](size_t v) { return std::string("x_") + std::to_string(v); };
+    s << "Minimize\n";
+    for (size_t i = 0; i < costs.size(); ++i) s << (costs[i] < 0 ? "-" : "+") << std::abs(costs[i]) << " " << var(i) << "\n";
+    s << "Subject To\n";
+    for (size_t b = 0; b < nr_bdds(); ++b) {  // flow through every BDD: one unit leaves the root, conservation at the inner nodes
+        const size_t d0 = delimiters[b], d1 = delimiters[b + 1];
+        const bddmma_instruction& root = instructions[d0];
+        s << "R_" << b << ": ";
+        if (!bot_sink(instructions[root.lo])) s << arc(b, d0, 0);
+        if (!bot_sink(instructions[root.hi])) s << " + " << arc(b, d0, 1);
+        s << " = 1\n";
+        std::vector<std::vector<std::array<size_t, 2>>> incoming(d1 - d0);
+        if (!sink(instructions[root.lo])) incoming[root.lo - d0].push_back({d0, 0});
+        if (!sink(instructions[root.hi])) incoming[root.hi - d0].push_back({d0, 1});
+        for (size_t i = d0 + 1; i + 2 < d1; ++i) {
+            const bddmma_instruction& in = instructions[i];
+            s << "FC_" << b << "_" << i - d0 << ": ";
+            if (!bot_sink(instructions[in.lo])) s << arc(b, i, 0);
+            if (!bot_sink(instructions[in.hi])) s << " + " << arc(b, i, 1);
+            for (const auto& nv : incoming[i - d0]) s << " - " << arc(b, nv[0], nv[1]);
+            s << " = 0\n";
+            if (!sink(instructions[in.lo])) incoming[in.lo - d0].push_back({i, 0});
+            if (!sink(instructions[in.hi])) incoming[in.hi - d0].push_back({i, 1});
+        }
+    }
+    for (size_t b = 0; b < nr_bdds(); ++b) {  // x_v = flow over the hi arcs of the layer of v
+        const size_t d0 = delimiters[b], d1 = delimiters[b + 1];
+        size_t cur = instructions[d0].index;
+        for (size_t i = d0; i + 2 < d1; ++i) {
+            const bddmma_instruction& in = instructions[i];
+            if (in.index != cur) {
+                s << " - " << var(cur) << " = 0\n";
+                cur = in.index;
+            }
+            if (!bot_sink(instructions[in.hi])) s << " + " << arc(b, i, 1);
+        }
+        s << " - " << var(cur) << " = 0\n";
+    }
+    s << "Bounds\n";
+    s << "Binaries\n";
+    for (size_t b = 0; b < nr_bdds(); ++b)
+        for (size_t i = delimiters[b]; i + 2 < delimiters[b + 1]; ++i) {
+            const bddmma_instruction& in = instructions[i];
+            if (!bot_sink(instructions[in.lo])) s << arc(b, i, 0) << "\n";
+            if (!bot_sink(instructions[in.hi])) s << arc(b, i, 1) << "\n";
+        }
+    s << "End\n";
+}
+
+void bdd_store::export_graphviz(size_t b, std::ostream& s) const
+{
+    const size_t d0 = delimiters[b], d1 = delimiters[b + 1];
+    s << "digraph BDD\n";
+    s << "{\n";
+    // (unordered containers as in the reference: the order of the clusters in the file is theirs)
+    std::unordered_map<size_t, std::string> clusters;
+    std::unordered_map<size_t, size_t> cluster_nodes;
+    for (size_t i = d0; i < d1; ++i) {
+        const bddmma_instruction& in = instructions[i];
+        if (sink(in)) {
+            std::string& str = clusters[std::numeric_limits<size_t>::max()];
+            str += std::to_string(i - d0) + (top_sink(in) ? " [label=\"top\"];\n" : " [label=\"bot\"];\n");
+        } else {
+            std::string& str = clusters[in.index];
+            str += std::to_string(i - d0) + " [label=\"" + std::to_string(in.index) + "\"];\n";
+            cluster_nodes[in.index] = i - d0;
+        }
+    }
+    for (auto& [idx, str] : clusters) {
+        s << "subgraph cluster_" << idx << " {\n";
+        s << str;
+        s << "color = blue\n";
+        s << "}\n";
+    }
+    std::vector<std::array<size_t, 2>> order;   // invisible arrows keep the clusters in variable order
+    for (auto [x, y] : cluster_nodes) order.push_back({x, y});
+    std::sort(order.begin(), order.end(), [](const auto& a, const auto& c) { return a[0] < c[0]; });
+    for (size_t c = 0; c + 1 < order.size(); ++c) s << order[c][1] << " -> " << order[c + 1][1] << " [style=invis];\n";
+    for (size_t i = d0; i < d1; ++i) {
+        const bddmma_instruction& in = instructions[i];
+        if (sink(in)) continue;
+        s << i - d0 << " -> " << in.hi - d0 << ";\n";
+        s << i - d0 << " -> " << in.lo - d0 << "[style=\"dashed\"];\n";
+    }
+    s << "}\n";
 }
 
 }  // namespace bddmma_host

@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <string>
 #include <utility>
+#include <ostream>
 #include <vector>
 
 #include "../../../include/bdd_mma.h"
@@ -59,6 +60,12 @@ public:
     std::pair<size_t, size_t> split_long_bdds(size_t nr_variables, size_t split_length, size_t parallelism = 256 * 2048 / 10,
                                               bool with_implication_bdd = false);
     size_t compute_split_length(size_t parallelism) const;  // bdd_preprocessor.cpp:32-121
+
+    // --- text exports ("export bdd lp" / "export bdd graph" of the driver, bdd_solver.cpp:400-410, :432-462)
+    // the network-flow LP over the arcs of all BDDs, linked by the original variables (bdd_collection.h:731-830); `costs[v]` = objective of x_v
+    void write_bdd_lp(std::ostream& s, const std::vector<double>& costs) const;
+    // one BDD as a Graphviz digraph, one cluster per variable (bdd_collection.h:663-729)
+    void export_graphviz(size_t b, std::ostream& s) const;
 
 private:
     // append one BDD given LOCAL child indices; TOP_LOCAL / BOT_LOCAL mark the sinks

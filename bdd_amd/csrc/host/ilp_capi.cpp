@@ -1,5 +1,7 @@
 // ilp_capi.cpp — extern "C" glue of include/bdd_ilp.h over ilp.hpp / bdd_store.hpp.  No exception crosses the ABI.
 #include <cstring>
+#include <fstream>
+#include <vector>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -114,5 +116,35 @@ uint64_t bddilp_bdds_nr_instructions(const bddilp_bdds* b) { return b->col.instr
 uint64_t bddilp_bdds_nr_variables(const bddilp_bdds* b) { return b->col.nr_variables(); }
 const bddmma_instruction* bddilp_bdds_instructions(const bddilp_bdds* b) { return b->col.instructions.data(); }
 const uint64_t* bddilp_bdds_delimiters(const bddilp_bdds* b) { return b->col.delimiters.data(); }
+
+static bddmma_host::bdd_store store_of(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds)
+{
+    bddmma_host::bdd_store c;
+    c.delimiters.assign(delims, delims + n_bdds + 1);
+    c.instructions.assign(instr, instr + delims[n_bdds]);
+    return c;
+}
+int bddilp_write_bdd_lp(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds, const double* costs, uint64_t n_costs,
+                        const char* path)
+{
+    return guarded(BDDILP_ERR_INVALID_ARGUMENT, [&] {
+        if (!instr || !delims || !path || (!costs && n_costs)) throw std::runtime_error("null argument");
+        std::ofstream f(path);
+        if (!f) throw std::runtime_error(std::string("cannot write ") + path);
+        store_of(instr, delims, n_bdds).write_bdd_lp(f, std::vector<double>(costs, costs + n_costs));
+        return BDDILP_OK;
+    });
+}
+int bddilp_export_graphviz(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds, uint64_t bdd_nr, const char* path)
+{
+    return guarded(BDDILP_ERR_INVALID_ARGUMENT, [&] {
+        if (!instr || !delims || !path) throw std::runtime_error("null argument");
+        if (bdd_nr >= n_bdds) throw std::runtime_error("bdd_nr out of range");
+        std::ofstream f(path);
+        if (!f) throw std::runtime_error(std::string("cannot write ") + path);
+        store_of(instr, delims, n_bdds).export_graphviz(bdd_nr, f);
+        return BDDILP_OK;
+    });
+}
 
 }  // extern "C"

@@ -7,6 +7,7 @@ pin against oracle/_ref); these do the same work in C++ — the language of the 
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 
 import numpy as np
@@ -102,3 +103,21 @@ def rows_to_bdd_collection(rows, split_length: int = None, nr_variables: int = 0
         return _collection_from_handle(L, b)
     finally:
         L.bddilp_bdds_destroy(b)
+
+
+def write_bdd_lp(col: BddCollection, costs, path: str) -> None:
+    """csrc/host: bdd_store::write_bdd_lp — the arc-flow LP of a BDD collection ("export bdd lp" of the driver)"""
+    L = capi.lib()
+    instr = np.ascontiguousarray(col.instr, dtype=np.uint64)
+    delims = np.ascontiguousarray(col.delims, dtype=np.uint64)
+    c = np.ascontiguousarray(costs, dtype=np.float64)
+    _check(L.bddilp_write_bdd_lp(instr.ctypes.data_as(C.c_void_p), delims.ctypes.data_as(C.c_void_p), col.nr_bdds(),
+                                 c.ctypes.data_as(C.c_void_p), c.size, os.fsencode(path)))
+
+
+def export_graphviz(col: BddCollection, bdd_nr: int, path: str) -> None:
+    """csrc/host: bdd_store::export_graphviz — one BDD as a Graphviz digraph ("export bdd graph" of the driver)"""
+    L = capi.lib()
+    instr = np.ascontiguousarray(col.instr, dtype=np.uint64)
+    delims = np.ascontiguousarray(col.delims, dtype=np.uint64)
+    _check(L.bddilp_export_graphviz(instr.ctypes.data_as(C.c_void_p), delims.ctypes.data_as(C.c_void_p), col.nr_bdds(), int(bdd_nr), os.fsencode(path)))

@@ -71,6 +71,14 @@ uint64_t bddilp_bdds_nr_variables(const bddilp_bdds* b);
 const bddmma_instruction* bddilp_bdds_instructions(const bddilp_bdds* b); /* [nr_instructions] */
 const uint64_t* bddilp_bdds_delimiters(const bddilp_bdds* b);             /* [nr_bdds + 1] */
 
+/* Text exports of a BDD collection given as flat arrays (the driver's "export bdd lp" / "export bdd graph",
+   reference src/bdd_solver/bdd_solver.cpp:400-410 and :432-462 -> include/bdd_collection/bdd_collection.h:731-830 and :663-729).
+   write_bdd_lp: the network-flow LP over the arcs of all BDDs, linked by the original variables, with objective costs[0 .. n_costs).
+   export_graphviz: BDD bdd_nr as a Graphviz digraph with one cluster per variable.  Both write `path`; 0 on success. */
+int bddilp_write_bdd_lp(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds, const double* costs, uint64_t n_costs,
+                        const char* path);
+int bddilp_export_graphviz(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds, uint64_t bdd_nr, const char* path);
+
 
 /* The benchmark's synthetic instance: random set cover, n_rows rows of k distinct variables, costs U(1,10)
  * (0 for variables in no row), all drawn from one std::mt19937_64(seed) — draw order in bdd_amd/csrc/host/instances.cpp.

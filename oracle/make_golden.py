@@ -116,10 +116,32 @@ def record_fullsize():
     np.savez_compressed(os.path.join(OUT, "fullsize_set_cover_mt.npz"), **out)
 
 
+def record_exports():
+    """tests/golden/exports.json: the reference's text exports (bdd_collection::write_bdd_lp, ::export_graphviz) of a small collection with
+    every constraint family, next to the collection itself — what "export bdd lp" / "export bdd graph" of the driver have to produce."""
+    import json
+    rc = RefCollection()
+    rc.add_simplex([0, 1, 2])
+    rc.add_covering([1, 3])
+    rc.add_linear([2, 3, 4], "<=", 5, [0, 2, 3])
+    rc.add_cardinality([0, 1, 2, 3, 4], 2)
+    rc.add_linear([3, 1, 4, 1, 5, 2, 6], ">=", 9, [1, 2, 4, 5, 6, 7, 8])
+    rc.add_all_equal([5, 7, 8])
+    col = rc.export()
+    costs = [1.5, -2.0, 1.0 / 3.0, 4.0, 1e-7, -12345.678, 0.0, 2.0, -0.25]
+    out = {"instr": [[int(x) for x in row] for row in col.instr], "delims": [int(x) for x in col.delims], "costs": costs,
+           "bdd_lp": rc.write_bdd_lp(costs), "graphviz": [rc.export_graphviz(b) for b in range(rc.nr_bdds())]}
+    json.dump(out, open(os.path.join(OUT, "exports.json"), "w"), indent=0)
+    print("exports.json:", rc.nr_bdds(), "BDDs,", len(out["bdd_lp"]), "bytes of LP")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--fullsize" in sys.argv:
         record_fullsize()
+        return
+    if "--exports" in sys.argv:
+        record_exports()
         return
     record_split("split_covering_10", lambda x: x.add_covering(list(range(10))), 3, 10)
     record_split("split_simplex_9", lambda x: x.add_simplex(list(range(9))), 4, 20)

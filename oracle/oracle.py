@@ -218,6 +218,22 @@ class RefCollection:
         self.R.ref_col_nr_bdds.restype = C.c_size_t
         return int(self.R.ref_col_nr_bdds(self.h))
 
+    def _text(self, fn, *args):
+        fn.restype = C.c_size_t
+        n = int(fn(self.h, *args, None, C.c_size_t(0)))
+        buf = C.create_string_buffer(n + 1)
+        fn(self.h, *args, buf, C.c_size_t(n + 1))
+        return buf.value.decode()
+
+    def write_bdd_lp(self, costs):
+        """reference bdd_collection::write_bdd_lp (bdd_collection.h:731-830)"""
+        c = np.ascontiguousarray(costs, dtype=np.float64)
+        return self._text(self.R.ref_col_write_bdd_lp, _p(c), C.c_size_t(c.size))
+
+    def export_graphviz(self, bdd_nr):
+        """reference bdd_collection::export_graphviz (bdd_collection.h:663-729)"""
+        return self._text(self.R.ref_col_export_graphviz, C.c_size_t(bdd_nr))
+
     def export(self):
         """-> bdd_amd.BddCollection holding the reference's instructions."""
         from bdd_amd.bdd_collection import BddCollection

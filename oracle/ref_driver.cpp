@@ -23,6 +23,9 @@
 #include "bdd_manager/bdd_mgr.h"
 #include "bdd_solver/bdd_branch_instruction.h"
 
+#include <sstream>
+#include <cstring>
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -311,6 +314,30 @@ void ref_col_export(void* c, uint64_t* instr, uint64_t* delims)
         }
     }
     delims[col.nr_bdds()] = k;
+}
+
+// text exports of the reference's bdd_collection (bdd_collection.h:663-830), for tests/golden/exports.json: the text is copied into
+// `out` (capacity `cap`); returns the length the whole text has
+static size_t copy_text(const std::string& t, char* out, size_t cap)
+{
+    if (out && cap) {
+        const size_t n = std::min(cap - 1, t.size());
+        std::memcpy(out, t.data(), n);
+        out[n] = 0;
+    }
+    return t.size();
+}
+size_t ref_col_write_bdd_lp(void* c, const double* costs, size_t n, char* out, size_t cap)
+{
+    std::ostringstream s;
+    static_cast<bdd_collection*>(c)->write_bdd_lp(s, costs, costs + n);
+    return copy_text(s.str(), out, cap);
+}
+size_t ref_col_export_graphviz(void* c, size_t bdd_nr, char* out, size_t cap)
+{
+    std::ostringstream s;
+    static_cast<bdd_collection*>(c)->export_graphviz(bdd_nr, s);
+    return copy_text(s.str(), out, cap);
 }
 
 #define MMA_API(SUF, REAL)                                                                                   \

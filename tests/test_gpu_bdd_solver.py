@@ -200,3 +200,26 @@ def test_eight_slot_rehearsal_on_one_gpu(tmp_path):
     assert sorted(r["seed"] for r in rows[:8]) == list(range(12345, 12353)) and all(r["ok"] for r in rows[:8])
     # equal work per slot: the eight bounds are those of eight DIFFERENT instances (no slot ran another one's seed twice)
     assert len({round(r["lower_bound"], 6) for r in rows[:8]}) == 8
+
+
+def test_export_keys_of_both_drivers(tmp_path):
+    """"export bdd lp" / "export bdd graph" (bdd_solver.cpp:400-410, :432-462) through the C++ driver and the Python driver: the same files,
+    equal to what the collection's own emitters give (tests/test_exports.py pins those on the reference's output)."""
+    import os
+    from bdd_amd import parse_lp, to_bdd_collection
+    lp = "Minimize\n1 x_1 + 2 x_2 + 1.5 x_3 - 1 x_4\nSubject To\nx_1 + x_2 + x_3 = 1\nx_2 + x_3 + x_4 >= 1\n2 x_1 + 3 x_3 + 4 x_4 <= 5\nEnd\n"
+    src = tmp_path / "p.lp"
+    src.write_text(lp)
+    ilp = parse_lp(lp)
+    col = to_bdd_collection(ilp)
+    want_lp = col.write_bdd_lp(ilp.objective)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bdd_amd", "csrc", "bdd_solver_cl")
+    for tag, cmd in (("cpp", [exe]), ("py", [sys.executable, "-m", "bdd_amd.bdd_solver_cl"])):
+        cfg = {"input": str(src), "relaxation solver": "cuda parallel mma", "termination criteria": {"maximum iterations": 20},
+               "export bdd lp": str(tmp_path / f"{tag}.lp"), "export bdd graph": str(tmp_path / f"{tag}_graph.dot")}
+        out = subprocess.run(cmd + [json.dumps(cfg)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert (tmp_path / f"{tag}.lp").read_text() == want_lp
+        for b in range(col.nr_bdds()):
+            got = (tmp_path / f"{tag}_graph_{b}.dot").read_text()
+            assert sorted(got.splitlines()) == sorted(col.export_graphviz(b).splitlines())
