@@ -655,6 +655,32 @@ def test_full_size_knapsack_and_covering_rows_vs_oracle():
     assert abs(sd.lower_bound_per_bdd().sum() - sd.lower_bound()) <= 1e-9 * abs(sd.lower_bound())
 
 
+def test_full_size_wide_packs_only_vs_oracle():
+    """25 000 general <= rows of 18 variables: 15.4 M nodes, layers of ~100 nodes, (almost) only wide packs — chained one BDD wide over three BDD
+    lengths by the automatic rule of this size (hop_root of the wide packs).  Bound and per-BDD bounds against the CPU oracle."""
+    from bdd_amd import native
+    rng = np.random.Generator(np.random.PCG64(1))
+    rows_n, k = 25000, 18
+    V = 5 * rows_n
+    rows = []
+    for _ in range(rows_n):
+        vs = np.sort(rng.choice(V, size=k, replace=False))
+        co = rng.integers(1, 30, size=k)
+        rows.append((co, vs, "<=", int(co.sum() // 2)))
+    col = native.rows_to_bdd_collection(rows)
+    assert col.nr_bdd_nodes() > 15_000_000
+    costs = -rng.uniform(1, 10, col.nr_variables())
+    sd = bdd_hip_parallel_mma(col, costs, precision="double")
+    sf = bdd_hip_parallel_mma(col, costs, precision="float")
+    o = Oracle(col, costs, "double", threads=min(os.cpu_count() or 1, 32))
+    for it in range(4):
+        sd.iteration(); sf.iteration(); o.iteration()
+        ref = o.lower_bound()
+        assert abs(sd.lower_bound() - ref) <= 1e-9 * abs(ref), (it, sd.lower_bound(), ref)
+        assert abs(sf.lower_bound() - ref) <= 1e-5 * abs(ref), (it, sf.lower_bound(), ref)
+    np.testing.assert_allclose(sd.lower_bound_per_bdd(), o.lower_bound_per_bdd(), rtol=1e-9, atol=1e-8)
+
+
 # ---------------------------------------------------------------- long BDDs: hop-window refills and several stage groups per pack
 @pytest.mark.parametrize("precision", ["double", "float"])
 @pytest.mark.parametrize("pack_width,stage_cap,wpb", [(64, 64, 4), (128, 640, 1), (256, 256, 2), (64, 128, 8),
