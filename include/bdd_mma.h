@@ -98,7 +98,8 @@ typedef struct bddmma_options {
                                   of the open pack hop by hop is tried a few hops further down, where those have become narrow again — BDDs
                                   of general linear rows are narrow at both ends and wide in the middle, and side by side from hop 0 they
                                   fill ~30 % of a pack's lanes.  Value = most hops a pack may have; 0: automatic (on when the instance is
-                                  large enough to keep ~2 700 packs of three BDD lengths), 1: off. */
+                                  large enough to keep ~2 700 packs of three BDD lengths), 1: off.  Applies to the wide packs too: a chained
+                                  wide pack is one BDD wide (automatic while >= ~500 packs and enough wavefronts for the chip remain). */
 } bddmma_options;
 
 /* ---- construction ------------------------------------------------------- */
