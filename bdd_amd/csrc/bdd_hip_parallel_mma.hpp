@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -75,6 +76,26 @@ class bdd_hip_parallel_mma {
         check(bddmma_num_bdds_per_var(h_, n.data()));
         return n.at(var);
     }
+    // nr_layers(hop) / nr_bdd_nodes(hop), bdd_cuda_base.h:106-113, for hop < nr_hops(): non-terminal layers / nodes at that distance from
+    // the roots (the reference counts the terminal layers of BDDs that end at the hop as well; nr_layers() here is non-terminal)
+    size_t nr_layers(const int hop_index) const { return per_hop(bddmma_layers_per_hop).at((size_t)hop_index); }
+    size_t nr_bdd_nodes(const int hop_index) const { return per_hop(bddmma_nodes_per_hop).at((size_t)hop_index); }
+    // var_constraint_indices(), bdd_cuda_base.h:121 / bdd_cuda_base.cu:1450-1461: (primal variable, BDD) of every dual variable, hop-major
+    std::pair<std::vector<int>, std::vector<int>> var_constraint_indices() const
+    {
+        std::vector<int32_t> v(nr_layers()), b(nr_layers());
+        check(bddmma_layer_variables(h_, v.data()));
+        check(bddmma_layer_bdds(h_, b.data()));
+        return {std::vector<int>(v.begin(), v.end()), std::vector<int>(b.begin(), b.end())};
+    }
+    std::vector<int> get_primal_variable_index() const { return var_constraint_indices().first; }
+    std::vector<int> get_bdd_index() const { return var_constraint_indices().second; }
+    std::vector<int> get_num_bdds_per_var() const
+    {
+        std::vector<int32_t> n(nr_variables());
+        check(bddmma_num_bdds_per_var(h_, n.data()));
+        return std::vector<int>(n.begin(), n.end());
+    }
 
     // ---- costs (bdd_cuda_base.cu:439-558)
     void update_costs(const std::vector<REAL>& cost_delta_0, const std::vector<REAL>& cost_delta_1)
@@ -92,6 +113,31 @@ class bdd_hip_parallel_mma {
         check(bddmma_primal_objective_vec(h_, v.data(), 0));
         return v;
     }
+    void compute_primal_objective_vec(REAL* dev_primal_obj) { check(bddmma_primal_objective_vec(h_, dev_primal_obj, 1)); }
+    // get_solver_costs / set_solver_costs, bdd_cuda_base.h:124-135 (bdd_cuda_base.cu:1308-1344): {lo, hi, deferred mm difference}, nr_layers() each.
+    // Device pointers as in the reference; the tuple-returning form hands out host vectors (no device_vector type here).
+    void get_solver_costs(REAL* dev_lo, REAL* dev_hi, REAL* dev_deferred_mm_diff) const
+    {
+        check(bddmma_get_solver_costs(h_, dev_lo, dev_hi, dev_deferred_mm_diff, 1));
+    }
+    using SOLVER_COSTS_VECS = std::tuple<std::vector<REAL>, std::vector<REAL>, std::vector<REAL>>;
+    SOLVER_COSTS_VECS get_solver_costs() const
+    {
+        const size_t L = nr_layers();
+        SOLVER_COSTS_VECS c{std::vector<REAL>(L), std::vector<REAL>(L), std::vector<REAL>(L)};
+        check(bddmma_get_solver_costs(h_, std::get<0>(c).data(), std::get<1>(c).data(), std::get<2>(c).data(), 0));
+        return c;
+    }
+    void set_solver_costs(const REAL* dev_lo, const REAL* dev_hi, const REAL* dev_deferred_mm_diff)
+    {
+        check(bddmma_set_solver_costs(h_, dev_lo, dev_hi, dev_deferred_mm_diff, 1));
+    }
+    void set_solver_costs(const SOLVER_COSTS_VECS& c)
+    {
+        if (std::get<0>(c).size() != nr_layers() || std::get<1>(c).size() != nr_layers() || std::get<2>(c).size() != nr_layers())
+            throw std::runtime_error("bdd_hip_parallel_mma: set_solver_costs needs nr_layers() entries per vector");
+        check(bddmma_set_solver_costs(h_, std::get<0>(c).data(), std::get<1>(c).data(), std::get<2>(c).data(), 0));
+    }
 
     // ---- sweeps and bounds
     void forward_run() { check(bddmma_forward_run(h_)); }
@@ -100,6 +146,14 @@ class bdd_hip_parallel_mma {
     {
         double lb;
         check(bddmma_lower_bound(h_, &lb));
+        return lb;
+    }
+    // lower_bound_per_bdd(device_ptr), bdd_cuda_base.h:70 (bdd_cuda_base.cu:1253-1259): nr_bdds() values
+    void lower_bound_per_bdd(REAL* dev_lb_per_bdd) { check(bddmma_lower_bound_per_bdd(h_, dev_lb_per_bdd, 1)); }
+    std::vector<REAL> lower_bound_per_bdd_host()
+    {
+        std::vector<REAL> lb(nr_bdds());
+        check(bddmma_lower_bound_per_bdd(h_, lb.data(), 0));
         return lb;
     }
 
@@ -122,6 +176,22 @@ class bdd_hip_parallel_mma {
         std::vector<std::vector<std::array<double, 2>>> out(nr_variables());
         for (size_t k = 0; k < L; ++k) out[var[k]].push_back({double(m0[k]), double(m1[k])});
         return out;
+    }
+    // min_marginals_cuda(get_sorted), bdd_cuda_base.h:84 (bdd_cuda_base.cu:716-749): (primal variable, mm_lo, mm_hi) per dual variable — what
+    // incremental_mm_agreement_rounding_cuda.cu:262-362 consumes; sorted by variable (then BDD) or in the solver's layer order.
+    // Device buffers of nr_layers() entries each, owned by the caller ...
+    void min_marginals_cuda(int32_t* dev_var, REAL* dev_mm_lo, REAL* dev_mm_hi, bool get_sorted = true)
+    {
+        check(bddmma_min_marginals(h_, get_sorted ? 1 : 0, dev_var, dev_mm_lo, dev_mm_hi, 1));
+    }
+    // ... or as host vectors
+    std::tuple<std::vector<int>, std::vector<REAL>, std::vector<REAL>> min_marginals_cuda(bool get_sorted = true)
+    {
+        const size_t L = nr_layers();
+        std::vector<int32_t> var(L);
+        std::vector<REAL> m0(L), m1(L);
+        check(bddmma_min_marginals(h_, get_sorted ? 1 : 0, var.data(), m0.data(), m1.data(), 0));
+        return {std::vector<int>(var.begin(), var.end()), std::move(m0), std::move(m1)};
     }
     // two_dim_variable_array<REAL> bdds_solution() (bdd_cuda_base.cu:1204-1233): [variable][bdd] -> 0 / 1, the argmin path of every BDD,
     // BDDs of a variable in ascending order (primal_variable_sorting_order_, :379-391); nested vectors instead of two_dim_variable_array
@@ -153,10 +223,31 @@ class bdd_hip_parallel_mma {
     void make_dual_feasible(REAL* dev_g) const { check(bddmma_make_dual_feasible(h_, dev_g, 1)); }
     void gradient_step(const REAL* dev_g, double step_size) { check(bddmma_gradient_step(h_, dev_g, step_size, 1)); }
 
+    // cereal save / load of the reference (bdd_cuda_base.h:167-170, bdd_cuda_base.cu:1486-1550; pickled by bdd_cuda_parallel_mma_py.cu:15-38):
+    // the archive is a file; it holds the device layout and the costs, load() rebuilds nothing
     void save(const std::string& path) const { check(bddmma_save(h_, path.c_str())); }
+    static bdd_hip_parallel_mma load(const std::string& path, int device = 0)
+    {
+        bddmma_solver* h = nullptr;
+        const int rc = bddmma_load(&h, device, path.c_str());
+        if (rc != BDDMMA_OK) throw std::runtime_error(std::string("bdd_hip_parallel_mma: ") + bddmma_last_error(nullptr));
+        if (bddmma_precision(h) != precision) {
+            bddmma_destroy(h);
+            throw std::runtime_error("bdd_hip_parallel_mma: the checkpoint was written by a solver of the other precision");
+        }
+        bdd_hip_parallel_mma s;
+        s.h_ = h;
+        return s;
+    }
     bddmma_solver* handle() { return h_; }
 
    private:
+    std::vector<uint64_t> per_hop(int (*f)(const bddmma_solver*, uint64_t*)) const
+    {
+        std::vector<uint64_t> n(nr_hops());
+        check(f(h_, n.data()));
+        return n;
+    }
     void check(int rc) const { check(rc, h_); }
     static void check(int rc, const bddmma_solver* h)
     {

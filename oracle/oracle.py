@@ -175,6 +175,110 @@ class Oracle:
         self._f("oracle_gradient_step")(self.h, _p(d), C.c_double(step))
 
 
+class CudaRuleOracle:
+    """CPU restatement of the reference's GPU solver bdd_cuda_parallel_mma<REAL> (oracle/cuda_rule_oracle.c): omega is an
+    argument, a layer with a non-finite min-marginal gets no update.  Layers are in BDD-major order, as in `Oracle`."""
+
+    def __init__(self, col, costs_hi=None, precision: str = "double"):
+        self.suf = {"double": "_f64", "float": "_f32"}[precision]
+        self.dtype = np.float64 if precision == "double" else np.float32
+        self.L = lib()
+        instr = np.ascontiguousarray(col.instr, dtype=np.uint64)
+        delims = np.ascontiguousarray(col.delims, dtype=np.uint64)
+        f = self._f("cr_create")
+        f.restype = C.c_void_p
+        self.h = C.c_void_p(f(_p(instr), _p(delims), C.c_uint64(col.nr_bdds())))
+        if costs_hi is not None:
+            self.update_costs([], costs_hi)
+
+    def _f(self, name):
+        return getattr(self.L, name + self.suf)
+
+    def __del__(self):
+        try:
+            self._f("cr_destroy")(self.h)
+        except Exception:
+            pass
+
+    def _u64(self, name):
+        f = self._f(name)
+        f.restype = C.c_uint64
+        return int(f(self.h))
+
+    def nr_variables(self): return self._u64("cr_nr_variables")
+    def nr_bdds(self): return self._u64("cr_nr_bdds")
+    def nr_layers(self): return self._u64("cr_nr_layers")
+
+    def _real(self, x):
+        return C.c_double(x) if self.dtype == np.float64 else C.c_float(x)
+
+    def layer_info(self):
+        var = np.zeros(self.nr_layers(), np.int64)
+        bdd = np.zeros(self.nr_layers(), np.int64)
+        self._f("cr_layer_info")(self.h, _p(var), _p(bdd))
+        return var, bdd
+
+    def update_costs(self, lo, hi):
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        self._f("cr_update_costs")(self.h, _p(lo), C.c_uint64(lo.size), _p(hi), C.c_uint64(hi.size))
+
+    def get_costs(self):
+        lo = np.zeros(self.nr_layers(), self.dtype)
+        hi = np.zeros(self.nr_layers(), self.dtype)
+        self._f("cr_get_layer_costs")(self.h, _p(lo), _p(hi))
+        return lo, hi
+
+    def set_costs(self, lo, hi):
+        lo = np.ascontiguousarray(lo, dtype=self.dtype)
+        hi = np.ascontiguousarray(hi, dtype=self.dtype)
+        assert lo.size == hi.size == self.nr_layers()
+        self._f("cr_set_layer_costs")(self.h, _p(lo), _p(hi))
+
+    def backward_run(self): self._f("cr_backward_run")(self.h)
+    def forward_run(self): self._f("cr_forward_run")(self.h)
+
+    def lower_bound(self) -> float:
+        f = self._f("cr_lower_bound")
+        f.restype = C.c_double
+        return float(f(self.h))
+
+    def forward_mm(self, omega, delta):
+        assert delta.dtype == self.dtype and delta.size == 2 * self.nr_variables()
+        self._f("cr_forward_mm")(self.h, self._real(omega), _p(delta))
+
+    def backward_mm(self, omega, delta):
+        assert delta.dtype == self.dtype and delta.size == 2 * self.nr_variables()
+        f = self._f("cr_backward_mm")
+        f.restype = C.c_int
+        if f(self.h, self._real(omega), _p(delta)) != 0:
+            raise RuntimeError("backward_mm needs a valid forward state")
+
+    def normalize_delta(self, delta):
+        assert delta.dtype == self.dtype and delta.size == 2 * self.nr_variables()
+        self._f("cr_normalize_delta")(self.h, _p(delta))
+
+    def iteration(self, omega=0.5): self._f("cr_iteration")(self.h, self._real(omega))
+    def distribute_delta(self): self._f("cr_distribute_delta")(self.h)
+
+    def delta(self):
+        out = np.zeros(2 * self.nr_variables(), self.dtype)
+        self._f("cr_get_delta")(self.h, _p(out))
+        return out
+
+    def mm(self):
+        """deferred min-marginal differences (deffered_mm_diff_) of the last pass, per layer"""
+        out = np.zeros(self.nr_layers(), self.dtype)
+        self._f("cr_get_mm")(self.h, _p(out))
+        return out
+
+    def min_marginals(self):
+        mm0 = np.zeros(self.nr_layers(), self.dtype)
+        mm1 = np.zeros(self.nr_layers(), self.dtype)
+        self._f("cr_min_marginals")(self.h, _p(mm0), _p(mm1))
+        return mm0, mm1
+
+
 class RefCollection:
     """BDD::bdd_collection of the reference (compiled from /root/reference), via oracle/_ref."""
 
