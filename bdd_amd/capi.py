@@ -54,6 +54,7 @@ SIGNATURES = {
     "bddmma_destroy": (None, [_V]),
     "bddmma_device_count": (_I, []),
     "bddmma_set_layout_threads": (_I, [_I]),
+    "bddmma_set_thread_layout_threads": (_I, [_I]),
     "bddmma_last_error": (C.c_char_p, [_V]),
     "bddmma_nr_variables": (_U64, [_V]),
     "bddmma_nr_bdds": (_U64, [_V]),

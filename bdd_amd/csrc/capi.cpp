@@ -101,6 +101,12 @@ int bddmma_set_layout_threads(int n)
     set_layout_threads((unsigned)n);
     return BDDMMA_OK;
 }
+int bddmma_set_thread_layout_threads(int n)
+{
+    if (n < 0) return BDDMMA_ERR_INVALID_ARGUMENT;
+    set_thread_layout_threads((unsigned)n);
+    return BDDMMA_OK;
+}
 
 void bddmma_destroy(bddmma_solver* s)
 {

@@ -256,10 +256,11 @@ std::vector<std::vector<std::array<double, 2>>> bdd_solver::min_marginals()
 
 // ---------------------------------------------------------------------------------------------- batch farm
 // one layout build per device slot at a time: each gets its share of the host cores (8 slots x 32 builder threads would oversubscribe them)
+// (set per worker thread: the process-wide value, which an application or a second concurrent batch may own, is left alone)
 static void share_layout_threads(size_t slots)
 {
     const unsigned hw = std::thread::hardware_concurrency();
-    bddmma_set_layout_threads((int)std::max<size_t>(1, std::min<size_t>(32, (hw ? hw : 1) / std::max<size_t>(1, slots))));
+    bddmma_set_thread_layout_threads((int)std::max<size_t>(1, std::min<size_t>(32, (hw ? hw : 1) / std::max<size_t>(1, slots))));
 }
 
 std::vector<batch_result> solve_batch(const std::vector<std::string>& configs, const std::vector<int>& devices, bool quiet)
@@ -268,6 +269,7 @@ std::vector<batch_result> solve_batch(const std::vector<std::string>& configs, c
     if (devices.empty()) throw std::runtime_error("solve_batch: no devices");
     std::atomic<size_t> next{0};
     auto worker = [&](int device) {
+        share_layout_threads(devices.size());
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= configs.size()) return;
@@ -289,11 +291,9 @@ std::vector<batch_result> solve_batch(const std::vector<std::string>& configs, c
             r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
     };
-    share_layout_threads(devices.size());
     std::vector<std::thread> th;
     for (int d : devices) th.emplace_back(worker, d);
     for (auto& t : th) t.join();
-    bddmma_set_layout_threads(0);
     return out;
 }
 
@@ -308,6 +308,7 @@ std::vector<bench_result> bench_set_cover(uint64_t n_vars, uint64_t n_rows, uint
     std::condition_variable cv;
     size_t ready = 0;
     auto worker = [&](size_t i) {
+        share_layout_threads(seeds.size());
         bench_result& r = out[i];
         r.device = devices[i % devices.size()];
         r.seed = seeds[i];
@@ -352,11 +353,9 @@ std::vector<bench_result> bench_set_cover(uint64_t n_vars, uint64_t n_rows, uint
         }
         if (s) bddmma_destroy(s);
     };
-    share_layout_threads(seeds.size());
     std::vector<std::thread> th;
     for (size_t i = 0; i < seeds.size(); ++i) th.emplace_back(worker, i);
     for (auto& t : th) t.join();
-    bddmma_set_layout_threads(0);
     if (aggregate) {
         double worst = 0;
         size_t n_ok = 0;

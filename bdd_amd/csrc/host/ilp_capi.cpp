@@ -117,8 +117,22 @@ uint64_t bddilp_bdds_nr_variables(const bddilp_bdds* b) { return b->col.nr_varia
 const bddmma_instruction* bddilp_bdds_instructions(const bddilp_bdds* b) { return b->col.instructions.data(); }
 const uint64_t* bddilp_bdds_delimiters(const bddilp_bdds* b) { return b->col.delimiters.data(); }
 
+// The emitters index instructions[lo / hi] and the per-BDD `incoming` tables directly: check what bddmma_create checks (monotone
+// delimiters, >= 1 node + 2 terminals per BDD, terminals last, arcs of a non-terminal node point forward inside their BDD) before
+// anything is written (out-of-bounds reads and writes on malformed input through a public C ABI).
 static bddmma_host::bdd_store store_of(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds)
 {
+    for (uint64_t b = 0; b < n_bdds; ++b) {
+        const uint64_t d0 = delims[b], d1 = delims[b + 1];
+        if (d1 < d0 || d1 - d0 < 3) throw std::runtime_error("BDD " + std::to_string(b) + ": fewer than 3 instructions or delimiters not ascending");
+        for (uint64_t i = d0; i < d1; ++i) {
+            const bool term = instr[i].index >= BDDMMA_BOTSINK;
+            if (term != (i + 2 >= d1)) throw std::runtime_error("BDD " + std::to_string(b) + ": the two terminals must be its last two instructions");
+            if (!term && (instr[i].lo <= i || instr[i].lo >= d1 || instr[i].hi <= i || instr[i].hi >= d1))
+                throw std::runtime_error("BDD " + std::to_string(b) + ": arc of instruction " + std::to_string(i) + " does not point forward inside the BDD");
+        }
+        if (instr[d1 - 2].index == instr[d1 - 1].index) throw std::runtime_error("BDD " + std::to_string(b) + ": needs one top and one bot sink");
+    }
     bddmma_host::bdd_store c;
     c.delimiters.assign(delims, delims + n_bdds + 1);
     c.instructions.assign(instr, instr + delims[n_bdds]);

@@ -2235,9 +2235,12 @@ __device__ __forceinline__ void hop_store(float2 v, rsrc_t rh, uint32_t voff, ui
 __device__ __forceinline__ void hop_store(double2 v, rsrc_t rh, uint32_t voff, uint32_t soff)
 {
     using u4 = decltype(__builtin_amdgcn_raw_buffer_load_b128(rh, 0, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rh, voff, soff, 0);
+    const u4 data = __builtin_bit_cast(u4, v);
+    __builtin_amdgcn_raw_buffer_store_b128(data, rh, voff, soff, 0);
 #ifndef BDDMMA_REPRODUCE_STORE_HAZARD
-    asm volatile("s_nop 0" ::: "memory");
+    // the data registers are an input of the nop: they stay live up to it, so no VALU write of them can be scheduled between the store and
+    // the wait state (the Makefile runs tools/isa_lint.py on every build)
+    asm volatile("s_nop 0" ::"v"(data) : "memory");
 #endif
 }
 // VAR: the three ingredients of the round-2 rewrite that was shelved (see the note above), separately switchable so that the rare

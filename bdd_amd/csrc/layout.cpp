@@ -19,13 +19,14 @@ namespace {
 // Host threads for the layout build (std::thread: no OpenMP runtime to link).  The reference builds its layout with ~10 device
 // sorts (bdd_cuda_base.cu:146-391); here it is host work, spread over the cores: f(begin, end, thread) over contiguous chunks.
 std::atomic<unsigned> g_layout_threads{0};  // bddmma_set_layout_threads: 0 = BDDMMA_THREADS, else min(cores, 32)
+thread_local unsigned t_layout_threads = 0; // bddmma_set_thread_layout_threads: the calling thread's builds only; wins over the process-wide value
 struct Par {
     unsigned nt = 1;
     Par()
     {
         const char* e = std::getenv("BDDMMA_THREADS");
         const unsigned hw = std::thread::hardware_concurrency();
-        const unsigned set = g_layout_threads.load(std::memory_order_relaxed);
+        const unsigned set = t_layout_threads ? t_layout_threads : g_layout_threads.load(std::memory_order_relaxed);
         nt = set ? set : (e ? (unsigned)std::atoi(e) : std::min(hw ? hw : 1u, 32u));
         if (nt < 1) nt = 1;
     }
@@ -77,6 +78,7 @@ struct PackBuilder {
     // where the BDDs already placed have become narrow again, as long as the pack stays within `max_hops` hops and no other BDD starts
     // at that hop (the kernels know one root slot per hop below the first).  0: every BDD starts at hop 0.
     uint32_t max_hops = 0;
+    bool chain_any = false;         // explicit pack_stagger: chain whatever fits (automatic mode: only BDDs that narrow again, see add)
     std::vector<uint16_t> root;     // per hop of the open pack: local slot of the BDD that starts there (hops > 0), or NO_ROOT
 
     // closed packs
@@ -120,6 +122,13 @@ struct PackBuilder {
         }
         return true;
     }
+    static bool chainable(const uint32_t* widths, uint32_t n)
+    {
+        uint64_t sum = 0;
+        uint32_t mx = 0;
+        for (uint32_t h = 0; h < n; ++h) { sum += widths[h]; mx = std::max(mx, widths[h]); }
+        return mx >= 4 && sum * 10 <= (uint64_t)mx * n * 6;  // mean layer width <= 0.6 of the widest layer
+    }
     // widths[0..n) = layer widths of the BDD.  Writes the slot position of every layer to pos[]; returns the hop of the pack at which
     // the BDD starts.
     uint32_t add(uint32_t order_idx, const uint32_t* widths, uint32_t n, uint32_t* pos)
@@ -127,7 +136,12 @@ struct PackBuilder {
         uint32_t d = 0;
         if (open) {
             bool fits = fits_at(0, widths, n);
-            if (!fits && max_hops > n) {
+            // Only BDDs that are narrow at their ends and wide in the middle are chained (general linear rows: mean layer width about a
+            // third of the widest).  Flat BDDs — covering, simplex, cardinality rows — never become narrow again: chained, each of them
+            // lengthens the pack by a hop for two lanes' worth of nodes (a staircase), and a staggered pack also costs the launch its four
+            // packs per workgroup and the resident sweeps.  Seen with keep_bdd_order or shape classes of < 256 members, which bypass the
+            // closed-form packing of form_narrow (300 k cover rows, 46 880 -> 112 492 wave-hops in automatic mode).
+            if (!fits && max_hops > n && (chain_any || chainable(widths, n))) {
                 for (uint32_t dd = 1; dd + n <= max_hops && dd <= used.size() && !fits; ++dd) {
                     if (dd < root.size() && root[dd] != NO_ROOT) continue;  // one BDD may start per hop
                     if (fits_at(dd, widths, n)) { fits = true; d = dd; }
@@ -222,6 +236,10 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     }
     if (WW < 64 || WW > 4096) {
         err = "wide_pack_width must be in [64, 4096]";
+        return BDDMMA_ERR_INVALID_ARGUMENT;
+    }
+    if (opts && opts->pack_stagger > 0xFFFFu) {  // hop counts of a pack are 16-bit in the resident pack headers
+        err = "pack_stagger must be <= 65535";
         return BDDMMA_ERR_INVALID_ARGUMENT;
     }
     if (opts && opts->pack_fill && (opts->pack_fill > W || opts->pack_fill < 2)) {
@@ -534,7 +552,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
             longest = std::max(longest, bdd_lay_ptr[b + 1] - bdd_lay_ptr[b]);
         }
         const uint32_t opt = opts ? opts->pack_stagger : 0;
-        if (opt >= 2) pn.max_hops = opt;
+        if (opt >= 2) { pn.max_hops = opt; pn.chain_any = true; }
         else if (opt == 0) {
             // (the pack count to keep was 4096 until the segmented minimum got its DPP folds; on those kernels 10 M knapsack nodes run at
             // 4 320 / 4 223 / 4 674 / 4 377 / 4 446 it/s with at most 28 / 36 / 42 / 48 / 56 hops per pack (6 724 ... 2 552 packs), the mixed
@@ -576,7 +594,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
             max_w = std::max(max_w, bdd_maxw[b]);
         }
         const uint32_t opt = opts ? opts->pack_stagger : 0;
-        if (opt >= 2) pw.max_hops = opt;
+        if (opt >= 2) { pw.max_hops = opt; pw.chain_any = true; }
         else if (opt == 0 && !order_w.empty()) {
             const uint32_t one_wide = std::min(WW, std::max(128u, (max_w + 63u) / 64u * 64u));
             const uint32_t w_st = opts && opts->wide_pack_width ? pw.width : std::max(one_wide, max_w);
@@ -998,5 +1016,6 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
 }
 
 void set_layout_threads(unsigned n) { g_layout_threads.store(n, std::memory_order_relaxed); }
+void set_thread_layout_threads(unsigned n) { t_layout_threads = n; }
 
 }  // namespace bddmma

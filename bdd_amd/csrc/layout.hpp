@@ -211,6 +211,9 @@ constexpr int LAYOUT_ARRAY_IDS = 40;
 // Host threads of the layout build: 0 = automatic (BDDMMA_THREADS, else min(cores, 32)).  Processes that build several layouts at once
 // (one per device slot: bddmma_host::solve_batch / bench_set_cover) share the cores through this.
 void set_layout_threads(unsigned n);
+// ... the same for the builds the calling thread starts (0 = follow the process-wide setting): what the batch farms use, so that two
+// concurrent batches, or an application's own bddmma_set_layout_threads, are not overwritten
+void set_thread_layout_threads(unsigned n);
 
 // Returns BDDMMA_OK or an error code; `err` receives the message.
 int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,

@@ -122,6 +122,10 @@ int bddmma_device_count(void);
  * builds one instance per GPU at the same time gives every build cores / #GPUs (the reference builds its layout on the device,
  * bdd_cuda_base.cu:146-391; here it is host work). */
 int bddmma_set_layout_threads(int n);
+/* The same limit for the builds started by the calling host thread only (0 = follow the process-wide setting).  One-solver-per-GPU host
+ * threads (include/cuda_utils.h:111-114 of the reference knows one device; the batch farm here has a thread per device) set it for
+ * themselves, so concurrent batches and the application's own process-wide value do not overwrite each other. */
+int bddmma_set_thread_layout_threads(int n);
 /* Error text of the last failed call on `s`; with s == NULL the last failed bddmma_create. */
 const char* bddmma_last_error(const bddmma_solver* s);
 

@@ -247,6 +247,114 @@ static void test_facades()
     CHECK(l.incremental_mm_agreement_rounding(0.1, 1.1, 50, 100).size() == 6);
 }
 
+// The remaining public members of bdd_cuda_base (bdd_cuda_base.h:70,84,106-135,167-170): lower_bound_per_bdd, min_marginals_cuda(get_sorted),
+// nr_layers(hop) / nr_bdd_nodes(hop), var_constraint_indices, get / set_solver_costs, load — one check each, host and device forms.
+template <typename REAL>
+static void test_base_members()
+{
+    const double tol = sizeof(REAL) == 8 ? 1e-9 : 1e-4;
+    std::vector<double> c(9, -1.0);
+    c[0] = c[3] = c[6] = -2.0;
+    bdd_hip_parallel_mma<REAL> s(matching(3), c);
+    for (int i = 0; i < 3; ++i) s.iteration();
+    const size_t L = s.nr_layers(), B = s.nr_bdds();
+    // per-hop sizes: six simplex BDDs over three variables each -> hop 0: 6 one-node layers, hops 1, 2: 6 two-node layers
+    CHECK(s.nr_hops() == 3);
+    CHECK(s.nr_layers(0) == 6 && s.nr_layers(1) == 6 && s.nr_layers(2) == 6);
+    CHECK(s.nr_bdd_nodes(0) == 6 && s.nr_bdd_nodes(1) == 12 && s.nr_bdd_nodes(2) == 12);
+    // (variable, BDD) of every dual variable: every BDD three times, every variable twice, consistent with nr_bdds(var)
+    const auto vc = s.var_constraint_indices();
+    CHECK(vc.first.size() == L && vc.second.size() == L);
+    std::vector<int> per_var(9, 0), per_bdd(B, 0);
+    for (size_t l = 0; l < L; ++l) { ++per_var[(size_t)vc.first[l]]; ++per_bdd[(size_t)vc.second[l]]; }
+    for (size_t v = 0; v < 9; ++v) CHECK(per_var[v] == 2 && s.nr_bdds(v) == 2 && s.get_num_bdds_per_var()[v] == 2);
+    for (size_t b = 0; b < B; ++b) CHECK(per_bdd[b] == 3);
+    // lower_bound_per_bdd: host form, device form, and the sum is lower_bound()
+    const auto lbh = s.lower_bound_per_bdd_host();
+    REAL* dlb = nullptr;
+    CHECK(hipMalloc((void**)&dlb, B * sizeof(REAL)) == hipSuccess);
+    s.lower_bound_per_bdd(dlb);
+    std::vector<REAL> lbd(B);
+    CHECK(hipMemcpy(lbd.data(), dlb, B * sizeof(REAL), hipMemcpyDeviceToHost) == hipSuccess);
+    double sum = 0;
+    for (size_t b = 0; b < B; ++b) { CHECK(lbd[b] == lbh[b]); sum += lbh[b]; }
+    CHECK_NEAR(sum, s.lower_bound(), tol);
+    (void)hipFree(dlb);
+    // min_marginals_cuda: sorted by variable = the nested min_marginals(); device form = host form; unsorted follows var_constraint_indices
+    const auto sorted = s.min_marginals_cuda(true);
+    const auto nested = s.min_marginals();
+    size_t k = 0;
+    for (size_t v = 0; v < 9; ++v)
+        for (const auto& m : nested[v]) {
+            CHECK(std::get<0>(sorted)[k] == (int)v);
+            CHECK(double(std::get<1>(sorted)[k]) == m[0] && double(std::get<2>(sorted)[k]) == m[1]);
+            ++k;
+        }
+    CHECK(k == L);
+    const auto unsorted = s.min_marginals_cuda(false);
+    for (size_t l = 0; l < L; ++l) CHECK(std::get<0>(unsorted)[l] == vc.first[l]);
+    int32_t* dv = nullptr;
+    REAL *d0 = nullptr, *d1 = nullptr;
+    CHECK(hipMalloc((void**)&dv, L * sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&d0, L * sizeof(REAL)) == hipSuccess &&
+          hipMalloc((void**)&d1, L * sizeof(REAL)) == hipSuccess);
+    s.min_marginals_cuda(dv, d0, d1, true);
+    std::vector<int32_t> hv(L);
+    std::vector<REAL> h0(L), h1(L);
+    CHECK(hipMemcpy(hv.data(), dv, L * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess);
+    CHECK(hipMemcpy(h0.data(), d0, L * sizeof(REAL), hipMemcpyDeviceToHost) == hipSuccess);
+    CHECK(hipMemcpy(h1.data(), d1, L * sizeof(REAL), hipMemcpyDeviceToHost) == hipSuccess);
+    for (size_t l = 0; l < L; ++l) CHECK(hv[l] == std::get<0>(sorted)[l] && h0[l] == std::get<1>(sorted)[l] && h1[l] == std::get<2>(sorted)[l]);
+    // get / set_solver_costs: a second solver that takes the first one's costs continues identically (device and host forms)
+    const auto costs = s.get_solver_costs();
+    CHECK(std::get<0>(costs).size() == L);
+    bdd_hip_parallel_mma<REAL> t(matching(3), std::vector<double>(9, 0.0)), u(matching(3), std::vector<double>(9, 0.0));
+    t.set_solver_costs(costs);
+    {
+        REAL* d2 = nullptr;
+        CHECK(hipMalloc((void**)&d2, L * sizeof(REAL)) == hipSuccess);
+        s.get_solver_costs(d0, d1, d2);
+        u.set_solver_costs(d0, d1, d2);
+        (void)hipFree(d2);
+    }
+    CHECK_NEAR(t.lower_bound(), s.lower_bound(), 0.0);
+    CHECK_NEAR(u.lower_bound(), s.lower_bound(), 0.0);
+    bool threw = false;
+    try {
+        auto bad = costs;
+        std::get<2>(bad).pop_back();
+        t.set_solver_costs(bad);
+    } catch (const std::runtime_error&) {
+        threw = true;
+    }
+    CHECK(threw);
+    (void)hipFree(dv); (void)hipFree(d0); (void)hipFree(d1);
+    // save / load: the loaded object is a solver of the same type in the same state; the other precision is refused
+    const std::string path = std::string("/tmp/bddmma_cpp_members_") + (sizeof(REAL) == 8 ? "f64" : "f32") + ".ckpt";
+    s.save(path);
+    auto r = bdd_hip_parallel_mma<REAL>::load(path);
+    CHECK(r.nr_layers() == L && r.nr_bdds() == B);
+    CHECK_NEAR(r.lower_bound(), s.lower_bound(), 0.0);
+    s.iteration();
+    r.iteration();
+    CHECK_NEAR(r.lower_bound(), s.lower_bound(), sizeof(REAL) == 8 ? 1e-12 : 1e-5);
+    threw = false;
+    try {
+        using OTHER = typename std::conditional<sizeof(REAL) == 8, float, double>::type;
+        (void)bdd_hip_parallel_mma<OTHER>::load(path);
+    } catch (const std::runtime_error&) {
+        threw = true;
+    }
+    CHECK(threw);
+    threw = false;
+    try {
+        (void)bdd_hip_parallel_mma<REAL>::load("/tmp/bddmma_no_such_file.ckpt");
+    } catch (const std::runtime_error&) {
+        threw = true;
+    }
+    CHECK(threw);
+    std::remove(path.c_str());
+}
+
 static void test_checkpoint()
 {
     std::vector<double> c(16, -1.0);
@@ -332,6 +440,8 @@ int main()
         {"L-BFGS wrapper, move construction <float>", test_lbfgs_and_move<float>},
         {"facades bdd_hip / bdd_lbfgs_hip_mma <double>", test_facades<double>},
         {"facades bdd_hip / bdd_lbfgs_hip_mma <float>", test_facades<float>},
+        {"remaining bdd_cuda_base members <double>", test_base_members<double>},
+        {"remaining bdd_cuda_base members <float>", test_base_members<float>},
         {"checkpoint", test_checkpoint},
         {"bdd_solver driver", test_driver},
     };

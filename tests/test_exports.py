@@ -55,3 +55,32 @@ def test_driver_writes_the_exports(tmp_path):
     out = (tmp_path / "out.lp").read_text()
     assert out.startswith("Minimize\n+1 x_0\n+2 x_1\n+1.5 x_2\nSubject To\nR_0: ") and out.endswith("End\n")
     assert (tmp_path / "graph_0.dot").read_text().startswith("digraph BDD\n{\n") and (tmp_path / "graph_1.dot").exists()
+
+
+def test_exports_refuse_malformed_collections(tmp_path):
+    """the emitters index the arrays directly, so the entry points validate what bddmma_create validates — a malformed
+    collection is an error return, never an out-of-bounds access"""
+    import pytest
+    z, col = load()
+    good_i, good_d = col.instr.copy(), col.delims.copy()
+    path = str(tmp_path / "x.out")
+
+    def broken(instr=None, delims=None):
+        c = BddCollection.from_arrays(good_i, good_d)      # (from_arrays validates as well: the damage goes in behind it)
+        if instr is not None:
+            c._chunks = [instr]
+        if delims is not None:
+            c._delims = [delims]
+        return c
+
+    cases = []
+    i = good_i.copy(); i[0, 0] = len(good_i) + 5; cases.append(broken(instr=i))                    # lo child outside the array
+    i = good_i.copy(); i[0, 1] = 0; cases.append(broken(instr=i))                                   # hi child points backwards (at itself)
+    i = good_i.copy(); i[int(good_d[1]) - 1, 2] = i[int(good_d[1]) - 2, 2]; cases.append(broken(instr=i))   # two equal sinks
+    d = good_d.copy(); d[1] = d[0] + 2; cases.append(broken(delims=d))                               # a BDD of two instructions
+    d = good_d.copy(); d[1], d[2] = d[2], d[1]; cases.append(broken(delims=d))                       # delimiters not ascending
+    for bad in cases:
+        with pytest.raises((RuntimeError, ValueError)):
+            native.write_bdd_lp(bad, z["costs"], path)
+        with pytest.raises((RuntimeError, ValueError)):
+            native.export_graphviz(bad, 0, path)

@@ -1,62 +1,19 @@
-"""ISA lint of the built library (CPU only): no unpadded VMEM-store write-data hazard.
-
-On gfx950 a VMEM store of more than 64 bits (buffer_store_dwordx3 / x4) needs one wait state before a VALU instruction overwrites
-its data registers.  hipcc pads the pair when the store's soffset is an immediate, but NOT when it is an SGPR — the ISA manuals
-exempt that form and LLVM's hazard recogniser follows them — and the hardware then stores the overwritten dword in ~1 % of the cases
-(tools/store_hazard.hip; profiles/r03_exchange_variant_rootcause.txt: this was the round-2 exchange rewrite's rare 1e-7 error).
-The kernels guard their 16-byte scalar-offset stores themselves (kernels.hpp: hop_store(double2)); this test disassembles the
-device code of libbdd_mma_hip.so and fails if any wide buffer store with an SGPR soffset is followed directly by a VALU write of one
-of its data registers."""
+"""ISA lint of the built library (CPU only): no unpadded VMEM-store write-data hazard — tools/isa_lint.py (which the Makefile also runs
+after linking) on libbdd_mma_hip.so; see there for the hazard."""
 import os
-import re
-import shutil
-import subprocess
+import sys
 
 import pytest
 
 from bdd_amd import capi
 
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-STORE = re.compile(r"^\s*buffer_store_dwordx[34]\s+v\[(\d+):(\d+)\],\s*\w+,\s*s\[\d+:\d+\],\s*(s\d+|m0|\d+|0x[0-9a-f]+)\b")
-VALU_DST = re.compile(r"^\s*(v_[a-z0-9_]+)\s+(?:v(\d+)|v\[(\d+):(\d+)\])\b")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+import isa_lint  # noqa: E402
 
 
-def disassemble(tmp_path):
-    lib = str(tmp_path / "lib.so")
-    shutil.copy(capi.LIB_PATH, lib)
-    subprocess.run([OBJDUMP, "--offloading", lib], check=True, capture_output=True)
-    parts = sorted(f for f in os.listdir(tmp_path) if "amdgcn" in f)
-    assert parts, "no device code object in the library"
-    text = []
-    for f in parts:
-        text += subprocess.run([OBJDUMP, "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout.splitlines()
-    return text
-
-
-@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
-def test_no_unpadded_wide_store_followed_by_a_valu_write_of_its_data(tmp_path):
-    lines = disassemble(tmp_path)
-    func, wide_sgpr, hits = "?", 0, []
-    pending = None  # (lo, hi, line) of a wide store with an SGPR soffset whose next instruction has not been seen yet
-    for l in lines:
-        if l.endswith(">:"):
-            func, pending = l.split("<")[-1][:-2], None
-            continue
-        ins = l.split("//")[0]
-        if not ins.strip() or not ins.startswith("\t"):
-            continue
-        if pending is not None:
-            m = VALU_DST.match(ins)
-            if m and not m.group(1).startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
-                lo = int(m.group(2)) if m.group(2) is not None else int(m.group(3))
-                hi = int(m.group(2)) if m.group(2) is not None else int(m.group(4))
-                if not (hi < pending[0] or lo > pending[1]):
-                    hits.append((func, pending[2].strip(), ins.strip()))
-            pending = None
-        m = STORE.match(ins)
-        if m and m.group(3).startswith(("s", "m")):
-            wide_sgpr += 1
-            pending = (int(m.group(1)), int(m.group(2)), ins)
+@pytest.mark.skipif(not os.path.exists(isa_lint.OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
+def test_no_unpadded_wide_store_followed_by_a_valu_write_of_its_data():
+    wide_sgpr, hits, stores = isa_lint.lint(capi.LIB_PATH)
     assert not hits, f"{len(hits)} unpadded store / VALU-write pairs, e.g. {hits[:3]}"
-    assert sum(1 for l in lines if "buffer_store_dword" in l) > 100   # the scan did see the kernels
+    assert stores > 100   # the scan did see the kernels
     print(f"{wide_sgpr} wide buffer stores with an SGPR soffset, all padded")

@@ -17,7 +17,8 @@ BOT = np.uint64(2**64 - 2)
 
 
 class Layout:
-    def __init__(self, col, pack_width=0, wide_pack_width=0, vars_per_bin=0, stage_cap=0, waves_per_block=0, exchange_by_variable=0, pack_fill=0, pack_stagger=0):
+    def __init__(self, col, pack_width=0, wide_pack_width=0, vars_per_bin=0, stage_cap=0, waves_per_block=0, exchange_by_variable=0, pack_fill=0, pack_stagger=0,
+                 keep_bdd_order=0):
         L = capi.lib()
         instr = np.ascontiguousarray(col.instr, dtype=np.uint64)
         delims = np.ascontiguousarray(col.delims, dtype=np.uint64)
@@ -26,6 +27,7 @@ class Layout:
         opts.exchange_by_variable = exchange_by_variable
         opts.pack_fill = pack_fill
         opts.pack_stagger = pack_stagger
+        opts.keep_bdd_order = keep_bdd_order
         rc = L.bddmma_layout_create(C.byref(h), instr.ctypes.data_as(C.c_void_p), delims.ctypes.data_as(C.c_void_p),
                                     col.nr_bdds(), C.byref(opts))
         capi.check(rc, None)
@@ -414,3 +416,25 @@ def test_pack_fill_trades_lanes_for_packs():
     assert len(packs_over) <= 1
     with pytest.raises(capi.BddMmaError, match="pack_fill"):
         Layout(col, pack_width=64, pack_fill=65)
+
+
+def test_automatic_stagger_leaves_flat_rows_side_by_side():
+    """flat BDDs (covering rows) never narrow again, so chaining them behind a full pack only builds a staircase — more
+    and longer packs, one pack per workgroup, no resident sweeps.  With keep_bdd_order the rows bypass the closed-form packing of uniform
+    shape runs and go through PackBuilder::add: the automatic mode must give the side-by-side layout there too, at a size where it is on."""
+    col, _ = random_set_cover(300_000, 150_000, 10, seed=1)     # 2.85 M nodes: automatic chaining allows 13 hops per pack
+    def hops(**kw):
+        lay = Layout(col, **kw)
+        s = lay.sets[0]
+        return lay.np_n, int(s["pack_hop_ptr"][-1]), int(np.diff(s["pack_hop_ptr"]).max()), lay.wpb
+    auto, side, forced = hops(keep_bdd_order=1), hops(keep_bdd_order=1, pack_stagger=1), hops(keep_bdd_order=1, pack_stagger=30)
+    assert auto == side                        # same packs, same total wave-hops, four packs per workgroup
+    assert auto[2] == 10 and auto[3] == 4
+    assert forced[1] > 3 * side[1] and forced[2] > 10 and forced[3] == 1   # what the explicit option still does (and the old automatic mode did)
+    assert hops() == side                      # grouped by shape (closed-form packing): unchanged
+
+
+def test_pack_stagger_is_bounded():
+    col, _ = random_set_cover(200, 100, 5, seed=2)
+    with pytest.raises(capi.BddMmaError, match="pack_stagger"):
+        Layout(col, pack_stagger=70_000)
