@@ -29,6 +29,9 @@ labels[3] = labels[2]
 for kind in (2, 3, 4):
     ms = s.time_kernel(kind, 50)
     z = np.loadtxt(f"{base}.{kind}", dtype=np.float64, ndmin=2)
+    if z.size == 0:
+        print(f"{names[kind]}: {ms * 1e3:.2f} us per launch, no stamps in this kernel (streaming sweeps)")
+        continue
     t = z[:, 1:]
     t0 = t[:, 0].min()
     tick_us = 0.01   # s_memtime: 100 MHz constant clock
