@@ -110,6 +110,10 @@ struct SolverT final : SolverBase {
     uint32_t *d_pack_hdr = nullptr, *d_quad_hdr = nullptr;
     bool use_res = false;
     uint32_t res_ns = 0, res_nl = 0, res_lds = 0;
+    // second generation (kernels.hpp: k_fwd_res2 / k_bwd_res2): per-lane records of ready-made LDS offsets, derived from the layout here
+    bool use_res2 = false;
+    uint32_t *d_res2_rec = nullptr, *d_res2_rec_off = nullptr;
+    uint32_t res2_n_words = 0, res2_lds = 0, res2_ns = 0, res2_nl = 0;
     uint32_t huge_pack_width = 0;
     unsigned char* d_huge_scratch = nullptr;  // frontier arrays of the huge packs (global memory instead of LDS)
 
@@ -346,7 +350,36 @@ struct SolverT final : SolverBase {
             const uint64_t wgs_per_cu = fits ? (160 * 1024) / (res_lds + static_lds) : 0;
             const bool all_in_flight = nb_.n_packs <= 2880 && (uint64_t)cdiv(nb_.n_packs, wpb) <= 256ull * std::min<uint64_t>(wgs_per_cu, 2048 / (64 * wpb));
             use_res = fits && mode != 1 && (mode == 2 || all_in_flight);
-            if (use_res) {
+            // Second generation (kernels.hpp: k_fwd_res2 / k_bwd_res2), packs of 64 slots with layers of <= 2 nodes: its LDS regions are sized in
+            // whole 1 KiB pieces of REAL values (no node words in LDS).  Chosen, like the first, while the packs are (nearly) all in flight at
+            // once.  Measured on random set cover (tools/sweep_res2.sh, profiles/r04_res2_sweep.txt), float, it/s streaming -> resident: 1.05 M
+            // nodes (1 563 packs) 28.1 k -> 35.0 k, 1.6 M 21.4 k -> 26.1 k, 2.1 M 19.0 k -> 19.9 k, 3.1 M (4 688 packs, 1.4 x what the CUs' LDS holds
+            // at once) 16.3 k -> 16.7 k, 4.2 M (128-slot streaming packs) 14.5 k -> 13.4 k; double gains only with every pack in flight.
+            // variant_flags bit 8: first generation only.
+            if (pack_width == 64 && !narrow_seg && mode != 1 && !(opts && (opts->variant_flags & 0x100u))) {
+                res2_ns = (L.res.max_slots + 1024 / (uint32_t)sizeof(REAL) - 1) / (1024 / (uint32_t)sizeof(REAL)) * (1024 / (uint32_t)sizeof(REAL));
+                res2_nl = (L.res.max_layers + 512 / (uint32_t)sizeof(REAL) - 1) / (512 / (uint32_t)sizeof(REAL)) * (512 / (uint32_t)sizeof(REAL));
+                res2_lds = wpb * stage_cap * 2 * (uint32_t)sizeof(REAL) + wpb * res2_wave_bytes(sizeof(REAL), res2_ns, res2_nl);
+                const uint64_t wgs2 = res2_lds + 256 <= 160 * 1024 ? std::min<uint64_t>((160 * 1024) / (res2_lds + 256), 2048 / (64 * wpb)) : 0;
+                const uint64_t in_flight = 256ull * wgs2 * wpb;  // packs the chip holds at once
+                const bool auto_ok = sizeof(REAL) == 4 ? (uint64_t)nb_.n_packs * 100 <= in_flight * 145 : (uint64_t)nb_.n_packs <= in_flight;
+                if (wgs2 && (mode == 2 || auto_ok)) {
+                    Res2Records R2;
+                    build_res2_records(L, sizeof(REAL), res2_ns, res2_nl, R2);
+                    if (R2.ok && R2.rec.size() * sizeof(uint32_t) < (1ull << 31)) {
+                        if ((rc = upload(&d_res2_rec, R2.rec))) return rc;
+                        if ((rc = upload(&d_res2_rec_off, R2.rec_off))) return rc;
+                        res2_n_words = (uint32_t)R2.rec.size();
+                        use_res2 = use_res = true;
+#define SET_RES2(W_)                                                                                                                            \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_res2<REAL, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)res2_lds)); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_res2<REAL, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)res2_lds));
+                        switch (wpb) { case 1: SET_RES2(1) break; case 2: SET_RES2(2) break; case 4: SET_RES2(4) break; default: SET_RES2(8) break; }
+#undef SET_RES2
+                    }
+                }
+            }
+            if (use_res && !use_res2) {
 #define SET_RES(R_, W_) \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_res<REAL, R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(res_lds + seg_bytes(wpb)))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_res<REAL, R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(res_lds + seg_bytes(wpb))));
@@ -485,7 +518,8 @@ struct SolverT final : SolverBase {
             const dim3 grid(narrow_grid(cdiv(nb_.n_packs, w))), block(64 * w);
             const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
 #define LAUNCH_N(R_, W_)                                                                                                      \
-    if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
+    if (res && use_res2) hipLaunchKernelGGL((k_fwd_res2<REAL, W_>), grid, block, res2_lds, stream, rd.pack_hdr, rd.quad_hdr, res2_ns, res2_nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d_res2_rec, d_res2_rec_off, res2_n_words, d, pk, omega); \
+    else if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
     else if (two_node) hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_, MODE != FWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
     else hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
@@ -555,7 +589,8 @@ struct SolverT final : SolverBase {
             const dim3 grid(narrow_grid(cdiv(nb_.n_packs, w))), block(64 * w);
             const ResDev rd{d_pack_hdr, d_quad_hdr, res_ns, res_nl};
 #define LAUNCH_N(R_, W_)                                                                                                      \
-    if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
+    if (res && use_res2) hipLaunchKernelGGL((k_bwd_res2<REAL, W_>), grid, block, res2_lds, stream, rd.pack_hdr, rd.quad_hdr, res2_ns, res2_nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d_res2_rec, d_res2_rec_off, res2_n_words, d, pk, omega); \
+    else if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
     else if (two_node) hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_, MODE != BWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
     else hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \

@@ -801,5 +801,17 @@ int bddmma_layout_copy(const bddmma_layout* l, int which, void* out)
         default: return BDDMMA_ERR_INVALID_ARGUMENT;
     }
 }
+int bddmma_layout_res2_records(const bddmma_layout* l, int real_size, uint32_t* info, uint32_t* words, uint32_t* rec_off)
+{
+    if (!l || !info || (real_size != 4 && real_size != 8)) return BDDMMA_ERR_INVALID_ARGUMENT;
+    const HostLayout& L = l->L;
+    const uint32_t ns = (L.res.max_slots + 255) / 256 * 256, nl = (L.res.max_layers + 127) / 128 * 128;  // as SolverT::init
+    Res2Records R;
+    build_res2_records(L, (uint32_t)real_size, ns, nl, R);
+    info[0] = R.ok ? 1u : 0u; info[1] = (uint32_t)R.rec.size(); info[2] = ns; info[3] = nl; info[4] = R.max_hops;
+    if (words && !R.rec.empty()) std::memcpy(words, R.rec.data(), R.rec.size() * sizeof(uint32_t));
+    if (rec_off && !R.rec_off.empty()) std::memcpy(rec_off, R.rec_off.data(), R.rec_off.size() * sizeof(uint32_t));
+    return BDDMMA_OK;
+}
 
 }  // extern "C"

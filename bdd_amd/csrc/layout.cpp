@@ -111,6 +111,9 @@ struct PackBuilder {
     }
     uint32_t place(uint32_t u, uint32_t w) const
     {
+        // narrow packs: a two-node layer starts at an even lane, so that its minimum is one DPP swap of neighbouring lanes
+        // (quad_perm [1, 0, 3, 2]; kernels.hpp: k_fwd_res2 / k_bwd_res2)
+        if (group && w == 2 && (u & 1u)) ++u;
         if (group && (u % group) + w > group) u = (u + group - 1) / group * group;
         return u;
     }
@@ -889,6 +892,12 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         // small instances: keep at least ~512 workgroups so that every CU has work
         if (!(opts && opts->waves_per_block))
             while (X.waves_per_block > 1 && Pn / X.waves_per_block < 512) X.waves_per_block /= 2;
+        // Instances of a few thousand narrow packs and nothing else are candidates for the resident sweeps, whose workgroups should be all in
+        // flight at once: one pack per workgroup packs the CUs' LDS best (a wave's 12-21 KB region; k_fwd_res2).  The entry arrays of such an
+        // instance stay in cache, so the longer runs of cooperative staging buy nothing there (1.05 M nodes, streaming: 28.0 k it/s with 1, 2 or 4).
+        // (64-slot packs, up to ~1.45 x what the chip holds at once in float; beyond that the streaming sweeps run, which want their 4: 3.1 M
+        // nodes 16.3 k it/s with 4, 16.0 k with 1; 4.2 M, packs of 128: 14.6 k / 13.8 k)
+        if (!(opts && opts->waves_per_block) && W == 64 && Pn <= 3700 && L.wide.n_packs() == 0 && L.huge.n_packs() == 0) X.waves_per_block = 1;
         // Instances with a sizeable share of wide packs (>= 10 % of the node slots): their solve sweeps share the narrow packs' launch
         // (k_fwd_mixed / k_bwd_mixed), so a wide pack gets 64 * waves_per_block threads — more than its hop width leaves threads idle
         // behind every barrier.  Knapsack benchmark (wide packs of 65-77 nodes): 4 -> 2 packs per workgroup 16.1 k -> 18.1 k it/s
@@ -1013,6 +1022,70 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
     }
     lap("vpos + resident headers");
     return BDDMMA_OK;
+}
+
+// layout.hpp: struct Res2Records
+void build_res2_records(const HostLayout& L, uint32_t S, uint32_t ns, uint32_t nl, Res2Records& out)
+{
+    out = Res2Records();
+    const PackSet& N = L.narrow;
+    const uint32_t P = N.n_packs(), W = L.pack_width;
+    if (!L.res.ok || P == 0 || W != 64 || L.narrow_word_off.size() != P) return;
+    if (res2_wave_bytes(S, ns, nl) > 0xFFFFu || (uint64_t)nl * 2 * S >= RES2_NO_STORE || (uint64_t)(ns + 64) * S >= 0xFFFFu) return;
+    const uint32_t T_OFF = res2_t_off(), F_OFF = res2_f_off(S, ns);
+    out.rec_off.assign(P, 0);
+    std::unordered_map<uint32_t, uint32_t> seen;  // word offset of a structure template -> its first record
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t q0 = N.pack_hop_ptr[p], q1 = N.pack_hop_ptr[p + 1], nh = q1 - q0;
+        const uint32_t s0 = N.hop_node_off[q0], l0 = N.hop_layer_off[q0];
+        out.max_hops = std::max(out.max_hops, nh);
+        if (N.hop_node_off[q1] - s0 > ns || N.hop_layer_off[q1] - l0 > nl || N.pack_steps[p] > 1) { out = Res2Records(); return; }
+        const auto it = seen.find(L.narrow_word_off[p]);
+        if (it != seen.end()) { out.rec_off[p] = it->second; continue; }
+        const uint32_t first = (uint32_t)(out.rec.size() / 4);
+        seen.emplace(L.narrow_word_off[p], first);
+        out.rec_off[p] = first;
+        out.rec.resize(out.rec.size() + (size_t)nh * 64 * 4);
+        uint32_t* r = &out.rec[(size_t)first * 4];
+        const uint32_t* words = &L.narrow_words_unique[L.narrow_word_off[p]];
+        for (uint32_t h = 0; h < nh; ++h) {
+            const uint32_t nb = N.hop_node_off[q0 + h] - s0, n = N.hop_node_off[q0 + h + 1] - N.hop_node_off[q0 + h];
+            const uint32_t nb_next = nb + n, lb = N.hop_layer_off[q0 + h] - l0;
+            if (n > 64) { out = Res2Records(); return; }
+            for (uint32_t j = 0; j < 64; ++j, r += 4) {
+                const uint32_t w = j < n ? words[nb + j] : nw_pad_word(W);
+                const uint32_t dummy = F_OFF + S * (ns + j);  // the lane's own entry behind the costs-from-root
+                if (w & NW_PAD) {
+                    const uint32_t bot = T_OFF + S * (ns + 1);
+                    r[0] = bot | (bot << 16);
+                    r[1] = dummy | (dummy << 16);
+                    r[2] = 0u | ((S * (ns + j)) << 16);  // own slot: past the pack's slots, so the global store drops it
+                    r[3] = RES2_PAD;
+                    continue;
+                }
+                uint32_t t[2], f[2];
+                for (int side = 0; side < 2; ++side) {
+                    const uint32_t c = side ? (w >> NW_CHILD_BITS) & NW_CHILD_MASK : w & NW_CHILD_MASK;
+                    if (c < W) {
+                        t[side] = T_OFF + S * (nb_next + c);
+                        f[side] = F_OFF + S * (nb_next + c);
+                    } else {
+                        t[side] = T_OFF + S * (ns + (c == nw_top(W) ? 0u : 1u));
+                        f[side] = dummy;
+                    }
+                }
+                const uint32_t ll = lb + ((w >> NW_LIDX_SHIFT) & NW_FIELD6);
+                const bool head = ((w >> NW_POS_SHIFT) & NW_FIELD6) == 0;
+                // a layout from before the pair alignment of PackBuilder::place (an older checkpoint): first-generation kernels
+                if ((w & NW_TWO) && head && (j & 1u)) { out = Res2Records(); return; }
+                r[0] = t[0] | (t[1] << 16);
+                r[1] = f[0] | (f[1] << 16);
+                r[2] = (ll * 2 * S) | ((S * (nb + j)) << 16);
+                r[3] = (head ? ll * 2 * S : RES2_NO_STORE) | ((w & NW_TWO ? 1u : 0u) << 16);
+            }
+        }
+    }
+    out.ok = true;
 }
 
 void set_layout_threads(unsigned n) { g_layout_threads.store(n, std::memory_order_relaxed); }

@@ -18,6 +18,11 @@
 
 #include "../../include/bdd_mma.h"
 
+#ifndef __host__   // pure C++ translation units (layout.cpp, capi.cpp): the few helpers shared with the kernels are plain inline functions
+#define __host__
+#define __device__
+#endif
+
 namespace bddmma {
 
 // ---- narrow node word (uint32) -------------------------------------------------------------
@@ -214,6 +219,32 @@ void set_layout_threads(unsigned n);
 // ... the same for the builds the calling thread starts (0 = follow the process-wide setting): what the batch farms use, so that two
 // concurrent batches, or an application's own bddmma_set_layout_threads, are not overwritten
 void set_thread_layout_threads(unsigned n);
+
+// ---- records of the resident sweeps, second generation (kernels.hpp: k_fwd_res2 / k_bwd_res2) -------------------------------------
+// The hop loop of the first resident sweeps spends ~165 instructions per 64 slots, ~25 of them floating point: the rest unpacks the
+// 4-byte node word and turns hop-local indices into LDS addresses (profiles/r03_1m_latency.txt, profiles/r04_hop_isa.txt).  A record
+// is everything a lane needs at one hop as ready-made 16-bit byte offsets into its wave's LDS region, one 16-byte load per lane and
+// hop, coalesced, for EVERY lane of the hop (hops are dense here: 64 records per hop, padding lanes included):
+//   .x  lo child: offset of its cost-from-terminal  |  hi child << 16        (sinks: the region's two constant entries)
+//   .y  lo child: offset of its cost-from-root (push target)  |  hi << 16    (sinks and padding: the lane's own dummy entry)
+//   .z  offset of the layer's {lo, hi} pair inside the cost / staging arrays  |  the node's own slot << 16 (same scale as the potentials)
+//   .w  the pair offset again if the lane is its layer's head, else RES2_NO_STORE  |  flags << 16 (bit 0: two-node layer); all ones: padding lane
+// Region of a wave (byte offsets, S = sizeof(REAL)): [T: (ns + 4) S | F: (ns + 64) S | {lo, hi}: nl 2 S]; ns / nl = the solver's
+// resident slot / layer capacity.  Records depend on S and on ns, so they are derived data, built when a solver is created (not
+// part of the checkpoint).  Packs that share their node words (structure templates) share their records.
+constexpr uint32_t RES2_NO_STORE = 0xFFF0u;
+constexpr uint32_t RES2_PAD = 0xFFFFFFFFu;
+struct Res2Records {
+    bool ok = false;                 // false: some offset does not fit 16 bits, packs are not 64 wide, ... -> first-generation kernels
+    std::vector<uint32_t> rec;       // 4 words per record
+    std::vector<uint32_t> rec_off;   // [narrow packs] first record of the pack (records, not words)
+    uint32_t max_hops = 0;
+};
+__host__ __device__ inline uint32_t res2_t_off() { return 0; }
+__host__ __device__ inline uint32_t res2_f_off(uint32_t real_size, uint32_t ns) { return (ns + 4u) * real_size; }
+__host__ __device__ inline uint32_t res2_c_off(uint32_t real_size, uint32_t ns) { return (ns + 4u) * real_size + (ns + 64u) * real_size; }
+__host__ __device__ inline uint32_t res2_wave_bytes(uint32_t real_size, uint32_t ns, uint32_t nl) { return res2_c_off(real_size, ns) + nl * 2u * real_size; }
+void build_res2_records(const HostLayout& L, uint32_t real_size, uint32_t ns, uint32_t nl, Res2Records& out);
 
 // Returns BDDMMA_OK or an error code; `err` receives the message.
 int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,

@@ -310,6 +310,10 @@ int bddmma_layout_create(bddmma_layout** out, const bddmma_instruction* instr, c
 void bddmma_layout_destroy(bddmma_layout* l);
 uint64_t bddmma_layout_size(const bddmma_layout* l, int what);
 int bddmma_layout_copy(const bddmma_layout* l, int which, void* out);
+/* The per-lane records of the second-generation resident sweeps (derived data, csrc/layout.hpp: Res2Records) for values of real_size
+ * bytes: info[0] = usable, [1] = number of 32-bit words (4 per record), [2] / [3] = the slot / layer capacity of a wave's LDS region the
+ * offsets assume, [4] = hops of the longest pack.  words (info[1] entries) and rec_off (one per narrow pack) may be NULL to query sizes. */
+int bddmma_layout_res2_records(const bddmma_layout* l, int real_size, uint32_t* info, uint32_t* words, uint32_t* rec_off);
 
 #ifdef __cplusplus
 }

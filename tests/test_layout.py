@@ -438,3 +438,77 @@ def test_pack_stagger_is_bounded():
     col, _ = random_set_cover(200, 100, 5, seed=2)
     with pytest.raises(capi.BddMmaError, match="pack_stagger"):
         Layout(col, pack_stagger=70_000)
+
+
+def res2_records(lay, real_size):
+    info = np.zeros(5, np.uint32)
+    capi.check(lay.L.bddmma_layout_res2_records(lay.h, real_size, info.ctypes.data_as(C.c_void_p), None, None), None)
+    words, off = np.zeros(max(int(info[1]), 1), np.uint32), np.zeros(max(lay.np_n, 1), np.uint32)
+    capi.check(lay.L.bddmma_layout_res2_records(lay.h, real_size, info.ctypes.data_as(C.c_void_p), words.ctypes.data_as(C.c_void_p),
+                                                off.ctypes.data_as(C.c_void_p)), None)
+    return bool(info[0]), words[:int(info[1])].reshape(-1, 4), off[:lay.np_n], int(info[2]), int(info[3])
+
+
+@pytest.mark.parametrize("real_size", [4, 8])
+def test_res2_records_restate_the_node_words(real_size):
+    """The per-lane records of the second-generation resident sweeps (layout.hpp: Res2Records) against the 4-byte node words they are
+    derived from: same children (as slots of the pack), same layer, head and two-node flags; padding lanes point at harmless places;
+    two-node layers start at even lanes (the DPP pair swap of kernels.hpp: pair_min_aligned relies on it)."""
+    col = BddCollection()
+    rng = np.random.Generator(np.random.PCG64(9))
+    for _ in range(300):
+        k = int(rng.integers(2, 12))
+        vs = np.sort(rng.choice(400, size=k, replace=False))
+        (col.add_covering if rng.random() < 0.6 else col.add_simplex)(vs)
+    for _ in range(20):
+        col.add_simplex([int(rng.integers(0, 400))])          # single-variable rows: one-node layers between the pairs
+    lay = Layout(col, pack_width=64)
+    ok, rec, rec_off, ns, nl = res2_records(lay, real_size)
+    assert ok and lay.pack_width == 64
+    S = real_size
+    T_OFF, F_OFF = 0, (ns + 4) * S
+    N = lay.sets[0]
+    seen_two = seen_one = 0
+    for p in range(lay.np_n):
+        q0, q1 = int(N["pack_hop_ptr"][p]), int(N["pack_hop_ptr"][p + 1])
+        s0, l0 = int(N["hop_node_off"][q0]), int(N["hop_layer_off"][q0])
+        for h in range(q1 - q0):
+            nb, ne = int(N["hop_node_off"][q0 + h]) - s0, int(N["hop_node_off"][q0 + h + 1]) - s0
+            lb = int(N["hop_layer_off"][q0 + h]) - l0
+            for j in range(64):
+                r = rec[int(rec_off[p]) + h * 64 + j]
+                w = int(lay.nwords[s0 + nb + j]) if j < ne - nb else 1 << 31
+                if w >> 31:
+                    assert r[3] == 0xFFFFFFFF
+                    assert r[0] & 0xFFFF == r[0] >> 16 == T_OFF + S * (ns + 1)                       # cost to terminal +inf on both sides
+                    assert r[1] & 0xFFFF == r[1] >> 16 == F_OFF + S * (ns + j)                       # pushes into the lane's own dummy entry
+                    assert (r[2] >> 16) == S * (ns + j)                                             # own slot past the pack: stores are dropped
+                    continue
+                lo, hi, pos, lidx, two = w & 511, (w >> 9) & 511, (w >> 18) & 63, (w >> 24) & 63, (w >> 30) & 1
+                for side, c in ((0, lo), (1, hi)):
+                    t = (r[0] >> (16 * side)) & 0xFFFF
+                    f = (r[1] >> (16 * side)) & 0xFFFF
+                    if c < 64:
+                        assert t == T_OFF + S * (ne + c) and f == F_OFF + S * (ne + c)
+                    else:
+                        assert t == T_OFF + S * (ns + (0 if c == 64 else 1)) and f == F_OFF + S * (ns + j)
+                ll = lb + lidx
+                assert r[2] & 0xFFFF == ll * 2 * S and r[2] >> 16 == S * (nb + j)
+                assert r[3] & 0xFFFF == (ll * 2 * S if pos == 0 else 0xFFF0)
+                assert (r[3] >> 16) == two
+                if two:
+                    assert (j - pos) % 2 == 0                                                       # aligned pair
+                    seen_two += 1
+                else:
+                    seen_one += 1
+    assert seen_two > 1000 and seen_one > 300
+    # packs of one structure template share their records; wider packs / wider layers have none
+    col2, _ = random_set_cover(3000, 2000, 8, seed=3)
+    lay2 = Layout(col2, pack_width=64)
+    ok2, rec2, off2, _, _ = res2_records(lay2, real_size)
+    assert ok2 and len(set(off2.tolist())) < lay2.np_n / 4 and rec2.shape[0] < lay2.np_n * 8 * 64 / 4
+    assert not res2_records(Layout(col2, pack_width=128), real_size)[0]
+    col3 = BddCollection()
+    col3.add_linear([3, 5, 7, 2, 4, 6, 1], "<=", 14, np.arange(7))
+    col3.add_covering([0, 1, 2])
+    assert not res2_records(Layout(col3, pack_width=64), real_size)[0]

@@ -136,7 +136,10 @@ def main():
         print(f"   whole kernel: {fmt(mix(ins))}")
         ls = loops(ins)
         # the hop loop: the loop with the most LDS instructions per instruction... report the three loops with the most LDS instructions
-        ranked = sorted(ls, key=lambda r: -sum(1 for _, op, _ in ins[r[0]:r[1] + 1] if op.startswith("ds_")))[:3]
+        # candidates: loops that hold LDS and VMEM instructions, shortest first (the hop loop is the shortest loop that stores);
+        # backward s_cbranch_execz jumps into shared blocks show up as longer pseudo-loops behind it
+        cand = [r for r in ls if any(op.startswith("ds_") for _, op, _ in ins[r[0]:r[1] + 1]) and any(op.startswith("buffer_store") for _, op, _ in ins[r[0]:r[1] + 1])]
+        ranked = sorted(cand, key=lambda r: r[1] - r[0])[:3]
         for s, e in ranked:
             body = ins[s:e + 1]
             print(f"   loop @{ins[s][0]:#x}..{ins[e][0]:#x}: {fmt(mix(body))}")
