@@ -114,6 +114,7 @@ SIGNATURES = {
     "bddmma_layout_size": (_U64, [_V, _I]),
     "bddmma_layout_copy": (_I, [_V, _I, _V]),
     "bddmma_layout_res2_records": (_I, [_V, _I, _V, _V, _V]),
+    "bddmma_layout_stream_records": (_I, [_V, _I, _V, _V, _V]),
 }
 
 # every symbol include/bdd_ilp.h declares (host-side input stage)

@@ -114,6 +114,10 @@ struct SolverT final : SolverBase {
     bool use_res2 = false;
     uint32_t *d_res2_rec = nullptr, *d_res2_rec_off = nullptr;
     uint32_t res2_n_words = 0, res2_lds = 0, res2_ns = 0, res2_nl = 0;
+    // streaming solve sweeps on per-lane records (kernels.hpp: k_fwd_narrow2 / k_bwd_narrow2)
+    bool use_narrow2 = false;
+    uint32_t *d_srec = nullptr, *d_srec_off = nullptr;
+    uint32_t srec_words = 0;
     uint32_t huge_pack_width = 0;
     unsigned char* d_huge_scratch = nullptr;  // frontier arrays of the huge packs (global memory instead of LDS)
 
@@ -394,6 +398,19 @@ struct SolverT final : SolverBase {
 #undef SET_RES
             }
         }
+        // streaming solve sweeps, second generation: packs of <= 2-node layers, not staggered, narrow packs only (the mixed launch keeps the first
+        // generation); variant_flags bit 9: first generation
+        if (nb_.n_packs && !use_res && !narrow_seg && !wb_.n_packs && !hb_.n_packs && !(opts && (opts->variant_flags & 0x200u))) {
+            StreamRecords SR;
+            build_stream_records(L, sizeof(REAL), SR);
+            const uint32_t static2 = L.ex.waves_per_block * ((2 * pack_width + 2 + pack_width + 2) * (uint32_t)sizeof(REAL) + 3 * 64 * 4 + 64);
+            if (SR.ok && stage_lds + static2 <= 64 * 1024) {
+                if ((rc = upload(&d_srec, SR.rec))) return rc;
+                if ((rc = upload(&d_srec_off, SR.rec_off))) return rc;
+                srec_words = (uint32_t)SR.rec.size();
+                use_narrow2 = true;
+            }
+        }
         if (wb_.n_packs) {
             // one workgroup per wide pack, thread t owns the nodes t + i * wide_threads of a hop (kernels.hpp: k_fwd_wide2)
             // two nodes of a hop per thread: half the wavefronts at the hop's two barriers and two independent chains per lane.  Wide-only
@@ -520,6 +537,7 @@ struct SolverT final : SolverBase {
 #define LAUNCH_N(R_, W_)                                                                                                      \
     if (res && use_res2) hipLaunchKernelGGL((k_fwd_res2<REAL, W_>), grid, block, res2_lds, stream, rd.pack_hdr, rd.quad_hdr, res2_ns, res2_nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d_res2_rec, d_res2_rec_off, res2_n_words, d, pk, omega); \
     else if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
+    else if (two_node && use_narrow2) hipLaunchKernelGGL((k_fwd_narrow2<REAL, R_, W_>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (two_node) hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_, MODE != FWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
     else hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
@@ -591,6 +609,7 @@ struct SolverT final : SolverBase {
 #define LAUNCH_N(R_, W_)                                                                                                      \
     if (res && use_res2) hipLaunchKernelGGL((k_bwd_res2<REAL, W_>), grid, block, res2_lds, stream, rd.pack_hdr, rd.quad_hdr, res2_ns, res2_nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d_res2_rec, d_res2_rec_off, res2_n_words, d, pk, omega); \
     else if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
+    else if (two_node && use_narrow2) hipLaunchKernelGGL((k_bwd_narrow2<REAL, R_, W_>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (two_node) hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_, MODE != BWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
     else hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \

@@ -814,4 +814,15 @@ int bddmma_layout_res2_records(const bddmma_layout* l, int real_size, uint32_t* 
     return BDDMMA_OK;
 }
 
+int bddmma_layout_stream_records(const bddmma_layout* l, int real_size, uint32_t* info, uint32_t* words, uint32_t* rec_off)
+{
+    if (!l || !info || (real_size != 4 && real_size != 8)) return BDDMMA_ERR_INVALID_ARGUMENT;
+    StreamRecords R;
+    build_stream_records(l->L, (uint32_t)real_size, R);
+    info[0] = R.ok ? 1u : 0u; info[1] = (uint32_t)R.rec.size();
+    if (words && !R.rec.empty()) std::memcpy(words, R.rec.data(), R.rec.size() * sizeof(uint32_t));
+    if (rec_off && !R.rec_off.empty()) std::memcpy(rec_off, R.rec_off.data(), R.rec_off.size() * sizeof(uint32_t));
+    return BDDMMA_OK;
+}
+
 }  // extern "C"

@@ -1651,6 +1651,430 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res2(RES2_ARGS, DevPtrs<REAL> 
 }
 
 // =============================================================================================
+// narrow packs, streaming sweeps, second generation: the solve sweeps on per-lane records
+// =============================================================================================
+// k_fwd_narrow / k_bwd_narrow spend 136 instructions per hop and 64 slots, 72 of them VALU of which 14 are floating point
+// (profiles/r04_hop_isa.txt): on the headline instance the vector ALUs are busy half of the sweep's duration with address arithmetic.
+// These kernels are the same sweeps — same pipeline (records two hops ahead, arc costs and potentials one), same staging rounds, same
+// arithmetic in the same order — with the 4-byte node word replaced by a 16-byte record of ready-made byte offsets into the hop's LDS
+// buffers (layout.hpp: StreamRecords): no unpacking, no sink / padding selects (constant entries; a private dummy entry per lane behind
+// the frontier), the layer index inside the hop instead of a ballot count per lane group, the head-only store as an offset past the
+// hop's layers, the two-node minimum as one DPP swap.  Records of a structure template are shared by its packs (L2 hits).
+// Solve sweeps of packs whose layers have <= 2 nodes and that are not staggered (SolverT::use_narrow2); everything else: first generation.
+__device__ __forceinline__ void hop_store(float2 v, rsrc_t rh, uint32_t voff, uint32_t soff);   // defined with the exchange kernels below
+__device__ __forceinline__ void hop_store(double2 v, rsrc_t rh, uint32_t voff, uint32_t soff);
+template <int R>
+__device__ __forceinline__ void load_recs(u4v (&r)[R], rsrc_t rr, uint32_t first_rec, int lane)
+{
+#pragma unroll
+    for (int g = 0; g < R; ++g) r[g] = __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)(lane + 64 * g) * 16u, first_rec * 16u, 0);
+}
+// {lo, hi} of the lanes' layers: the layer's offset inside the hop is the record's, the hop's first layer goes into the scalar offset
+template <typename REAL, int R>
+__device__ __forceinline__ void load_costs(typename Pair<REAL>::type (&c)[R], const u4v (&r)[R], rsrc_t lohi, uint32_t lbase)
+{
+    using P2 = typename Pair<REAL>::type;
+#pragma unroll
+    for (int g = 0; g < R; ++g) hop_load(c[g], lohi, r[g][2] & 0xFFFFu, lbase * (uint32_t)sizeof(P2));
+}
+
+template <typename REAL, int R, int WPB, int LA = BDDMMA_LOOKAHEAD>
+__device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ srec,
+                                                 const uint32_t* __restrict__ srec_off, uint32_t srec_words, REAL omega, uint32_t block_id)
+{
+    constexpr int W = 64 * R;
+    constexpr uint32_t S = sizeof(REAL);
+    using P2 = typename Pair<REAL>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    P2* sD = reinterpret_cast<P2*>(dyn_lds);
+    __shared__ __attribute__((aligned(16))) REAL sF_[WPB][2][2 * W + 2];  // frontier of the current / next hop; [W], [W + 1] unused, [W + 2 + j]: lane slot j's dummy push target
+    __shared__ __attribute__((aligned(16))) REAL sT_[WPB][2][W + 2];      // costs-from-terminal of the next hop (written one hop ahead); [W] = 0 (top), [W + 1] = +inf (bot)
+    __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN], sOffR_[WPB][HOP_WIN];
+    const uint32_t tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int lane = tid & 63;
+    unsigned char* sFw = reinterpret_cast<unsigned char*>(&sF_[wave][0][0]);
+    unsigned char* sTw = reinterpret_cast<unsigned char*>(&sT_[wave][0][0]);
+    constexpr uint32_t F_STRIDE = (2 * W + 2) * S, T_STRIDE = (W + 2) * S;
+    const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
+    const uint32_t quad = block_to_pack(block_id, n_quads, pk.xcd_chunk);
+    BDDMMA_EXIT_IF(quad >= n_quads, d)
+    const uint32_t p = quad * WPB + wave;
+    const bool has_pack = p < pk.n_packs;
+    const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
+    const uint32_t rbase = has_pack ? srec_off[p] : 0;
+    const REAL INF = inf_v<REAL>();
+    const NarrowRs<REAL> rs(d);
+    const rsrc_t rr = make_rsrc(srec, srec_words);
+    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1};
+    auto off = [&](uint32_t q) { return hw.node_off(q); };
+    constexpr int D = LA;
+    uint32_t o[2 * D + 3];
+    uint32_t lb[D + 2];  // first layer of hops q .. q + D + 1
+    u4v rc[2 * D + 1][R];
+    REAL tr[D + 1][R];
+    P2 Lr[D + 1][R];
+#pragma unroll
+    for (int i = 0; i < 2 * D + 3; ++i) o[i] = 0;
+#pragma unroll
+    for (int i = 0; i < D + 2; ++i) lb[i] = 0;
+    if (has_pack) {
+        hw.fill(pk, q0, lane);
+#pragma unroll
+        for (int i = 0; i < 2 * D + 3; ++i) o[i] = off(q0 + i);
+#pragma unroll
+        for (int i = 0; i < D + 2; ++i) lb[i] = hw.layer_off(q0 + i);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t j = lane + 64 * r;
+            lds_st<REAL>(sFw, j * S, (j < o[1] - o[0]) ? REAL(0) : INF);  // every slot of hop 0 is a root (flush_costs_from_root)
+        }
+        if (lane < 4) lds_st<REAL>(sTw, (uint32_t)(lane >> 1) * T_STRIDE + (W + (lane & 1)) * S, (lane & 1) ? INF : REAL(0));
+#pragma unroll
+        for (int i = 0; i < 2 * D; ++i) load_recs<R>(rc[i], rr, rbase + (uint32_t)i * W, lane);  // (past the last hop: some other records, never used)
+        {
+            REAL t1[R];
+            load_vals<REAL, R>(t1, d.T, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
+#pragma unroll
+            for (int i = 0; i < D; ++i) load_vals<REAL, R>(tr[i], d.T, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t j = lane + 64 * r;
+                if (j < o[2] - o[1]) lds_st<REAL>(sTw, j * S, t1[r]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) load_costs<REAL, R>(Lr[i], rc[i], rs.lohi, lb[i]);
+        wave_sync();
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2 * D; ++i)
+#pragma unroll
+            for (int r = 0; r < R; ++r) rc[i][r] = u4v{0u, 0u, 0u, RES2_PAD};
+    }
+    uint32_t cur = 0;
+    uint32_t q = q0;
+    const uint32_t g0 = has_pack ? pk.pack_group_ptr[p] : 0;
+    const uint32_t ng = has_pack ? pk.pack_group_ptr[p + 1] - g0 : 0;
+    const uint32_t r0 = pk.quad_round_ptr[quad];
+    const uint32_t n_rounds = pk.quad_round_ptr[quad + 1] - r0;
+    const uint32_t db = (uint32_t)wave * pk.stage_cap * (uint32_t)sizeof(P2);  // this wave's slots of the staging area
+    for (uint32_t k = 0; k < n_rounds; ++k) {
+        uint32_t gl0 = 0, cnt = 0, qe = q1;
+        uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
+        {
+            const uint32_t c0 = pk.cs_ptr[r0 + k];
+            cnt = pk.cs_ptr[r0 + k + 1] - c0;
+            stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
+            if (k < ng) {
+                gl0 = pk.grp_layer_off[g0 + k];
+                qe = pk.grp_hop_end[g0 + k];
+            } else {
+                qe = q;  // this pack has no k-th group: no hops in this round
+            }
+            if (WPB > 1) __syncthreads(); else wave_sync();
+        }
+        auto hop = [&]() {
+            if (q + 2 * D + 3 >= hw.base + HOP_WIN && hw.base + HOP_WIN <= q1) hw.fill(pk, q, lane);
+            const uint32_t nb = o[0];
+            const uint32_t n3 = o[3] - o[2];  // slots of hop q+2
+            const uint32_t fc = cur * F_STRIDE, fn = (cur ^ 1u) * F_STRIDE, tc = cur * T_STRIDE, tn = (cur ^ 1u) * T_STRIDE;
+            const uint32_t stg = db + (lb[0] - gl0) * (uint32_t)sizeof(P2);  // the hop's first layer inside the wave's staging slots
+            // ---- global prefetch: records of hop q+2D, T of hop q+D+2, arc costs of hop q+D
+            load_recs<R>(rc[2 * D], rr, rbase + (q - q0 + 2 * D) * W, lane);
+            load_vals<REAL, R>(tr[D], d.T, o[D + 2], o[D + 3] - o[D + 2], lane);
+            load_costs<REAL, R>(Lr[D], rc[D], rs.lohi, lb[D]);
+            u4v (&ra)[R] = rc[0];
+            P2 (&La)[R] = Lr[0];
+            // ---- the hop's LDS reads, one batch
+            REAL f[R], tl[R], th[R];
+            P2 dd[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t j = lane + 64 * r;
+                f[r] = lds_ld<REAL>(sFw, fc + j * S);
+                tl[r] = lds_ld<REAL>(sTw, tc + (ra[r][0] & 0xFFFFu));  // sinks: [W] = 0, [W+1] = +inf; padding lanes: +inf
+                th[r] = lds_ld<REAL>(sTw, tc + (ra[r][0] >> 16));
+                dd[r] = lds_ld<P2>(dyn_lds, stg + (ra[r][2] & 0xFFFFu));
+            }
+            const uint32_t o_new = off(q + 2 * D + 3);
+            const uint32_t l_next = hw.layer_off(q + D + 2);
+            // ---- set-up of the next hop's buffers (nothing above depends on it)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t j = lane + 64 * r;
+                if (j < n3) lds_st<REAL>(sTw, tn + j * S, tr[0][r]);  // T of hop q+2, gathered by hop q+1
+                lds_st<REAL>(sFw, fn + j * S, INF);
+            }
+            wave_sync();
+            // ---- arithmetic
+            P2 nc[R];
+            REAL mmv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const REAL lc = La[r].x, hc = La[r].y;
+                REAL m0 = (f[r] + lc) + tl[r], m1 = (f[r] + hc) + th[r];
+                pair_min_aligned(m0, m1, (ra[r][3] & 1u) != 0);
+                const REAL mm = mm_diff1(m0, m1, omega);
+                mmv[r] = mm;
+                nc[r].x = (lc + min0(mm)) + dd[r].x;
+                nc[r].y = (hc + min0_neg(mm)) + dd[r].y;
+            }
+            // ---- writes: new arc costs (heads), staged min-marginal differences, pushes into the next frontier, costs-from-root
+            const rsrc_t rl = hop_rsrc(reinterpret_cast<const P2*>(d.lohi), lb[0], lb[1] - lb[0]);  // ends with the hop's layers: RES2_NO_STORE is dropped
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                hop_store(nc[r], rl, ra[r][2] >> 16, lb[0] * (uint32_t)sizeof(P2));
+                if (ra[r][3] != RES2_PAD) lds_st<REAL>(dyn_lds, stg + (ra[r][2] & 0xFFFFu), mmv[r]);  // every lane of a layer holds the same value
+                lds_min(reinterpret_cast<REAL*>(sFw + fn + (ra[r][1] & 0xFFFFu)), f[r] + nc[r].x);  // sinks / padding: the lane's own dummy entry
+                lds_min(reinterpret_cast<REAL*>(sFw + fn + (ra[r][1] >> 16)), f[r] + nc[r].y);
+            }
+            store_vals<R>(f, d.F, nb, o[1] - o[0], lane, pk.nt_potentials);
+            wave_sync();
+            cur ^= 1u;
+            // ---- rotate the pipeline registers
+#pragma unroll
+            for (int i = 0; i < 2 * D + 2; ++i) o[i] = o[i + 1];
+            o[2 * D + 2] = o_new;
+#pragma unroll
+            for (int i = 0; i < D + 1; ++i) lb[i] = lb[i + 1];
+            lb[D + 1] = l_next;
+#pragma unroll
+            for (int i = 0; i < 2 * D; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r) rc[i][r] = rc[i + 1][r];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    Lr[i][r] = Lr[i + 1][r];
+                    tr[i][r] = tr[i + 1][r];
+                }
+            ++q;
+        };
+        while (q + HOP_UNROLL <= qe) {
+#pragma unroll
+            for (int u = 0; u < HOP_UNROLL; ++u) hop();
+        }
+        while (q < qe) hop();
+        {
+            if (WPB > 1) __syncthreads(); else wave_sync();
+            stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);  // min-marginal differences of the round -> entry array
+            if (WPB > 1) __syncthreads();                        // the next round overwrites the staging area
+        }
+    }
+}
+
+// register budget: the records' ring costs 18 VGPRs more than the node words' (109 / 131 instead of 92 / 123 in the forward sweep, float / double,
+// R = 2); asking for 5 / 4 waves per SIMD makes the allocator stay at 96 / 128 without spilling
+#ifndef BDDMMA_N2_WAVES
+#define BDDMMA_N2_WAVES(REAL, R) ((R) <= 2 ? (sizeof(REAL) == 4 ? 5 : 4) : 1)
+#endif
+template <typename REAL, int R, int WPB>
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N2_WAVES(REAL, R)))) k_fwd_narrow2(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ srec, const uint32_t* __restrict__ srec_off,
+                                                          uint32_t srec_words, REAL omega)
+{
+    fwd_narrow2_body<REAL, R, WPB>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x);
+}
+
+template <typename REAL, int R, int WPB, int LA = BDDMMA_LOOKAHEAD>
+__device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ srec,
+                                                 const uint32_t* __restrict__ srec_off, uint32_t srec_words, REAL omega, uint32_t block_id)
+{
+    constexpr int W = 64 * R;
+    constexpr uint32_t S = sizeof(REAL);
+    using P2 = typename Pair<REAL>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    P2* sD = reinterpret_cast<P2*>(dyn_lds);
+    __shared__ __attribute__((aligned(16))) REAL sT_[WPB][2][W + 2];  // per wave; +2: sink entries TOP = W (0) and BOT = W + 1 (+inf)
+    __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN], sOffR_[WPB][HOP_WIN];
+    const uint32_t tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int lane = tid & 63;
+    unsigned char* sTw = reinterpret_cast<unsigned char*>(&sT_[wave][0][0]);
+    constexpr uint32_t T_STRIDE = (W + 2) * S;
+    const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
+    const uint32_t quad = block_to_pack(block_id, n_quads, pk.xcd_chunk);
+    BDDMMA_EXIT_IF(quad >= n_quads, d)
+    const uint32_t p = quad * WPB + wave;
+    const bool has_pack = p < pk.n_packs;
+    const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
+    const uint32_t rbase = has_pack ? srec_off[p] : 0;
+    const REAL INF = inf_v<REAL>();
+    const NarrowRs<REAL> rs(d);
+    const rsrc_t rr = make_rsrc(srec, srec_words);
+    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1};
+    auto nb_of = [&](uint32_t q) { return hw.node_off(q); };
+    // pipeline mirrored from k_fwd_narrow2 (see k_bwd_narrow): before hop q is processed (q counts down) the wave holds the records of hops
+    // q .. q-2D+1, the costs-from-root of hops q .. q-D and the arc costs of hops q .. q-D+1.  o[i] = first slot of hop q+1-i,
+    // lb[i] = first layer of hop q+1-i (hops below q0: those of q0).
+    constexpr int D = LA;
+    uint32_t o[2 * D + 2];
+    uint32_t lb[D + 2];
+    u4v rc[2 * D + 1][R];
+    REAL fr[D + 2][R];
+    P2 Lr[D + 1][R];
+#pragma unroll
+    for (int i = 0; i < 2 * D + 2; ++i) o[i] = 0;
+#pragma unroll
+    for (int i = 0; i < D + 2; ++i) lb[i] = 0;
+    uint32_t q = q1;
+    // record of hop h of the pack (h may run below 0 at the pipeline's end: any record, never used)
+    auto rec_of = [&](uint32_t qq) { return rbase + (qq >= q0 ? qq - q0 : 0u) * W; };
+    if (has_pack) {
+        if (lane < 4) lds_st<REAL>(sTw, (uint32_t)(lane >> 1) * T_STRIDE + (W + (lane & 1)) * S, (lane & 1) ? INF : REAL(0));
+        hw.fill(pk, q1 + 1 > q0 + HOP_WIN ? q1 + 1 - HOP_WIN : q0, lane);  // window ends at record q1
+#pragma unroll
+        for (int i = 0; i < 2 * D + 2; ++i) o[i] = nb_of(q1 >= q0 + i ? q1 - i : q0);
+#pragma unroll
+        for (int i = 0; i < D + 2; ++i) lb[i] = hw.layer_off(q1 >= q0 + i ? q1 - i : q0);
+#pragma unroll
+        for (int i = 0; i < 2 * D; ++i) load_recs<R>(rc[i], rr, rec_of(q1 >= q0 + i + 1 ? q1 - 1 - i : q0), lane);  // hop q1-1-i
+#pragma unroll
+        for (int i = 0; i < D + 1; ++i) load_vals<REAL, R>(fr[i], d.F, o[i + 1], o[i] - o[i + 1], lane);            // F of hop q1-1-i
+#pragma unroll
+        for (int i = 0; i < D; ++i) load_costs<REAL, R>(Lr[i], rc[i], rs.lohi, lb[i + 1]);                          // hop q1-1-i starts at layer lb[i+1]
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2 * D; ++i)
+#pragma unroll
+            for (int r = 0; r < R; ++r) rc[i][r] = u4v{0u, 0u, 0u, RES2_PAD};
+    }
+    uint32_t cur = 0;
+    const uint32_t g0 = has_pack ? pk.pack_group_ptr[p] : 0;
+    const uint32_t ng = has_pack ? pk.pack_group_ptr[p + 1] - g0 : 0;
+    const uint32_t r0 = pk.quad_round_ptr[quad];
+    const uint32_t n_rounds = pk.quad_round_ptr[quad + 1] - r0;
+    P2* sDw = sD + (size_t)wave * pk.stage_cap;
+    const uint32_t db = (uint32_t)wave * pk.stage_cap * (uint32_t)sizeof(P2);
+    for (uint32_t k = n_rounds; k-- > 0;) {  // same rounds as the forward sweep, in reverse
+        uint32_t gl0 = 0, cnt = 0, qs = q0;
+        uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
+        {
+            const uint32_t c0 = pk.cs_ptr[r0 + k];
+            cnt = pk.cs_ptr[r0 + k + 1] - c0;
+            stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
+            if (k < ng) {
+                gl0 = pk.grp_layer_off[g0 + k];
+                qs = (k == 0) ? q0 : pk.grp_hop_end[g0 + k - 1];
+            } else {
+                qs = q;  // no k-th group in this pack
+            }
+            if (WPB > 1) __syncthreads(); else wave_sync();
+        }
+        auto hop = [&]() {
+            --q;
+            if (q < hw.base + 2 * D + 1 && hw.base > q0) hw.fill(pk, q + 1 > q0 + HOP_WIN ? q + 1 - HOP_WIN : q0, lane);
+            const uint32_t nb = o[1];
+            const uint32_t tc = cur * T_STRIDE, tn = (cur ^ 1u) * T_STRIDE;
+            const uint32_t stg = db + (lb[1] - gl0) * (uint32_t)sizeof(P2);  // hop q starts at layer lb[1]
+            // ---- prefetch: records of hop q-2D, F of hop q-D-1, arc costs of hop q-D
+            load_recs<R>(rc[2 * D], rr, rec_of(q >= q0 + 2 * D ? q - 2 * D : q0), lane);
+            load_vals<REAL, R>(fr[D + 1], d.F, o[D + 2], o[D + 1] - o[D + 2], lane);
+            load_costs<REAL, R>(Lr[D], rc[D], rs.lohi, lb[D + 1]);
+            u4v (&ra)[R] = rc[0];
+            REAL (&fa)[R] = fr[0];
+            P2 (&La)[R] = Lr[0];
+            // ---- LDS reads
+            REAL tl[R], th[R];
+            P2 dd[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                tl[r] = lds_ld<REAL>(sTw, tc + (ra[r][0] & 0xFFFFu));  // sinks: [W] = 0, [W+1] = +inf
+                th[r] = lds_ld<REAL>(sTw, tc + (ra[r][0] >> 16));
+                dd[r] = lds_ld<P2>(dyn_lds, stg + (ra[r][2] & 0xFFFFu));
+            }
+            const uint32_t o_new = (q >= q0 + 2 * D + 1) ? nb_of(q - 1 - 2 * D) : o[2 * D + 1];
+            const uint32_t l_next = hw.layer_off(q >= q0 + D + 1 ? q - 1 - D : q0);
+            // ---- arithmetic
+            REAL t[R], mmv[R];
+            P2 nc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const REAL lc = La[r].x, hc = La[r].y;
+                REAL m0 = (fa[r] + lc) + tl[r], m1 = (fa[r] + hc) + th[r];
+                pair_min_aligned(m0, m1, (ra[r][3] & 1u) != 0);
+                const REAL mm = mm_diff1(m0, m1, omega);
+                mmv[r] = mm;
+                nc[r].x = (lc + min0(mm)) + dd[r].x;
+                nc[r].y = (hc + min0_neg(mm)) + dd[r].y;
+                t[r] = rmin(nc[r].y + th[r], nc[r].x + tl[r]);
+            }
+            // ---- writes
+            const rsrc_t rl = hop_rsrc(reinterpret_cast<const P2*>(d.lohi), lb[1], lb[0] - lb[1]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t j = lane + 64 * r;
+                hop_store(nc[r], rl, ra[r][2] >> 16, lb[1] * (uint32_t)sizeof(P2));
+                if (ra[r][3] != RES2_PAD) {
+                    lds_st<REAL>(dyn_lds, stg + (ra[r][2] & 0xFFFFu), mmv[r]);
+                    lds_st<REAL>(sTw, tn + j * S, t[r]);
+                }
+            }
+            store_vals<R>(t, d.T, nb, o[0] - o[1], lane, pk.nt_potentials);
+            wave_sync();
+            cur ^= 1u;
+#pragma unroll
+            for (int i = 0; i < 2 * D + 1; ++i) o[i] = o[i + 1];
+            o[2 * D + 1] = o_new;
+#pragma unroll
+            for (int i = 0; i < D + 1; ++i) lb[i] = lb[i + 1];
+            lb[D + 1] = l_next;
+#pragma unroll
+            for (int i = 0; i < 2 * D; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r) rc[i][r] = rc[i + 1][r];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r) Lr[i][r] = Lr[i + 1][r];
+#pragma unroll
+            for (int i = 0; i < D + 1; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r) fr[i][r] = fr[i + 1][r];
+        };
+        while (q >= qs + HOP_UNROLL) {
+#pragma unroll
+            for (int u = 0; u < HOP_UNROLL; ++u) hop();
+        }
+        while (q > qs) hop();
+        {
+            if (WPB > 1) __syncthreads(); else wave_sync();
+            stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
+            if (d.mm_layer != nullptr && k < ng) {  // uniform per wave: this wave's group occupies the layers [gl0, next group) and its own LDS slots
+                const uint32_t nlay = pk.grp_layer_off[g0 + k + 1] - gl0;
+                const rsrc_t rml = make_rsrc(d.mm_layer, d.n_layers);
+#pragma unroll
+                for (int u = 0; u < STAGE_ITERS; ++u) {
+                    const uint32_t j = lane + 64u * u;
+                    const REAL mv = sDw[j < nlay ? j : 0].x;
+                    bstore(mv, rml, j < nlay ? (gl0 + j) * (uint32_t)sizeof(REAL) : OOB);
+                }
+            }
+            if (WPB > 1) __syncthreads();
+        }
+    }
+    if (!has_pack) return;
+    // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251)
+    const uint32_t n0 = nb_of(q0 + 1) - nb_of(q0);
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t j = lane + 64 * r;
+        if (j < n0) s += (double)lds_ld<REAL>(sTw, cur * T_STRIDE + j * S);
+    }
+    for (int off2 = 32; off2 > 0; off2 >>= 1) s += __shfl_down(s, off2);
+    if (lane == 0) d.lb_partial[pk.lb_base + p] = s;
+}
+
+template <typename REAL, int R, int WPB>
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N2_WAVES(REAL, R)))) k_bwd_narrow2(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ srec, const uint32_t* __restrict__ srec_off,
+                                                          uint32_t srec_words, REAL omega)
+{
+    bwd_narrow2_body<REAL, R, WPB>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x);
+}
+
+// =============================================================================================
 // wide packs: one workgroup per pack; layers may span waves, so the layer min goes through LDS
 // =============================================================================================
 constexpr int WIDE_THREADS = 256;

@@ -1088,6 +1088,65 @@ void build_res2_records(const HostLayout& L, uint32_t S, uint32_t ns, uint32_t n
     out.ok = true;
 }
 
+// layout.hpp: struct StreamRecords
+void build_stream_records(const HostLayout& L, uint32_t S, StreamRecords& out)
+{
+    out = StreamRecords();
+    const PackSet& N = L.narrow;
+    const uint32_t P = N.n_packs(), W = L.pack_width;
+    if (P == 0 || L.narrow_word_off.size() != P || N.hop_root.size() + 1 != N.hop_node_off.size()) return;
+    if ((2u * W + 2u) * S >= RES2_NO_STORE || (uint64_t)W * 2 * S >= RES2_NO_STORE) return;
+    for (uint16_t r : N.hop_root)
+        if (r != NO_ROOT) return;  // staggered packs: roots below the first hop are known to the first-generation kernels only
+    for (uint8_t st : N.pack_steps)
+        if (st > 1) return;        // layers wider than two nodes
+    out.rec_off.assign(P, 0);
+    std::unordered_map<uint32_t, uint32_t> seen;  // word offset of a structure template -> its first record
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t q0 = N.pack_hop_ptr[p], q1 = N.pack_hop_ptr[p + 1], nh = q1 - q0;
+        const uint32_t s0 = N.hop_node_off[q0];
+        const auto it = seen.find(L.narrow_word_off[p]);
+        if (it != seen.end()) { out.rec_off[p] = it->second; continue; }
+        const uint64_t first = out.rec.size() / 4;
+        if ((first + (uint64_t)nh * W) * 16 >= (1ull << 31)) { out = StreamRecords(); return; }
+        seen.emplace(L.narrow_word_off[p], (uint32_t)first);
+        out.rec_off[p] = (uint32_t)first;
+        out.rec.resize(out.rec.size() + (size_t)nh * W * 4);
+        uint32_t* r = &out.rec[(size_t)first * 4];
+        const uint32_t* words = &L.narrow_words_unique[L.narrow_word_off[p]];
+        for (uint32_t h = 0; h < nh; ++h) {
+            const uint32_t nb = N.hop_node_off[q0 + h] - s0, n = N.hop_node_off[q0 + h + 1] - N.hop_node_off[q0 + h];
+            if (n > W) { out = StreamRecords(); return; }
+            uint32_t grp_first = 0;  // layers of the hop's lower 64-lane groups
+            for (uint32_t j = 0; j < W; ++j, r += 4) {
+                if (j > 0 && j % 64 == 0) {  // hop-local index of this lane group's first layer = number of heads before it
+                    grp_first = 0;
+                    for (uint32_t i = 0; i < j && i < n; ++i)
+                        if (!(words[nb + i] & NW_PAD) && ((words[nb + i] >> NW_POS_SHIFT) & NW_FIELD6) == 0) ++grp_first;
+                }
+                const uint32_t w = j < n ? words[nb + j] : nw_pad_word(W);
+                const uint32_t dummy = (W + 2 + j) * S;
+                if (w & NW_PAD) {
+                    r[0] = ((W + 1) * S) | (((W + 1) * S) << 16);  // cost to terminal +inf on both sides
+                    r[1] = dummy | (dummy << 16);
+                    r[2] = 0u | (RES2_NO_STORE << 16);
+                    r[3] = RES2_PAD;
+                    continue;
+                }
+                const uint32_t lo = w & NW_CHILD_MASK, hi = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
+                const uint32_t lq = (grp_first + ((w >> NW_LIDX_SHIFT) & NW_FIELD6)) * 2 * S;
+                const bool head = ((w >> NW_POS_SHIFT) & NW_FIELD6) == 0;
+                if ((w & NW_TWO) && head && (j & 1u)) { out = StreamRecords(); return; }  // layout from before the pair alignment
+                r[0] = (lo * S) | ((hi * S) << 16);                                        // sinks: W, W + 1 are the constant entries
+                r[1] = (lo < W ? lo * S : dummy) | ((hi < W ? hi * S : dummy) << 16);
+                r[2] = lq | ((head ? lq : RES2_NO_STORE) << 16);
+                r[3] = (w & NW_TWO) ? 1u : 0u;
+            }
+        }
+    }
+    out.ok = true;
+}
+
 void set_layout_threads(unsigned n) { g_layout_threads.store(n, std::memory_order_relaxed); }
 void set_thread_layout_threads(unsigned n) { t_layout_threads = n; }
 

@@ -246,6 +246,21 @@ __host__ __device__ inline uint32_t res2_c_off(uint32_t real_size, uint32_t ns) 
 __host__ __device__ inline uint32_t res2_wave_bytes(uint32_t real_size, uint32_t ns, uint32_t nl) { return res2_c_off(real_size, ns) + nl * 2u * real_size; }
 void build_res2_records(const HostLayout& L, uint32_t real_size, uint32_t ns, uint32_t nl, Res2Records& out);
 
+// ---- records of the streaming sweeps, second generation (kernels.hpp: k_fwd_narrow2 / k_bwd_narrow2) --------------------------------
+// The same idea for the streaming kernels, whose hop works out of per-hop LDS buffers (frontier, children's costs-from-terminal) instead of
+// the whole pack: a lane's record at a hop holds byte offsets into THOSE buffers.  pack_width records per hop (dense), 16 bytes each:
+//   .x  lo child: offset of its cost-from-terminal in the hop buffer (index * S; sinks: the two constant entries behind the slots)  |  hi << 16
+//   .y  lo child: offset of its cost-from-root in the next frontier  |  hi << 16       (sinks and padding: the lane's own dummy entry, (W + 2 + j) S)
+//   .z  2 S * (index of the node's layer among the layers of its hop)  |  the same if the lane is its layer's head, else RES2_NO_STORE, << 16
+//   .w  flags (bit 0: two-node layer); all ones: padding lane
+// Packs of <= 2-node layers that are not staggered; packs of one structure template share their records.
+struct StreamRecords {
+    bool ok = false;
+    std::vector<uint32_t> rec;      // 4 words per record
+    std::vector<uint32_t> rec_off;  // [narrow packs] first record of the pack
+};
+void build_stream_records(const HostLayout& L, uint32_t real_size, StreamRecords& out);
+
 // Returns BDDMMA_OK or an error code; `err` receives the message.
 int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
                  const bddmma_options* opts, HostLayout& out, std::string& err, bool keep_debug_maps,

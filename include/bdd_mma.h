@@ -314,6 +314,8 @@ int bddmma_layout_copy(const bddmma_layout* l, int which, void* out);
  * bytes: info[0] = usable, [1] = number of 32-bit words (4 per record), [2] / [3] = the slot / layer capacity of a wave's LDS region the
  * offsets assume, [4] = hops of the longest pack.  words (info[1] entries) and rec_off (one per narrow pack) may be NULL to query sizes. */
 int bddmma_layout_res2_records(const bddmma_layout* l, int real_size, uint32_t* info, uint32_t* words, uint32_t* rec_off);
+/* The same for the records of the second-generation streaming sweeps (csrc/layout.hpp: StreamRecords): info[0] = usable, [1] = words. */
+int bddmma_layout_stream_records(const bddmma_layout* l, int real_size, uint32_t* info, uint32_t* words, uint32_t* rec_off);
 
 #ifdef __cplusplus
 }

@@ -512,3 +512,58 @@ def test_res2_records_restate_the_node_words(real_size):
     col3.add_linear([3, 5, 7, 2, 4, 6, 1], "<=", 14, np.arange(7))
     col3.add_covering([0, 1, 2])
     assert not res2_records(Layout(col3, pack_width=64), real_size)[0]
+
+
+@pytest.mark.parametrize("real_size,pack_width", [(4, 64), (4, 128), (8, 128), (4, 256)])
+def test_stream_records_restate_the_node_words(real_size, pack_width):
+    """The records of the second-generation streaming sweeps (layout.hpp: StreamRecords): offsets into the hop's LDS buffers, the layer's
+    index inside the hop (over all 64-lane groups), the head-only store offset, against the node words."""
+    col = BddCollection()
+    rng = np.random.Generator(np.random.PCG64(19))
+    for _ in range(900):
+        k = int(rng.integers(2, 12))
+        vs = np.sort(rng.choice(600, size=k, replace=False))
+        (col.add_covering if rng.random() < 0.6 else col.add_simplex)(vs)
+    for _ in range(30):
+        col.add_simplex([int(rng.integers(0, 600))])
+    lay = Layout(col, pack_width=pack_width)
+    info = np.zeros(5, np.uint32)
+    capi.check(lay.L.bddmma_layout_stream_records(lay.h, real_size, info.ctypes.data_as(C.c_void_p), None, None), None)
+    assert info[0] == 1
+    words, off = np.zeros(int(info[1]), np.uint32), np.zeros(lay.np_n, np.uint32)
+    capi.check(lay.L.bddmma_layout_stream_records(lay.h, real_size, info.ctypes.data_as(C.c_void_p), words.ctypes.data_as(C.c_void_p),
+                                                  off.ctypes.data_as(C.c_void_p)), None)
+    rec = words.reshape(-1, 4)
+    S, W = real_size, pack_width
+    N = lay.sets[0]
+    checked = 0
+    for p in range(lay.np_n):
+        q0, q1 = int(N["pack_hop_ptr"][p]), int(N["pack_hop_ptr"][p + 1])
+        s0 = int(N["hop_node_off"][q0])
+        for h in range(q1 - q0):
+            nb, ne = int(N["hop_node_off"][q0 + h]) - s0, int(N["hop_node_off"][q0 + h + 1]) - s0
+            heads = 0
+            for j in range(W):
+                r = rec[int(off[p]) + h * W + j]
+                w = int(lay.nwords[s0 + nb + j]) if j < ne - nb else 1 << 31
+                if w >> 31:
+                    assert r[3] == 0xFFFFFFFF and r[0] & 0xFFFF == r[0] >> 16 == (W + 1) * S
+                    assert r[1] & 0xFFFF == r[1] >> 16 == (W + 2 + j) * S and r[2] >> 16 == 0xFFF0
+                    continue
+                lo, hi, pos, two = w & 511, (w >> 9) & 511, (w >> 18) & 63, (w >> 30) & 1
+                assert r[0] & 0xFFFF == lo * S and r[0] >> 16 == hi * S
+                assert r[1] & 0xFFFF == (lo * S if lo < W else (W + 2 + j) * S) and r[1] >> 16 == (hi * S if hi < W else (W + 2 + j) * S)
+                if pos == 0:
+                    heads += 1
+                lq = (heads - 1) * 2 * S                                   # layers are numbered left to right over the whole hop
+                assert r[2] & 0xFFFF == lq and r[2] >> 16 == (lq if pos == 0 else 0xFFF0) and r[3] == two
+                assert not two or (j - pos) % 2 == 0
+                checked += 1
+            assert heads == int(N["hop_layer_off"][q0 + h + 1]) - int(N["hop_layer_off"][q0 + h])
+    assert checked > 5000
+    # staggered packs and layers wider than two nodes keep the first generation
+    col3 = BddCollection()
+    col3.add_linear([3, 5, 7, 2, 4, 6, 1], "<=", 14, np.arange(7))
+    col3.add_covering([0, 1, 2])
+    capi.check(lay.L.bddmma_layout_stream_records(Layout(col3, pack_width=64).h, real_size, info.ctypes.data_as(C.c_void_p), None, None), None)
+    assert info[0] == 0
