@@ -38,6 +38,10 @@ thread_local std::string g_create_error;
 static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------
+// accumulator type of the exchange kernel's LDS tile (kernels.hpp: k_exchange_reduce); experiments: -DBDDMMA_EX_ACC=REAL
+#ifndef BDDMMA_EX_ACC
+#define BDDMMA_EX_ACC double
+#endif
 template <typename REAL>
 struct SolverT final : SolverBase {
     // device buffers
@@ -324,11 +328,11 @@ struct SolverT final : SolverBase {
         for (REAL* p : {d_delta_var, d_delta_c}) HIPCHK(hipMemsetAsync(p, 0, 2 * n_vars * sizeof(REAL), stream));
         for (REAL* p : {d_delta_lay, d_delta_lay_c}) HIPCHK(hipMemsetAsync(p, 0, 2 * n_layers * sizeof(REAL), stream));
 #define SET_DYN(K, BYTES) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
-        SET_DYN((k_exchange_reduce<REAL, double, EX_ITER>), exch_lds);
-        SET_DYN((k_exchange_reduce<REAL, double, EX_RAW>), exch_lds);
-        SET_DYN((k_exchange_reduce<REAL, double, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, true>), exch_lds);  // run_plain()'s instantiation
-        SET_DYN((k_exchange_reduce<REAL, double, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, false, 7>), exch_lds);
-        SET_DYN((k_exchange_reduce<REAL, double, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, true, 7>), exch_lds);
+        SET_DYN((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_ITER>), exch_lds);
+        SET_DYN((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_RAW>), exch_lds);
+        SET_DYN((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, true>), exch_lds);  // run_plain()'s instantiation
+        SET_DYN((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, false, 7>), exch_lds);
+        SET_DYN((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, true, 7>), exch_lds);
         opts_variant = opts ? opts->variant_flags : 0u;
         mixed_fwd = (opts_variant & 2u) == 0;
         // measured in double: 7.1 M nodes (490 MB resident) lose 12 % with non-temporal potentials, 10.5 M (720 MB) gain 4 %
@@ -644,7 +648,7 @@ struct SolverT final : SolverBase {
             hipLaunchKernelGGL((k_delta_gather<REAL, false>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr,
                                d_vpos, delta_var, (uint32_t)n_vars, RunGate{});
         else
-            hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_RAW>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
+            hipLaunchKernelGGL((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_RAW>), dim3(n_bins), dim3(EX_THREADS), exch_lds, stream, d_mm_binned,
                                d_bin_ptr, d_bvar, (const uint32_t*)nullptr, 0u, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers, d_nbdds, delta_var,
                                (REAL*)nullptr, RunStep{});
     }
@@ -668,7 +672,7 @@ struct SolverT final : SolverBase {
             // 1.05 M nodes 4.7 -> 4.4 us per launch.  variant_flags bit 6 selects the round-2 form (0), bits 3-5 any combination for the
             // 256-thread kernel (the bisection of profiles/r03_exchange_variant_rootcause.txt).
 #define LAUNCH_EX(T_, U_, N_, RUN_, V_)                                                                                                              \
-    hipLaunchKernelGGL((k_exchange_reduce<REAL, double, EX_ITER, T_, U_, N_, RUN_, V_>), dim3(n_bins + ((RUN_) && rstep.ctl != nullptr ? 1u : 0u)), dim3(T_), exch_lds, stream, d_mm_binned, d_bin_ptr, \
+    hipLaunchKernelGGL((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_ITER, T_, U_, N_, RUN_, V_>), dim3(n_bins + ((RUN_) && rstep.ctl != nullptr ? 1u : 0u)), dim3(T_), exch_lds, stream, d_mm_binned, d_bin_ptr, \
                        d_bvar, gate().stop, gate().iter, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers, d_nbdds, (REAL*)nullptr, d_delta_lay, rstep)
 #define LAUNCH_EX_RV(T_, U_, N_)                                                                        \
     do {                                                                                                \
