@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "layout.hpp"
 
@@ -2832,7 +2833,12 @@ __device__ __forceinline__ void run_ctl_step(const RunStep& r)
 template <typename REAL>
 __device__ __forceinline__ void lds_add(REAL* p, REAL v)
 {
+#ifdef BDDMMA_EXP_INT_ATOMIC  // timing experiment only (wrong results): the rate of the integer LDS atomic of the same width
+    using U = typename std::conditional<sizeof(REAL) == 8, unsigned long long, unsigned int>::type;
+    __hip_atomic_fetch_add(reinterpret_cast<U*>(p), __builtin_bit_cast(U, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f32 / ds_add_f64
+#endif
 }
 
 // Exchange kernel: one workgroup per bin of variables; the bin's 2*vars_per_bin accumulators live in LDS.
