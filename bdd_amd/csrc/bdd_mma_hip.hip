@@ -119,7 +119,7 @@ struct SolverT final : SolverBase {
     uint32_t *d_res2_rec = nullptr, *d_res2_rec_off = nullptr;
     uint32_t res2_n_words = 0, res2_lds = 0, res2_ns = 0, res2_nl = 0;
     // streaming solve sweeps on per-lane records (kernels.hpp: k_fwd_narrow2 / k_bwd_narrow2)
-    bool use_narrow2 = false;
+    bool use_narrow2 = false, narrow_gen = false;  // narrow_gen: layers wider than two nodes or staggered packs -> the kernels' general form
     uint32_t *d_srec = nullptr, *d_srec_off = nullptr;
     uint32_t srec_words = 0;
     uint32_t huge_pack_width = 0;
@@ -363,8 +363,8 @@ struct SolverT final : SolverBase {
             // once.  Measured on random set cover (tools/sweep_res2.sh, profiles/r04_res2_sweep.txt), float, it/s streaming -> resident: 1.05 M
             // nodes (1 563 packs) 28.1 k -> 35.0 k, 1.6 M 21.4 k -> 26.1 k, 2.1 M 19.0 k -> 19.9 k, 3.1 M (4 688 packs, 1.4 x what the CUs' LDS holds
             // at once) 16.3 k -> 16.7 k, 4.2 M (128-slot streaming packs) 14.5 k -> 13.4 k; double gains only with every pack in flight.
-            // variant_flags bit 8: first generation only.
-            if (pack_width == 64 && !narrow_seg && mode != 1 && !(opts && (opts->variant_flags & 0x100u))) {
+            // variant_flags bit 11: first generation only.
+            if (pack_width == 64 && !narrow_seg && mode != 1 && !(opts && (opts->variant_flags & 0x800u))) {
                 res2_ns = (L.res.max_slots + 1024 / (uint32_t)sizeof(REAL) - 1) / (1024 / (uint32_t)sizeof(REAL)) * (1024 / (uint32_t)sizeof(REAL));
                 res2_nl = (L.res.max_layers + 512 / (uint32_t)sizeof(REAL) - 1) / (512 / (uint32_t)sizeof(REAL)) * (512 / (uint32_t)sizeof(REAL));
                 res2_lds = wpb * stage_cap * 2 * (uint32_t)sizeof(REAL) + wpb * res2_wave_bytes(sizeof(REAL), res2_ns, res2_nl);
@@ -402,17 +402,25 @@ struct SolverT final : SolverBase {
 #undef SET_RES
             }
         }
-        // streaming solve sweeps, second generation: packs of <= 2-node layers, not staggered, narrow packs only (the mixed launch keeps the first
-        // generation); variant_flags bit 9: first generation
-        if (nb_.n_packs && !use_res && !narrow_seg && !wb_.n_packs && !hb_.n_packs && !(opts && (opts->variant_flags & 0x200u))) {
+        // streaming solve sweeps, second generation (kernels.hpp: k_fwd_narrow2 / k_bwd_narrow2): every narrow pack; the general form (GEN) where
+        // layers are wider than two nodes or packs are staggered.  variant_flags bit 12: first generation; bit 13: records also where they are not
+        // shared (the differential tests run the general form on random instances that way)
+        uint32_t narrow2_static = 0;
+        if (nb_.n_packs && !use_res && !wb_.n_packs && !(opts && (opts->variant_flags & 0x1000u))) {
             StreamRecords SR;
             build_stream_records(L, sizeof(REAL), SR);
-            const uint32_t static2 = L.ex.waves_per_block * ((2 * pack_width + 2 + pack_width + 2) * (uint32_t)sizeof(REAL) + 3 * 64 * 4 + 64);
-            if (SR.ok && stage_lds + static2 <= 64 * 1024) {
+            narrow2_static = L.ex.waves_per_block * ((2 * pack_width + 2 + pack_width + 2) * (uint32_t)sizeof(REAL) + 3 * 64 * 4 + 64);
+            // ... where the records are shared by the packs of a structure template (every row of a constraint family): 16 bytes per lane and hop
+            // that are not shared cost more bandwidth than the instructions they save (general linear rows: k_fwd_mixed).  Limit: the records
+            // hold at most a quarter of what the potentials of the narrow packs do.
+            const bool shared = SR.rec.size() * sizeof(uint32_t) <= (uint64_t)L.narrow_slots * sizeof(REAL) / 2 || (opts && (opts->variant_flags & 0x2000u));
+            if (SR.ok && shared && stage_lds + narrow2_static + seg_bytes(L.ex.waves_per_block) <= 64 * 1024) {
                 if ((rc = upload(&d_srec, SR.rec))) return rc;
                 if ((rc = upload(&d_srec_off, SR.rec_off))) return rc;
                 srec_words = (uint32_t)SR.rec.size();
                 use_narrow2 = true;
+                narrow_gen = narrow_seg;
+                for (uint16_t r : L.narrow.hop_root) narrow_gen = narrow_gen || r != NO_ROOT;
             }
         }
         if (wb_.n_packs) {
@@ -541,7 +549,8 @@ struct SolverT final : SolverBase {
 #define LAUNCH_N(R_, W_)                                                                                                      \
     if (res && use_res2) hipLaunchKernelGGL((k_fwd_res2<REAL, W_>), grid, block, res2_lds, stream, rd.pack_hdr, rd.quad_hdr, res2_ns, res2_nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d_res2_rec, d_res2_rec_off, res2_n_words, d, pk, omega); \
     else if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
-    else if (two_node && use_narrow2) hipLaunchKernelGGL((k_fwd_narrow2<REAL, R_, W_>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
+    else if (MODE == FWD_SOLVE && use_narrow2 && narrow_gen) hipLaunchKernelGGL((k_fwd_narrow2<REAL, R_, W_, true>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
+    else if (MODE == FWD_SOLVE && use_narrow2) hipLaunchKernelGGL((k_fwd_narrow2<REAL, R_, W_, false>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (two_node) hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_, MODE != FWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
     else hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \
@@ -613,7 +622,8 @@ struct SolverT final : SolverBase {
 #define LAUNCH_N(R_, W_)                                                                                                      \
     if (res && use_res2) hipLaunchKernelGGL((k_bwd_res2<REAL, W_>), grid, block, res2_lds, stream, rd.pack_hdr, rd.quad_hdr, res2_ns, res2_nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d_res2_rec, d_res2_rec_off, res2_n_words, d, pk, omega); \
     else if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
-    else if (two_node && use_narrow2) hipLaunchKernelGGL((k_bwd_narrow2<REAL, R_, W_>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
+    else if (MODE == BWD_SOLVE && use_narrow2 && narrow_gen) hipLaunchKernelGGL((k_bwd_narrow2<REAL, R_, W_, true>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
+    else if (MODE == BWD_SOLVE && use_narrow2) hipLaunchKernelGGL((k_bwd_narrow2<REAL, R_, W_, false>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (two_node) hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_, MODE != BWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
     else hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_>), grid, block, dyn, stream, d, pk, omega)
 #define LAUNCH_W(R_) \

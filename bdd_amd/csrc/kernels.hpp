@@ -1679,7 +1679,7 @@ __device__ __forceinline__ void load_costs(typename Pair<REAL>::type (&c)[R], co
     for (int g = 0; g < R; ++g) hop_load(c[g], lohi, r[g][2] & 0xFFFFu, lbase * (uint32_t)sizeof(P2));
 }
 
-template <typename REAL, int R, int WPB, int LA = BDDMMA_LOOKAHEAD>
+template <typename REAL, int R, int WPB, bool GEN, int LA = BDDMMA_LOOKAHEAD>
 __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ srec,
                                                  const uint32_t* __restrict__ srec_off, uint32_t srec_words, REAL omega, uint32_t block_id)
 {
@@ -1704,6 +1704,10 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
     const bool has_pack = p < pk.n_packs;
     const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
     const uint32_t rbase = has_pack ? srec_off[p] : 0;
+    // GEN: packs with layers wider than two nodes (LDS segmented minimum, seg_min2: per-wave scratch behind the rest of the dynamic LDS) and
+    // staggered packs (a BDD root below the pack's first hop, PackDev::hop_root)
+    const int steps = GEN ? (has_pack ? pk.pack_steps[p] : 0) : 1;
+    REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
     const REAL INF = inf_v<REAL>();
     const NarrowRs<REAL> rs(d);
     const rsrc_t rr = make_rsrc(srec, srec_words);
@@ -1751,10 +1755,11 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
 #pragma unroll
         for (int i = 0; i < 2 * D; ++i)
 #pragma unroll
-            for (int r = 0; r < R; ++r) rc[i][r] = u4v{0u, 0u, 0u, RES2_PAD};
+            for (int r = 0; r < R; ++r) rc[i][r] = u4v{0u, 0u, 0u, SREC_PAD};
     }
     uint32_t cur = 0;
     uint32_t q = q0;
+    uint32_t rt = NO_ROOT;  // GEN: root slot of hop q when a BDD starts there; the first hop's roots are set up above
     const uint32_t g0 = has_pack ? pk.pack_group_ptr[p] : 0;
     const uint32_t ng = has_pack ? pk.pack_group_ptr[p + 1] - g0 : 0;
     const uint32_t r0 = pk.quad_round_ptr[quad];
@@ -1794,12 +1799,14 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
             for (int r = 0; r < R; ++r) {
                 const uint32_t j = lane + 64 * r;
                 f[r] = lds_ld<REAL>(sFw, fc + j * S);
+                if (GEN && j == rt) f[r] = REAL(0);  // a BDD that starts at this hop: its root has no parents (flush_costs_from_root)
                 tl[r] = lds_ld<REAL>(sTw, tc + (ra[r][0] & 0xFFFFu));  // sinks: [W] = 0, [W+1] = +inf; padding lanes: +inf
                 th[r] = lds_ld<REAL>(sTw, tc + (ra[r][0] >> 16));
                 dd[r] = lds_ld<P2>(dyn_lds, stg + (ra[r][2] & 0xFFFFu));
             }
             const uint32_t o_new = off(q + 2 * D + 3);
             const uint32_t l_next = hw.layer_off(q + D + 2);
+            const uint32_t rt_next = GEN ? hw.root_of(q + 1) : (uint32_t)NO_ROOT;
             // ---- set-up of the next hop's buffers (nothing above depends on it)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -1815,7 +1822,8 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
             for (int r = 0; r < R; ++r) {
                 const REAL lc = La[r].x, hc = La[r].y;
                 REAL m0 = (f[r] + lc) + tl[r], m1 = (f[r] + hc) + th[r];
-                pair_min_aligned(m0, m1, (ra[r][3] & 1u) != 0);
+                if (!GEN || steps <= 1) pair_min_aligned(m0, m1, (ra[r][3] & 1u) != 0);
+                else seg_min2(m0, m1, lane, (ra[r][3] >> 8) & 63u, 0u, steps, sM);
                 const REAL mm = mm_diff1(m0, m1, omega);
                 mmv[r] = mm;
                 nc[r].x = (lc + min0(mm)) + dd[r].x;
@@ -1826,7 +1834,7 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 hop_store(nc[r], rl, ra[r][2] >> 16, lb[0] * (uint32_t)sizeof(P2));
-                if (ra[r][3] != RES2_PAD) lds_st<REAL>(dyn_lds, stg + (ra[r][2] & 0xFFFFu), mmv[r]);  // every lane of a layer holds the same value
+                if (!(ra[r][3] & SREC_PAD)) lds_st<REAL>(dyn_lds, stg + (ra[r][2] & 0xFFFFu), mmv[r]);  // every lane of a layer holds the same value
                 lds_min(reinterpret_cast<REAL*>(sFw + fn + (ra[r][1] & 0xFFFFu)), f[r] + nc[r].x);  // sinks / padding: the lane's own dummy entry
                 lds_min(reinterpret_cast<REAL*>(sFw + fn + (ra[r][1] >> 16)), f[r] + nc[r].y);
             }
@@ -1840,6 +1848,7 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
 #pragma unroll
             for (int i = 0; i < D + 1; ++i) lb[i] = lb[i + 1];
             lb[D + 1] = l_next;
+            rt = rt_next;
 #pragma unroll
             for (int i = 0; i < 2 * D; ++i)
 #pragma unroll
@@ -1871,14 +1880,14 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
 #ifndef BDDMMA_N2_WAVES
 #define BDDMMA_N2_WAVES(REAL, R) ((R) <= 2 ? (sizeof(REAL) == 4 ? 5 : 4) : 1)
 #endif
-template <typename REAL, int R, int WPB>
+template <typename REAL, int R, int WPB, bool GEN>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N2_WAVES(REAL, R)))) k_fwd_narrow2(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ srec, const uint32_t* __restrict__ srec_off,
                                                           uint32_t srec_words, REAL omega)
 {
-    fwd_narrow2_body<REAL, R, WPB>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x);
+    fwd_narrow2_body<REAL, R, WPB, GEN>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x);
 }
 
-template <typename REAL, int R, int WPB, int LA = BDDMMA_LOOKAHEAD>
+template <typename REAL, int R, int WPB, bool GEN, int LA = BDDMMA_LOOKAHEAD>
 __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ srec,
                                                  const uint32_t* __restrict__ srec_off, uint32_t srec_words, REAL omega, uint32_t block_id)
 {
@@ -1904,6 +1913,9 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
     const REAL INF = inf_v<REAL>();
     const NarrowRs<REAL> rs(d);
     const rsrc_t rr = make_rsrc(srec, srec_words);
+    const int steps = GEN ? (has_pack ? pk.pack_steps[p] : 0) : 1;  // see k_fwd_narrow2
+    REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
+    double lb_stag = 0.0;  // GEN: costs-to-terminal of the roots below the pack's first hop (staggered packs), for the lower bound
     HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1};
     auto nb_of = [&](uint32_t q) { return hw.node_off(q); };
     // pipeline mirrored from k_fwd_narrow2 (see k_bwd_narrow): before hop q is processed (q counts down) the wave holds the records of hops
@@ -1939,7 +1951,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
 #pragma unroll
         for (int i = 0; i < 2 * D; ++i)
 #pragma unroll
-            for (int r = 0; r < R; ++r) rc[i][r] = u4v{0u, 0u, 0u, RES2_PAD};
+            for (int r = 0; r < R; ++r) rc[i][r] = u4v{0u, 0u, 0u, SREC_PAD};
     }
     uint32_t cur = 0;
     const uint32_t g0 = has_pack ? pk.pack_group_ptr[p] : 0;
@@ -1987,6 +1999,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
             }
             const uint32_t o_new = (q >= q0 + 2 * D + 1) ? nb_of(q - 1 - 2 * D) : o[2 * D + 1];
             const uint32_t l_next = hw.layer_off(q >= q0 + D + 1 ? q - 1 - D : q0);
+            const uint32_t rt = (GEN && q > q0) ? hw.root_of(q) : (uint32_t)NO_ROOT;  // the first hop's roots are summed behind the loop
             // ---- arithmetic
             REAL t[R], mmv[R];
             P2 nc[R];
@@ -1994,7 +2007,8 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
             for (int r = 0; r < R; ++r) {
                 const REAL lc = La[r].x, hc = La[r].y;
                 REAL m0 = (fa[r] + lc) + tl[r], m1 = (fa[r] + hc) + th[r];
-                pair_min_aligned(m0, m1, (ra[r][3] & 1u) != 0);
+                if (!GEN || steps <= 1) pair_min_aligned(m0, m1, (ra[r][3] & 1u) != 0);
+                else seg_min2(m0, m1, lane, (ra[r][3] >> 8) & 63u, 0u, steps, sM);
                 const REAL mm = mm_diff1(m0, m1, omega);
                 mmv[r] = mm;
                 nc[r].x = (lc + min0(mm)) + dd[r].x;
@@ -2007,10 +2021,11 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
             for (int r = 0; r < R; ++r) {
                 const uint32_t j = lane + 64 * r;
                 hop_store(nc[r], rl, ra[r][2] >> 16, lb[1] * (uint32_t)sizeof(P2));
-                if (ra[r][3] != RES2_PAD) {
+                if (!(ra[r][3] & SREC_PAD)) {
                     lds_st<REAL>(dyn_lds, stg + (ra[r][2] & 0xFFFFu), mmv[r]);
                     lds_st<REAL>(sTw, tn + j * S, t[r]);
                 }
+                if (GEN && j == rt) lb_stag += (double)t[r];
             }
             store_vals<R>(t, d.T, nb, o[0] - o[1], lane, pk.nt_potentials);
             wave_sync();
@@ -2058,7 +2073,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
     if (!has_pack) return;
     // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251)
     const uint32_t n0 = nb_of(q0 + 1) - nb_of(q0);
-    double s = 0.0;
+    double s = lb_stag;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t j = lane + 64 * r;
@@ -2068,11 +2083,11 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
     if (lane == 0) d.lb_partial[pk.lb_base + p] = s;
 }
 
-template <typename REAL, int R, int WPB>
+template <typename REAL, int R, int WPB, bool GEN>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N2_WAVES(REAL, R)))) k_bwd_narrow2(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ srec, const uint32_t* __restrict__ srec_off,
                                                           uint32_t srec_words, REAL omega)
 {
-    bwd_narrow2_body<REAL, R, WPB>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x);
+    bwd_narrow2_body<REAL, R, WPB, GEN>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x);
 }
 
 // =============================================================================================
@@ -2739,6 +2754,9 @@ __global__ void __launch_bounds__(1024) k_bwd_wide2(DevPtrs<REAL> d, PackDev pk,
 // NPT = nodes of a wide hop per thread).  Sequential launches add their times (61 us = 36 + 20 + boundary on the knapsack
 // benchmark), a second stream costs more in event fork / join than it returns; inside one grid the two kinds of workgroups simply
 // share the CUs.
+// (the narrow part stays first generation: instances with wide packs are general linear rows, whose BDDs share no structure templates, and
+// per-lane records that are not shared cost four times the node words' bytes — 40 000 knapsack rows, 10 M nodes: sweeps 73 / 73 us with
+// node words, 91 / 110 us with records, profiles/r04_widebench.txt)
 template <typename REAL, int R, int WPB, int NPT>
 __global__ void __launch_bounds__(64 * WPB) k_fwd_mixed(DevPtrs<REAL> d, PackDev pkn, PackDev pkw, REAL omega, uint32_t ww)
 {

@@ -1096,10 +1096,6 @@ void build_stream_records(const HostLayout& L, uint32_t S, StreamRecords& out)
     const uint32_t P = N.n_packs(), W = L.pack_width;
     if (P == 0 || L.narrow_word_off.size() != P || N.hop_root.size() + 1 != N.hop_node_off.size()) return;
     if ((2u * W + 2u) * S >= RES2_NO_STORE || (uint64_t)W * 2 * S >= RES2_NO_STORE) return;
-    for (uint16_t r : N.hop_root)
-        if (r != NO_ROOT) return;  // staggered packs: roots below the first hop are known to the first-generation kernels only
-    for (uint8_t st : N.pack_steps)
-        if (st > 1) return;        // layers wider than two nodes
     out.rec_off.assign(P, 0);
     std::unordered_map<uint32_t, uint32_t> seen;  // word offset of a structure template -> its first record
     for (uint32_t p = 0; p < P; ++p) {
@@ -1130,17 +1126,18 @@ void build_stream_records(const HostLayout& L, uint32_t S, StreamRecords& out)
                     r[0] = ((W + 1) * S) | (((W + 1) * S) << 16);  // cost to terminal +inf on both sides
                     r[1] = dummy | (dummy << 16);
                     r[2] = 0u | (RES2_NO_STORE << 16);
-                    r[3] = RES2_PAD;
+                    r[3] = SREC_PAD;
                     continue;
                 }
                 const uint32_t lo = w & NW_CHILD_MASK, hi = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
                 const uint32_t lq = (grp_first + ((w >> NW_LIDX_SHIFT) & NW_FIELD6)) * 2 * S;
                 const bool head = ((w >> NW_POS_SHIFT) & NW_FIELD6) == 0;
-                if ((w & NW_TWO) && head && (j & 1u)) { out = StreamRecords(); return; }  // layout from before the pair alignment
+                // packs of <= 2-node layers take the DPP swap of aligned pairs: a layout from before the pair alignment keeps the first generation
+                if (N.pack_steps[p] <= 1 && (w & NW_TWO) && head && (j & 1u)) { out = StreamRecords(); return; }
                 r[0] = (lo * S) | ((hi * S) << 16);                                        // sinks: W, W + 1 are the constant entries
                 r[1] = (lo < W ? lo * S : dummy) | ((hi < W ? hi * S : dummy) << 16);
                 r[2] = lq | ((head ? lq : RES2_NO_STORE) << 16);
-                r[3] = (w & NW_TWO) ? 1u : 0u;
+                r[3] = ((w & NW_TWO) ? 1u : 0u) | (((w >> NW_POS_SHIFT) & NW_FIELD6) << 8);
             }
         }
     }

@@ -252,8 +252,9 @@ void build_res2_records(const HostLayout& L, uint32_t real_size, uint32_t ns, ui
 //   .x  lo child: offset of its cost-from-terminal in the hop buffer (index * S; sinks: the two constant entries behind the slots)  |  hi << 16
 //   .y  lo child: offset of its cost-from-root in the next frontier  |  hi << 16       (sinks and padding: the lane's own dummy entry, (W + 2 + j) S)
 //   .z  2 S * (index of the node's layer among the layers of its hop)  |  the same if the lane is its layer's head, else RES2_NO_STORE, << 16
-//   .w  flags (bit 0: two-node layer); all ones: padding lane
-// Packs of <= 2-node layers that are not staggered; packs of one structure template share their records.
+//   .w  bit 0: two-node layer; bits 8..13: position of the node inside its layer (the LDS segmented minimum of wider layers); bit 31: padding lane
+// Packs of one structure template share their records.
+constexpr uint32_t SREC_PAD = 0x80000000u;
 struct StreamRecords {
     bool ok = false;
     std::vector<uint32_t> rec;      // 4 words per record

@@ -90,7 +90,10 @@ typedef struct bddmma_options {
                                   bit 7 / bit 8: narrow workgroups mapped to XCDs in contiguous eighths / in interleaved chunks of 32
                                                  (default: interleaved when the eighths' hop counts differ by more than 10 %)
                                   bit 9 / bit 10: make_dual_feasible of the L-BFGS direction through the staging tables / by gathers
-                                                  (default: staged from 500 000 layers on) */
+                                                  (default: staged from 500 000 layers on)
+                                  bit 11: resident sweeps of the first generation only (node words in LDS; default: per-lane records, k_fwd_res2)
+                                  bit 12: streaming solve sweeps of the first generation only (default: per-lane records where packs share them)
+                                  bit 13: per-lane records for the streaming solve sweeps also where packs do not share them */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
                                   instance (NOTES.md section 6: the sweeps are bound by instructions issued, not by latency), kept for experiments */

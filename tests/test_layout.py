@@ -547,7 +547,7 @@ def test_stream_records_restate_the_node_words(real_size, pack_width):
                 r = rec[int(off[p]) + h * W + j]
                 w = int(lay.nwords[s0 + nb + j]) if j < ne - nb else 1 << 31
                 if w >> 31:
-                    assert r[3] == 0xFFFFFFFF and r[0] & 0xFFFF == r[0] >> 16 == (W + 1) * S
+                    assert r[3] == 0x80000000 and r[0] & 0xFFFF == r[0] >> 16 == (W + 1) * S
                     assert r[1] & 0xFFFF == r[1] >> 16 == (W + 2 + j) * S and r[2] >> 16 == 0xFFF0
                     continue
                 lo, hi, pos, two = w & 511, (w >> 9) & 511, (w >> 18) & 63, (w >> 30) & 1
@@ -556,14 +556,21 @@ def test_stream_records_restate_the_node_words(real_size, pack_width):
                 if pos == 0:
                     heads += 1
                 lq = (heads - 1) * 2 * S                                   # layers are numbered left to right over the whole hop
-                assert r[2] & 0xFFFF == lq and r[2] >> 16 == (lq if pos == 0 else 0xFFF0) and r[3] == two
+                assert r[2] & 0xFFFF == lq and r[2] >> 16 == (lq if pos == 0 else 0xFFF0) and r[3] == (two | (pos << 8))
                 assert not two or (j - pos) % 2 == 0
                 checked += 1
             assert heads == int(N["hop_layer_off"][q0 + h + 1]) - int(N["hop_layer_off"][q0 + h])
     assert checked > 5000
-    # staggered packs and layers wider than two nodes keep the first generation
+    # layers wider than two nodes and staggered packs have records too (position inside the layer for the LDS segmented minimum)
     col3 = BddCollection()
-    col3.add_linear([3, 5, 7, 2, 4, 6, 1], "<=", 14, np.arange(7))
-    col3.add_covering([0, 1, 2])
-    capi.check(lay.L.bddmma_layout_stream_records(Layout(col3, pack_width=64).h, real_size, info.ctypes.data_as(C.c_void_p), None, None), None)
-    assert info[0] == 0
+    for _ in range(40):
+        co = rng.integers(1, 9, size=9)
+        col3.add_linear(co, "<=", int(co.sum() // 2), np.sort(rng.choice(60, size=9, replace=False)))
+    lay3 = Layout(col3, pack_width=64, pack_stagger=24)
+    capi.check(lay3.L.bddmma_layout_stream_records(lay3.h, real_size, info.ctypes.data_as(C.c_void_p), None, None), None)
+    assert info[0] == 1
+    w3 = np.zeros(int(info[1]), np.uint32)
+    capi.check(lay3.L.bddmma_layout_stream_records(lay3.h, real_size, info.ctypes.data_as(C.c_void_p), w3.ctypes.data_as(C.c_void_p), None), None)
+    r3 = w3.reshape(-1, 4)
+    real = (r3[:, 3] & 0x80000000) == 0
+    assert ((r3[real, 3] >> 8) & 63).max() >= 3          # nodes at position >= 3 of their layer exist
