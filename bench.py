@@ -341,7 +341,7 @@ def roofline(prof, sizes, R, its_per_gpu, args, sfx, triad_gbs, copy_gbs, reside
 def hbm_only_fractions():
     """frac_whole_iteration of the 105 M-node instance (V = 10 M, B = 5 M, k = 10: 4.5 / 7.2 GB resident, no Infinity-Cache help), measured
     with tools/kbench.py and committed in profiles/ (None if the file is missing)."""
-    for name in ("r03_hbm_only_105m.json", "r02_hbm_only_105m.json"):
+    for name in ("r04_hbm_only_105m.json", "r03_hbm_only_105m.json", "r02_hbm_only_105m.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             d = json.load(open(path))
@@ -385,7 +385,7 @@ def measured_traffic(kernel, args, sfx):
     tag = {(1_000_000, 500_000, 10): "10m", (100_000, 50_000, 10): "1m"}.get((args.vars, args.rows, args.k))
     if tag is None or args.deterministic or args.pack_width or args.wpb or args.vars_per_bin or args.stage_cap:
         return None, None, None
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         rel = os.path.join("profiles", f"{rnd}_{tag}_{sfx}", "traffic.json")
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
@@ -396,14 +396,19 @@ def measured_traffic(kernel, args, sfx):
         want = "k_fwd_narrow" if kernel == "forward_mm" else "k_bwd_narrow"
         real = "float" if sfx == "f32" else "double"   # one profile holds both precisions: the default bench run times both
         sweep = None
-        for name, v in d.items():
-            m = re.search(want + "<" + real + r", \d+, (\d+), \d+(?:, \w+)?>", name)   # <REAL, R, MODE, waves per block[, SEG]>; MODE 1 = solve
-            if m and m.group(1) == "1":
+        for name, v in d.items():   # second-generation streaming solve sweeps: <REAL, R, waves per block, GEN>
+            if isinstance(v, dict) and re.search(want + "2<" + real + r", \d+, \d+, \w+>", name):
                 sweep = v["hbm_bytes"]
         if sweep is None:
-            for name, v in d.items():   # small instances: the resident sweeps
-                if re.search(want.replace("_narrow", "_res") + "<" + real + ",", name):
+            for name, v in d.items():
+                m = re.search(want + "<" + real + r", \d+, (\d+), \d+(?:, \w+)?>", name)   # <REAL, R, MODE, waves per block[, SEG]>; MODE 1 = solve
+                if m and m.group(1) == "1":
                     sweep = v["hbm_bytes"]
+        if sweep is None:
+            for res in ("_res2", "_res"):   # small instances: the resident sweeps, second / first generation
+                for name, v in d.items():
+                    if sweep is None and isinstance(v, dict) and re.search(want.replace("_narrow", res) + "<" + real + ",", name):
+                        sweep = v["hbm_bytes"]
         exch = next((v["hbm_bytes"] for name, v in d.items() if "k_exchange_reduce<" + real + "," in name and isinstance(v, dict)), None)
         if sweep is not None:
             return sweep, exch, rel
