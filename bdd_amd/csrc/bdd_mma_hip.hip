@@ -413,7 +413,12 @@ struct SolverT final : SolverBase {
             // ... where the records are shared by the packs of a structure template (every row of a constraint family): 16 bytes per lane and hop
             // that are not shared cost more bandwidth than the instructions they save (general linear rows: k_fwd_mixed).  Limit: the records
             // hold at most a quarter of what the potentials of the narrow packs do.
-            const bool shared = SR.rec.size() * sizeof(uint32_t) <= (uint64_t)L.narrow_slots * sizeof(REAL) / 2 || (opts && (opts->variant_flags & 0x2000u));
+            // ... and, in float, while the instance is small enough for the caches to help (tools/kbench.py, same-box A/B first / second
+            // generation, it/s): 10.5 M nodes 8 190 / 8 540, 21 M 3 520 / 3 495, 42 M 1 605 / 1 596, 105 M 642 / 618 — once the sweeps run at
+            // the HBM rate the instructions saved buy nothing and the records' L2 traffic costs a little; double: 4 273 / 4 353 and 339 / 357.
+            const bool forced = opts && (opts->variant_flags & 0x2000u);
+            const bool shared = forced || (SR.rec.size() * sizeof(uint32_t) <= (uint64_t)L.narrow_slots * sizeof(REAL) / 2 &&
+                                           (sizeof(REAL) == 8 || n_slots <= 16'000'000ull));
             if (SR.ok && shared && stage_lds + narrow2_static + seg_bytes(L.ex.waves_per_block) <= 64 * 1024) {
                 if ((rc = upload(&d_srec, SR.rec))) return rc;
                 if ((rc = upload(&d_srec_off, SR.rec_off))) return rc;

@@ -679,9 +679,10 @@ def test_full_size_wide_packs_only_vs_oracle():
 
 # ---------------------------------------------------------------- long BDDs: hop-window refills and several stage groups per pack
 @pytest.mark.parametrize("precision", ["double", "float"])
+@pytest.mark.parametrize("variant", [0, 0x2000])   # 0x2000: the second-generation streaming sweeps (per-lane records) although these packs share none
 @pytest.mark.parametrize("pack_width,stage_cap,wpb", [(64, 64, 4), (128, 640, 1), (256, 256, 2), (64, 128, 8),
                                                       (256, 640, 4)])   # last: > 64 KiB of LDS per workgroup in double
-def test_long_bdds_vs_oracle(precision, pack_width, stage_cap, wpb):
+def test_long_bdds_vs_oracle(precision, pack_width, stage_cap, wpb, variant):
     rng = np.random.Generator(np.random.PCG64(33))
     V = 700
     col = BddCollection()
@@ -695,7 +696,7 @@ def test_long_bdds_vs_oracle(precision, pack_width, stage_cap, wpb):
         k = int(rng.integers(65, 140))                                      # longer than one 64-entry hop window
         col.add_simplex(np.sort(rng.choice(V, size=k, replace=False)))
     costs = rng.normal(0, 2, col.nr_variables()).round(3)
-    s = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=pack_width, stage_cap=stage_cap, waves_per_block=wpb)
+    s = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=pack_width, stage_cap=stage_cap, waves_per_block=wpb, variant_flags=variant)
     o = Oracle(col, costs, precision)
     assert s.nr_hops() == 300
     assert close(s.lower_bound(), o.lower_bound(), precision, 10)
@@ -714,6 +715,36 @@ def test_long_bdds_vs_oracle(precision, pack_width, stage_cap, wpb):
         m = bdd == b
         x = np.zeros(col.nr_variables()); x[v[m]] = sol[m]
         assert col.evaluate(b, x)
+
+
+@pytest.mark.parametrize("precision", ["double", "float"])
+@pytest.mark.parametrize("wpb", [0, 2, 4])
+def test_resident_sweeps_with_up_to_sixty_hops(precision, wpb):
+    """Rows of 17-60 variables on a small instance: resident packs of more than 16 hops (k_fwd_res2 / k_bwd_res2 walk them in blocks of 16
+    with a ring of eight prefetched records), one / two / four packs per workgroup, against the first generation and the oracle."""
+    rng = np.random.Generator(np.random.PCG64(61))
+    V = 900
+    col = BddCollection()
+    for k in (17, 24, 31, 33, 47, 60):
+        for _ in range(40):
+            vs = np.sort(rng.choice(V, size=k, replace=False))
+            (col.add_covering if rng.random() < 0.5 else col.add_simplex)(vs)
+    costs = rng.normal(0, 2, col.nr_variables()).round(3)
+    s = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=64, resident_sweeps=2, waves_per_block=wpb)
+    g1 = bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=64, resident_sweeps=2, waves_per_block=wpb, variant_flags=0x800)
+    o = Oracle(col, costs, precision)
+    assert s.nr_hops() == 60
+    for it in range(15):
+        s.iteration(); g1.iteration(); o.iteration()
+        assert close(s.lower_bound(), o.lower_bound(), precision, 10), it
+        assert close(g1.lower_bound(), o.lower_bound(), precision, 10), it
+    lo, hi, mm = s.get_solver_costs()
+    lo1, hi1, mm1 = g1.get_solver_costs()
+    tol = dict(rtol=1e-9, atol=1e-9) if precision == "double" else dict(rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(lo, lo1, **tol)
+    np.testing.assert_allclose(hi, hi1, **tol)
+    np.testing.assert_allclose(mm, mm1, **tol)
+    np.testing.assert_allclose(s.lower_bound_per_bdd(), o.lower_bound_per_bdd(), rtol=TOL[precision]["rel"], atol=10 * TOL[precision]["abs"])
 
 
 @pytest.mark.parametrize("precision", ["double", "float"])
