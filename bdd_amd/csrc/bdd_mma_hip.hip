@@ -67,6 +67,7 @@ struct SolverT final : SolverBase {
     uint32_t wpb = 1;
     bool entry_by_var = false;  // entries ordered by (variable, bdd): exchange = k_exchange_byvar
     bool exch_small = false, exch_medium = false;
+    bool big = false;  // some array reaches 4 GiB (or variant_flags bit 14, for the tests): kernels.hpp DevPtrs::big
     uint32_t opts_variant = 0;  // bddmma_options.variant_flags (A/B switches of kernel variants)
     bool narrow_seg = false;  // some narrow pack has layers wider than two nodes: seg_min2 goes through LDS and needs scratch
     uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0, stage_lds = 0, exch_lds = 0, n_narrow_layers = 0;
@@ -209,12 +210,19 @@ struct SolverT final : SolverBase {
         lay_scalars = layout_scalars(L);
         if (opts) saved_opts = *opts;
         deterministic = opts && opts->deterministic;
-        // the kernels address every array through a buffer descriptor with 32-bit byte offsets (kernels.hpp: make_rsrc);
-        // an access past 4 GiB would be dropped silently, so refuse such instances up front
-        if ((uint64_t)n_slots * sizeof(REAL) >= (1ull << 32) || 2ull * n_layers * sizeof(REAL) >= (1ull << 32)) {
-            err = "instance too large for 32-bit buffer offsets: " + std::to_string(n_slots) + " node slots, " + std::to_string(n_layers) +
-                  " layers of " + std::to_string(sizeof(REAL)) + "-byte values (each array must stay below 4 GiB)";
-            return BDDMMA_ERR_UNSUPPORTED;
+        // Arrays of 4 GiB and more (>= 512 M slots or 256 M layers in double; the reference indexes nodes with int: 2^31).  The narrow sweeps
+        // and the exchange address F / T / {lo, hi} and the entry arrays relative to their pack / bin (HopWindow, exchange_reduce_body) and
+        // stage with 64-bit addresses then (DevPtrs::big); what still carries absolute 32-bit byte offsets is refused for such instances
+        // below: wide and huge packs, the deterministic and by-variable exchanges, resident sweeps (small instances anyway), the L-BFGS
+        // wrapper's vector passes.
+        big = (uint64_t)n_slots * sizeof(REAL) >= 0xFFFF0000ull || 2ull * n_layers * sizeof(REAL) >= 0xFFFF0000ull || (opts && (opts->variant_flags & 0x4000u));
+        if ((uint64_t)n_slots * sizeof(REAL) >= 0xFFFF0000ull || 2ull * n_layers * sizeof(REAL) >= 0xFFFF0000ull) {
+            if (L.wide.n_packs() || L.huge.n_packs() || deterministic || L.ex.entry_by_var) {
+                err = "instance too large for the 32-bit buffer offsets of this configuration: " + std::to_string(n_slots) + " node slots, " +
+                      std::to_string(n_layers) + " layers of " + std::to_string(sizeof(REAL)) +
+                      "-byte values (arrays of 4 GiB and more are supported for narrow packs with the binned exchange)";
+                return BDDMMA_ERR_UNSUPPORTED;
+            }
         }
         int rc;
         if ((rc = upload(&d_nwords, L.narrow_words_unique, 1))) return rc;
@@ -283,10 +291,6 @@ struct SolverT final : SolverBase {
         for (uint8_t st : L.narrow.pack_steps) narrow_seg = narrow_seg || st >= 2;
         vars_per_bin = L.ex.vars_per_bin; n_bins = L.ex.n_bins; stage_cap = L.ex.stage_cap;
         n_narrow_layers = L.ex.grp_layer_off.empty() ? 0 : L.ex.grp_layer_off.back();
-        if (2 * n_layers * sizeof(REAL) >= 0xFFFFFFFFull || n_slots * sizeof(REAL) >= 0xFFFFFFFFull) {
-            err = "instance too large for the 32-bit buffer offsets of the sweep kernels";
-            return BDDMMA_ERR_UNSUPPORTED;
-        }
         stage_lds = L.ex.waves_per_block * stage_cap * 2 * (uint32_t)sizeof(REAL);
         exch_lds = vars_per_bin * 2 * (uint32_t)sizeof(double);  // accumulators are double for both precisions
         // LDS of a narrow solve workgroup: the dynamic staging area + the kernel's static arrays (frontier F x2 and T per wave, the hop
@@ -357,14 +361,14 @@ struct SolverT final : SolverBase {
             // streaming kernels hide their latency and the resident ones only lose occupancy to their LDS footprint.
             const uint64_t wgs_per_cu = fits ? (160 * 1024) / (res_lds + static_lds) : 0;
             const bool all_in_flight = nb_.n_packs <= 2880 && (uint64_t)cdiv(nb_.n_packs, wpb) <= 256ull * std::min<uint64_t>(wgs_per_cu, 2048 / (64 * wpb));
-            use_res = fits && mode != 1 && (mode == 2 || all_in_flight);
+            use_res = fits && mode != 1 && (mode == 2 || all_in_flight) && !big;
             // Second generation (kernels.hpp: k_fwd_res2 / k_bwd_res2), packs of 64 slots with layers of <= 2 nodes: its LDS regions are sized in
             // whole 1 KiB pieces of REAL values (no node words in LDS).  Chosen, like the first, while the packs are (nearly) all in flight at
             // once.  Measured on random set cover (tools/sweep_res2.sh, profiles/r04_res2_sweep.txt), float, it/s streaming -> resident: 1.05 M
             // nodes (1 563 packs) 28.1 k -> 35.0 k, 1.6 M 21.4 k -> 26.1 k, 2.1 M 19.0 k -> 19.9 k, 3.1 M (4 688 packs, 1.4 x what the CUs' LDS holds
             // at once) 16.3 k -> 16.7 k, 4.2 M (128-slot streaming packs) 14.5 k -> 13.4 k; double gains only with every pack in flight.
             // variant_flags bit 11: first generation only.
-            if (pack_width == 64 && !narrow_seg && mode != 1 && !(opts && (opts->variant_flags & 0x800u))) {
+            if (pack_width == 64 && !narrow_seg && mode != 1 && !big && !(opts && (opts->variant_flags & 0x800u))) {
                 res2_ns = (L.res.max_slots + 1024 / (uint32_t)sizeof(REAL) - 1) / (1024 / (uint32_t)sizeof(REAL)) * (1024 / (uint32_t)sizeof(REAL));
                 res2_nl = (L.res.max_layers + 512 / (uint32_t)sizeof(REAL) - 1) / (512 / (uint32_t)sizeof(REAL)) * (512 / (uint32_t)sizeof(REAL));
                 res2_lds = wpb * stage_cap * 2 * (uint32_t)sizeof(REAL) + wpb * res2_wave_bytes(sizeof(REAL), res2_ns, res2_nl);
@@ -483,6 +487,7 @@ struct SolverT final : SolverBase {
         d.mm_layer = d_mm_layer;  // nullptr until an L-BFGS wrapper asks for it (lbfgs_views)
         d.stop = run_stop;
         d.run_iter = run_iter;
+        d.big = big ? 1u : 0u;
         return d;
     }
     PackDev pdev(const PackBufs& b, uint32_t lb_base, uint32_t seg_off = 0) const

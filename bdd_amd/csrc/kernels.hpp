@@ -61,6 +61,7 @@ struct DevPtrs {
     // workgroups dispatched after workgroup 0 had latched it returned without doing their share of the exchange.
     const uint32_t* stop;
     uint32_t run_iter;
+    uint32_t big;            // an entry- or slot-indexed array reaches 4 GiB: the staging transfers use 64-bit addresses (stage_load / stage_flush)
 };
 struct RunGate {  // the same pair for the kernels that do not take a DevPtrs
     const uint32_t* stop = nullptr;
@@ -438,8 +439,14 @@ __device__ __forceinline__ void bstore(double2 v, rsrc_t r, uint32_t off)
 template <typename REAL>
 struct NarrowRs {
     rsrc_t words, T, F, lohi, cse, css, dlay, mm;
+    const REAL* dlay_p;  // the entry arrays as plain pointers: instances whose arrays reach 4 GiB address them with 64 bits (DevPtrs::big)
+    REAL* mm_p;
+    bool big;
     __device__ __forceinline__ explicit NarrowRs(const DevPtrs<REAL>& d)
     {
+        dlay_p = d.delta_lay;
+        mm_p = d.mm_binned;
+        big = d.big != 0;
         words = make_rsrc(d.nwords, d.n_nwords);
         T = make_rsrc(d.T, d.n_slots);
         F = make_rsrc(d.F, d.n_slots);
@@ -449,6 +456,8 @@ struct NarrowRs {
         dlay = make_rsrc(d.delta_lay, 2ull * d.n_layers);
         mm = make_rsrc(d.mm_binned, d.n_layers);
     }
+    // {lo, hi} from the pack's first layer on (see HopWindow: layer indices in the sweeps are relative to it)
+    __device__ __forceinline__ void rebase_layers(const DevPtrs<REAL>& d, uint32_t l0) { lohi = make_rsrc(d.lohi + 2 * (size_t)l0, 2ull * (d.n_layers - l0)); }
 };
 
 // Cooperative stage transfer between the entry arrays and LDS: the WPB waves of a workgroup sweep WPB
@@ -472,11 +481,20 @@ __device__ __forceinline__ void stage_load(typename Pair<REAL>::type* sD, uint32
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         P2 v[STAGE_ITERS / 2];
+        if (rs.big) {  // uniform: 64-bit addresses (entry * 8 or 16 bytes does not fit the 32-bit buffer offset); unused slots read entry 0
 #pragma unroll
-        for (int u = 0; u < STAGE_ITERS / 2; ++u) {
-            const int k = half * (STAGE_ITERS / 2) + u;
-            const uint32_t i = 64 * WPB * k + tid;
-            bload(v[u], rs.dlay, i < cnt ? e[k] * (uint32_t)sizeof(P2) : OOB);
+            for (int u = 0; u < STAGE_ITERS / 2; ++u) {
+                const int k = half * (STAGE_ITERS / 2) + u;
+                const uint32_t i = 64 * WPB * k + tid;
+                v[u] = reinterpret_cast<const P2*>(rs.dlay_p)[i < cnt ? e[k] : 0u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < STAGE_ITERS / 2; ++u) {
+                const int k = half * (STAGE_ITERS / 2) + u;
+                const uint32_t i = 64 * WPB * k + tid;
+                bload(v[u], rs.dlay, i < cnt ? e[k] * (uint32_t)sizeof(P2) : OOB);
+            }
         }
 #pragma unroll
         for (int u = 0; u < STAGE_ITERS / 2; ++u) {
@@ -491,6 +509,14 @@ template <typename REAL, int WPB>
 __device__ __forceinline__ void stage_flush(const typename Pair<REAL>::type* sD, const uint32_t (&e)[STAGE_ITERS],
                                             const uint32_t (&sl)[STAGE_ITERS], const NarrowRs<REAL>& rs, uint32_t cnt, uint32_t tid)
 {
+    if (rs.big) {
+#pragma unroll
+        for (int u = 0; u < STAGE_ITERS; ++u) {
+            const uint32_t i = 64 * WPB * u + tid;
+            if (i < cnt) rs.mm_p[e[u]] = sD[sl[u]].x;
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < STAGE_ITERS; ++u) {
         const uint32_t i = 64 * WPB * u + tid;
@@ -528,12 +554,16 @@ struct HopWindow {
     uint32_t* root;   // LDS [HOP_WIN]: PackDev::hop_root of the record (NO_ROOT past the pack's last hop)
     uint32_t base;    // record index of window slot 0
     uint32_t q1;      // one past the pack's last hop record (offsets clamp there)
+    // Offsets are kept RELATIVE to the pack's first slot / layer (round 4): the sweeps address F, T and {lo, hi} through pointers
+    // rebased to the pack (64-bit, once per pack), so that the 32-bit byte offsets of the buffer instructions stay small whatever the
+    // arrays' size — arrays beyond 4 GiB (>= 512 M slots in double) no longer overflow them.
+    uint32_t n0, l0;  // the pack's first slot and first layer
     __device__ __forceinline__ void fill(const PackDev& pk, uint32_t new_base, int lane)
     {
         base = new_base;
         const uint32_t q = min(new_base + (uint32_t)lane, q1);
-        node[lane] = pk.hop_node_off[q];
-        layer[lane] = pk.hop_layer_off[q];
+        node[lane] = pk.hop_node_off[q] - n0;
+        layer[lane] = pk.hop_layer_off[q] - l0;
         root[lane] = new_base + (uint32_t)lane < q1 ? (uint32_t)pk.hop_root[q] : (uint32_t)NO_ROOT;
         wave_sync();
     }
@@ -702,13 +732,19 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
     const int steps = SEG ? (has_pack ? pk.pack_steps[p] : 0) : 1;
     const REAL INF = inf_v<REAL>();
-    const NarrowRs<REAL> rs(d);
+    const uint32_t slot_first = has_pack ? pk.hop_node_off[q0] : 0, l0 = has_pack ? pk.hop_layer_off[q0] : 0;  // the pack's first slot / layer: everything below is relative to them (HopWindow)
+    NarrowRs<REAL> rs(d);
+    rs.rebase_layers(d, l0);
+    REAL* const Tp = d.T + slot_first;
+    REAL* const Fp = d.F + slot_first;
+    const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
+    (void)lohi_p;
     // hop_node_off / hop_layer_off have one entry past the last hop of the last pack, so index q1 is
     // always readable; offsets beyond q1 are clamped (those hops have no nodes for this pack)
-    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1};
+    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1, slot_first, l0};
     auto off = [&](uint32_t q) { return hw.node_off(q); };
     // word address of slot s of this pack = s + wd (the pack's words live in a sequence shared by all packs of its structure)
-    const uint32_t wd = has_pack ? pk.pack_word_off[p] - pk.hop_node_off[q0] : 0;
+    const uint32_t wd = has_pack ? pk.pack_word_off[p] : 0;  // (slot offsets are relative to the pack's first slot)
     // Software pipeline with a look-ahead of D hops: at the start of hop q the wave holds the node words of hops q .. q+2D-1, the
     // costs-from-terminal of hops q+2 .. q+D+1 (those of hop q+1 are already in LDS) and the layer data of hops q .. q+D-1; during hop q
     // it requests the words of hop q+2D, T of hop q+D+2 and — from the words of hop q+D, which were requested D hops ago — the layer
@@ -738,9 +774,9 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
         for (int i = 0; i < 2 * D; ++i) load_words<R>(wr[i], d.nwords, o[i] + wd, o[i + 1] - o[i], lane);   // none past the last hop
         if (NEED_T) {
             REAL t1[R];
-            load_vals<REAL, R>(t1, d.T, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
+            load_vals<REAL, R>(t1, Tp, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
 #pragma unroll
-            for (int i = 0; i < D; ++i) load_vals<REAL, R>(tr[i], d.T, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
+            for (int i = 0; i < D; ++i) load_vals<REAL, R>(tr[i], Tp, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t j = lane + 64 * r;
@@ -772,7 +808,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             cnt = pk.cs_ptr[r0 + k + 1] - c0;
             stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
             if (k < ng) {
-                gl0 = pk.grp_layer_off[g0 + k];
+                gl0 = pk.grp_layer_off[g0 + k] - l0;
                 qe = pk.grp_hop_end[g0 + k];
             } else {
                 qe = q;  // this pack has no k-th group: no hops in this round
@@ -794,7 +830,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             const uint32_t n3 = o[3] - o[2];  // slots of hop q+2
             // ---- global prefetch
             load_words<R>(wr[2 * D], d.nwords, o[2 * D] + wd, o[2 * D + 1] - o[2 * D], lane);
-            if (NEED_T) load_vals<REAL, R>(tr[D], d.T, o[D + 2], o[D + 3] - o[D + 2], lane);
+            if (NEED_T) load_vals<REAL, R>(tr[D], Tp, o[D + 2], o[D + 3] - o[D + 2], lane);
             load_layer<REAL, R>(Lr[D], wr[D], lcur, rs);  // all padding past the last hop: no loads
             uint32_t (&wa)[R] = wr[0];
             HopLayer<REAL, R>& La = Lr[0];
@@ -872,7 +908,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                         const REAL hi_path = f[r] + (th[r] + La.c[r].y);  // backward_step_with_path_costs, :633-640
                         const REAL lo_path = f[r] + (tl[r] + La.c[r].x);
                         const bool take_lo = (hi_path - lo_path) > 0;
-                        d.sol_out[La.lg[r]] = take_lo ? 0 : 1;
+                        d.sol_out[l0 + La.lg[r]] = take_lo ? 0 : 1;
                         sAct[cur ^ 1][take_lo ? lo_i : hi_i] = 1;  // sink entries are dummies
                     }
                 }
@@ -888,7 +924,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             }
             // (the argmin-path sweep leaves the stored costs-from-root alone: nothing reads them after it, and it is 38 MB of the ~120 MB the
             // sweep moves at 10.5 M nodes)
-            if (MODE != FWD_SOLUTION) store_vals<R>(f, d.F, nb, o[1] - o[0], lane, pk.nt_potentials);
+            if (MODE != FWD_SOLUTION) store_vals<R>(f, Fp, nb, o[1] - o[0], lane, pk.nt_potentials);
             wave_sync();
             cur ^= 1;
             // ---- rotate the pipeline registers
@@ -955,12 +991,18 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
     const int steps = SEG ? (has_pack ? pk.pack_steps[p] : 0) : 1;
     const REAL INF = inf_v<REAL>();
-    const NarrowRs<REAL> rs(d);
-    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1};
+    const uint32_t slot_first = has_pack ? pk.hop_node_off[q0] : 0, l0 = has_pack ? pk.hop_layer_off[q0] : 0;  // the pack's first slot / layer: everything below is relative to them (HopWindow)
+    NarrowRs<REAL> rs(d);
+    rs.rebase_layers(d, l0);
+    REAL* const Tp = d.T + slot_first;
+    REAL* const Fp = d.F + slot_first;
+    const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
+    (void)lohi_p;
+    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1, slot_first, l0};
     double lb_stag = 0.0;  // costs-to-terminal of the roots below the pack's first hop (staggered packs), for the lower bound
     // node range of hop q; hops below q0 (pipeline run-off) are empty
     auto nb_of = [&](uint32_t q) { return hw.node_off(q); };
-    const uint32_t wd = has_pack ? pk.pack_word_off[p] - pk.hop_node_off[q0] : 0;  // see k_fwd_narrow
+    const uint32_t wd = has_pack ? pk.pack_word_off[p] : 0;  // (slot offsets are relative to the pack's first slot)  // see k_fwd_narrow
     // Software pipeline with a look-ahead of D hops, mirrored from k_fwd_narrow: before hop q is processed (q counts down) the wave
     // holds the node words of hops q .. q-2D+1, the costs-from-root of hops q .. q-D and the layer data of hops q .. q-D+1; during the hop
     // it requests the words of hop q-2D, F of hop q-D-1 and the layer data of hop q-D.  o[i] = first slot of hop q+1-i (hops below q0
@@ -985,7 +1027,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
         for (int i = 0; i < 2 * D; ++i) load_words<R>(wr[i], d.nwords, o[i + 1] + wd, o[i] - o[i + 1], lane);  // hop q1-1-i (none below q0)
         if (NEED_F) {
 #pragma unroll
-            for (int i = 0; i < D + 1; ++i) load_vals<REAL, R>(fr[i], d.F, o[i + 1], o[i] - o[i + 1], lane);   // F of hop q1-1-i
+            for (int i = 0; i < D + 1; ++i) load_vals<REAL, R>(fr[i], Fp, o[i + 1], o[i] - o[i + 1], lane);   // F of hop q1-1-i
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) load_layer<REAL, R>(Lr[i], wr[i], hw.layer_off(q1 >= q0 + i + 1 ? q1 - 1 - i : q0), rs);
@@ -1009,7 +1051,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             cnt = pk.cs_ptr[r0 + k + 1] - c0;
             stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
             if (k < ng) {
-                gl0 = pk.grp_layer_off[g0 + k];
+                gl0 = pk.grp_layer_off[g0 + k] - l0;
                 qs = (k == 0) ? q0 : pk.grp_hop_end[g0 + k - 1];
             } else {
                 qs = q;  // no k-th group in this pack
@@ -1023,7 +1065,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             const uint32_t nb = o[1];
             // ---- prefetch: words of hop q-2D, F of hop q-D-1, layer data of hop q-D
             load_words<R>(wr[2 * D], d.nwords, o[2 * D + 1] + wd, o[2 * D] - o[2 * D + 1], lane);
-            if (NEED_F) load_vals<REAL, R>(fr[D + 1], d.F, o[D + 2], o[D + 1] - o[D + 2], lane);
+            if (NEED_F) load_vals<REAL, R>(fr[D + 1], Fp, o[D + 2], o[D + 1] - o[D + 2], lane);
             load_layer<REAL, R>(Lr[D], wr[D], lcur, rs);  // all padding below the first hop: no loads
             uint32_t (&wa)[R] = wr[0];
             REAL (&fa)[R] = fr[0];
@@ -1087,14 +1129,14 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                 }
                 if (MODE == BWD_MARGINALS) {
                     if (nw_head(w)) {
-                        d.mm0_out[La.lg[r]] = lp[r];
-                        d.mm1_out[La.lg[r]] = hp[r];
+                        d.mm0_out[l0 + La.lg[r]] = lp[r];
+                        d.mm1_out[l0 + La.lg[r]] = hp[r];
                     }
                 }
                 if (act) sT[cur ^ 1][j] = t[r];
                 if (j == rt) lb_stag += (double)t[r];
             }
-            store_vals<R>(t, d.T, nb, o[0] - o[1], lane, pk.nt_potentials);
+            store_vals<R>(t, Tp, nb, o[0] - o[1], lane, pk.nt_potentials);
             wave_sync();
             cur ^= 1;
 #pragma unroll
@@ -1123,13 +1165,17 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             if (WPB > 1) __syncthreads(); else wave_sync();
             stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
             if (d.mm_layer != nullptr && k < ng) {  // uniform per wave: this wave's group occupies the layers [gl0, next group) and its own LDS slots
-                const uint32_t nlay = pk.grp_layer_off[g0 + k + 1] - gl0;
+                const uint32_t nlay = pk.grp_layer_off[g0 + k + 1] - (gl0 + l0);
                 const rsrc_t rml = make_rsrc(d.mm_layer, d.n_layers);
 #pragma unroll
                 for (int u = 0; u < STAGE_ITERS; ++u) {  // straight-line: the LDS reads and the stores of all slices are independent
                     const uint32_t j = lane + 64u * u;
                     const REAL mv = sDw[j < nlay ? j : 0].x;
-                    bstore(mv, rml, j < nlay ? (gl0 + j) * (uint32_t)sizeof(REAL) : OOB);
+                    if (rs.big) {
+                        if (j < nlay) d.mm_layer[(size_t)gl0 + l0 + j] = mv;
+                    } else {
+                        bstore(mv, rml, j < nlay ? (gl0 + l0 + j) * (uint32_t)sizeof(REAL) : OOB);
+                    }
                 }
             }
             if (WPB > 1) __syncthreads();
@@ -1709,9 +1755,15 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
     const int steps = GEN ? (has_pack ? pk.pack_steps[p] : 0) : 1;
     REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
     const REAL INF = inf_v<REAL>();
-    const NarrowRs<REAL> rs(d);
+    const uint32_t slot_first = has_pack ? pk.hop_node_off[q0] : 0, l0 = has_pack ? pk.hop_layer_off[q0] : 0;  // the pack's first slot / layer: everything below is relative to them (HopWindow)
+    NarrowRs<REAL> rs(d);
+    rs.rebase_layers(d, l0);
+    REAL* const Tp = d.T + slot_first;
+    REAL* const Fp = d.F + slot_first;
+    const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
+    (void)lohi_p;
     const rsrc_t rr = make_rsrc(srec, srec_words);
-    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1};
+    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1, slot_first, l0};
     auto off = [&](uint32_t q) { return hw.node_off(q); };
     constexpr int D = LA;
     uint32_t o[2 * D + 3];
@@ -1739,9 +1791,9 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
         for (int i = 0; i < 2 * D; ++i) load_recs<R>(rc[i], rr, rbase + (uint32_t)i * W, lane);  // (past the last hop: some other records, never used)
         {
             REAL t1[R];
-            load_vals<REAL, R>(t1, d.T, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
+            load_vals<REAL, R>(t1, Tp, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
 #pragma unroll
-            for (int i = 0; i < D; ++i) load_vals<REAL, R>(tr[i], d.T, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
+            for (int i = 0; i < D; ++i) load_vals<REAL, R>(tr[i], Tp, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t j = lane + 64 * r;
@@ -1773,7 +1825,7 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
             cnt = pk.cs_ptr[r0 + k + 1] - c0;
             stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
             if (k < ng) {
-                gl0 = pk.grp_layer_off[g0 + k];
+                gl0 = pk.grp_layer_off[g0 + k] - l0;
                 qe = pk.grp_hop_end[g0 + k];
             } else {
                 qe = q;  // this pack has no k-th group: no hops in this round
@@ -1788,7 +1840,7 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
             const uint32_t stg = db + (lb[0] - gl0) * (uint32_t)sizeof(P2);  // the hop's first layer inside the wave's staging slots
             // ---- global prefetch: records of hop q+2D, T of hop q+D+2, arc costs of hop q+D
             load_recs<R>(rc[2 * D], rr, rbase + (q - q0 + 2 * D) * W, lane);
-            load_vals<REAL, R>(tr[D], d.T, o[D + 2], o[D + 3] - o[D + 2], lane);
+            load_vals<REAL, R>(tr[D], Tp, o[D + 2], o[D + 3] - o[D + 2], lane);
             load_costs<REAL, R>(Lr[D], rc[D], rs.lohi, lb[D]);
             u4v (&ra)[R] = rc[0];
             P2 (&La)[R] = Lr[0];
@@ -1830,7 +1882,7 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
                 nc[r].y = (hc + min0_neg(mm)) + dd[r].y;
             }
             // ---- writes: new arc costs (heads), staged min-marginal differences, pushes into the next frontier, costs-from-root
-            const rsrc_t rl = hop_rsrc(reinterpret_cast<const P2*>(d.lohi), lb[0], lb[1] - lb[0]);  // ends with the hop's layers: RES2_NO_STORE is dropped
+            const rsrc_t rl = hop_rsrc(reinterpret_cast<const P2*>(lohi_p), lb[0], lb[1] - lb[0]);  // ends with the hop's layers: RES2_NO_STORE is dropped
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 hop_store(nc[r], rl, ra[r][2] >> 16, lb[0] * (uint32_t)sizeof(P2));
@@ -1838,7 +1890,7 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
                 lds_min(reinterpret_cast<REAL*>(sFw + fn + (ra[r][1] & 0xFFFFu)), f[r] + nc[r].x);  // sinks / padding: the lane's own dummy entry
                 lds_min(reinterpret_cast<REAL*>(sFw + fn + (ra[r][1] >> 16)), f[r] + nc[r].y);
             }
-            store_vals<R>(f, d.F, nb, o[1] - o[0], lane, pk.nt_potentials);
+            store_vals<R>(f, Fp, nb, o[1] - o[0], lane, pk.nt_potentials);
             wave_sync();
             cur ^= 1u;
             // ---- rotate the pipeline registers
@@ -1911,12 +1963,18 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
     const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
     const uint32_t rbase = has_pack ? srec_off[p] : 0;
     const REAL INF = inf_v<REAL>();
-    const NarrowRs<REAL> rs(d);
+    const uint32_t slot_first = has_pack ? pk.hop_node_off[q0] : 0, l0 = has_pack ? pk.hop_layer_off[q0] : 0;  // the pack's first slot / layer: everything below is relative to them (HopWindow)
+    NarrowRs<REAL> rs(d);
+    rs.rebase_layers(d, l0);
+    REAL* const Tp = d.T + slot_first;
+    REAL* const Fp = d.F + slot_first;
+    const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
+    (void)lohi_p;
     const rsrc_t rr = make_rsrc(srec, srec_words);
     const int steps = GEN ? (has_pack ? pk.pack_steps[p] : 0) : 1;  // see k_fwd_narrow2
     REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
     double lb_stag = 0.0;  // GEN: costs-to-terminal of the roots below the pack's first hop (staggered packs), for the lower bound
-    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1};
+    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1, slot_first, l0};
     auto nb_of = [&](uint32_t q) { return hw.node_off(q); };
     // pipeline mirrored from k_fwd_narrow2 (see k_bwd_narrow): before hop q is processed (q counts down) the wave holds the records of hops
     // q .. q-2D+1, the costs-from-root of hops q .. q-D and the arc costs of hops q .. q-D+1.  o[i] = first slot of hop q+1-i,
@@ -1944,7 +2002,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
 #pragma unroll
         for (int i = 0; i < 2 * D; ++i) load_recs<R>(rc[i], rr, rec_of(q1 >= q0 + i + 1 ? q1 - 1 - i : q0), lane);  // hop q1-1-i
 #pragma unroll
-        for (int i = 0; i < D + 1; ++i) load_vals<REAL, R>(fr[i], d.F, o[i + 1], o[i] - o[i + 1], lane);            // F of hop q1-1-i
+        for (int i = 0; i < D + 1; ++i) load_vals<REAL, R>(fr[i], Fp, o[i + 1], o[i] - o[i + 1], lane);            // F of hop q1-1-i
 #pragma unroll
         for (int i = 0; i < D; ++i) load_costs<REAL, R>(Lr[i], rc[i], rs.lohi, lb[i + 1]);                          // hop q1-1-i starts at layer lb[i+1]
     } else {
@@ -1968,7 +2026,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
             cnt = pk.cs_ptr[r0 + k + 1] - c0;
             stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
             if (k < ng) {
-                gl0 = pk.grp_layer_off[g0 + k];
+                gl0 = pk.grp_layer_off[g0 + k] - l0;
                 qs = (k == 0) ? q0 : pk.grp_hop_end[g0 + k - 1];
             } else {
                 qs = q;  // no k-th group in this pack
@@ -1983,7 +2041,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
             const uint32_t stg = db + (lb[1] - gl0) * (uint32_t)sizeof(P2);  // hop q starts at layer lb[1]
             // ---- prefetch: records of hop q-2D, F of hop q-D-1, arc costs of hop q-D
             load_recs<R>(rc[2 * D], rr, rec_of(q >= q0 + 2 * D ? q - 2 * D : q0), lane);
-            load_vals<REAL, R>(fr[D + 1], d.F, o[D + 2], o[D + 1] - o[D + 2], lane);
+            load_vals<REAL, R>(fr[D + 1], Fp, o[D + 2], o[D + 1] - o[D + 2], lane);
             load_costs<REAL, R>(Lr[D], rc[D], rs.lohi, lb[D + 1]);
             u4v (&ra)[R] = rc[0];
             REAL (&fa)[R] = fr[0];
@@ -2016,7 +2074,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
                 t[r] = rmin(nc[r].y + th[r], nc[r].x + tl[r]);
             }
             // ---- writes
-            const rsrc_t rl = hop_rsrc(reinterpret_cast<const P2*>(d.lohi), lb[1], lb[0] - lb[1]);
+            const rsrc_t rl = hop_rsrc(reinterpret_cast<const P2*>(lohi_p), lb[1], lb[0] - lb[1]);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t j = lane + 64 * r;
@@ -2027,7 +2085,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
                 }
                 if (GEN && j == rt) lb_stag += (double)t[r];
             }
-            store_vals<R>(t, d.T, nb, o[0] - o[1], lane, pk.nt_potentials);
+            store_vals<R>(t, Tp, nb, o[0] - o[1], lane, pk.nt_potentials);
             wave_sync();
             cur ^= 1u;
 #pragma unroll
@@ -2058,13 +2116,17 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
             if (WPB > 1) __syncthreads(); else wave_sync();
             stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
             if (d.mm_layer != nullptr && k < ng) {  // uniform per wave: this wave's group occupies the layers [gl0, next group) and its own LDS slots
-                const uint32_t nlay = pk.grp_layer_off[g0 + k + 1] - gl0;
+                const uint32_t nlay = pk.grp_layer_off[g0 + k + 1] - (gl0 + l0);
                 const rsrc_t rml = make_rsrc(d.mm_layer, d.n_layers);
 #pragma unroll
                 for (int u = 0; u < STAGE_ITERS; ++u) {
                     const uint32_t j = lane + 64u * u;
                     const REAL mv = sDw[j < nlay ? j : 0].x;
-                    bstore(mv, rml, j < nlay ? (gl0 + j) * (uint32_t)sizeof(REAL) : OOB);
+                    if (rs.big) {
+                        if (j < nlay) d.mm_layer[(size_t)gl0 + l0 + j] = mv;
+                    } else {
+                        bstore(mv, rml, j < nlay ? (gl0 + l0 + j) * (uint32_t)sizeof(REAL) : OOB);
+                    }
                 }
             }
             if (WPB > 1) __syncthreads();
@@ -2934,7 +2996,14 @@ __device__ __forceinline__ bool exchange_reduce_body(const REAL* __restrict__ mm
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t v0 = b * vars_per_bin;
     const uint32_t nv = min(vars_per_bin, n_vars - v0);
-    const uint32_t e0 = bin_ptr[b], e1 = bin_ptr[b + 1];
+    // the bin's ranges of the entry arrays, rebased (64-bit, once): entry offsets below are relative to the bin's first entry, so the arrays
+    // may exceed the 4 GiB that a 32-bit buffer offset reaches
+    const uint32_t e0_abs = bin_ptr[b], e1_abs = bin_ptr[b + 1];
+    mm_binned += e0_abs;
+    bvar += e0_abs;
+    if (delta_lay) delta_lay += 2 * (size_t)e0_abs;
+    const uint32_t e0 = 0, e1 = e1_abs - e0_abs;
+    n_entries = e1;
     BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 0);
     constexpr bool SOFF_L = (VAR & EXV_SOFF_LOADS) != 0, SOFF_S = (VAR & EXV_SOFF_STORES) != 0, ONE_ATOMIC = (VAR & EXV_ONE_ATOMIC) != 0;
     const rsrc_t rmm = make_rsrc(mm_binned, SOFF_L ? e1 : n_entries), rev = make_rsrc(bvar, SOFF_L ? e1 : n_entries);

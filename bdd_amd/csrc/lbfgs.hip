@@ -703,6 +703,11 @@ struct Lbfgs final : bddmma_lbfgs {
         device = b->device;
         LHIP(hipSetDevice(device));
         n = (uint32_t)b->n_layers;
+        // the vector passes and the staged projection (k_stage_transpose, k_project_entries) carry 32-bit byte offsets into per-layer / per-entry arrays
+        if (2ull * b->n_layers * (b->precision == BDDMMA_F64 ? 8 : 4) >= 0xFFFF0000ull) {
+            err = "the L-BFGS wrapper supports instances whose per-layer arrays stay below 4 GiB";
+            return BDDMMA_ERR_UNSUPPORTED;
+        }
         st = (hipStream_t)b->stream_handle();
         step_size = p.init_step_size;
         int rc;

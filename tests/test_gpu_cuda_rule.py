@@ -208,7 +208,7 @@ def test_omega_and_forced_variables_fuzz(seed):
     opts = dict(pack_width=pw, waves_per_block=wpb, stage_cap=max(cap, pw), vars_per_bin=int(rng.choice([0, 64, 256])),
                 wide_pack_width=int(rng.choice([0, 64, 128, 256])), keep_bdd_order=bool(rng.integers(0, 2)),
                 resident_sweeps=int(rng.choice([0, 1, 2])), exchange_by_variable=int(rng.choice([0, 0, 2])),
-                variant_flags=int(rng.choice([0, 0, 1, 2, 3])) | int(rng.choice([0, 0x800, 0x1000, 0x2000, 0x2000])), pack_fill=int(rng.choice([0, 0, pw // 2, 16])),
+                variant_flags=int(rng.choice([0, 0, 1, 2, 3])) | int(rng.choice([0, 0x800, 0x1000, 0x2000, 0x2000])) | int(rng.choice([0, 0, 0x4000])), pack_fill=int(rng.choice([0, 0, pw // 2, 16])),
                 pack_stagger=int(rng.choice([0, 1, 24, 60, 200])))
     what = f"seed {seed} omega {omega} {opts}"
     n_it = int(rng.integers(3, 20))
@@ -237,7 +237,8 @@ def test_omega_and_forced_variables_fuzz(seed):
 FORCED_OPTS = [dict(), dict(pack_width=64, waves_per_block=1), dict(pack_width=256, waves_per_block=8, stage_cap=256),
                dict(resident_sweeps=1), dict(resident_sweeps=2), dict(wide_pack_width=64, pack_width=64), dict(exchange_by_variable=2),
                dict(deterministic=1), dict(pack_stagger=24, keep_bdd_order=True), dict(variant_flags=0x2000, resident_sweeps=1),
-               dict(variant_flags=0x2000, resident_sweeps=1, pack_stagger=24, keep_bdd_order=True), dict(variant_flags=0x1800)]
+               dict(variant_flags=0x2000, resident_sweeps=1, pack_stagger=24, keep_bdd_order=True), dict(variant_flags=0x1800),
+               dict(variant_flags=0x4000), dict(variant_flags=0x6000)]
 
 
 @pytest.mark.parametrize("precision", ["double", "float"])
