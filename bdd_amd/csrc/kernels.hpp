@@ -439,11 +439,15 @@ __device__ __forceinline__ void bstore(double2 v, rsrc_t r, uint32_t off)
 template <typename REAL>
 struct NarrowRs {
     rsrc_t words, T, F, lohi, cse, css, dlay, mm;
+    const uint32_t* cse_p;  // the staging tables as plain pointers (stage_load rebases them to its round)
+    const uint16_t* css_p;
     const REAL* dlay_p;  // the entry arrays as plain pointers: instances whose arrays reach 4 GiB address them with 64 bits (DevPtrs::big)
     REAL* mm_p;
     bool big;
     __device__ __forceinline__ explicit NarrowRs(const DevPtrs<REAL>& d)
     {
+        cse_p = d.cs_entry;
+        css_p = d.cs_slot;
         dlay_p = d.delta_lay;
         mm_p = d.mm_binned;
         big = d.big != 0;
@@ -472,11 +476,13 @@ __device__ __forceinline__ void stage_load(typename Pair<REAL>::type* sD, uint32
                                            const NarrowRs<REAL>& rs, uint32_t c0, uint32_t cnt, uint32_t tid)
 {
     using P2 = typename Pair<REAL>::type;
+    // (the round's range of the staging tables, rebased: item offsets stay small whatever the tables' size)
+    const rsrc_t rce = make_rsrc(rs.cse_p + c0, cnt), rcs = make_rsrc(rs.css_p + c0, cnt);
 #pragma unroll
     for (int u = 0; u < STAGE_ITERS; ++u) {
         const uint32_t i = 64 * WPB * u + tid;
-        e[u] = bload_u32(rs.cse, i < cnt ? (c0 + i) * 4u : OOB);
-        sl[u] = bload_u16(rs.css, i < cnt ? (c0 + i) * 2u : OOB);
+        e[u] = bload_u32(rce, i * 4u);   // past the round: dropped
+        sl[u] = bload_u16(rcs, i * 2u);
     }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
