@@ -1756,6 +1756,7 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
     const bool has_pack = p < pk.n_packs;
     const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
     const uint32_t rbase = has_pack ? srec_off[p] : 0;
+    BDDMMA_STAMP(p, 0);
     // GEN: packs with layers wider than two nodes (LDS segmented minimum, seg_min2: per-wave scratch behind the rest of the dynamic LDS) and
     // staggered packs (a BDD root below the pack's first hop, PackDev::hop_root)
     const int steps = GEN ? (has_pack ? pk.pack_steps[p] : 0) : 1;
@@ -1837,6 +1838,7 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
                 qe = q;  // this pack has no k-th group: no hops in this round
             }
             if (WPB > 1) __syncthreads(); else wave_sync();
+            BDDMMA_STAMP(p, 1);
         }
         auto hop = [&]() {
             if (q + 2 * D + 3 >= hw.base + HOP_WIN && hw.base + HOP_WIN <= q1) hw.fill(pk, q, lane);
@@ -1926,8 +1928,11 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
         }
         while (q < qe) hop();
         {
+            BDDMMA_STAMP(p, 3);
             if (WPB > 1) __syncthreads(); else wave_sync();
+            BDDMMA_STAMP(p, 2);
             stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);  // min-marginal differences of the round -> entry array
+            BDDMMA_STAMP(p, 4);
             if (WPB > 1) __syncthreads();                        // the next round overwrites the staging area
         }
     }
@@ -1968,6 +1973,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
     const bool has_pack = p < pk.n_packs;
     const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
     const uint32_t rbase = has_pack ? srec_off[p] : 0;
+    BDDMMA_STAMP(p, 0);
     const REAL INF = inf_v<REAL>();
     const uint32_t slot_first = has_pack ? pk.hop_node_off[q0] : 0, l0 = has_pack ? pk.hop_layer_off[q0] : 0;  // the pack's first slot / layer: everything below is relative to them (HopWindow)
     NarrowRs<REAL> rs(d);
@@ -2038,6 +2044,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
                 qs = q;  // no k-th group in this pack
             }
             if (WPB > 1) __syncthreads(); else wave_sync();
+            BDDMMA_STAMP(p, 1);
         }
         auto hop = [&]() {
             --q;
@@ -2119,8 +2126,11 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
         }
         while (q > qs) hop();
         {
+            BDDMMA_STAMP(p, 3);
             if (WPB > 1) __syncthreads(); else wave_sync();
+            BDDMMA_STAMP(p, 2);
             stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
+            BDDMMA_STAMP(p, 4);
             if (d.mm_layer != nullptr && k < ng) {  // uniform per wave: this wave's group occupies the layers [gl0, next group) and its own LDS slots
                 const uint32_t nlay = pk.grp_layer_off[g0 + k + 1] - (gl0 + l0);
                 const rsrc_t rml = make_rsrc(d.mm_layer, d.n_layers);
