@@ -88,8 +88,8 @@ struct SolverT final : SolverBase {
     uint32_t run_iter = 0;                            // index of the iteration being queued by run_plain() (kernels.hpp: DevPtrs::run_iter)
     RunGate gate() const { return RunGate{run_stop, run_iter}; }
     RunStep run_step{};                               // {partials, count, ctl, host}: what the launch that ends an iteration gets
-    REAL* d_mm_layer = nullptr;   // deferred min-marginal differences in layer order, written by the backward solve sweeps once an L-BFGS wrapper uses them
-    bool mm_layer_valid = false;  // equal to d_mm_binned (permuted): true after a backward solve sweep, false after anything else that writes the deferred values
+    REAL* d_x_layer = nullptr;    // net_solver_costs x = (hi - lo) + deferred mm in layer order, written by the backward solve sweeps once an L-BFGS wrapper uses them
+    bool x_layer_valid = false;   // true after a backward solve sweep, false after anything else that writes arc costs or deferred values
     CostQuot* d_cost_q = nullptr;      // update_costs: per-variable quotients (kernels.hpp: k_cost_quotients)
     uint8_t* d_cost_flags = nullptr;
     uint32_t* d_counts = nullptr;
@@ -484,7 +484,7 @@ struct SolverT final : SolverBase {
         d.n_slots = (uint32_t)n_slots; d.n_layers = (uint32_t)n_layers; d.n_narrow_layers = n_narrow_layers;
         d.lb_partial = d_lb_partial;
         d.mm0_out = d_tmp0; d.mm1_out = d_tmp1; d.sol_out = d_sol;
-        d.mm_layer = d_mm_layer;  // nullptr until an L-BFGS wrapper asks for it (lbfgs_views)
+        d.x_layer = d_x_layer;  // nullptr until an L-BFGS wrapper asks for it (lbfgs_views)
         d.stop = run_stop;
         d.run_iter = run_iter;
         d.big = big ? 1u : 0u;
@@ -817,7 +817,7 @@ struct SolverT final : SolverBase {
         int rc;
         if (!bwd_valid && (rc = backward_run())) return rc;  // bdd_cuda_parallel_mma.cu:211-212
         rc = launch_fwd<FWD_SOLVE>(delta_lay, omega, BDDMMA_K_FORWARD_MM);
-        mm_layer_valid = false;  // the forward sweep rewrites the deferred values by entry only
+        x_layer_valid = false;  // the forward sweep rewrites the deferred values by entry only
         if (rc) return rc;
         fwd_valid = true;
         bwd_valid = false;
@@ -831,7 +831,7 @@ struct SolverT final : SolverBase {
         }
         int rc = launch_bwd<BWD_SOLVE>(delta_lay, omega, BDDMMA_K_BACKWARD_MM);
         if (rc) return rc;
-        mm_layer_valid = d_mm_layer != nullptr;
+        x_layer_valid = d_x_layer != nullptr;
         fwd_valid = false;
         bwd_valid = true;
         return BDDMMA_OK;
@@ -998,11 +998,11 @@ struct SolverT final : SolverBase {
     {
         HIPCHK(hipSetDevice(device));
         hipLaunchKernelGGL((k_distribute_delta<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lo, d_hi, d_mm_binned, d_lpos, (uint32_t)n_layers);
-        mm_layer_valid = false;
+        x_layer_valid = false;
         HIPCHK(hipMemsetAsync(d_delta_var, 0, 2 * n_vars * sizeof(REAL), stream));  // bdd_cuda_base.cu:1428
         HIPCHK(hipMemsetAsync(d_delta_lay, 0, 2 * n_layers * sizeof(REAL), stream));
         delta_var_valid = true;
-        fwd_valid = bwd_valid = false;
+        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
@@ -1061,7 +1061,7 @@ struct SolverT final : SolverBase {
         HIPCHK(hipSetDevice(device));
         int rc = elem_precision == BDDMMA_F64 ? update_both<double>(lo, n_lo, hi, n_hi, on_device) : update_both<float>(lo, n_lo, hi, n_hi, on_device);
         if (rc) return rc;
-        fwd_valid = bwd_valid = false;
+        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
@@ -1074,7 +1074,7 @@ struct SolverT final : SolverBase {
             const REAL cc = REAL(c / (double)(k1 - k0));
             hipLaunchKernelGGL((k_set_cost<REAL>), dim3(cdiv(k1 - k0, 64)), dim3(64), 0, stream, d_hi, d_var_layers, k0, k1, cc);
         }
-        fwd_valid = bwd_valid = false;
+        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
@@ -1118,12 +1118,12 @@ struct SolverT final : SolverBase {
             hipLaunchKernelGGL((k_strided_copy<REAL>), g, b, 0, stream, d_hi, 2u, (const REAL*)d_tmp0, 1u, (uint32_t)n_layers);
         }
         if (mm) {
-            mm_layer_valid = false;
+            x_layer_valid = false;
             HIPCHK(hipMemcpyAsync(d_tmp0, mm, n_layers * sizeof(REAL), k, stream));
             hipLaunchKernelGGL((k_layers_to_entries<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_tmp0, d_lpos, d_mm_binned, (uint32_t)n_layers);
         }
         HIPCHK(hipStreamSynchronize(stream));
-        fwd_valid = bwd_valid = false;
+        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
         return BDDMMA_OK;
     }
     int primal_objective_vec(void* out, int on_device) override
@@ -1205,12 +1205,12 @@ struct SolverT final : SolverBase {
         HIPCHK(e);
         return BDDMMA_OK;
     }
-    int bdds_solution_async(char* dev_out) override
+    int bdds_solution_async(char* dev_out, int prezeroed) override
     {
         HIPCHK(hipSetDevice(device));
         int rc;
         if ((rc = backward_run())) return rc;
-        HIPCHK(hipMemsetAsync(dev_out, 0, n_layers, stream));
+        if (!prezeroed) HIPCHK(hipMemsetAsync(dev_out, 0, n_layers, stream));
         char* const own = d_sol;
         d_sol = dev_out;  // ptrs() hands d_sol to the sweep
         rc = launch_fwd<FWD_SOLUTION>(nullptr, REAL(0), BDDMMA_K_OTHER);
@@ -1222,13 +1222,13 @@ struct SolverT final : SolverBase {
     {
         HIPCHK(hipSetDevice(device));
         int rc;
-        if (!d_mm_layer && (rc = dalloc(&d_mm_layer, n_layers))) return rc;
-        if (!mm_layer_valid) {
-            hipLaunchKernelGGL((k_entries_to_layers<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_mm_binned, d_lpos, d_mm_layer, (uint32_t)n_layers);
+        if (!d_x_layer && (rc = dalloc(&d_x_layer, n_layers))) return rc;
+        if (!x_layer_valid) {  // the first call, or something other than a backward solve sweep has changed costs / deferred values since
+            hipLaunchKernelGGL((k_net_costs<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_lo, d_hi, d_mm_binned, d_lpos, d_x_layer, (uint32_t)n_layers);
             HIPCHK(hipGetLastError());
-            mm_layer_valid = true;
+            x_layer_valid = true;
         }
-        *out = LbfgsViews{d_lohi, d_mm_layer};
+        *out = LbfgsViews{d_x_layer};
         return BDDMMA_OK;
     }
     int net_solver_costs(void* out, int on_device) override
@@ -1256,7 +1256,7 @@ struct SolverT final : SolverBase {
         const REAL* p = (const REAL*)g;
         if (!on_device) { HIPCHK(hipMemcpyAsync(d_tmp0, g, n_layers * sizeof(REAL), hipMemcpyHostToDevice, stream)); p = d_tmp0; }
         hipLaunchKernelGGL((k_gradient_step<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_hi, p, REAL(step), (uint32_t)n_layers);
-        fwd_valid = bwd_valid = false;
+        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
@@ -1323,6 +1323,45 @@ struct SolverT final : SolverBase {
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
+    // The same for a vector that is a linear combination of stored ones (the L-BFGS direction): formed inside the layers -> entries pass
+    // (kernels.hpp: k_stage_lincomb).  Instances of narrow packs only; variant_flags bit 15: not offered (the wrapper writes the direction
+    // and calls projection_means).
+    bool projection_fuses_lincomb() const override { return use_staged_projection() && n_layers == n_narrow_layers && !(opts_variant & 0x8000u); }
+    int projection_means_lincomb(const LinComb& lc, const void* tag) override
+    {
+        HIPCHK(hipSetDevice(device));
+        int rc;
+        if (!projection_fuses_lincomb() || lc.ns < 1 || lc.ns > LINCOMB_MAX) { err = "projection_means_lincomb: not available for this instance"; return BDDMMA_ERR_INVALID_ARGUMENT; }
+        proj_staged = true;
+        proj_pending = false;
+        proj_of = tag;
+        if (!d_proj_dir && (rc = dalloc(&d_proj_dir, n_layers))) return rc;
+        if (!d_proj_ent && (rc = dalloc(&d_proj_ent, n_layers))) return rc;
+        const uint32_t plds = vars_per_bin * (uint32_t)sizeof(double);
+        if (!proj_attr_set) {
+            if (plds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_entries<REAL, EX_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+            proj_attr_set = true;
+        }
+        {
+            const PackDev pk = pdev(nb_, 0);
+            const uint32_t n_quads = (uint32_t)cdiv(nb_.n_packs, wpb);
+            const uint32_t lds = wpb * stage_cap * (uint32_t)sizeof(REAL);
+#define LAUNCH_LC(W_, NS_) hipLaunchKernelGGL((k_stage_lincomb<REAL, W_, NS_>), dim3(n_quads), dim3(64 * W_), lds, stream, lc, d_proj_ent, pk, (const uint32_t*)d_cs_entry, \
+                                              (const uint16_t*)d_cs_slot, n_narrow_layers, (uint32_t)n_layers)
+#define LAUNCH_LCW(W_) do { if (lc.ns == 5) LAUNCH_LC(W_, 5); else LAUNCH_LC(W_, 0); } while (0)
+            switch (wpb) { case 1: LAUNCH_LCW(1); break; case 2: LAUNCH_LCW(2); break; case 4: LAUNCH_LCW(4); break; default: LAUNCH_LCW(8); break; }
+#undef LAUNCH_LCW
+#undef LAUNCH_LC
+        }
+#define LAUNCH_P(T_) hipLaunchKernelGGL((k_project_entries<REAL, T_>), dim3(n_bins), dim3(T_), plds, stream, d_proj_ent, d_bin_ptr, d_bvar, d_nbdds, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers)
+        if (exch_small) LAUNCH_P(EXS_THREADS);
+        else if (exch_medium) LAUNCH_P(EXM_THREADS);
+        else LAUNCH_P(EX_THREADS);
+#undef LAUNCH_P
+        proj_pending = true;
+        HIPCHK(hipGetLastError());
+        return BDDMMA_OK;
+    }
     // ... then any number of steps along the projected vector
     int gradient_step_projected(const void* g, double step) override
     {
@@ -1343,13 +1382,13 @@ struct SolverT final : SolverBase {
             } else {
                 hipLaunchKernelGGL((k_gradient_step<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_hi, (const REAL*)d_proj_dir, REAL(step), (uint32_t)n_layers);
             }
-            fwd_valid = bwd_valid = false;
+            fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
             HIPCHK(hipGetLastError());
             return BDDMMA_OK;
         }
         if (!d_proj_q) { err = "gradient_step_projected without projection_means"; return BDDMMA_ERR_INVALID_ARGUMENT; }
         hipLaunchKernelGGL((k_gradient_step_projected<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_hi, (const REAL*)g, d_proj_q, (const uint32_t*)d_var, REAL(step), (uint32_t)n_layers);
-        fwd_valid = bwd_valid = false;
+        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
@@ -1442,8 +1481,8 @@ struct SolverT final : SolverBase {
         float f = 0.f;
         HIPCHK(hipEventElapsedTime(&f, ev_t0, ev_t1));
         *ms = f;
-        fwd_valid = bwd_valid = false;
-        mm_layer_valid = false;
+        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
+        x_layer_valid = false;
 #ifdef BDDMMA_STAMPS
         if (const char* path = std::getenv("BDDMMA_STAMPS_FILE")) {  // one more launch with per-wave phase stamps (kernels.hpp: BDDMMA_STAMP)
             const size_t slots = 0x100000u + 65536u * 16u;

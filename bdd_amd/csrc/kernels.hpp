@@ -49,7 +49,8 @@ struct DevPtrs {
     uint32_t n_layers;
     uint32_t n_narrow_layers;
     double* lb_partial;      // per pack (narrow packs first, then wide)
-    REAL* mm_layer;          // BWD_SOLVE: the min-marginal differences also in layer order (nullptr: not wanted; SolverT::lbfgs_views)
+    REAL* x_layer;           // BWD_SOLVE: net_solver_costs x = (hi' - lo') + mm (bdd_cuda_parallel_mma.cu:432-463) in layer order, formed by the sweep itself
+                             // from the new arc costs and the deferred difference (nullptr: not wanted; SolverT::lbfgs_views)
     REAL* mm0_out;           // BWD_MARGINALS outputs, per layer
     REAL* mm1_out;
     char* sol_out;           // FWD_SOLUTION output, per layer
@@ -1131,7 +1132,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                     uint32_t soff = head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB;  // see k_fwd_narrow
                     asm volatile("" : "+v"(soff));
                     bstore(nc, rs.lohi, soff);
-                    if (head) sDw[La.lg[r] - gl0].x = mmv[r];
+                    if (head) sDw[La.lg[r] - gl0] = P2{mmv[r], nhi[r] - nlo[r]};  // .y: hi' - lo' for x_layer (the delta pair has been consumed)
                 }
                 if (MODE == BWD_MARGINALS) {
                     if (nw_head(w)) {
@@ -1170,15 +1171,16 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
         if (MODE == BWD_SOLVE) {
             if (WPB > 1) __syncthreads(); else wave_sync();
             stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
-            if (d.mm_layer != nullptr && k < ng) {  // uniform per wave: this wave's group occupies the layers [gl0, next group) and its own LDS slots
+            if (d.x_layer != nullptr && k < ng) {  // uniform per wave: this wave's group occupies the layers [gl0, next group) and its own LDS slots
                 const uint32_t nlay = pk.grp_layer_off[g0 + k + 1] - (gl0 + l0);
-                const rsrc_t rml = make_rsrc(d.mm_layer, d.n_layers);
+                const rsrc_t rml = make_rsrc(d.x_layer, d.n_layers);
 #pragma unroll
                 for (int u = 0; u < STAGE_ITERS; ++u) {  // straight-line: the LDS reads and the stores of all slices are independent
                     const uint32_t j = lane + 64u * u;
-                    const REAL mv = sDw[j < nlay ? j : 0].x;
+                    const P2 pv = sDw[j < nlay ? j : 0];
+                    const REAL mv = pv.y + pv.x;  // (hi' - lo') + mm
                     if (rs.big) {
-                        if (j < nlay) d.mm_layer[(size_t)gl0 + l0 + j] = mv;
+                        if (j < nlay) d.x_layer[(size_t)gl0 + l0 + j] = mv;
                     } else {
                         bstore(mv, rml, j < nlay ? (gl0 + l0 + j) * (uint32_t)sizeof(REAL) : OOB);
                     }
@@ -1454,7 +1456,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(RES_LEADING_ARGS, DevPtrs<
             nc.x = nlo;
             nc.y = nhi;
             bstore(nc, rs.lohi, head ? (layer0 + ll) * (uint32_t)sizeof(P2) : OOB);
-            if (head) sDw[ll].x = mm;
+            if (head) sDw[ll] = P2{mm, nhi - nlo};  // .y: hi' - lo' for x_layer
             if (act) sT[cur ^ 1][j] = t;
             bstore(t, rs.T, act ? (slot0 + nb + j) * (uint32_t)sizeof(REAL) : OOB);
         }
@@ -1466,8 +1468,8 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res(RES_LEADING_ARGS, DevPtrs<
     stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
     BDDMMA_STAMP(p, 4);
     if (!has_pack) return;
-    if (d.mm_layer != nullptr)
-        for (uint32_t j = lane; j < nlayers; j += 64) d.mm_layer[layer0 + j] = sDw[j].x;
+    if (d.x_layer != nullptr)
+        for (uint32_t j = lane; j < nlayers; j += 64) d.x_layer[layer0 + j] = sDw[j].y + sDw[j].x;  // (hi' - lo') + mm
     // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251)
     const uint32_t n0 = __builtin_amdgcn_readfirstlane(sOffN[1]);
     double sum = 0.0;
@@ -1678,7 +1680,7 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res2(RES2_ARGS, DevPtrs<REAL> 
         const REAL t = rmin(nc.y + th, nc.x + tl);
         bstore(nc, rC, r[3] & 0xFFFFu);
         if (real) {
-            lds_st<REAL>(dyn_lds, db + ll, mm);
+            lds_st<P2>(dyn_lds, db + ll, P2{mm, nc.y - nc.x});  // .y: hi' - lo' for x_layer
             lds_st<REAL>(dyn_lds, wb + fs, t);
         }
         bstore(t, rT, fs);
@@ -1695,8 +1697,8 @@ __global__ void __launch_bounds__(64 * WPB) k_bwd_res2(RES2_ARGS, DevPtrs<REAL> 
     stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
     BDDMMA_STAMP(p, 4);
     if (!has_pack) return;
-    if (d.mm_layer != nullptr)
-        for (uint32_t j = lane; j < nlayers; j += 64) d.mm_layer[layer0 + j] = sDw[j].x;
+    if (d.x_layer != nullptr)
+        for (uint32_t j = lane; j < nlayers; j += 64) d.x_layer[layer0 + j] = sDw[j].y + sDw[j].x;  // (hi' - lo') + mm
     // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251); every node of the first hop is a root
     double lb = rroot[3] != RES2_PAD ? (double)lds_ld<REAL>(dyn_lds, wb + (rroot[2] >> 16)) : 0.0;
     for (int off2 = 32; off2 > 0; off2 >>= 1) lb += __shfl_down(lb, off2);
@@ -2093,7 +2095,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
                 const uint32_t j = lane + 64 * r;
                 hop_store(nc[r], rl, ra[r][2] >> 16, lb[1] * (uint32_t)sizeof(P2));
                 if (!(ra[r][3] & SREC_PAD)) {
-                    lds_st<REAL>(dyn_lds, stg + (ra[r][2] & 0xFFFFu), mmv[r]);
+                    lds_st<P2>(dyn_lds, stg + (ra[r][2] & 0xFFFFu), P2{mmv[r], nc[r].y - nc[r].x});  // .y: hi' - lo' for x_layer
                     lds_st<REAL>(sTw, tn + j * S, t[r]);
                 }
                 if (GEN && j == rt) lb_stag += (double)t[r];
@@ -2131,15 +2133,16 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
             BDDMMA_STAMP(p, 2);
             stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
             BDDMMA_STAMP(p, 4);
-            if (d.mm_layer != nullptr && k < ng) {  // uniform per wave: this wave's group occupies the layers [gl0, next group) and its own LDS slots
+            if (d.x_layer != nullptr && k < ng) {  // uniform per wave: this wave's group occupies the layers [gl0, next group) and its own LDS slots
                 const uint32_t nlay = pk.grp_layer_off[g0 + k + 1] - (gl0 + l0);
-                const rsrc_t rml = make_rsrc(d.mm_layer, d.n_layers);
+                const rsrc_t rml = make_rsrc(d.x_layer, d.n_layers);
 #pragma unroll
                 for (int u = 0; u < STAGE_ITERS; ++u) {
                     const uint32_t j = lane + 64u * u;
-                    const REAL mv = sDw[j < nlay ? j : 0].x;
+                    const P2 pv = sDw[j < nlay ? j : 0];
+                    const REAL mv = pv.y + pv.x;  // (hi' - lo') + mm
                     if (rs.big) {
-                        if (j < nlay) d.mm_layer[(size_t)gl0 + l0 + j] = mv;
+                        if (j < nlay) d.x_layer[(size_t)gl0 + l0 + j] = mv;
                     } else {
                         bstore(mv, rml, j < nlay ? (gl0 + l0 + j) * (uint32_t)sizeof(REAL) : OOB);
                     }
@@ -2356,7 +2359,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, Pack
                     d.lohi[2 * (size_t)(lbase + l)] = nlo;
                     d.lohi[2 * (size_t)(lbase + l) + 1] = nhi;
                     d.mm_binned[e] = mm;
-                    if (d.mm_layer != nullptr) d.mm_layer[lbase + l] = mm;
+                    if (d.x_layer != nullptr) d.x_layer[lbase + l] = (nhi - nlo) + mm;
                 }
             } else {
                 t = rmin(th + s.hc[l], tl + s.lc[l]);
@@ -2778,7 +2781,7 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
                 nc.y = nhi;
                 bstore(nc, rs.lohi, head ? (lb + l) * (uint32_t)sizeof(P2) : OOB);
                 bstore(mm, rs.mm, head ? E0[i] * (uint32_t)sizeof(REAL) : OOB);
-                if (d.mm_layer != nullptr && head) d.mm_layer[lb + l] = mm;
+                if (d.x_layer != nullptr && head) d.x_layer[lb + l] = (nhi - nlo) + mm;
             } else {
                 t = rmin(th[i] + C0[i].y, tl[i] + C0[i].x);  // backward_step, bdd_cuda_base.cu:646-667
                 if (MODE == BWD_MARGINALS && head) {
@@ -3584,6 +3587,109 @@ __global__ void __launch_bounds__(64 * WPB) k_stage_transpose(const REAL* __rest
             }
             __syncthreads();
         }
+    }
+}
+
+// k_stage_transpose<..., 0> whose input is not an array but a linear combination of stored vectors evaluated on the fly (layout.hpp:
+// LinComb — the L-BFGS direction q = g + sum cy y + sum cs s of lbfgs.hip, same operations in the same order as its k_lb_direction):
+// the direction goes straight from the history into the staging area and leaves in entry order, instead of being written in layer
+// order by one pass and read back by the next (2 x 20 / 40 MB and a launch at 5 M layers).  A lane forms four consecutive layers per trip —
+// 16-byte loads of the REAL vectors, 4-byte loads of the char vectors, as the wrapper's own passes — starting at the multiple of 4 at or
+// below the group's first layer; what falls outside the group is computed and dropped.
+typedef uint32_t lc_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint64_t lc_u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lc_ld4(float (&v)[4], const float* p)
+{
+    const lc_u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const lc_u32x4*>(p));
+    const uint32_t w[4] = {x.x, x.y, x.z, x.w};  // (__builtin_bit_cast straight from a vector element was seen to take element 0 for every one)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(float, w[i]);
+}
+__device__ __forceinline__ void lc_ld4(double (&v)[4], const double* p)
+{
+    const lc_u64x2 a = __builtin_nontemporal_load(reinterpret_cast<const lc_u64x2*>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const lc_u64x2*>(p) + 1);
+    const uint64_t w[4] = {a.x, a.y, b.x, b.y};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(double, w[i]);
+}
+template <typename REAL, int WPB, int NS>  // NS = 0: lc.ns vectors, known at run time only
+__global__ void __launch_bounds__(64 * WPB) k_stage_lincomb(LinComb lc, REAL* __restrict__ out, PackDev pk, const uint32_t* __restrict__ cs_entry,
+                                                             const uint16_t* __restrict__ cs_slot, uint32_t n_narrow_layers, uint32_t n_layers)
+{
+    constexpr int NK = NS > 0 ? NS : LINCOMB_MAX;
+    const int ns = NS > 0 ? NS : lc.ns;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    REAL* sD = reinterpret_cast<REAL*>(dyn_lds);
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t quad = blockIdx.x;
+    const uint32_t p = quad * WPB + wave;
+    const bool has_pack = p < pk.n_packs;
+    const uint32_t g0 = has_pack ? pk.pack_group_ptr[p] : 0;
+    const uint32_t ng = has_pack ? pk.pack_group_ptr[p + 1] - g0 : 0;
+    const uint32_t r0 = pk.quad_round_ptr[quad], n_rounds = pk.quad_round_ptr[quad + 1] - r0;
+    const rsrc_t rse = make_rsrc(cs_entry, n_narrow_layers), rss = make_rsrc(cs_slot, n_narrow_layers);
+    const rsrc_t rout = make_rsrc(out, n_layers);
+    REAL* sDw = sD + (size_t)wave * pk.stage_cap;
+    const REAL* sk[NK];
+    const char* yk[NK];
+    double cy[NK], cs[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const uint32_t ps = k < ns ? lc.order[k] : 0u;
+        sk[k] = reinterpret_cast<const REAL*>(lc.S) + (size_t)ps * lc.slot;
+        yk[k] = lc.Y + (size_t)ps * lc.slot;
+        cy[k] = k < ns ? lc.cy[ps] : 0.0;
+        cs[k] = k < ns ? lc.cs[ps] : 0.0;
+    }
+    for (uint32_t k = 0; k < n_rounds; ++k) {
+        const uint32_t c0 = pk.cs_ptr[r0 + k], cnt = pk.cs_ptr[r0 + k + 1] - c0;
+        uint32_t gl0 = 0, gn = 0;
+        if (k < ng) {
+            gl0 = pk.grp_layer_off[g0 + k];
+            gn = pk.grp_layer_off[g0 + k + 1] - gl0;
+        }
+        uint32_t e[STAGE_ITERS], sl[STAGE_ITERS];
+#pragma unroll
+        for (int u = 0; u < STAGE_ITERS; ++u) {
+            const uint32_t i = 64 * WPB * u + tid;
+            e[u] = bload_u32(rse, i < cnt ? (c0 + i) * 4u : OOB);
+            sl[u] = bload_u16(rss, i < cnt ? (c0 + i) * 2u : OOB);
+        }
+        const uint32_t a0 = gl0 & ~3u;
+        const uint32_t nch = gn ? (gl0 + gn - a0 + 3u) / 4u : 0u;
+        for (uint32_t c = lane; c < nch; c += 64) {
+            const size_t j = (size_t)a0 + 4 * (size_t)c;
+            const uint32_t g4 = *reinterpret_cast<const uint32_t*>(lc.g + j);
+            uint32_t y4[NK];
+            REAL s4[NK][4];
+#pragma unroll
+            for (int h = 0; h < NK; ++h)
+                if (h < ns) {
+                    y4[h] = *reinterpret_cast<const uint32_t*>(yk[h] + j);
+                    lc_ld4(s4[h], sk[h] + j);
+                }
+#pragma unroll
+            for (int el = 0; el < 4; ++el) {
+                double q = (double)(char)(signed char)((g4 >> (8 * el)) & 0xFFu);
+#pragma unroll
+                for (int h = 0; h < NK; ++h)
+                    if (h < ns) q += cy[h] * (double)(char)(signed char)((y4[h] >> (8 * el)) & 0xFFu);
+#pragma unroll
+                for (int h = 0; h < NK; ++h)
+                    if (h < ns) q += cs[h] * (double)s4[h][el];
+                const uint32_t li = (uint32_t)(j + el) - gl0;  // (wraps below the group's first layer)
+                if (li < gn) sDw[li] = REAL(q);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < STAGE_ITERS; ++u) {
+            const uint32_t i = 64 * WPB * u + tid;
+            const REAL v = sD[i < cnt ? sl[u] : 0];
+            bstore(v, rout, i < cnt ? e[u] * (uint32_t)sizeof(REAL) : OOB);
+        }
+        __syncthreads();  // the next round overwrites the staging area
     }
 }
 

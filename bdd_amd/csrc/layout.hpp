@@ -262,6 +262,23 @@ struct StreamRecords {
 };
 void build_stream_records(const HostLayout& L, uint32_t real_size, StreamRecords& out);
 
+// A per-layer vector given as a linear combination of stored ones (the L-BFGS direction, lbfgs.hip: q = g + sum_k cy[order[k]] Y[order[k]]
+// + sum_k cs[order[k]] S[order[k]], accumulated in double in that order and rounded to REAL once): what the wrapper hands to
+// SolverBase::projection_means_lincomb so that the direction is formed inside the first pass of its projection instead of being written
+// and read back.  All pointers are device pointers; S (REAL) and Y (char) hold slots of `slot` elements (a multiple of 64, so every slot
+// is 16-byte aligned and may be read up to the next multiple of 4 past its last element); g is readable up to the same bound.
+struct LinComb {
+    const char* g;
+    const void* S;
+    const char* Y;
+    uint64_t slot;
+    const double* cy;       // by physical slot
+    const double* cs;
+    const uint32_t* order;  // physical slots of the ns kept vectors, oldest first
+    int ns;                 // <= LINCOMB_MAX
+};
+constexpr int LINCOMB_MAX = 8;
+
 // Returns BDDMMA_OK or an error code; `err` receives the message.
 int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
                  const bddmma_options* opts, HostLayout& out, std::string& err, bool keep_debug_maps,

@@ -344,8 +344,8 @@ __device__ __forceinline__ void stc4(char* p, const char (&v)[4])
 }
 
 template <typename REAL, int NS>
-static __global__ void __launch_bounds__(256) k_lb_store_gram(const REAL* __restrict__ lohi, const REAL* __restrict__ mm_layer,
-                                                              REAL* __restrict__ prev_x, const char* __restrict__ cur_g, char* __restrict__ prev_g,
+static __global__ void __launch_bounds__(256) k_lb_store_gram(const REAL* __restrict__ x_layer,
+                                                              REAL* __restrict__ prev_x, char* __restrict__ cur_g, char* __restrict__ prev_g,
                                                               REAL* __restrict__ S, char* __restrict__ Y, size_t slot, const LbDev* __restrict__ st,
                                                               double* __restrict__ partial, uint32_t n)
 {
@@ -367,13 +367,13 @@ static __global__ void __launch_bounds__(256) k_lb_store_gram(const REAL* __rest
     double acc[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) acc[d] = 0.0;
-    // one element: x = hi - lo + mm (k_net_costs), s = x - x_prev, y = g_prev - g (lbfgs_impl.h:81,100), and the products
-    auto element = [&](const REAL lo, const REAL hi, const REAL mmv, const char g, const REAL xp, const char gp, const REAL (&sv_)[NK], const char (&yv_)[NK],
-                       REAL& x_out, REAL& s_out, char& y_out) {
-        const REAL x = (hi - lo) + mmv;
+    // one element: x = hi - lo + mm (net_solver_costs: formed by the backward solve sweep, SolverBase::lbfgs_views), s = x - x_prev,
+    // y = g_prev - g (lbfgs_impl.h:81,100), and the products
+    auto element = [&](const REAL x, const char g, const REAL xp, const char gp, const REAL (&sv_)[NK], const char (&yv_)[NK],
+                       REAL& s_out, char& y_out) {
         const REAL sv = REAL(x - xp);
         const char yv = (char)(gp - g);
-        x_out = x; s_out = sv; y_out = yv;
+        s_out = sv; y_out = yv;
         const double ds = have_prev ? (double)sv : 0.0, dy = have_prev ? (double)yv : 0.0, dg = (double)g;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
@@ -394,11 +394,9 @@ static __global__ void __launch_bounds__(256) k_lb_store_gram(const REAL* __rest
     const uint64_t n4 = n / 4, stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n4; c += stride) {
         const uint64_t j = 4 * c;
-        REAL c0[4], c1[4], mmv[4], xp[4] = {REAL(0), REAL(0), REAL(0), REAL(0)}, sv_[NK][4];
+        REAL x4[4], xp[4] = {REAL(0), REAL(0), REAL(0), REAL(0)}, sv_[NK][4];
         char g[4], gp[4] = {0, 0, 0, 0}, yv_[NK][4];
-        ld4(c0, lohi + 2 * j);        // {lo, hi} of elements j, j + 1
-        ld4(c1, lohi + 2 * j + 4);    // ... j + 2, j + 3
-        ld4(mmv, mm_layer + j);
+        ld4(x4, x_layer + j);
         ldc4(g, cur_g + j);
         if (have_prev) {
             ld4(xp, prev_x + j);
@@ -409,7 +407,7 @@ static __global__ void __launch_bounds__(256) k_lb_store_gram(const REAL* __rest
             ld4(sv_[k], sk[k] + j);
             ldc4(yv_[k], yk[k] + j);
         }
-        REAL x4[4], s4[4];
+        REAL s4[4];
         char y4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -417,8 +415,7 @@ static __global__ void __launch_bounds__(256) k_lb_store_gram(const REAL* __rest
             char ye[NK];
 #pragma unroll
             for (int k = 0; k < NS; ++k) { se[k] = sv_[k][e]; ye[k] = yv_[k][e]; }
-            const REAL lo = e < 2 ? c0[2 * e] : c1[2 * (e - 2)], hi = e < 2 ? c0[2 * e + 1] : c1[2 * (e - 2) + 1];
-            element(lo, hi, mmv[e], g[e], xp[e], gp[e], se, ye, x4[e], s4[e], y4[e]);
+            element(x4[e], g[e], xp[e], gp[e], se, ye, s4[e], y4[e]);
         }
         if (have_prev) {
             st4(sw + j, s4);
@@ -426,6 +423,7 @@ static __global__ void __launch_bounds__(256) k_lb_store_gram(const REAL* __rest
         }
         st4(prev_x + j, x4);
         stc4(prev_g + j, g);
+        *reinterpret_cast<uint32_t*>(cur_g + j) = 0u;  // the next argmin-path sweep only writes the layers on a path (bdds_solution_async, prezeroed)
     }
     if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) {  // the last n % 4 elements
         const uint64_t i = 4 * n4 + threadIdx.x;
@@ -433,12 +431,15 @@ static __global__ void __launch_bounds__(256) k_lb_store_gram(const REAL* __rest
         char ye[NK];
 #pragma unroll
         for (int k = 0; k < NS; ++k) { se[k] = sk[k][i]; ye[k] = yk[k][i]; }
-        REAL x, sv;
+        REAL sv;
         char yv;
-        element(lohi[2 * i], lohi[2 * i + 1], mm_layer[i], cur_g[i], have_prev ? prev_x[i] : REAL(0), have_prev ? prev_g[i] : (char)0, se, ye, x, sv, yv);
+        const REAL x = x_layer[i];
+        const char g = cur_g[i];
+        element(x, g, have_prev ? prev_x[i] : REAL(0), have_prev ? prev_g[i] : (char)0, se, ye, sv, yv);
         if (have_prev) { sw[i] = sv; yw[i] = yv; }
         prev_x[i] = x;
-        prev_g[i] = cur_g[i];
+        prev_g[i] = g;
+        cur_g[i] = 0;
     }
     // per-block partial sums, layout [dot][block]: in-wave trees for all dots, ONE barrier, then thread d adds the four waves' values
     // (a barrier pair per dot cost ~4 us per workgroup for the 35 dots of a history of five)
@@ -664,6 +665,7 @@ struct Lbfgs final : bddmma_lbfgs {
     // first trial step's bound of the next iteration (slot 1), so the steady L-BFGS iteration has one host wait instead of two.  While
     // it is pending, lb_history's last entry is a placeholder.
     bool lb_pending = false;
+    uint64_t lb_pending_epoch = 0;  // SolverBase::cost_epoch when it was enqueued: costs changed behind the wrapper's back make it history only
     double step_size = 0;
     int unsuccessful = 0;
     bool prev_stored = false;
@@ -682,6 +684,7 @@ struct Lbfgs final : bddmma_lbfgs {
     double* d_gpartial = nullptr;
     size_t slot = 0;         // elements between two slots of S / Y (n rounded up to 64: 16-byte aligned slots for the vector loads)
     int h_count = 0;         // pairs kept: read back while the history fills up, constant (= history_size) afterwards
+    bool fused_dir = false;  // this iteration's direction is formed inside the solver's projection (projection_means_lincomb)
 
     int device = 0;  // cached: the wrapped solver may already be gone when the wrapper is destroyed
     ~Lbfgs() override
@@ -714,7 +717,8 @@ struct Lbfgs final : bddmma_lbfgs {
         if (p.history_size >= SC_DOT) { err = "history size must be < 32"; return BDDMMA_ERR_INVALID_ARGUMENT; }
         const char* two_loop = std::getenv("BDDMMA_LBFGS_TWO_LOOP");
         gram = p.history_size <= LB_MAXS && !(two_loop && two_loop[0] == '1');
-        if ((rc = alloc(&prev_x, n)) || (rc = alloc(&dir, n)) || (rc = alloc(&prev_g, n)) || (rc = alloc(&cur_g, n))) return rc;
+        // (the char vectors are read four at a time up to the next multiple of 4 past the last layer: k_stage_lincomb)
+        if ((rc = alloc(&prev_x, n)) || (rc = alloc(&dir, n)) || (rc = alloc(&prev_g, (size_t)n + 64)) || (rc = alloc(&cur_g, (size_t)n + 64))) return rc;
         if (gram) {
             slot = ((size_t)n + 63) & ~(size_t)63;
             if ((rc = alloc(&S, (size_t)(p.history_size + 1) * slot)) || (rc = alloc(&Y, (size_t)(p.history_size + 1) * slot)) ||
@@ -724,6 +728,7 @@ struct Lbfgs final : bddmma_lbfgs {
             LHIP(hipHostGetDevicePointer((void**)&d_lb_host, h_lb, 0));
             std::memset((void*)h_lb, 0, sizeof(LbHost));
             LHIP(hipMemsetAsync(d_lb, 0, sizeof(LbDev), st));
+            LHIP(hipMemsetAsync(cur_g, 0, n, st));
             return 0;
         }
         if ((rc = alloc(&cur_x, n)) || (rc = alloc(&d_partial, 2048)) || (rc = alloc(&d_scalar, SC_COUNT))) return rc;
@@ -768,8 +773,8 @@ struct Lbfgs final : bddmma_lbfgs {
         if (rcv) { err = b->err; return rcv; }
         const uint32_t nb = std::min<uint32_t>(LB_BLOCKS, std::max<uint32_t>(1, (n / 4 + 255) / 256));
 #define LB_STORE(NS_)                                                                                                                      \
-    hipLaunchKernelGGL((k_lb_store_gram<REAL, NS_>), dim3(nb), dim3(256), 0, st, (const REAL*)v.lohi, (const REAL*)v.mm_layer, prev_x,            \
-                       (const char*)cur_g, prev_g, S, Y, slot, (const LbDev*)d_lb, d_gpartial, n)
+    hipLaunchKernelGGL((k_lb_store_gram<REAL, NS_>), dim3(nb), dim3(256), 0, st, (const REAL*)v.x_layer, prev_x, cur_g, prev_g, S, Y, slot,     \
+                       (const LbDev*)d_lb, d_gpartial, n)
         switch (h_count) {
             case 0: LB_STORE(0); break;
             case 1: LB_STORE(1); break;
@@ -793,7 +798,7 @@ struct Lbfgs final : bddmma_lbfgs {
     int direction_gram()
     {
         const dim3 g(std::min<uint32_t>(4096, std::max<uint32_t>(1, (n / 4 + 255) / 256))), b(256);
-#define LB_DIR(NS_) hipLaunchKernelGGL((k_lb_direction<REAL, NS_>), g, b, 0, st, dir, (const char*)cur_g, (const REAL*)S, (const char*)Y, slot, (const LbDev*)d_lb, n)
+#define LB_DIR(NS_) hipLaunchKernelGGL((k_lb_direction<REAL, NS_>), g, b, 0, st, dir, (const char*)prev_g, (const REAL*)S, (const char*)Y, slot, (const LbDev*)d_lb, n)
         switch (p.history_size) {
             case 2: LB_DIR(2); break;
             case 3: LB_DIR(3); break;
@@ -985,13 +990,21 @@ struct Lbfgs final : bddmma_lbfgs {
             lb_history.push_back(lb);
         }
         bool lbfgs_step;
+        // The pending bound doubles as "the bound before the step" of this iteration's search — true only while nobody else has changed the
+        // costs since (set_cost, update_costs, gradient_step ... on the solver itself; the reference's search calls lower_bound() afresh,
+        // lbfgs_impl.h:165): otherwise it is fetched now, as the history entry it also is, and the search computes its own.
+        if (lb_pending && b->cost_epoch != lb_pending_epoch && (rc = resolve_pending())) return rc;
         if (gram) {
-            if ((rc = b->bdds_solution_async(cur_g))) { err = b->err; return rc; }
+            // (cur_g is all 0 here: zeroed at init and by every store pass after its last read; the direction reads the copy in prev_g)
+            if ((rc = b->bdds_solution_async(cur_g, 1))) { err = b->err; return rc; }
             // the branch is taken when the history is full AFTER this store: it may complete it
             const bool may = unsuccessful <= 5 && (int)lb_history.size() >= p.history_size && h_count + 1 >= p.history_size;
             if ((rc = store_iterate_gram(may ? 1 : 0))) return rc;
             lbfgs_step = may && h_count >= p.history_size;
-            if (lbfgs_step && (rc = direction_gram())) return rc;
+            // the direction: its own pass (k_lb_direction), or — where the solver's projection takes a linear combination — formed inside
+            // the projection's first pass straight from the history (SolverBase::projection_means_lincomb)
+            fused_dir = lbfgs_step && b->projection_fuses_lincomb();
+            if (lbfgs_step && !fused_dir && (rc = direction_gram())) return rc;
         } else {
             if ((rc = b->bdds_solution(0, cur_g, 1))) { err = b->err; return rc; }
             if ((rc = store_iterate())) return rc;
@@ -999,7 +1012,12 @@ struct Lbfgs final : bddmma_lbfgs {
             if (lbfgs_step && (rc = compute_direction())) return rc;
         }
         if (lbfgs_step) {
-            if ((rc = b->projection_means(dir))) { err = b->err; return rc; }  // make_dual_feasible(direction), applied inside the steps
+            // make_dual_feasible(direction), applied inside the steps
+            if (gram && fused_dir) {
+                // (prev_g holds the current subgradient: the store pass has copied it there)
+                const LinComb lc{prev_g, S, Y, (uint64_t)slot, &d_lb->cy[0], &d_lb->cs[0], &d_lb->order[0], p.history_size};
+                if ((rc = b->projection_means_lincomb(lc, dir))) { err = b->err; return rc; }
+            } else if ((rc = b->projection_means(dir))) { err = b->err; return rc; }
             if ((rc = search_step_size_and_apply())) return rc;
             last_kind = 1;
             ++lbfgs_iterations;
@@ -1015,6 +1033,7 @@ struct Lbfgs final : bddmma_lbfgs {
             if ((rc = b->lower_bound_enqueue(0))) { err = b->err; return rc; }
             lb_history.push_back(0.0);
             lb_pending = true;
+            lb_pending_epoch = b->cost_epoch;
         } else {
             if ((rc = lower_bound(&lb))) return rc;
             lb_history.push_back(lb);

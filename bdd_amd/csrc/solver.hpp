@@ -20,6 +20,7 @@ struct SolverBase {
     uint32_t pack_width = 0, wide_pack_width = 0, wide_slot_base = 0;
     uint64_t dev_bytes = 0;
     bool fwd_valid = false, bwd_valid = false;  // forward_state_valid_ / backward_state_valid_ (bdd_cuda_base.h:205-206)
+    uint64_t cost_epoch = 0;                    // counts the calls that changed arc costs other than through a solve sweep (update_costs, set_cost, gradient steps, ...)
     bool deterministic = false;
     std::vector<uint64_t> nodes_per_hop, layers_per_hop;
     std::vector<int32_t> h_nbdds, h_layer_var, h_layer_bdd;
@@ -71,18 +72,22 @@ struct SolverBase {
     virtual int gradient_step(const void* g, double step, int on_device) = 0;
     virtual int projection_means(const void* g_dev) = 0;                       // per-variable means of a device vector, kept inside the solver
     virtual int gradient_step_projected(const void* g_dev, double step) = 0;   // costs += step * (g - its per-variable mean)
+    // projection_means of a vector that is a linear combination of stored ones (layout.hpp: LinComb), formed on the fly; `tag` is what
+    // gradient_step_projected will be called with.  Only where projection_fuses_lincomb() (staged projection, narrow packs only).
+    virtual bool projection_fuses_lincomb() const = 0;
+    virtual int projection_means_lincomb(const LinComb& lc, const void* tag) = 0;
     virtual void* stream_handle() = 0;
     // L-BFGS wrapper (lbfgs.hip): the argmin paths straight into a device buffer with nothing but stream order (bdds_solution() also
-    // copies and synchronises), and the arrays net_solver_costs() is made of, so that x = hi - lo + deferred mm is formed inside the
-    // wrapper's own pass instead of being written and read back
+    // copies and synchronises; `prezeroed`: the caller has left the buffer all 0, the sweep only writes the layers on a path), and
+    // net_solver_costs() as a view: x = (hi - lo) + deferred mm per layer.
     struct LbfgsViews {
-        const void* lohi;          // {lo, hi} per layer, REAL
-        const void* mm_layer;      // deferred min-marginal differences per layer, REAL (the sweeps keep them by entry; see lbfgs_views)
+        const void* x_layer;       // REAL per layer
     };
-    virtual int bdds_solution_async(char* dev_out) = 0;
-    // From the first call on the backward solve sweeps also write their min-marginal differences in layer order (one coalesced 4-8 byte
-    // store per layer), so that the wrapper reads x without the 5 M random gathers of net_solver_costs(); rebuilt by a gather when
-    // something else changed the deferred values since the last backward sweep.
+    virtual int bdds_solution_async(char* dev_out, int prezeroed) = 0;
+    // From the first call on the backward solve sweeps also write x in layer order (one coalesced 4-8 byte store per layer, formed from
+    // the new arc costs and the deferred difference while both are in the sweep's hands), so that the wrapper reads x without the 5 M random
+    // gathers of net_solver_costs() and without re-reading {lo, hi}; rebuilt by net_solver_costs()'s gather when something else has changed
+    // costs or deferred values since the last backward solve sweep.
     virtual int lbfgs_views(LbfgsViews* out) = 0;
     virtual int time_kernel(int kind, uint64_t reps, double* ms) = 0;
     // one round of perturb_primal_costs (incremental_mm_agreement_rounding_cuda.cu:262-331); counts = #one,#zero,#equal,#inconsistent

@@ -23,7 +23,7 @@ from oracle.oracle import Oracle
 pytestmark = pytest.mark.gpu
 
 
-def run_lbfgs_pair(col, costs, precision, iters, threads=1, solver_options=None, **params):
+def run_lbfgs_pair(col, costs, precision, iters, threads=1, solver_options=None, between=None, **params):
     s = bdd_hip_parallel_mma(col, costs, precision=precision, **(solver_options or {}))
     l = bdd_hip_lbfgs(s, **params)
     o = LbfgsOracle(Oracle(col, costs, precision, threads=threads), **params)
@@ -35,6 +35,8 @@ def run_lbfgs_pair(col, costs, precision, iters, threads=1, solver_options=None,
     n_lbfgs = 0
     prev_lb = -np.inf
     for it in range(iters):
+        if between is not None and between(it, s, l, o):   # something done to both sides between two iterations; True: the costs have changed
+            prev_lb = -np.inf
         l.iteration()
         o.iteration()
         st = l.state()
@@ -96,6 +98,50 @@ def test_lbfgs_staged_projection_vs_oracle(precision, options):
     for every shape of the tables: 1 / 2 / 4 / 8 packs per workgroup, 256- / 512- / 1024-thread bins, several rounds per quad."""
     col, costs = random_set_cover(3000 if options.get("vars_per_bin", 0) < 2048 else 20000, 2500, 8, seed=5)
     n_lbfgs, _ = run_lbfgs_pair(col, costs, precision, 40, solver_options=dict(variant_flags=STAGED, **options))
+    assert n_lbfgs >= 10
+
+
+UNFUSED = 0x8000   # variant_flags bit 15: the direction as its own pass (k_lb_direction) instead of inside the projection's first pass
+
+
+@pytest.mark.parametrize("precision", ["double", "float"])
+@pytest.mark.parametrize("flags,params,options", [(STAGED | UNFUSED, {}, {}), (STAGED, dict(history_size=3), {}), (STAGED, dict(history_size=8), dict(waves_per_block=2)),
+                                                  (STAGED | UNFUSED, dict(history_size=3), dict(waves_per_block=1, pack_width=64)),
+                                                  (STAGED, dict(history_size=2), dict(waves_per_block=8, stage_cap=128, vars_per_bin=64))])
+def test_lbfgs_direction_inside_the_projection_vs_oracle(precision, flags, params, options):
+    """Where the projection is staged and all packs are narrow the direction is formed inside its layers -> entries pass straight from the
+    history (k_stage_lincomb; test_lbfgs_staged_projection_vs_oracle runs that path with the default history of five): other history sizes
+    (the run-time form of the kernel), and the separate direction pass, which instances with wide packs and small ones still take."""
+    col, costs = random_set_cover(3000, 2500, 8, seed=11)
+    n_lbfgs, _ = run_lbfgs_pair(col, costs, precision, 40, solver_options=dict(variant_flags=flags, **options), **params)
+    assert n_lbfgs >= 10
+
+
+@pytest.mark.parametrize("flags", [0, STAGED])
+def test_lbfgs_sees_cost_changes_between_iterations(flags):
+    """x = hi - lo + deferred mm reaches the wrapper as a view the backward solve sweep writes (SolverBase::lbfgs_views); whatever else
+    changes costs between two iterations — update_costs through the wrapper (flushes the history, lbfgs_impl.h:343-364), update_costs /
+    set_cost on the solver itself, distribute_delta — must make the next iteration rebuild it."""
+    col, costs = random_set_cover(2500, 2000, 7, seed=3)
+    rng = np.random.Generator(np.random.PCG64(17))
+    nv = col.nr_variables()
+
+    def between(it, s, l, o):
+        if it == 14:      # through the wrapper: history flushed on both sides
+            d = rng.uniform(-0.2, 0.3, nv).round(4)
+            l.update_costs(np.zeros(0), d)
+            o.update_costs(np.zeros(0), d)
+        elif it == 27:    # behind the wrapper's back: the history stays, x must still be the current one
+            d = rng.uniform(-0.05, 0.05, nv).round(4)
+            s.update_costs(np.zeros(0), d)
+            o.s.update_costs(np.zeros(0), d)
+        elif it == 33:
+            s.set_cost(0.125, 5)
+            d = np.zeros(nv); d[5] = 0.125
+            o.s.update_costs(np.zeros(0), d)
+        return it in (14, 27, 33)
+
+    n_lbfgs, _ = run_lbfgs_pair(col, costs, "double", 45, solver_options=dict(variant_flags=flags), between=between)
     assert n_lbfgs >= 10
 
 
