@@ -1005,6 +1005,8 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
     (void)lohi_p;
+    const rsrc_t rxl = make_rsrc(d.x_layer != nullptr ? d.x_layer + l0 : d.x_layer, d.x_layer != nullptr ? d.n_layers - l0 : 0u);  // DevPtrs::x_layer, from the pack's first layer on
+    (void)rxl;
     HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1, slot_first, l0};
     double lb_stag = 0.0;  // costs-to-terminal of the roots below the pack's first hop (staggered packs), for the lower bound
     // node range of hop q; hops below q0 (pipeline run-off) are empty
@@ -1132,7 +1134,13 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
                     uint32_t soff = head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB;  // see k_fwd_narrow
                     asm volatile("" : "+v"(soff));
                     bstore(nc, rs.lohi, soff);
-                    if (head) sDw[La.lg[r] - gl0] = P2{mmv[r], nhi[r] - nlo[r]};  // .y: hi' - lo' for x_layer (the delta pair has been consumed)
+                    if (head) sDw[La.lg[r] - gl0].x = mmv[r];
+                    if (d.x_layer != nullptr) {  // uniform: net_solver_costs in layer order for an L-BFGS wrapper, straight from the hop (as a pass over the staging
+                        // area behind the round it cost 13 us of a 41 us sweep at 10.5 M nodes, tools/xlayer_cost.py)
+                        uint32_t xoff = head ? La.lg[r] * (uint32_t)sizeof(REAL) : OOB;
+                        asm volatile("" : "+v"(xoff));
+                        bstore((nhi[r] - nlo[r]) + mmv[r], rxl, xoff);
+                    }
                 }
                 if (MODE == BWD_MARGINALS) {
                     if (nw_head(w)) {
@@ -1171,21 +1179,6 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
         if (MODE == BWD_SOLVE) {
             if (WPB > 1) __syncthreads(); else wave_sync();
             stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
-            if (d.x_layer != nullptr && k < ng) {  // uniform per wave: this wave's group occupies the layers [gl0, next group) and its own LDS slots
-                const uint32_t nlay = pk.grp_layer_off[g0 + k + 1] - (gl0 + l0);
-                const rsrc_t rml = make_rsrc(d.x_layer, d.n_layers);
-#pragma unroll
-                for (int u = 0; u < STAGE_ITERS; ++u) {  // straight-line: the LDS reads and the stores of all slices are independent
-                    const uint32_t j = lane + 64u * u;
-                    const P2 pv = sDw[j < nlay ? j : 0];
-                    const REAL mv = pv.y + pv.x;  // (hi' - lo') + mm
-                    if (rs.big) {
-                        if (j < nlay) d.x_layer[(size_t)gl0 + l0 + j] = mv;
-                    } else {
-                        bstore(mv, rml, j < nlay ? (gl0 + l0 + j) * (uint32_t)sizeof(REAL) : OOB);
-                    }
-                }
-            }
             if (WPB > 1) __syncthreads();
         }
     }
@@ -1984,6 +1977,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
     (void)lohi_p;
+    REAL* const x_p = d.x_layer != nullptr ? d.x_layer + l0 : nullptr;  // DevPtrs::x_layer, from the pack's first layer on
     const rsrc_t rr = make_rsrc(srec, srec_words);
     const int steps = GEN ? (has_pack ? pk.pack_steps[p] : 0) : 1;  // see k_fwd_narrow2
     REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
@@ -2095,10 +2089,16 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
                 const uint32_t j = lane + 64 * r;
                 hop_store(nc[r], rl, ra[r][2] >> 16, lb[1] * (uint32_t)sizeof(P2));
                 if (!(ra[r][3] & SREC_PAD)) {
-                    lds_st<P2>(dyn_lds, stg + (ra[r][2] & 0xFFFFu), P2{mmv[r], nc[r].y - nc[r].x});  // .y: hi' - lo' for x_layer
+                    lds_st<REAL>(dyn_lds, stg + (ra[r][2] & 0xFFFFu), mmv[r]);
                     lds_st<REAL>(sTw, tn + j * S, t[r]);
                 }
                 if (GEN && j == rt) lb_stag += (double)t[r];
+            }
+            if (x_p != nullptr) {  // uniform: net_solver_costs x = (hi' - lo') + mm in layer order for an L-BFGS wrapper, heads only, straight from the hop
+                // (as a pass over the staging area behind the round it cost 13 us of a 41 us sweep at 10.5 M nodes, tools/xlayer_cost.py)
+                const rsrc_t rx = hop_rsrc(x_p, lb[1], lb[0] - lb[1]);  // ends with the hop's layers: half of RES2_NO_STORE is dropped as well
+#pragma unroll
+                for (int r = 0; r < R; ++r) hop_store((nc[r].y - nc[r].x) + mmv[r], rx, (ra[r][2] >> 16) >> 1, lb[1] * S);
             }
             store_vals<R>(t, Tp, nb, o[0] - o[1], lane, pk.nt_potentials);
             wave_sync();
@@ -2133,21 +2133,6 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
             BDDMMA_STAMP(p, 2);
             stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
             BDDMMA_STAMP(p, 4);
-            if (d.x_layer != nullptr && k < ng) {  // uniform per wave: this wave's group occupies the layers [gl0, next group) and its own LDS slots
-                const uint32_t nlay = pk.grp_layer_off[g0 + k + 1] - (gl0 + l0);
-                const rsrc_t rml = make_rsrc(d.x_layer, d.n_layers);
-#pragma unroll
-                for (int u = 0; u < STAGE_ITERS; ++u) {
-                    const uint32_t j = lane + 64u * u;
-                    const P2 pv = sDw[j < nlay ? j : 0];
-                    const REAL mv = pv.y + pv.x;  // (hi' - lo') + mm
-                    if (rs.big) {
-                        if (j < nlay) d.x_layer[(size_t)gl0 + l0 + j] = mv;
-                    } else {
-                        bstore(mv, rml, j < nlay ? (gl0 + l0 + j) * (uint32_t)sizeof(REAL) : OOB);
-                    }
-                }
-            }
             if (WPB > 1) __syncthreads();
         }
     }
