@@ -2884,7 +2884,15 @@ __device__ __forceinline__ void run_ctl_step(const RunStep& r)
     if (threadIdx.x == 0) c = *r.ctl;
     for (uint32_t vw = wave; vw < 16; vw += nw) {
         double acc = 0.0;
-        for (uint32_t i = vw * 64 + lane; i < r.n; i += 1024) acc += r.part[i];
+        uint32_t i = vw * 64 + lane;
+        for (; i + 7 * 1024u < r.n; i += 8 * 1024u) {  // eight loads in flight, additions in the plain loop's order (see k_lb_reduce)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = r.part[i + u * 1024u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; i < r.n; i += 1024) acc += r.part[i];
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
         if (lane == 0) run_red[vw] = acc;
     }
@@ -3358,11 +3366,23 @@ __global__ void k_set_cost(REAL* __restrict__ hi, const uint32_t* __restrict__ v
 }
 
 // Deterministic fixed-shape reduction of the per-pack partial lower bounds.
-static __global__ void k_lb_reduce(const double* __restrict__ part, uint32_t n, double* __restrict__ out)
+// `seq_out` (pinned host memory, may be null): receives `seq` after the bound has been written — the host polls it instead of waiting for
+// the stream (an interrupt-driven wait was measured to leave the GPU idle for 26 us per bound read in the L-BFGS loop, tools/gaps.sh).
+static __global__ void k_lb_reduce(const double* __restrict__ part, uint32_t n, double* __restrict__ out, uint64_t* seq_out = nullptr, uint64_t seq = 0)
 {
     __shared__ double red[16];
     double acc = 0.0;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) acc += part[i];
+    // a thread's partial sums eight at a time: their loads are in flight together, the additions keep the order of the plain loop (as a
+    // plain loop every element was a dependent round trip: 4.7 us per launch for the 7 813 packs of the 10.5 M-node instance)
+    uint32_t i = threadIdx.x;
+    for (; i + 7 * blockDim.x < n; i += 8 * blockDim.x) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[i + u * blockDim.x];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; i < n; i += blockDim.x) acc += part[i];
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -3370,6 +3390,10 @@ static __global__ void k_lb_reduce(const double* __restrict__ part, uint32_t n, 
         double t = 0.0;
         for (uint32_t i = 0; i < blockDim.x / 64; ++i) t += red[i];
         *out = t;
+        if (seq_out != nullptr) {
+            __threadfence_system();
+            *reinterpret_cast<volatile uint64_t*>(seq_out) = seq;
+        }
     }
 }
 
