@@ -104,6 +104,17 @@ def test_lbfgs_staged_projection_vs_oracle(precision, options):
 UNFUSED = 0x8000   # variant_flags bit 15: the direction as its own pass (k_lb_direction) instead of inside the projection's first pass
 
 
+@pytest.mark.parametrize("flags", [0, STAGED])
+def test_lbfgs_rejected_trial_steps_vs_oracle(flags):
+    """A large initial step and a demanding required increase: most first trial steps are rejected, several trials per iteration, some
+    iterations end without a step (the branches of lbfgs_impl.h:186-215 the default parameters rarely take)."""
+    col, costs = random_set_cover(3000, 2500, 8, seed=29)
+    s_opts = dict(variant_flags=flags)
+    n_lbfgs, _ = run_lbfgs_pair(col, costs, "double", 45, solver_options=s_opts, init_step_size=1e-2, req_rel_lb_increase=5e-2,
+                                step_size_decrease_factor=0.6, step_size_increase_factor=1.3)
+    assert n_lbfgs >= 10
+
+
 @pytest.mark.parametrize("precision", ["double", "float"])
 @pytest.mark.parametrize("flags,params,options", [(STAGED | UNFUSED, {}, {}), (STAGED, dict(history_size=3), {}), (STAGED, dict(history_size=8), dict(waves_per_block=2)),
                                                   (STAGED | UNFUSED, dict(history_size=3), dict(waves_per_block=1, pack_width=64)),
