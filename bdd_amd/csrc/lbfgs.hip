@@ -471,20 +471,30 @@ static __global__ void __launch_bounds__(1024) k_lb_finalize(const double* __res
     }
     const int nd = lb_ndots(ns);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int d = (int)wave; d < nd; d += 16) {
-        // nb <= LB_BLOCKS = 12 x 64: the lane's partial sums in one batch of loads, added in the order of the plain loop
-        double pp[LB_BLOCKS / 64];
+    {
+        // nb <= LB_BLOCKS = 12 x 64 partial sums per dot product, up to four dot products per wave (d = wave, wave + 16, ...): ALL of a lane's
+        // partial sums in one batch of loads (one memory round trip instead of one per dot product), added in the order of the plain loop
+        constexpr int DPW = (lb_ndots(LB_MAXS) + 15) / 16;
+        double pp[DPW][LB_BLOCKS / 64];
 #pragma unroll
-        for (int u = 0; u < LB_BLOCKS / 64; ++u) {
-            const uint32_t b = lane + 64u * u;
-            pp[u] = b < nb ? partial[(size_t)d * nb + b] : 0.0;
+        for (int r = 0; r < DPW; ++r) {
+            const int d = (int)wave + 16 * r;
+#pragma unroll
+            for (int u = 0; u < LB_BLOCKS / 64; ++u) {
+                const uint32_t b = lane + 64u * u;
+                pp[r][u] = (d < nd && b < nb) ? partial[(size_t)d * nb + b] : 0.0;
+            }
         }
-        double a = 0.0;
 #pragma unroll
-        for (int u = 0; u < LB_BLOCKS / 64; ++u)
-            if (lane + 64u * u < nb) a += pp[u];
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
-        if (lane == 0) dots[d] = a;
+        for (int r = 0; r < DPW; ++r) {
+            const int d = (int)wave + 16 * r;
+            double a = 0.0;
+#pragma unroll
+            for (int u = 0; u < LB_BLOCKS / 64; ++u)
+                if (lane + 64u * u < nb) a += pp[r][u];
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+            if (lane == 0 && d < nd) dots[d] = a;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -571,7 +581,7 @@ static __global__ void __launch_bounds__(1024) k_lb_finalize(const double* __res
         if (act) { T.cy[pr] = cy; T.cs[pr] = cs; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && host != nullptr) {  // (null once the history is full: the host no longer reads the count)
         volatile LbHost* h = host;
         h->rho_inv_new = T.rho_inv_new;
         h->count = T.count;
@@ -787,7 +797,8 @@ struct Lbfgs final : bddmma_lbfgs {
             default: LB_STORE(8); break;
         }
 #undef LB_STORE
-        hipLaunchKernelGGL(k_lb_finalize, dim3(1), dim3(1024), 0, st, (const double*)d_gpartial, nb, h_count, p.history_size, want_dir, d_lb, d_lb_host);
+        hipLaunchKernelGGL(k_lb_finalize, dim3(1), dim3(1024), 0, st, (const double*)d_gpartial, nb, h_count, p.history_size, want_dir, d_lb,
+                           h_count < p.history_size ? d_lb_host : (LbHost*)nullptr);
         LHIP(hipGetLastError());
         if (h_count < p.history_size) {
             LHIP(hipStreamSynchronize(st));
