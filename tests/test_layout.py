@@ -434,6 +434,19 @@ def test_automatic_stagger_leaves_flat_rows_side_by_side():
     assert hops() == side                      # grouped by shape (closed-form packing): unchanged
 
 
+def test_large_instances_get_eight_packs_per_workgroup():
+    """The entries a sweep workgroup stages per bin form one run in the entry arrays; where four packs give runs shorter than six entries
+    (many bins: 105 M nodes, or here a small bin size) the automatic choice is eight packs per workgroup (layout.cpp; measured +5-9 % at
+    105 M nodes).  Few bins, few packs or an explicit option: unchanged.  (Eight-pack tables decode back to the input: test_roundtrip_long_bdds_many_groups.)"""
+    col, _ = random_set_cover(300_000, 280_000, 10, seed=2)     # 4 375 packs of 128 slots
+    assert Layout(col).wpb == 4                                 # 74 bins: a workgroup of four stages ~35 entries per bin
+    many = Layout(col, vars_per_bin=256)                        # 1 172 bins: ~2 entries
+    assert many.np_n >= 4096 and many.wpb == 8
+    assert Layout(col, vars_per_bin=256, waves_per_block=4).wpb == 4
+    small, _ = random_set_cover(100_000, 50_000, 10, seed=2)
+    assert Layout(small, vars_per_bin=64).wpb <= 4              # too few packs for workgroups of eight to fill the chip
+
+
 def test_pack_stagger_is_bounded():
     col, _ = random_set_cover(200, 100, 5, seed=2)
     with pytest.raises(capi.BddMmaError, match="pack_stagger"):
