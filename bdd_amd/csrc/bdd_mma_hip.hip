@@ -94,6 +94,13 @@ struct SolverT final : SolverBase {
     RunStep run_step{};                               // {partials, count, ctl, host}: what the launch that ends an iteration gets
     REAL* d_x_layer = nullptr;    // net_solver_costs x = (hi - lo) + deferred mm in layer order, written by the backward solve sweeps once an L-BFGS wrapper uses them
     bool x_layer_valid = false;   // true after a backward solve sweep, false after anything else that writes arc costs or deferred values
+    // every call that changes arc costs other than through a solve sweep: both sweep states and the x view are stale, and an L-BFGS wrapper's
+    // pending bound is no longer "the bound of the current costs" (SolverBase::cost_epoch)
+    void costs_changed()
+    {
+        fwd_valid = bwd_valid = x_layer_valid = false;
+        ++cost_epoch;
+    }
     CostQuot* d_cost_q = nullptr;      // update_costs: per-variable quotients (kernels.hpp: k_cost_quotients)
     uint8_t* d_cost_flags = nullptr;
     uint32_t* d_counts = nullptr;
@@ -1031,7 +1038,7 @@ struct SolverT final : SolverBase {
         HIPCHK(hipMemsetAsync(d_delta_var, 0, 2 * n_vars * sizeof(REAL), stream));  // bdd_cuda_base.cu:1428
         HIPCHK(hipMemsetAsync(d_delta_lay, 0, 2 * n_layers * sizeof(REAL), stream));
         delta_var_valid = true;
-        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
+        costs_changed();
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
@@ -1090,7 +1097,7 @@ struct SolverT final : SolverBase {
         HIPCHK(hipSetDevice(device));
         int rc = elem_precision == BDDMMA_F64 ? update_both<double>(lo, n_lo, hi, n_hi, on_device) : update_both<float>(lo, n_lo, hi, n_hi, on_device);
         if (rc) return rc;
-        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
+        costs_changed();
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
@@ -1103,7 +1110,7 @@ struct SolverT final : SolverBase {
             const REAL cc = REAL(c / (double)(k1 - k0));
             hipLaunchKernelGGL((k_set_cost<REAL>), dim3(cdiv(k1 - k0, 64)), dim3(64), 0, stream, d_hi, d_var_layers, k0, k1, cc);
         }
-        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
+        costs_changed();
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
@@ -1152,7 +1159,7 @@ struct SolverT final : SolverBase {
             hipLaunchKernelGGL((k_layers_to_entries<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_tmp0, d_lpos, d_mm_binned, (uint32_t)n_layers);
         }
         HIPCHK(hipStreamSynchronize(stream));
-        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
+        costs_changed();
         return BDDMMA_OK;
     }
     int primal_objective_vec(void* out, int on_device) override
@@ -1285,7 +1292,7 @@ struct SolverT final : SolverBase {
         const REAL* p = (const REAL*)g;
         if (!on_device) { HIPCHK(hipMemcpyAsync(d_tmp0, g, n_layers * sizeof(REAL), hipMemcpyHostToDevice, stream)); p = d_tmp0; }
         hipLaunchKernelGGL((k_gradient_step<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_hi, p, REAL(step), (uint32_t)n_layers);
-        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
+        costs_changed();
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
@@ -1411,13 +1418,13 @@ struct SolverT final : SolverBase {
             } else {
                 hipLaunchKernelGGL((k_gradient_step<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_hi, (const REAL*)d_proj_dir, REAL(step), (uint32_t)n_layers);
             }
-            fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
+            costs_changed();
             HIPCHK(hipGetLastError());
             return BDDMMA_OK;
         }
         if (!d_proj_q) { err = "gradient_step_projected without projection_means"; return BDDMMA_ERR_INVALID_ARGUMENT; }
         hipLaunchKernelGGL((k_gradient_step_projected<REAL>), dim3(cdiv(n_layers, 256)), dim3(256), 0, stream, d_hi, (const REAL*)g, d_proj_q, (const uint32_t*)d_var, REAL(step), (uint32_t)n_layers);
-        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
+        costs_changed();
         HIPCHK(hipGetLastError());
         return BDDMMA_OK;
     }
@@ -1510,7 +1517,7 @@ struct SolverT final : SolverBase {
         float f = 0.f;
         HIPCHK(hipEventElapsedTime(&f, ev_t0, ev_t1));
         *ms = f;
-        fwd_valid = bwd_valid = x_layer_valid = false, ++cost_epoch;
+        costs_changed();
         x_layer_valid = false;
 #ifdef BDDMMA_STAMPS
         if (const char* path = std::getenv("BDDMMA_STAMPS_FILE")) {  // one more launch with per-wave phase stamps (kernels.hpp: BDDMMA_STAMP)
