@@ -133,6 +133,11 @@ struct SolverT final : SolverBase {
     // streaming solve sweeps on per-lane records (kernels.hpp: k_fwd_narrow2 / k_bwd_narrow2)
     bool use_narrow2 = false, narrow_gen = false;  // narrow_gen: layers wider than two nodes or staggered packs -> the kernels' general form
     uint32_t *d_srec = nullptr, *d_srec_off = nullptr;
+    // the streaming sweeps of the narrow packs start from the resident headers where those hold (one stage group per pack, one round per quad, no
+    // staggered packs; layout.hpp: struct Resident) — variant_flags bit 16: from the hop / group / round tables as before
+    bool res_hdr_ok = false;
+    const uint32_t* n2_hdr_pack() const { return (res_hdr_ok && !(opts_variant & 0x10000u)) ? d_pack_hdr : nullptr; }
+    const uint32_t* n2_hdr_quad() const { return (res_hdr_ok && !(opts_variant & 0x10000u)) ? d_quad_hdr : nullptr; }
     uint32_t srec_words = 0;
     uint32_t huge_pack_width = 0;
     unsigned char* d_huge_scratch = nullptr;  // frontier arrays of the huge packs (global memory instead of LDS)
@@ -362,6 +367,7 @@ struct SolverT final : SolverBase {
         // kernels are latency-bound (few waves per SIMD); resident_sweeps = 1 turns them off, = 2 forces them on
         if ((rc = upload(&d_pack_hdr, L.res.pack_hdr, 34))) return rc;
         if ((rc = upload(&d_quad_hdr, L.res.quad_hdr, 35))) return rc;
+        res_hdr_ok = L.res.ok && nb_.n_packs > 0;
         if (nb_.n_packs && L.res.ok) {
             res_ns = (L.res.max_slots + 255) / 256 * 256;
             res_nl = (L.res.max_layers + 127) / 128 * 128;
@@ -506,9 +512,10 @@ struct SolverT final : SolverBase {
     }
     PackDev pdev(const PackBufs& b, uint32_t lb_base, uint32_t seg_off = 0) const
     {
+        const bool narrow_set = &b == &nb_;
         return PackDev{b.pack_hop_ptr, b.hop_node_off, b.hop_layer_off, b.pack_steps, b.hop_root, d_pack_word_off,
                        d_pack_group_ptr, d_grp_layer_off, d_grp_hop_end, d_quad_round_ptr, d_cs_ptr, stage_cap, seg_off, b.n_packs, lb_base,
-                       nt_potentials, xcd_chunk()};
+                       nt_potentials, xcd_chunk(), narrow_set ? n2_hdr_pack() : nullptr, narrow_set ? n2_hdr_quad() : nullptr};
     }
     // dynamic LDS of a narrow launch with `w` waves per workgroup: `base` bytes of the kernel's own use, then (only when some pack has
     // layers wider than two nodes) the seg_min2 scratch, 128 REALs per wave

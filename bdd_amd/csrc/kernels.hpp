@@ -99,6 +99,11 @@ struct PackDev {
     uint32_t lb_base;  // index of this set's first pack in lb_partial
     uint32_t nt_potentials;  // streaming narrow sweeps, double: store F / T non-temporally (see hop_store)
     uint32_t xcd_chunk;      // block_to_pack: workgroups per chunk of the XCD-interleaved map (0: contiguous eighths)
+    // narrow packs, streaming sweeps: the resident headers (layout.hpp: struct Resident — 8 words per pack, 4 per quad) where they hold for the
+    // whole set (one stage group per pack, one round per quad, no staggered packs), else null: a wave then has its pack's hop / slot / layer /
+    // word ranges and its quad's range of the staging tables after ONE round trip instead of two dependent ones each
+    const uint32_t* hdr_pack;
+    const uint32_t* hdr_quad;
 };
 
 // -DBDDMMA_STAMPS (tools/build_variant.sh): per-wave s_memrealtime stamps at the phase boundaries of the small-instance kernels, for
@@ -472,11 +477,12 @@ struct NarrowRs {
 // (entry, slot) pairs stay in registers for the write-back of the min-marginal differences.
 constexpr int STAGE_ITERS = 10;  // stage_cap <= 64 * STAGE_ITERS
 
+// (two halves, so that a kernel that knows its round's item range early — resident headers — can have the tables on their way while it sets
+// up its pipeline: stage_load_tables issues the table loads, stage_load_pairs the dependent pair loads and the scatter into LDS)
 template <typename REAL, int WPB>
-__device__ __forceinline__ void stage_load(typename Pair<REAL>::type* sD, uint32_t (&e)[STAGE_ITERS], uint32_t (&sl)[STAGE_ITERS],
-                                           const NarrowRs<REAL>& rs, uint32_t c0, uint32_t cnt, uint32_t tid)
+__device__ __forceinline__ void stage_load_tables(uint32_t (&e)[STAGE_ITERS], uint32_t (&sl)[STAGE_ITERS], const NarrowRs<REAL>& rs, uint32_t c0, uint32_t cnt,
+                                                  uint32_t tid)
 {
-    using P2 = typename Pair<REAL>::type;
     // (the round's range of the staging tables, rebased: item offsets stay small whatever the tables' size)
     const rsrc_t rce = make_rsrc(rs.cse_p + c0, cnt), rcs = make_rsrc(rs.css_p + c0, cnt);
 #pragma unroll
@@ -485,6 +491,12 @@ __device__ __forceinline__ void stage_load(typename Pair<REAL>::type* sD, uint32
         e[u] = bload_u32(rce, i * 4u);   // past the round: dropped
         sl[u] = bload_u16(rcs, i * 2u);
     }
+}
+template <typename REAL, int WPB>
+__device__ __forceinline__ void stage_load_pairs(typename Pair<REAL>::type* sD, const uint32_t (&e)[STAGE_ITERS], const uint32_t (&sl)[STAGE_ITERS],
+                                                 const NarrowRs<REAL>& rs, uint32_t cnt, uint32_t tid)
+{
+    using P2 = typename Pair<REAL>::type;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         P2 v[STAGE_ITERS / 2];
@@ -510,6 +522,13 @@ __device__ __forceinline__ void stage_load(typename Pair<REAL>::type* sD, uint32
             if (i < cnt) sD[sl[k]] = v[u];
         }
     }
+}
+template <typename REAL, int WPB>
+__device__ __forceinline__ void stage_load(typename Pair<REAL>::type* sD, uint32_t (&e)[STAGE_ITERS], uint32_t (&sl)[STAGE_ITERS],
+                                           const NarrowRs<REAL>& rs, uint32_t c0, uint32_t cnt, uint32_t tid)
+{
+    stage_load_tables<REAL, WPB>(e, sl, rs, c0, cnt, tid);
+    stage_load_pairs<REAL, WPB>(sD, e, sl, rs, cnt, tid);
 }
 
 template <typename REAL, int WPB>
@@ -736,12 +755,18 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     BDDMMA_EXIT_IF(quad >= n_quads, d)  // uniform for the workgroup
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;  // the last quad may be partial: such a wave only helps staging
-    const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
+    const bool hdr = pk.hdr_pack != nullptr;  // uniform: resident headers (PackDev::hdr_pack)
+    const uint32_t* const hp = hdr ? pk.hdr_pack + 8 * (size_t)(has_pack ? p : 0) : nullptr;
+    const uint32_t q0 = !has_pack ? 0 : (hdr ? hp[4] : pk.pack_hop_ptr[p]);
+    const uint32_t q1 = !has_pack ? 0 : (hdr ? q0 + (hp[5] & 0xFFFFu) : pk.pack_hop_ptr[p + 1]);
+    const uint32_t c0_h = (hdr && MODE == FWD_SOLVE) ? pk.hdr_quad[4 * (size_t)quad] : 0, cnt_h = (hdr && MODE == FWD_SOLVE) ? pk.hdr_quad[4 * (size_t)quad + 1] : 0;
     const int steps = SEG ? (has_pack ? pk.pack_steps[p] : 0) : 1;
     const REAL INF = inf_v<REAL>();
-    const uint32_t slot_first = has_pack ? pk.hop_node_off[q0] : 0, l0 = has_pack ? pk.hop_layer_off[q0] : 0;  // the pack's first slot / layer: everything below is relative to them (HopWindow)
+    const uint32_t slot_first = !has_pack ? 0 : (hdr ? hp[0] : pk.hop_node_off[q0]), l0 = !has_pack ? 0 : (hdr ? hp[2] : pk.hop_layer_off[q0]);  // the pack's first slot / layer: everything below is relative to them (HopWindow)
     NarrowRs<REAL> rs(d);
     rs.rebase_layers(d, l0);
+    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
+    if (hdr && MODE == FWD_SOLVE) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
     REAL* const Tp = d.T + slot_first;
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
@@ -751,7 +776,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1, slot_first, l0};
     auto off = [&](uint32_t q) { return hw.node_off(q); };
     // word address of slot s of this pack = s + wd (the pack's words live in a sequence shared by all packs of its structure)
-    const uint32_t wd = has_pack ? pk.pack_word_off[p] : 0;  // (slot offsets are relative to the pack's first slot)
+    const uint32_t wd = !has_pack ? 0 : (hdr ? hp[6] : pk.pack_word_off[p]);  // (slot offsets are relative to the pack's first slot)
     // Software pipeline with a look-ahead of D hops: at the start of hop q the wave holds the node words of hops q .. q+2D-1, the
     // costs-from-terminal of hops q+2 .. q+D+1 (those of hop q+1 are already in LDS) and the layer data of hops q .. q+D-1; during hop q
     // it requests the words of hop q+2D, T of hop q+D+2 and — from the words of hop q+D, which were requested D hops ago — the layer
@@ -802,19 +827,25 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     int cur = 0;
     uint32_t q = q0;
     uint32_t rt = NO_ROOT;  // root slot of hop q when a BDD starts there (staggered packs); the first hop's roots are set up above
-    const uint32_t g0 = (MODE == FWD_SOLVE && has_pack) ? pk.pack_group_ptr[p] : 0;
-    const uint32_t ng = (MODE == FWD_SOLVE && has_pack) ? pk.pack_group_ptr[p + 1] - g0 : 0;
-    const uint32_t r0 = (MODE == FWD_SOLVE) ? pk.quad_round_ptr[quad] : 0;
-    const uint32_t n_rounds = (MODE == FWD_SOLVE) ? pk.quad_round_ptr[quad + 1] - r0 : 1;
+    const uint32_t g0 = (MODE == FWD_SOLVE && has_pack && !hdr) ? pk.pack_group_ptr[p] : 0;
+    const uint32_t ng = (MODE == FWD_SOLVE && has_pack) ? (hdr ? 1u : pk.pack_group_ptr[p + 1] - g0) : 0;
+    const uint32_t r0 = (MODE == FWD_SOLVE && !hdr) ? pk.quad_round_ptr[quad] : 0;
+    const uint32_t n_rounds = (MODE == FWD_SOLVE && !hdr) ? pk.quad_round_ptr[quad + 1] - r0 : 1;
     P2* sDw = sD + (size_t)wave * pk.stage_cap;  // this wave's slots of the staging area
     for (uint32_t k = 0; k < n_rounds; ++k) {
         uint32_t gl0 = 0, cnt = 0, qe = q1;
-        uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
         if (MODE == FWD_SOLVE) {
-            const uint32_t c0 = pk.cs_ptr[r0 + k];
-            cnt = pk.cs_ptr[r0 + k + 1] - c0;
-            stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
-            if (k < ng) {
+            if (hdr) {
+                cnt = cnt_h;
+                stage_load_pairs<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
+            } else {
+                const uint32_t c0 = pk.cs_ptr[r0 + k];
+                cnt = pk.cs_ptr[r0 + k + 1] - c0;
+                stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
+            }
+            if (hdr) {
+                qe = has_pack ? q1 : q;  // one group: the whole pack
+            } else if (k < ng) {
                 gl0 = pk.grp_layer_off[g0 + k] - l0;
                 qe = pk.grp_hop_end[g0 + k];
             } else {
@@ -995,12 +1026,18 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
-    const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
+    const bool hdr = pk.hdr_pack != nullptr;  // uniform: resident headers (PackDev::hdr_pack)
+    const uint32_t* const hp = hdr ? pk.hdr_pack + 8 * (size_t)(has_pack ? p : 0) : nullptr;
+    const uint32_t q0 = !has_pack ? 0 : (hdr ? hp[4] : pk.pack_hop_ptr[p]);
+    const uint32_t q1 = !has_pack ? 0 : (hdr ? q0 + (hp[5] & 0xFFFFu) : pk.pack_hop_ptr[p + 1]);
+    const uint32_t c0_h = (hdr && MODE == BWD_SOLVE) ? pk.hdr_quad[4 * (size_t)quad] : 0, cnt_h = (hdr && MODE == BWD_SOLVE) ? pk.hdr_quad[4 * (size_t)quad + 1] : 0;
     const int steps = SEG ? (has_pack ? pk.pack_steps[p] : 0) : 1;
     const REAL INF = inf_v<REAL>();
-    const uint32_t slot_first = has_pack ? pk.hop_node_off[q0] : 0, l0 = has_pack ? pk.hop_layer_off[q0] : 0;  // the pack's first slot / layer: everything below is relative to them (HopWindow)
+    const uint32_t slot_first = !has_pack ? 0 : (hdr ? hp[0] : pk.hop_node_off[q0]), l0 = !has_pack ? 0 : (hdr ? hp[2] : pk.hop_layer_off[q0]);  // the pack's first slot / layer: everything below is relative to them (HopWindow)
     NarrowRs<REAL> rs(d);
     rs.rebase_layers(d, l0);
+    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
+    if (hdr && MODE == BWD_SOLVE) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
     REAL* const Tp = d.T + slot_first;
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
@@ -1011,7 +1048,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     double lb_stag = 0.0;  // costs-to-terminal of the roots below the pack's first hop (staggered packs), for the lower bound
     // node range of hop q; hops below q0 (pipeline run-off) are empty
     auto nb_of = [&](uint32_t q) { return hw.node_off(q); };
-    const uint32_t wd = has_pack ? pk.pack_word_off[p] : 0;  // (slot offsets are relative to the pack's first slot)  // see k_fwd_narrow
+    const uint32_t wd = !has_pack ? 0 : (hdr ? hp[6] : pk.pack_word_off[p]);  // (slot offsets are relative to the pack's first slot)  // see k_fwd_narrow
     // Software pipeline with a look-ahead of D hops, mirrored from k_fwd_narrow: before hop q is processed (q counts down) the wave
     // holds the node words of hops q .. q-2D+1, the costs-from-root of hops q .. q-D and the layer data of hops q .. q-D+1; during the hop
     // it requests the words of hop q-2D, F of hop q-D-1 and the layer data of hop q-D.  o[i] = first slot of hop q+1-i (hops below q0
@@ -1047,19 +1084,25 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             for (int r = 0; r < R; ++r) wr[i][r] = nw_pad_word(64 * R);
     }
     int cur = 0;
-    const uint32_t g0 = (MODE == BWD_SOLVE && has_pack) ? pk.pack_group_ptr[p] : 0;
-    const uint32_t ng = (MODE == BWD_SOLVE && has_pack) ? pk.pack_group_ptr[p + 1] - g0 : 0;
-    const uint32_t r0 = (MODE == BWD_SOLVE) ? pk.quad_round_ptr[quad] : 0;
-    const uint32_t n_rounds = (MODE == BWD_SOLVE) ? pk.quad_round_ptr[quad + 1] - r0 : 1;
+    const uint32_t g0 = (MODE == BWD_SOLVE && has_pack && !hdr) ? pk.pack_group_ptr[p] : 0;
+    const uint32_t ng = (MODE == BWD_SOLVE && has_pack) ? (hdr ? 1u : pk.pack_group_ptr[p + 1] - g0) : 0;
+    const uint32_t r0 = (MODE == BWD_SOLVE && !hdr) ? pk.quad_round_ptr[quad] : 0;
+    const uint32_t n_rounds = (MODE == BWD_SOLVE && !hdr) ? pk.quad_round_ptr[quad + 1] - r0 : 1;
     P2* sDw = sD + (size_t)wave * pk.stage_cap;
     for (uint32_t k = n_rounds; k-- > 0;) {  // same rounds as the forward sweep, in reverse
         uint32_t gl0 = 0, cnt = 0, qs = q0;
-        uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
         if (MODE == BWD_SOLVE) {
-            const uint32_t c0 = pk.cs_ptr[r0 + k];
-            cnt = pk.cs_ptr[r0 + k + 1] - c0;
-            stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
-            if (k < ng) {
+            if (hdr) {
+                cnt = cnt_h;
+                stage_load_pairs<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
+            } else {
+                const uint32_t c0 = pk.cs_ptr[r0 + k];
+                cnt = pk.cs_ptr[r0 + k + 1] - c0;
+                stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
+            }
+            if (hdr) {
+                qs = has_pack ? q0 : q;  // one group: the whole pack
+            } else if (k < ng) {
                 gl0 = pk.grp_layer_off[g0 + k] - l0;
                 qs = (k == 0) ? q0 : pk.grp_hop_end[g0 + k - 1];
             } else {
@@ -1728,7 +1771,8 @@ __device__ __forceinline__ void load_costs(typename Pair<REAL>::type (&c)[R], co
 
 template <typename REAL, int R, int WPB, bool GEN, int LA = BDDMMA_LOOKAHEAD>
 __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ srec,
-                                                 const uint32_t* __restrict__ srec_off, uint32_t srec_words, REAL omega, uint32_t block_id)
+                                                 const uint32_t* __restrict__ srec_off, uint32_t srec_words, REAL omega, uint32_t block_id,
+                                                 const uint32_t* __restrict__ hdr_pack = nullptr, const uint32_t* __restrict__ hdr_quad = nullptr)
 {
     constexpr int W = 64 * R;
     constexpr uint32_t S = sizeof(REAL);
@@ -1749,17 +1793,27 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
     BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
-    const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
+    // Resident headers (layout.hpp: struct Resident; given when every pack has one stage group and every quad one round): the pack's hop /
+    // slot / layer ranges and the quad's range of the staging tables in ONE round trip — without them q0 -> {first slot, first layer} and
+    // quad -> round -> item range are two dependent round trips each, and all workgroups of a launch walk those chains at the same time
+    // (the first ~10 us of a sweep move little: profiles/r04_sweep_timeline.txt).
+    const bool hdr = hdr_pack != nullptr;  // uniform
+    const uint32_t* const hp = hdr ? hdr_pack + 8 * (size_t)(has_pack ? p : 0) : nullptr;
+    const uint32_t q0 = !has_pack ? 0 : (hdr ? hp[4] : pk.pack_hop_ptr[p]);
+    const uint32_t q1 = !has_pack ? 0 : (hdr ? q0 + (hp[5] & 0xFFFFu) : pk.pack_hop_ptr[p + 1]);
     const uint32_t rbase = has_pack ? srec_off[p] : 0;
+    const uint32_t c0_h = hdr ? hdr_quad[4 * (size_t)quad] : 0, cnt_h = hdr ? hdr_quad[4 * (size_t)quad + 1] : 0;
     BDDMMA_STAMP(p, 0);
     // GEN: packs with layers wider than two nodes (LDS segmented minimum, seg_min2: per-wave scratch behind the rest of the dynamic LDS) and
     // staggered packs (a BDD root below the pack's first hop, PackDev::hop_root)
     const int steps = GEN ? (has_pack ? pk.pack_steps[p] : 0) : 1;
     REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
     const REAL INF = inf_v<REAL>();
-    const uint32_t slot_first = has_pack ? pk.hop_node_off[q0] : 0, l0 = has_pack ? pk.hop_layer_off[q0] : 0;  // the pack's first slot / layer: everything below is relative to them (HopWindow)
+    const uint32_t slot_first = !has_pack ? 0 : (hdr ? hp[0] : pk.hop_node_off[q0]), l0 = !has_pack ? 0 : (hdr ? hp[2] : pk.hop_layer_off[q0]);  // the pack's first slot / layer: everything below is relative to them (HopWindow)
     NarrowRs<REAL> rs(d);
     rs.rebase_layers(d, l0);
+    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
+    if (hdr) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
     REAL* const Tp = d.T + slot_first;
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
@@ -1814,19 +1868,25 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
     uint32_t cur = 0;
     uint32_t q = q0;
     uint32_t rt = NO_ROOT;  // GEN: root slot of hop q when a BDD starts there; the first hop's roots are set up above
-    const uint32_t g0 = has_pack ? pk.pack_group_ptr[p] : 0;
-    const uint32_t ng = has_pack ? pk.pack_group_ptr[p + 1] - g0 : 0;
-    const uint32_t r0 = pk.quad_round_ptr[quad];
-    const uint32_t n_rounds = pk.quad_round_ptr[quad + 1] - r0;
+    const uint32_t g0 = (has_pack && !hdr) ? pk.pack_group_ptr[p] : 0;
+    const uint32_t ng = !has_pack ? 0 : (hdr ? 1u : pk.pack_group_ptr[p + 1] - g0);
+    const uint32_t r0 = hdr ? 0 : pk.quad_round_ptr[quad];
+    const uint32_t n_rounds = hdr ? 1u : pk.quad_round_ptr[quad + 1] - r0;
     const uint32_t db = (uint32_t)wave * pk.stage_cap * (uint32_t)sizeof(P2);  // this wave's slots of the staging area
     for (uint32_t k = 0; k < n_rounds; ++k) {
         uint32_t gl0 = 0, cnt = 0, qe = q1;
-        uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
         {
-            const uint32_t c0 = pk.cs_ptr[r0 + k];
-            cnt = pk.cs_ptr[r0 + k + 1] - c0;
-            stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
-            if (k < ng) {
+            if (hdr) {
+                cnt = cnt_h;
+                stage_load_pairs<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
+            } else {
+                const uint32_t c0 = pk.cs_ptr[r0 + k];
+                cnt = pk.cs_ptr[r0 + k + 1] - c0;
+                stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
+            }
+            if (hdr) {
+                qe = has_pack ? q1 : q;  // one group: the whole pack
+            } else if (k < ng) {
                 gl0 = pk.grp_layer_off[g0 + k] - l0;
                 qe = pk.grp_hop_end[g0 + k];
             } else {
@@ -1942,12 +2002,13 @@ template <typename REAL, int R, int WPB, bool GEN>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N2_WAVES(REAL, R)))) k_fwd_narrow2(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ srec, const uint32_t* __restrict__ srec_off,
                                                           uint32_t srec_words, REAL omega)
 {
-    fwd_narrow2_body<REAL, R, WPB, GEN>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x);
+    fwd_narrow2_body<REAL, R, WPB, GEN>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x, pk.hdr_pack, pk.hdr_quad);
 }
 
 template <typename REAL, int R, int WPB, bool GEN, int LA = BDDMMA_LOOKAHEAD>
 __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ srec,
-                                                 const uint32_t* __restrict__ srec_off, uint32_t srec_words, REAL omega, uint32_t block_id)
+                                                 const uint32_t* __restrict__ srec_off, uint32_t srec_words, REAL omega, uint32_t block_id,
+                                                 const uint32_t* __restrict__ hdr_pack = nullptr, const uint32_t* __restrict__ hdr_quad = nullptr)
 {
     constexpr int W = 64 * R;
     constexpr uint32_t S = sizeof(REAL);
@@ -1966,13 +2027,19 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
     BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
-    const uint32_t q0 = has_pack ? pk.pack_hop_ptr[p] : 0, q1 = has_pack ? pk.pack_hop_ptr[p + 1] : 0;
+    const bool hdr = hdr_pack != nullptr;  // uniform: resident headers, see fwd_narrow2_body
+    const uint32_t* const hp = hdr ? hdr_pack + 8 * (size_t)(has_pack ? p : 0) : nullptr;
+    const uint32_t q0 = !has_pack ? 0 : (hdr ? hp[4] : pk.pack_hop_ptr[p]);
+    const uint32_t q1 = !has_pack ? 0 : (hdr ? q0 + (hp[5] & 0xFFFFu) : pk.pack_hop_ptr[p + 1]);
     const uint32_t rbase = has_pack ? srec_off[p] : 0;
+    const uint32_t c0_h = hdr ? hdr_quad[4 * (size_t)quad] : 0, cnt_h = hdr ? hdr_quad[4 * (size_t)quad + 1] : 0;
     BDDMMA_STAMP(p, 0);
     const REAL INF = inf_v<REAL>();
-    const uint32_t slot_first = has_pack ? pk.hop_node_off[q0] : 0, l0 = has_pack ? pk.hop_layer_off[q0] : 0;  // the pack's first slot / layer: everything below is relative to them (HopWindow)
+    const uint32_t slot_first = !has_pack ? 0 : (hdr ? hp[0] : pk.hop_node_off[q0]), l0 = !has_pack ? 0 : (hdr ? hp[2] : pk.hop_layer_off[q0]);  // the pack's first slot / layer: everything below is relative to them (HopWindow)
     NarrowRs<REAL> rs(d);
     rs.rebase_layers(d, l0);
+    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
+    if (hdr) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
     REAL* const Tp = d.T + slot_first;
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
@@ -2020,20 +2087,26 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
             for (int r = 0; r < R; ++r) rc[i][r] = u4v{0u, 0u, 0u, SREC_PAD};
     }
     uint32_t cur = 0;
-    const uint32_t g0 = has_pack ? pk.pack_group_ptr[p] : 0;
-    const uint32_t ng = has_pack ? pk.pack_group_ptr[p + 1] - g0 : 0;
-    const uint32_t r0 = pk.quad_round_ptr[quad];
-    const uint32_t n_rounds = pk.quad_round_ptr[quad + 1] - r0;
+    const uint32_t g0 = (has_pack && !hdr) ? pk.pack_group_ptr[p] : 0;
+    const uint32_t ng = !has_pack ? 0 : (hdr ? 1u : pk.pack_group_ptr[p + 1] - g0);
+    const uint32_t r0 = hdr ? 0 : pk.quad_round_ptr[quad];
+    const uint32_t n_rounds = hdr ? 1u : pk.quad_round_ptr[quad + 1] - r0;
     P2* sDw = sD + (size_t)wave * pk.stage_cap;
     const uint32_t db = (uint32_t)wave * pk.stage_cap * (uint32_t)sizeof(P2);
     for (uint32_t k = n_rounds; k-- > 0;) {  // same rounds as the forward sweep, in reverse
         uint32_t gl0 = 0, cnt = 0, qs = q0;
-        uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
         {
-            const uint32_t c0 = pk.cs_ptr[r0 + k];
-            cnt = pk.cs_ptr[r0 + k + 1] - c0;
-            stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
-            if (k < ng) {
+            if (hdr) {
+                cnt = cnt_h;
+                stage_load_pairs<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
+            } else {
+                const uint32_t c0 = pk.cs_ptr[r0 + k];
+                cnt = pk.cs_ptr[r0 + k + 1] - c0;
+                stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
+            }
+            if (hdr) {
+                qs = has_pack ? q0 : q;  // one group: the whole pack
+            } else if (k < ng) {
                 gl0 = pk.grp_layer_off[g0 + k] - l0;
                 qs = (k == 0) ? q0 : pk.grp_hop_end[g0 + k - 1];
             } else {
@@ -2153,7 +2226,7 @@ template <typename REAL, int R, int WPB, bool GEN>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N2_WAVES(REAL, R)))) k_bwd_narrow2(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ srec, const uint32_t* __restrict__ srec_off,
                                                           uint32_t srec_words, REAL omega)
 {
-    bwd_narrow2_body<REAL, R, WPB, GEN>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x);
+    bwd_narrow2_body<REAL, R, WPB, GEN>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x, pk.hdr_pack, pk.hdr_quad);
 }
 
 // =============================================================================================

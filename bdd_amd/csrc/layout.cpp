@@ -896,13 +896,15 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         // (layers of four packs) / bins entries long — 10 at 10.5 M nodes float, 1 at 105 M, where the sweeps fall from 5.7 to 4.2 TB/s on their
         // counter bytes.  Eight packs double it.  Measured (tools/kbench.py --wpb 4 / 8, one box each, it/s): 10.5 M nodes float (run 10.4) 8 546 /
         // 8 488, double (5.2) 4 225 / 4 251; 15.8 M 4 437 / 4 414 and 2 659 / 2 707; 21 M 3 516 / 3 557 and 1 832 / 1 868; 42 M 1 620 / 1 632 and
-        // 884 / 906; 105 M 596 / 630 and 314 / 331.  Rule: 8 when the run of four packs is shorter than 6 entries.
+        // 884 / 906; 105 M 596 / 630 and 314 / 331.  With the sweeps starting from the resident headers (PackDev::hdr_pack; later in the round)
+        // the double 10.5 M case is a tie (4 276 / 4 273, 4 319 / 4 263: four packs keep the per-lane records, eight exceed their 64 KB), 105 M
+        // still 599 / 640 and 318 / 332.  Rule: 8 when the run of four packs is shorter than 4.5 entries.
         if (!(opts && opts->waves_per_block) && X.waves_per_block == 4 && Pn >= 8 * 512 && X.n_bins > 0) {
             const double run4 = (double)L.n_layers / ((double)Pn / 4.0) / (double)X.n_bins;
             // (LDS of a sweep workgroup of eight, as SolverT::init adds it up: staging pairs + frontier / potentials / hop window per wave + the
             // segmented-minimum scratch)
             const uint64_t lds8 = 8ull * X.stage_cap * 2 * real_size + 8ull * (3ull * (W + 2) * real_size + 2 * 64 * 4 + 2) + 8ull * 128 * real_size;
-            if (run4 < 6.0 && lds8 <= 150 * 1024) X.waves_per_block = 8;
+            if (run4 < 4.5 && lds8 <= 150 * 1024) X.waves_per_block = 8;
         }
         // Instances of a few thousand narrow packs and nothing else are candidates for the resident sweeps, whose workgroups should be all in
         // flight at once: one pack per workgroup packs the CUs' LDS best (a wave's 12-21 KB region; k_fwd_res2).  The entry arrays of such an

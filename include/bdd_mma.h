@@ -96,7 +96,9 @@ typedef struct bddmma_options {
                                   bit 13: per-lane records for the streaming solve sweeps also where packs do not share them
                                   bit 14: the staging transfers with 64-bit addresses, as for arrays of 4 GiB and more (no resident sweeps)
                                   bit 15: the L-BFGS direction as its own pass (default: formed inside the projection's first pass where that is staged
-                                          and all packs are narrow) */
+                                          and all packs are narrow)
+                                  bit 16: the streaming sweeps of the narrow packs find their pack and their staging range through the hop / group /
+                                          round tables (default: from the resident headers where every pack has one stage group) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
                                   instance (NOTES.md section 6: the sweeps are bound by instructions issued, not by latency), kept for experiments */

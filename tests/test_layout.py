@@ -435,8 +435,8 @@ def test_automatic_stagger_leaves_flat_rows_side_by_side():
 
 
 def test_large_instances_get_eight_packs_per_workgroup():
-    """The entries a sweep workgroup stages per bin form one run in the entry arrays; where four packs give runs shorter than six entries
-    (many bins: 105 M nodes, or here a small bin size) the automatic choice is eight packs per workgroup (layout.cpp; measured +5-9 % at
+    """The entries a sweep workgroup stages per bin form one run in the entry arrays; where four packs give runs shorter than 4.5 entries
+    (many bins: 105 M nodes, or here a small bin size; threshold 4.5 entries) the automatic choice is eight packs per workgroup (layout.cpp; measured +5-9 % at
     105 M nodes).  Few bins, few packs or an explicit option: unchanged.  (Eight-pack tables decode back to the input: test_roundtrip_long_bdds_many_groups.)"""
     col, _ = random_set_cover(300_000, 280_000, 10, seed=2)     # 4 375 packs of 128 slots
     assert Layout(col).wpb == 4                                 # 74 bins: a workgroup of four stages ~35 entries per bin
