@@ -48,6 +48,39 @@ bool ilp_input::feasible(const std::vector<char>& x) const
     return true;
 }
 
+ilp_input ilp_input::reduce(const std::set<size_t>& zeros, const std::set<size_t>& ones) const
+{
+    ilp_input r;
+    r.constant = constant;
+    std::vector<size_t> map(nr_variables(), SIZE_MAX);
+    for (size_t i = 0; i < nr_variables(); ++i) {
+        if (zeros.count(i) && ones.count(i)) throw std::runtime_error("variable '" + var_names[i] + "' is fixed to 0 and to 1");
+        if (ones.count(i)) r.constant += objective[i];
+        if (!zeros.count(i) && !ones.count(i)) {
+            map[i] = r.var(var_names[i]);
+            r.objective[map[i]] = objective[i];
+        }
+    }
+    for (const auto& c : constraints) {
+        constraint n;
+        n.name = c.name;
+        n.ineq = c.ineq;
+        n.rhs = c.rhs;
+        for (size_t k = 0; k < c.variables.size(); ++k) {
+            const size_t v = c.variables[k];
+            if (zeros.count(v)) continue;
+            if (ones.count(v)) { n.rhs -= c.coefficients[k]; continue; }
+            n.coefficients.push_back(c.coefficients[k]);
+            n.variables.push_back(map[v]);
+        }
+        if (!n.variables.empty()) { r.constraints.push_back(std::move(n)); continue; }
+        // nothing left: the row reads `0 {<=,=,>=} rhs`
+        const bool ok = c.ineq == ineq_t::le ? 0 <= n.rhs : c.ineq == ineq_t::eq ? 0 == n.rhs : 0 >= n.rhs;
+        if (!ok) throw std::runtime_error("reduced model not feasible due to violated constraint " + c.name);
+    }
+    return r;
+}
+
 void ilp_input::normalize()
 {
     for (auto& c : constraints) {
@@ -155,6 +188,14 @@ std::vector<term> scan_terms(const std::string& s, const char* what, bool allow_
         double sign = 1.0;
         bool has_sign = false;
         if (s[p] == '+' || s[p] == '-') { sign = s[p] == '-' ? -1.0 : 1.0; has_sign = true; ++p; }
+        if (!has_sign && !out.empty()) {
+            // The reference grammar wants a sign in front of every term but the first (ILP_parser.cpp:54-60,100-104;
+            // OPB_parser.cpp:43,57).  In a row `x y`, `x*y` and `2 x * y` are products of variables
+            // (inequality_monomial, ILP_parser.cpp:86-98) which to_bdds() has no converter for: refused, not read as sums.
+            if (std::string(what) == "constraint")
+                throw std::runtime_error("nonlinear constraint (product of variables) near '" + s.substr(start, 40) + "' is not supported");
+            throw std::runtime_error(std::string("cannot parse ") + what + ": term without a sign near '" + s.substr(start, 40) + "'");
+        }
         skip();
         double num = 1.0;
         const size_t nn = scan_number(s, p, &num);
@@ -174,6 +215,59 @@ std::vector<term> scan_terms(const std::string& s, const char* what, bool allow_
         throw std::runtime_error(std::string("cannot parse ") + what + " near '" + s.substr(start, 40) + "'");
     }
     return out;
+}
+
+// One line of the Bounds section.  The reference's four forms (ILP_parser.cpp:128-131: `x = v`, `x <= v`, `v <= x`,
+// `lb <= x <= ub`, v in {0, 1}) and their mirror images with `>=`; its own test inputs hold `x2 >= 0`
+// (test/test_ILP_parser.cpp:15).  Anything else is an error: the line would change the model if it meant something.
+void scan_bound(const ilp_input& ilp, const std::string& line, std::set<size_t>& zeros, std::set<size_t>& ones)
+{
+    std::vector<std::string> tok;  // operands and relations in turn
+    size_t p = 0;
+    while (p < line.size()) {
+        if (std::isspace((unsigned char)line[p])) { ++p; continue; }
+        if ((line[p] == '<' || line[p] == '>') && p + 1 < line.size() && line[p + 1] == '=') { tok.push_back(line.substr(p, 2)); p += 2; continue; }
+        if (line[p] == '=') { tok.push_back("="); ++p; continue; }
+        size_t q = p;
+        if (is_var_start(line[p])) while (q < line.size() && is_var_char(line[q])) ++q;
+        else while (q < line.size() && !std::isspace((unsigned char)line[q]) && line[q] != '<' && line[q] != '>' && line[q] != '=') ++q;
+        if (q == p) ++q;  // a lone `<` or `>`: its own token, refused below
+        tok.push_back(line.substr(p, q - p));
+        p = q;
+    }
+    const auto bad = [&](const std::string& why) { return std::runtime_error("cannot read Bounds line '" + line + "': " + why); };
+    const auto is_rel = [](const std::string& t) { return t == "<=" || t == ">=" || t == "="; };
+    const auto value = [&](const std::string& t) -> int {
+        if (t == "0" || t == "+0" || t == "0.0") return 0;
+        if (t == "1" || t == "+1" || t == "1.0") return 1;
+        throw bad("a bound of a binary variable is 0 or 1");
+    };
+    const auto variable = [&](const std::string& t) -> size_t {
+        if (!ilp.has_var(t)) throw bad("variable '" + t + "' is in no row and not in the objective");
+        return ilp.var_index(t);
+    };
+    const auto lower = [&](size_t v, int b) { if (b == 1) ones.insert(v); };   // b <= x
+    const auto upper = [&](size_t v, int b) { if (b == 0) zeros.insert(v); };  // x <= b
+    size_t v = 0;
+    if (tok.size() == 3 && is_rel(tok[1])) {
+        const bool var_first = is_var_start(tok[0][0]);
+        v = variable(var_first ? tok[0] : tok[2]);
+        const int b = value(var_first ? tok[2] : tok[0]);
+        const std::string& rel = tok[1];
+        if (rel == "=") { lower(v, b); upper(v, b); }
+        else if ((rel == "<=") == var_first) upper(v, b);
+        else lower(v, b);
+    } else if (tok.size() == 5 && tok[1] == tok[3] && (tok[1] == "<=" || tok[1] == ">=")) {
+        v = variable(tok[2]);
+        const int a = value(tok[0]), c = value(tok[4]);
+        const int lb = tok[1] == "<=" ? a : c, ub = tok[1] == "<=" ? c : a;
+        if (lb > ub) throw bad("lower bound above upper bound");
+        lower(v, lb);
+        upper(v, ub);
+    } else {
+        throw bad("expected `x = v`, `x <= v`, `x >= v`, `v <= x`, `v >= x` or `lb <= x <= ub`");
+    }
+    if (zeros.count(v) && ones.count(v)) throw bad("variable is fixed to 0 and to 1");
 }
 
 bool is_keyword_line(const std::string& line, std::initializer_list<const char*> words)
@@ -224,10 +318,11 @@ ilp_input parse_lp(const std::string& text)
     for (const auto& t : scan_terms(obj, "objective", true, &ilp.constant)) ilp.objective[ilp.var(t.name)] += t.coeff;
 
     std::string pending;
+    size_t i_sec = lines.size();
     for (size_t i = i_st + 1; i < lines.size(); ++i) {
         const std::string s = trim(lines[i]);
         if (s.empty()) continue;
-        if (is_keyword_line(s, {"end", "bounds", "binaries", "binary", "generals", "general", "coalesce"})) break;
+        if (is_keyword_line(s, {"end", "bounds", "binaries", "binary", "generals", "general", "coalesce"})) { i_sec = i; break; }
         pending = trim(pending + " " + s);
         // relation: first of <=, >=, =
         size_t rp = std::string::npos, rl = 0;
@@ -269,6 +364,20 @@ ilp_input parse_lp(const std::string& text)
         pending.clear();
     }
     if (!pending.empty()) throw std::runtime_error("incomplete constraint: '" + pending.substr(0, 60) + "'");
+
+    // Sections behind the rows.  `Bounds` lines fix variables (ILP_parser.cpp:128-131,343-436); the lists of the other
+    // sections are skipped, every variable being binary anyway (:144, `until<end_line>`).
+    std::set<size_t> zeros, ones;
+    bool in_bounds = false;
+    for (size_t i = i_sec; i < lines.size(); ++i) {
+        const std::string s = trim(lines[i]);
+        if (s.empty()) continue;
+        if (is_keyword_line(s, {"end"})) break;
+        if (is_keyword_line(s, {"bounds"})) { in_bounds = true; continue; }
+        if (is_keyword_line(s, {"binaries", "binary", "generals", "general", "coalesce"})) { in_bounds = false; continue; }
+        if (in_bounds) scan_bound(ilp, s, zeros, ones);
+    }
+    if (!zeros.empty() || !ones.empty()) return ilp.reduce(zeros, ones);
     return ilp;
 }
 

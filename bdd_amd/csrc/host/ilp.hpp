@@ -1,11 +1,13 @@
 // ilp.hpp — 0/1 ILP model, reader for the .lp subset the reference parses, ILP -> QBDDs (host C++17).
 //
 // Mirrors LPMP::ILP_input and the PEGTL grammar of src/ILP/ILP_parser.cpp:24-140 (Minimize, objective terms,
-// Subject To, optionally named rows, Bounds / Binaries sections ignored, End); variable indices are assigned
+// Subject To, optionally named rows, Bounds = variable fixations, Binaries / Generals lists skipped, End; products
+// of variables in a row are refused); variable indices are assigned
 // in order of first appearance, objective first (ILP_parser.cpp:246-254, :316-327).  to_bdds() is
 // bdd_preprocessor::add_ilp for linear rows (src/bdd_conversion/bdd_preprocessor.cpp:123-336).
 // bdd_amd/ilp.py is the same reader in Python; tests/test_native_host.py checks they agree.
 #pragma once
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -34,6 +36,12 @@ public:
 
     size_t nr_variables() const { return var_names.size(); }
     size_t var(const std::string& name);  // index of `name`, created on first use
+    bool has_var(const std::string& name) const { return index_.count(name) != 0; }
+    size_t var_index(const std::string& name) const { return index_.at(name); }
+    // ILP_input::reduce (src/ILP/ILP_input.cpp:508-591): the model without the fixed variables — a variable fixed to 1
+    // moves its objective coefficient into the constant and its row coefficients to the right-hand sides; a row that
+    // loses every term is checked (`0 <rel> rhs`, throws if violated) and dropped.  Remaining variables keep their order.
+    ilp_input reduce(const std::set<size_t>& zeros, const std::set<size_t>& ones) const;
     double evaluate(const std::vector<char>& x) const;
     bool feasible(const std::vector<char>& x) const;
     std::string write_lp() const;

@@ -3,7 +3,8 @@
 Mirrors (host-side, Python) the input stage either side of the hot path:
   * ``ILP`` / ``parse_lp``: reference ``LPMP::ILP_input`` + the PEGTL grammar in
     src/ILP/ILP_parser.cpp:24-140 (``Minimize``, objective terms, ``Subject To``, optionally
-    named rows, ``Bounds`` / ``Binaries`` sections ignored, ``End``).  Variable indices are
+    named rows, ``Bounds`` = variable fixations applied as ``ILP_input::reduce`` does, ``Binaries`` /
+    ``Generals`` lists skipped, ``End``; products of variables in a row are refused).  Variable indices are
     assigned in order of first appearance, objective first (ILP_parser.cpp:246-254, :316-327).
   * ``to_bdd_collection``: ``bdd_preprocessor::add_ilp`` (src/bdd_conversion/bdd_preprocessor.cpp:123-336)
     for linear rows: simplex rows -> ``simplex_constraint`` (:172-188), everything else ->
@@ -72,6 +73,38 @@ class ILP:
                 return False
         return True
 
+    def reduce(self, zeros, ones) -> "ILP":
+        """ILP_input::reduce (src/ILP/ILP_input.cpp:508-591): the model without the fixed variables.  A variable
+        fixed to 1 moves its objective coefficient into the constant and its row coefficients to the right-hand
+        sides; a row that loses every term is checked (`0 <rel> rhs`) and dropped; the others keep their order."""
+        zeros, ones = set(zeros), set(ones)
+        r = ILP()
+        r.constant = self.constant
+        vmap = {}
+        for i, name in enumerate(self.var_names):
+            if i in zeros and i in ones:
+                raise ValueError(f"variable '{name}' is fixed to 0 and to 1")
+            if i in ones:
+                r.constant += self.objective[i]
+            elif i not in zeros:
+                vmap[i] = r.var(name)
+                r.objective[vmap[i]] = self.objective[i]
+        for c in self.constraints:
+            cs, vs, rhs = [], [], c.rhs
+            for a, v in zip(c.coefficients, c.variables):
+                if v in zeros:
+                    continue
+                if v in ones:
+                    rhs -= a
+                    continue
+                cs.append(a)
+                vs.append(vmap[v])
+            if vs:
+                r.constraints.append(Constraint(cs, vs, c.ineq, rhs, c.name))
+            elif not (0 <= rhs if c.ineq == "<=" else (0 == rhs if c.ineq == "=" else 0 >= rhs)):
+                raise ValueError(f"reduced model not feasible due to violated constraint {c.name}")
+        return r
+
     def write_lp(self) -> str:
         def term(c, name, first):
             sign = "-" if c < 0 else ("" if first else "+")
@@ -109,11 +142,76 @@ def _parse_terms(s: str, what: str):
             if not rest:
                 break
             raise ValueError(f"cannot parse {what} near '{rest[:40]}'")
+        if m.group(1) is None and terms:
+            # every term but the first carries a sign (ILP_parser.cpp:54-60,100-104; OPB_parser.cpp:43,57); in a row,
+            # `x y`, `x*y`, `2 x * y` are products of variables (inequality_monomial, :86-98): refused, not read as sums
+            near = s[pos:].strip()[:40]
+            if what == "constraint":
+                raise ValueError(f"nonlinear constraint (product of variables) near '{near}' is not supported")
+            raise ValueError(f"cannot parse {what}: term without a sign near '{near}'")
         sign = -1.0 if m.group(1) == "-" else 1.0
         coeff = float(m.group(2)) if m.group(2) is not None else 1.0
         terms.append((sign * coeff, m.group(3)))
         pos = m.end()
     return terms
+
+
+_BOUND_TOK = re.compile(rf"\s*(<=|>=|=|{_VAR}|[^\s<>=]+)")
+
+
+def _parse_bound(ilp: "ILP", line: str, zeros: set, ones: set) -> None:
+    """One line of the Bounds section: the reference's four forms (ILP_parser.cpp:128-131: `x = v`, `x <= v`,
+    `v <= x`, `lb <= x <= ub`, v in {0, 1}) and their mirror images with `>=` (the reference's own test input has
+    `x2 >= 0`, test/test_ILP_parser.cpp:15).  Anything else raises: it would change the model if it meant something."""
+    tok = _BOUND_TOK.findall(line)
+
+    def bad(why):
+        return ValueError(f"cannot read Bounds line '{line}': {why}")
+
+    def value(t):
+        if t in ("0", "+0", "0.0"):
+            return 0
+        if t in ("1", "+1", "1.0"):
+            return 1
+        raise bad("a bound of a binary variable is 0 or 1")
+
+    def variable(t):
+        if t not in ilp._index:
+            raise bad(f"variable '{t}' is in no row and not in the objective")
+        return ilp._index[t]
+
+    def lower(v, b):      # b <= x
+        if b == 1:
+            ones.add(v)
+
+    def upper(v, b):      # x <= b
+        if b == 0:
+            zeros.add(v)
+
+    rel = ("<=", ">=", "=")
+    if len(tok) == 3 and tok[1] in rel:
+        var_first = tok[0][0].isalpha()
+        v = variable(tok[0] if var_first else tok[2])
+        b = value(tok[2] if var_first else tok[0])
+        if tok[1] == "=":
+            lower(v, b)
+            upper(v, b)
+        elif (tok[1] == "<=") == var_first:
+            upper(v, b)
+        else:
+            lower(v, b)
+    elif len(tok) == 5 and tok[1] == tok[3] and tok[1] in ("<=", ">="):
+        v = variable(tok[2])
+        a, c = value(tok[0]), value(tok[4])
+        lb, ub = (a, c) if tok[1] == "<=" else (c, a)
+        if lb > ub:
+            raise bad("lower bound above upper bound")
+        lower(v, lb)
+        upper(v, ub)
+    else:
+        raise bad("expected `x = v`, `x <= v`, `x >= v`, `v <= x`, `v >= x` or `lb <= x <= ub`")
+    if v in zeros and v in ones:
+        raise bad("variable is fixed to 0 and to 1")
 
 
 def parse_lp(text: str) -> ILP:
@@ -139,11 +237,14 @@ def parse_lp(text: str) -> ILP:
         ilp.objective[ilp.var(name)] += c
     # constraints: a row may span several lines; it ends at the line holding the relation + rhs
     pending = ""
-    for ln in rest.splitlines():
+    rest_lines = rest.splitlines()
+    i_sec = len(rest_lines)
+    for i, ln in enumerate(rest_lines):
         s = ln.strip()
         if not s:
             continue
         if re.match(r"^end\s*$", s, re.I) or _SECTION.match(s):
+            i_sec = i
             break
         pending = (pending + " " + s).strip()
         mi = _INEQ.search(pending)
@@ -166,6 +267,23 @@ def parse_lp(text: str) -> ILP:
         pending = ""
     if pending:
         raise ValueError(f"incomplete constraint: '{pending[:60]}'")
+    # sections behind the rows: Bounds lines fix variables (ILP_parser.cpp:128-131,343-436), the lists of the other
+    # sections are skipped — every variable is binary anyway (:144, `until<end_line>`)
+    zeros, ones, in_bounds = set(), set(), False
+    for ln in rest_lines[i_sec:]:
+        s = ln.strip()
+        if not s:
+            continue
+        if re.match(r"^end\s*$", s, re.I):
+            break
+        ms = _SECTION.match(s)
+        if ms:
+            in_bounds = ms.group(1).lower() == "bounds"
+            continue
+        if in_bounds:
+            _parse_bound(ilp, s, zeros, ones)
+    if zeros or ones:
+        return ilp.reduce(zeros, ones)
     return ilp
 
 

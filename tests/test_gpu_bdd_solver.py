@@ -223,3 +223,53 @@ def test_export_keys_of_both_drivers(tmp_path):
         for b in range(col.nr_bdds()):
             got = (tmp_path / f"{tag}_graph_{b}.dot").read_text()
             assert sorted(got.splitlines()) == sorted(col.export_graphviz(b).splitlines())
+
+
+SHORT_MRF_CHAIN = """Minimize
+3 mu_1_0 + 1 mu_1_1
+- 1 mu_2_0 + 0 mu_2_1
++ 1 mu_00 + 2 mu_10 + 1 mu_01 + 0 mu_11
+Subject To
+mu_1_0 + mu_1_1 = 1
+mu_2_0 + mu_2_1 = 1
+mu_00 + mu_10 + mu_01 + mu_11 = 1
+mu_1_0 - mu_00 - mu_01 = 0
+mu_1_1 - mu_10 - mu_11 = 0
+mu_2_0 - mu_00 - mu_10 = 0
+mu_2_1 - mu_01 - mu_11 = 0
+"""
+
+
+@pytest.mark.parametrize("front_end", ["python", "pybind", "bdd_solver_cl"])
+def test_bounds_fixations_known_answers(front_end, tmp_path):
+    """test/test_bdd_solver_fix_variable.cpp:6-48: short_mrf_chain has bound 1; with mu_2_1 fixed to 0 it is 2, with mu_1_1 = 0 on top
+    of that 3 (1e-6, 20 iterations there).  The fixations arrive through the `Bounds` section of the .lp text here
+    (ILP_parser.cpp:128-131,343-436 -> ILP_input::reduce), which every front end reads with the same two readers."""
+    import os
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bdd_amd", "csrc", "bdd_solver_cl")
+    for bounds, want in (("", 1.0), ("Bounds\n mu_2_1 = 0\n", 2.0), ("Bounds\n mu_2_1 = 0\n mu_1_1 <= 0\n", 3.0), ("Bounds\n 1 <= mu_2_0\n 0 <= mu_1_1 <= 0\n", 3.0)):
+        c = cfg(SHORT_MRF_CHAIN + bounds + "End\n")
+        if front_end == "python":
+            lb = bdd_solver(c, quiet=True).solve().lower_bound()
+        elif front_end == "pybind":
+            from bdd_amd import bdd_solver_py
+            lb = bdd_solver_py.bdd_solver(c, quiet=True).solve().lower_bound()
+        else:
+            p = tmp_path / "c.json"
+            p.write_text(json.dumps(c))
+            out = subprocess.run([exe, "--batch", str(p), "--devices", "0", "--quiet"], capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0, out.stderr
+            lb = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")][0]["lower_bound"]
+        assert abs(lb - want) <= 1e-6, (bounds, lb)
+    # a row of products is refused by every front end (test/test_ILP_parser.cpp:28-33 is the reference's vector for the form)
+    bad = cfg("Minimize\nx1 + x2 + x3\nSubject To\nx1*x2 + x3 >= 1\nEnd\n")
+    if front_end == "bdd_solver_cl":
+        out = subprocess.run([exe, json.dumps(bad)], capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "nonlinear" in (out.stderr + out.stdout)
+    else:
+        with pytest.raises(Exception, match="nonlinear"):
+            if front_end == "python":
+                bdd_solver(bad, quiet=True)
+            else:
+                from bdd_amd import bdd_solver_py
+                bdd_solver_py.bdd_solver(bad, quiet=True)
