@@ -70,6 +70,7 @@ struct SolverT final : SolverBase {
     bool exch_small = false, exch_medium = false;
     bool big = false;  // some array reaches 4 GiB (or variant_flags bit 14, for the tests): kernels.hpp DevPtrs::big
     uint32_t opts_variant = 0;  // bddmma_options.variant_flags (A/B switches of kernel variants)
+    uint32_t n_cus = 256, lds_cu = 160 * 1024;  // hipDeviceProp of `device` (init)
     bool narrow_seg = false;  // some narrow pack has layers wider than two nodes: seg_min2 goes through LDS and needs scratch
     uint32_t vars_per_bin = 0, n_bins = 0, stage_cap = 0, stage_lds = 0, exch_lds = 0, n_narrow_layers = 0;
     double *d_lb_partial = nullptr, *d_lb = nullptr;
@@ -214,6 +215,13 @@ struct SolverT final : SolverBase {
     int init(const HostLayout& L, const bddmma_options* opts)
     {
         HIPCHK(hipSetDevice(device));
+        {
+            ChipInfo chip;
+            std::string e;
+            if (query_chip(device, &chip, e)) { err = e; return BDDMMA_ERR_DEVICE; }
+            n_cus = chip.n_cus;
+            lds_cu = chip.lds_bytes;
+        }
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreate(&ev_t0));
         HIPCHK(hipEventCreate(&ev_t1));
@@ -314,7 +322,7 @@ struct SolverT final : SolverBase {
         // attribute (pack_width 256, double, 4 waves per block is ~67 KiB); above what a CU has the options are refused here,
         // not at the first sweep.
         const uint32_t narrow_static = L.ex.waves_per_block * (3 * (pack_width + 2) * (uint32_t)sizeof(REAL) + 2 * 64 * 4 + 2) + seg_bytes(L.ex.waves_per_block);
-        if (exch_lds > 160 * 1024 - 1024 || stage_lds + narrow_static > 160 * 1024 - 1024) {
+        if (exch_lds > lds_cu - 1024 || stage_lds + narrow_static > lds_cu - 1024) {
             err = "vars_per_bin / stage_cap / waves_per_block need more LDS than a CU has (" + std::to_string(stage_lds + narrow_static) + " B per sweep workgroup)";
             return BDDMMA_ERR_INVALID_ARGUMENT;
         }
@@ -338,9 +346,9 @@ struct SolverT final : SolverBase {
         if ((rc = dalloc(&d_delta_var, 2 * n_vars))) return rc;
         if ((rc = dalloc(&d_delta_c, 2 * n_vars))) return rc;
         if ((rc = dalloc(&d_lb_partial, nb_.n_packs + wb_.n_packs + hb_.n_packs))) return rc;
-        HIPCHK(hipHostMalloc((void**)&h_lb, 3 * sizeof(double), hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void**)&h_lb, 3 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         HIPCHK(hipHostGetDevicePointer((void**)&d_lb, h_lb, 0));
-        HIPCHK(hipHostMalloc((void**)&h_lb_seq, 3 * sizeof(uint64_t), hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void**)&h_lb_seq, 3 * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent));
         HIPCHK(hipHostGetDevicePointer((void**)&d_lb_seq, h_lb_seq, 0));
         std::memset((void*)h_lb_seq, 0, 3 * sizeof(uint64_t));
         if ((rc = dalloc(&d_counts, 4))) return rc;
@@ -374,13 +382,13 @@ struct SolverT final : SolverBase {
             res_lds = wpb * stage_cap * 2 * (uint32_t)sizeof(REAL) + wpb * res_wave_bytes(sizeof(REAL), res_ns, res_nl);
             const uint32_t static_lds = wpb * (2 * (pack_width + 2) * (uint32_t)sizeof(REAL) + 512) + seg_bytes(wpb);
             const uint32_t mode = opts ? opts->resident_sweeps : 0;
-            const bool fits = res_lds + static_lds <= 160 * 1024 - 512;
+            const bool fits = res_lds + static_lds <= lds_cu - 512;
             // automatic choice: small instances only — fewer than 3 waves per SIMD (2880 packs: with the round-2 kernels the resident sweeps
             // win by 3-6 % from 1 900 to 2 800 packs and lose 10 % at 3 125), all workgroups in flight at once with their LDS slices.  Measured (float, sweep fwd / bwd in us, streaming vs resident): 1 M nodes (1563 packs) 12.1 / 12.2 vs 11.4 / 10.5;
             // 2 M 18.5 / 19.1 vs 20.5 / 19.7; 4 M 27.3 / 25.5 vs 41.8 / 39.0; 10.5 M 50 / 45 vs 108 / 98 — with more waves per SIMD the
             // streaming kernels hide their latency and the resident ones only lose occupancy to their LDS footprint.
-            const uint64_t wgs_per_cu = fits ? (160 * 1024) / (res_lds + static_lds) : 0;
-            const bool all_in_flight = nb_.n_packs <= 2880 && (uint64_t)cdiv(nb_.n_packs, wpb) <= 256ull * std::min<uint64_t>(wgs_per_cu, 2048 / (64 * wpb));
+            const uint64_t wgs_per_cu = fits ? (lds_cu) / (res_lds + static_lds) : 0;
+            const bool all_in_flight = (uint64_t)nb_.n_packs * 256 <= 2880ull * n_cus && (uint64_t)cdiv(nb_.n_packs, wpb) <= (uint64_t)n_cus * std::min<uint64_t>(wgs_per_cu, 2048 / (64 * wpb));
             use_res = fits && mode != 1 && (mode == 2 || all_in_flight) && !big;
             // Second generation (kernels.hpp: k_fwd_res2 / k_bwd_res2), packs of 64 slots with layers of <= 2 nodes: its LDS regions are sized in
             // whole 1 KiB pieces of REAL values (no node words in LDS).  Chosen, like the first, while the packs are (nearly) all in flight at
@@ -389,11 +397,11 @@ struct SolverT final : SolverBase {
             // at once) 16.3 k -> 16.7 k, 4.2 M (128-slot streaming packs) 14.5 k -> 13.4 k; double gains only with every pack in flight.
             // variant_flags bit 11: first generation only.
             if (pack_width == 64 && !narrow_seg && mode != 1 && !big && !(opts && (opts->variant_flags & 0x800u))) {
-                res2_ns = (L.res.max_slots + 1024 / (uint32_t)sizeof(REAL) - 1) / (1024 / (uint32_t)sizeof(REAL)) * (1024 / (uint32_t)sizeof(REAL));
-                res2_nl = (L.res.max_layers + 512 / (uint32_t)sizeof(REAL) - 1) / (512 / (uint32_t)sizeof(REAL)) * (512 / (uint32_t)sizeof(REAL));
+                res2_ns = res2_slot_capacity((uint32_t)sizeof(REAL), L.res.max_slots);
+                res2_nl = res2_layer_capacity((uint32_t)sizeof(REAL), L.res.max_layers);
                 res2_lds = wpb * stage_cap * 2 * (uint32_t)sizeof(REAL) + wpb * res2_wave_bytes(sizeof(REAL), res2_ns, res2_nl);
-                const uint64_t wgs2 = res2_lds + 256 <= 160 * 1024 ? std::min<uint64_t>((160 * 1024) / (res2_lds + 256), 2048 / (64 * wpb)) : 0;
-                const uint64_t in_flight = 256ull * wgs2 * wpb;  // packs the chip holds at once
+                const uint64_t wgs2 = res2_lds + 256 <= lds_cu ? std::min<uint64_t>((lds_cu) / (res2_lds + 256), 2048 / (64 * wpb)) : 0;
+                const uint64_t in_flight = (uint64_t)n_cus * wgs2 * wpb;  // packs the chip holds at once
                 const bool auto_ok = sizeof(REAL) == 4 ? (uint64_t)nb_.n_packs * 100 <= in_flight * 145 : (uint64_t)nb_.n_packs <= in_flight;
                 if (wgs2 && (mode == 2 || auto_ok)) {
                     Res2Records R2;
@@ -465,7 +473,7 @@ struct SolverT final : SolverBase {
             wide_npt = (wide_pack_width + wide_threads - 1) / wide_threads;
             wide_npt = wide_npt <= 1 ? 1 : (wide_npt <= 2 ? 2 : 4);
             wide_lds = (uint32_t)wide2_lds_bytes(sizeof(REAL), wide_pack_width, true);
-            if (wide_lds > 160 * 1024 || wide_pack_width > 4096) {
+            if (wide_lds > lds_cu || wide_pack_width > 4096) {
                 err = "wide_pack_width " + std::to_string(wide_pack_width) + " needs " + std::to_string(wide_lds) + " B of LDS (> 160 KiB)";
                 return BDDMMA_ERR_UNSUPPORTED;
             }
@@ -796,6 +804,7 @@ struct SolverT final : SolverBase {
         const auto t0 = std::chrono::steady_clock::now();
         uint32_t spins = 0;
         while (*w != lb_seq_expect[k]) {
+            __builtin_ia32_pause();
             if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) {
                 HIPCHK(hipStreamSynchronize(stream));
                 if (*w != lb_seq_expect[k]) { err = "lower bound: the reduce kernel did not report"; return BDDMMA_ERR_DEVICE; }
@@ -902,7 +911,7 @@ struct SolverT final : SolverBase {
         auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
         if (!d_run_ctl) {
             HIPCHK(hipMalloc((void**)&d_run_ctl, sizeof(RunCtl)));
-            HIPCHK(hipHostMalloc((void**)&h_run, sizeof(RunHost), hipHostMallocMapped));
+            HIPCHK(hipHostMalloc((void**)&h_run, sizeof(RunHost), hipHostMallocMapped | hipHostMallocCoherent));
             HIPCHK(hipHostGetDevicePointer((void**)&d_run_host, h_run, 0));
         }
         double lb_initial;
@@ -1624,6 +1633,18 @@ int device_count()
 {
     int count = 0;
     return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
+
+int query_chip(int device, ChipInfo* out, std::string& err)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return BDDMMA_OK;  // create_solver reports it; defaults meanwhile
+    hipDeviceProp_t prop;
+    const hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return BDDMMA_ERR_DEVICE; }
+    if (prop.multiProcessorCount > 0) out->n_cus = (uint32_t)prop.multiProcessorCount;
+    if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) out->lds_bytes = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
+    return BDDMMA_OK;
 }
 
 int create_solver(SolverBase** out, int precision, int device, const HostLayout& L, const bddmma_options* opts, std::string& err)

@@ -68,7 +68,10 @@ int bddmma_create(bddmma_solver** out, int precision, int device, const bddmma_i
             t_last = now;
         };
         HostLayout L;
-        int rc = build_layout(instr, bdd_delims, n_bdds, opts, L, g_err, false, precision == BDDMMA_F64 ? 8 : 4);
+        ChipInfo chip;
+        int rc = query_chip(device, &chip, g_err);
+        if (rc) return rc;
+        rc = build_layout(instr, bdd_delims, n_bdds, opts, L, g_err, false, precision == BDDMMA_F64 ? 8 : 4, chip);
         if (rc) return rc;
         lap("host layout");
         SolverBase* impl = nullptr;
@@ -805,7 +808,7 @@ int bddmma_layout_res2_records(const bddmma_layout* l, int real_size, uint32_t* 
 {
     if (!l || !info || (real_size != 4 && real_size != 8)) return BDDMMA_ERR_INVALID_ARGUMENT;
     const HostLayout& L = l->L;
-    const uint32_t ns = (L.res.max_slots + 255) / 256 * 256, nl = (L.res.max_layers + 127) / 128 * 128;  // as SolverT::init
+    const uint32_t ns = res2_slot_capacity((uint32_t)real_size, L.res.max_slots), nl = res2_layer_capacity((uint32_t)real_size, L.res.max_layers);  // as SolverT::init
     Res2Records R;
     build_res2_records(L, (uint32_t)real_size, ns, nl, R);
     info[0] = R.ok ? 1u : 0u; info[1] = (uint32_t)R.rec.size(); info[2] = ns; info[3] = nl; info[4] = R.max_hops;

@@ -143,9 +143,10 @@ int bddilp_write_bdd_lp(const bddmma_instruction* instr, const uint64_t* delims,
 {
     return guarded(BDDILP_ERR_INVALID_ARGUMENT, [&] {
         if (!instr || !delims || !path || (!costs && n_costs)) throw std::runtime_error("null argument");
+        const bdd_store store = store_of(instr, delims, n_bdds);  // validated before the file is opened (opening truncates it)
         std::ofstream f(path);
         if (!f) throw std::runtime_error(std::string("cannot write ") + path);
-        store_of(instr, delims, n_bdds).write_bdd_lp(f, std::vector<double>(costs, costs + n_costs));
+        store.write_bdd_lp(f, std::vector<double>(costs, costs + n_costs));
         return BDDILP_OK;
     });
 }
@@ -154,9 +155,10 @@ int bddilp_export_graphviz(const bddmma_instruction* instr, const uint64_t* deli
     return guarded(BDDILP_ERR_INVALID_ARGUMENT, [&] {
         if (!instr || !delims || !path) throw std::runtime_error("null argument");
         if (bdd_nr >= n_bdds) throw std::runtime_error("bdd_nr out of range");
+        const bdd_store store = store_of(instr, delims, n_bdds);
         std::ofstream f(path);
         if (!f) throw std::runtime_error(std::string("cannot write ") + path);
-        store_of(instr, delims, n_bdds).export_graphviz(bdd_nr, f);
+        store.export_graphviz(bdd_nr, f);
         return BDDILP_OK;
     });
 }

@@ -186,12 +186,12 @@ struct PackBuilder {
 }  // namespace
 
 static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
-                          const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps, uint32_t real_size);
+                          const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps, uint32_t real_size, ChipInfo chip);
 
 int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
-                 const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps, uint32_t real_size)
+                 const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps, uint32_t real_size, ChipInfo chip)
 {
-    int rc = build_layout_w(instr, delims, n_bdds, opts, L, err, keep_debug_maps, real_size);
+    int rc = build_layout_w(instr, delims, n_bdds, opts, L, err, keep_debug_maps, real_size, chip);
     // Few packs (small instance, or few but long BDDs): a sweep is then bound by the latency of one pack's
     // hop chain, so prefer more, narrower packs.  Only when the caller left pack_width open.
     // (threshold measured on random set cover: 2.1 M nodes = 1 563 packs of 128: 64-wide 18.5 / 19.1 us per sweep vs 19.7 / 18.3; 4.2 M nodes =
@@ -209,13 +209,13 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
         o.pack_width = 64;
         HostLayout L2;
         std::string err2;
-        if (build_layout_w(instr, delims, n_bdds, &o, L2, err2, keep_debug_maps, real_size) == BDDMMA_OK) L = std::move(L2);
+        if (build_layout_w(instr, delims, n_bdds, &o, L2, err2, keep_debug_maps, real_size, chip) == BDDMMA_OK) L = std::move(L2);
     }
     return rc;
 }
 
 static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
-                          const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps, uint32_t real_size)
+                          const bddmma_options* opts, HostLayout& L, std::string& err, bool keep_debug_maps, uint32_t real_size, ChipInfo chip)
 {
     L = HostLayout();
     // BDDMMA_LAYOUT_TIMING=1: phase times on stderr
@@ -911,7 +911,14 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         // instance stay in cache, so the longer runs of cooperative staging buy nothing there (1.05 M nodes, streaming: 28.0 k it/s with 1, 2 or 4).
         // (64-slot packs, up to ~1.45 x what the chip holds at once in float; beyond that the streaming sweeps run, which want their 4: 3.1 M
         // nodes 16.3 k it/s with 4, 16.0 k with 1; 4.2 M, packs of 128: 14.6 k / 13.8 k)
-        if (!(opts && opts->waves_per_block) && W == 64 && Pn <= 3700 && L.wide.n_packs() == 0 && L.huge.n_packs() == 0) X.waves_per_block = 1;
+        // Only where those sweeps can be chosen at all (SolverT::init: layers of at most two nodes, resident sweeps not switched off) — the
+        // streaming sweeps of any other instance keep their four packs per workgroup and the staging runs that go with them.  3 700 packs
+        // on 256 CUs, scaled with the CU count.
+        bool two_node_layers = true;
+        for (uint8_t st : L.narrow.pack_steps) two_node_layers = two_node_layers && st < 2;
+        if (!(opts && opts->waves_per_block) && W == 64 && (uint64_t)Pn * 256 <= 3700ull * chip.n_cus && L.wide.n_packs() == 0 && L.huge.n_packs() == 0 &&
+            two_node_layers && !(opts && opts->resident_sweeps == 1))
+            X.waves_per_block = 1;
         // Instances with a sizeable share of wide packs (>= 10 % of the node slots): their solve sweeps share the narrow packs' launch
         // (k_fwd_mixed / k_bwd_mixed), so a wide pack gets 64 * waves_per_block threads — more than its hop width leaves threads idle
         // behind every barrier.  Knapsack benchmark (wide packs of 65-77 nodes): 4 -> 2 packs per workgroup 16.1 k -> 18.1 k it/s

@@ -244,6 +244,11 @@ __host__ __device__ inline uint32_t res2_t_off() { return 0; }
 __host__ __device__ inline uint32_t res2_f_off(uint32_t real_size, uint32_t ns) { return (ns + 4u) * real_size; }
 __host__ __device__ inline uint32_t res2_c_off(uint32_t real_size, uint32_t ns) { return (ns + 4u) * real_size + (ns + 64u) * real_size; }
 __host__ __device__ inline uint32_t res2_wave_bytes(uint32_t real_size, uint32_t ns, uint32_t nl) { return res2_c_off(real_size, ns) + nl * 2u * real_size; }
+// capacities of a wave's region: slots to a multiple of 1 KB of potentials, layers to a multiple of 512 B (the ONE place that rounds
+// them: SolverT::init and the record builder's test entry bddmma_layout_res2_records use it, so the 16-bit offset guards are
+// exercised at the capacities the GPU runs with)
+inline uint32_t res2_slot_capacity(uint32_t real_size, uint32_t max_slots) { const uint32_t q = 1024u / real_size; return (max_slots + q - 1) / q * q; }
+inline uint32_t res2_layer_capacity(uint32_t real_size, uint32_t max_layers) { const uint32_t q = 512u / real_size; return (max_layers + q - 1) / q * q; }
 void build_res2_records(const HostLayout& L, uint32_t real_size, uint32_t ns, uint32_t nl, Res2Records& out);
 
 // ---- records of the streaming sweeps, second generation (kernels.hpp: k_fwd_narrow2 / k_bwd_narrow2) --------------------------------
@@ -279,9 +284,16 @@ struct LinComb {
 };
 constexpr int LINCOMB_MAX = 8;
 
+// What the automatic layout rules and the kernel selection need to know about the chip (bddmma_create reads it from hipDeviceProp:
+// query_chip, bdd_mma_hip.hip; the defaults are MI355X and are what the CPU-side layout entry points use).
+struct ChipInfo {
+    uint32_t n_cus = 256;
+    uint32_t lds_bytes = 160 * 1024;  // per CU
+};
+
 // Returns BDDMMA_OK or an error code; `err` receives the message.
 int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
                  const bddmma_options* opts, HostLayout& out, std::string& err, bool keep_debug_maps,
-                 uint32_t real_size = 4);
+                 uint32_t real_size = 4, ChipInfo chip = ChipInfo{});
 
 }  // namespace bddmma

@@ -734,7 +734,7 @@ struct Lbfgs final : bddmma_lbfgs {
             if ((rc = alloc(&S, (size_t)(p.history_size + 1) * slot)) || (rc = alloc(&Y, (size_t)(p.history_size + 1) * slot)) ||
                 (rc = alloc(&d_gpartial, (size_t)lb_ndots(LB_MAXS) * LB_BLOCKS)) || (rc = alloc(&d_lb, 1)))
                 return rc;
-            LHIP(hipHostMalloc((void**)&h_lb, sizeof(LbHost), hipHostMallocMapped));
+            LHIP(hipHostMalloc((void**)&h_lb, sizeof(LbHost), hipHostMallocMapped | hipHostMallocCoherent));
             LHIP(hipHostGetDevicePointer((void**)&d_lb_host, h_lb, 0));
             std::memset((void*)h_lb, 0, sizeof(LbHost));
             LHIP(hipMemsetAsync(d_lb, 0, sizeof(LbDev), st));

@@ -106,6 +106,7 @@ struct SolverBase {
 };
 
 int device_count();
+int query_chip(int device, ChipInfo* out, std::string& err);  // CU count and LDS per CU of `device` (hipDeviceProp)
 int create_solver(SolverBase** out, int precision, int device, const HostLayout& L, const bddmma_options* opts, std::string& err);
 
 }  // namespace bddmma

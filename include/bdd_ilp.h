@@ -74,7 +74,10 @@ const uint64_t* bddilp_bdds_delimiters(const bddilp_bdds* b);             /* [nr
 /* Text exports of a BDD collection given as flat arrays (the driver's "export bdd lp" / "export bdd graph",
    reference src/bdd_solver/bdd_solver.cpp:400-410 and :432-462 -> include/bdd_collection/bdd_collection.h:731-830 and :663-729).
    write_bdd_lp: the network-flow LP over the arcs of all BDDs, linked by the original variables, with objective costs[0 .. n_costs).
-   export_graphviz: BDD bdd_nr as a Graphviz digraph with one cluster per variable.  Both write `path`; 0 on success. */
+   export_graphviz: BDD bdd_nr as a Graphviz digraph with one cluster per variable.  Both write `path`; 0 on success.
+   The caller guarantees delims[0 .. n_bdds] and instr[0 .. delims[n_bdds]) (no array length crosses the ABI); the arrays are
+   validated (ascending delimiters, terminals last, forward arcs inside each BDD) BEFORE `path` is opened, so a malformed
+   collection leaves an existing file untouched. */
 int bddilp_write_bdd_lp(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds, const double* costs, uint64_t n_costs,
                         const char* path);
 int bddilp_export_graphviz(const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds, uint64_t bdd_nr, const char* path);

@@ -8,7 +8,10 @@ form and LLVM's hazard recogniser follows them — and the hardware then stores 
 (kernels.hpp: hop_store(double2)); this disassembles the device code and reports every wide buffer store with an SGPR soffset that is
 followed directly by a VALU write of one of its data registers.
 
-usage: isa_lint.py <library.so>     exit code 1 on a hit; 0 (with a note) when llvm-objdump is not installed"""
+The same check covers global_store_dwordx3 / x4 with an SGPR base (`saddr`), the form the 64-bit `big` paths can emit.
+
+usage: isa_lint.py <library.so>     exit code 1 on a hit; 0 (with a note) when llvm-objdump is not installed; 3 when the
+disassembly itself failed (the Makefile keeps the library then: a tool failure is not a finding)"""
 import os
 import re
 import shutil
@@ -18,6 +21,7 @@ import tempfile
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 STORE = re.compile(r"^\s*buffer_store_dwordx[34]\s+v\[(\d+):(\d+)\],\s*\w+,\s*s\[\d+:\d+\],\s*(s\d+|m0|\d+|0x[0-9a-f]+)\b")
+GSTORE = re.compile(r"^\s*global_store_dwordx[34]\s+v(?:\d+|\[\d+:\d+\]),\s*v\[(\d+):(\d+)\],\s*(s\[\d+:\d+\]|off)\b")
 VALU_DST = re.compile(r"^\s*(v_[a-z0-9_]+)\s+(?:v(\d+)|v\[(\d+):(\d+)\])\b")
 
 
@@ -54,19 +58,23 @@ def lint(lib_path):
                 if not (hi < pending[0] or lo > pending[1]):
                     hits.append((func, pending[2].strip(), ins.strip()))
             pending = None
-        m = STORE.match(ins)
+        m = STORE.match(ins) or GSTORE.match(ins)
         if m and m.group(3).startswith(("s", "m")):
             wide_sgpr += 1
             pending = (int(m.group(1)), int(m.group(2)), ins)
-    return wide_sgpr, hits, sum(1 for l in lines if "buffer_store_dword" in l)
+    return wide_sgpr, hits, sum(1 for l in lines if "buffer_store_dword" in l or "global_store_dword" in l)
 
 
 if __name__ == "__main__":
     if not os.path.exists(OBJDUMP):
         print("[isa_lint] llvm-objdump not found: skipped")
         sys.exit(0)
-    n, hits, stores = lint(sys.argv[1])
+    try:
+        n, hits, stores = lint(sys.argv[1])
+    except (subprocess.CalledProcessError, OSError, AssertionError) as e:
+        print(f"[isa_lint] WARNING: could not disassemble {sys.argv[1]} ({e}): NOT linted")
+        sys.exit(3)
     if hits:
         print(f"[isa_lint] {len(hits)} unpadded wide store / VALU-write pairs, e.g. {hits[:3]}")
         sys.exit(1)
-    print(f"[isa_lint] {stores} buffer stores, {n} wide ones with an SGPR soffset, all padded")
+    print(f"[isa_lint] {stores} buffer / global stores, {n} wide ones with an SGPR offset or base, all padded")
