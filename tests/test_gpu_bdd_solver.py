@@ -240,28 +240,49 @@ mu_2_1 - mu_01 - mu_11 = 0
 """
 
 
+def _front_end_bound(front_end, c, tmp_path):
+    import os
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bdd_amd", "csrc", "bdd_solver_cl")
+    if front_end == "python":
+        return bdd_solver(c, quiet=True).solve().lower_bound()
+    if front_end == "pybind":
+        from bdd_amd import bdd_solver_py
+        return bdd_solver_py.bdd_solver(c, quiet=True).solve().lower_bound()
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps(c))
+    out = subprocess.run([exe, "--batch", str(p), "--devices", "0", "--quiet"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    return [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")][0]["lower_bound"]
+
+
 @pytest.mark.parametrize("front_end", ["python", "pybind", "bdd_solver_cl"])
 def test_bounds_fixations_known_answers(front_end, tmp_path):
     """test/test_bdd_solver_fix_variable.cpp:6-48: short_mrf_chain has bound 1; with mu_2_1 fixed to 0 it is 2, with mu_1_1 = 0 on top
-    of that 3 (1e-6, 20 iterations there).  The fixations arrive through the `Bounds` section of the .lp text here
-    (ILP_parser.cpp:128-131,343-436 -> ILP_input::reduce), which every front end reads with the same two readers."""
+    of that 3 (1e-6; the reference states them for its CPU solvers).  The fixations arrive through the `Bounds` section of the .lp text
+    here (ILP_parser.cpp:128-131,343-436 -> ILP_input::reduce), which every front end reads with the same two readers.
+    The third value is where the reference's GPU rule shows: `mu_1_1 = 0` turns the row `mu_1_1 - mu_10 - mu_11 = 0` into one that forces
+    mu_10 and mu_11 to 0, and a layer with a non-finite min-marginal exchanges nothing on the GPU (bdd_cuda_parallel_mma.cu:83-84; the
+    CPU solver lets the infinity through), so the cost share parked on the forced arcs stays there: the GPU solver's fixpoint is 2.48538874...,
+    a valid but weaker bound, equal to the restated CUDA rule (oracle/cuda_rule_oracle.c) to 1e-9, while the CPU rule on the same BDDs
+    gives the reference's 3.  Written with the other variable of each pair fixed to 1 the same model has no such row and the GPU gives 3."""
+    from bdd_amd import parse_lp, to_bdd_collection
+    from oracle.oracle import CudaRuleOracle, Oracle
+    for bounds, want in (("", 1.0), ("Bounds\n mu_2_1 = 0\n", 2.0), ("Bounds\n 1 <= mu_2_0\n 0 <= mu_1_1 <= 0\n", 3.0), ("Bounds\n mu_2_0 = 1\n mu_1_0 >= 1\n", 3.0)):
+        lb = _front_end_bound(front_end, cfg(SHORT_MRF_CHAIN + bounds + "End\n"), tmp_path)
+        assert abs(lb - want) <= 1e-6, (bounds, lb)
+    lp = SHORT_MRF_CHAIN + "Bounds\n mu_2_1 = 0\n mu_1_1 <= 0\n" + "End\n"
+    lb = _front_end_bound(front_end, cfg(lp), tmp_path)
+    ilp = parse_lp(lp)
+    col = to_bdd_collection(ilp)
+    cpu, gpu_rule = Oracle(col, np.array(ilp.objective), "double"), CudaRuleOracle(col, np.array(ilp.objective), "double")
+    for _ in range(200):
+        cpu.iteration()
+        gpu_rule.iteration(0.5)
+    assert abs(cpu.lower_bound() + ilp.constant - 3.0) <= 1e-6            # test_bdd_solver_fix_variable.cpp:46-48
+    assert abs(lb - (gpu_rule.lower_bound() + ilp.constant)) <= 1e-9 and 2.4 < lb <= 3.0 + 1e-9
+    # a row of products is refused by every front end (test/test_ILP_parser.cpp:28-33 is the reference's vector for the form)
     import os
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bdd_amd", "csrc", "bdd_solver_cl")
-    for bounds, want in (("", 1.0), ("Bounds\n mu_2_1 = 0\n", 2.0), ("Bounds\n mu_2_1 = 0\n mu_1_1 <= 0\n", 3.0), ("Bounds\n 1 <= mu_2_0\n 0 <= mu_1_1 <= 0\n", 3.0)):
-        c = cfg(SHORT_MRF_CHAIN + bounds + "End\n")
-        if front_end == "python":
-            lb = bdd_solver(c, quiet=True).solve().lower_bound()
-        elif front_end == "pybind":
-            from bdd_amd import bdd_solver_py
-            lb = bdd_solver_py.bdd_solver(c, quiet=True).solve().lower_bound()
-        else:
-            p = tmp_path / "c.json"
-            p.write_text(json.dumps(c))
-            out = subprocess.run([exe, "--batch", str(p), "--devices", "0", "--quiet"], capture_output=True, text=True, timeout=300)
-            assert out.returncode == 0, out.stderr
-            lb = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")][0]["lower_bound"]
-        assert abs(lb - want) <= 1e-6, (bounds, lb)
-    # a row of products is refused by every front end (test/test_ILP_parser.cpp:28-33 is the reference's vector for the form)
     bad = cfg("Minimize\nx1 + x2 + x3\nSubject To\nx1*x2 + x3 >= 1\nEnd\n")
     if front_end == "bdd_solver_cl":
         out = subprocess.run([exe, json.dumps(bad)], capture_output=True, text=True, timeout=300)

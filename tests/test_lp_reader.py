@@ -140,3 +140,24 @@ def test_fixation_equals_solving_the_restricted_model_by_enumeration():
                          if full.feasible(x) and all(x[full.var_names.index(k)] == v for k, v in fix.items())), default=None)
         best_red = min((red.evaluate(x) for x in itertools.product((0, 1), repeat=red.nr_variables()) if red.feasible(x)), default=None)
         assert best_full == best_red, fix
+
+
+def test_fix_variable_known_answers_on_the_two_oracles():
+    """test/test_bdd_solver_fix_variable.cpp:6-48 with the fixations written as Bounds: 1, 2 and 3 with the CPU rule; the GPU rule
+    (no exchange on a layer with a non-finite min-marginal, bdd_cuda_parallel_mma.cu:83-84) stops at 2.4853887... on the third,
+    whose reduced model has a row that forces two variables to 0 — the value the GPU tests expect of the HIP solver."""
+    import numpy as np
+    from bdd_amd import to_bdd_collection
+    from oracle.oracle import CudaRuleOracle, Oracle
+    chain = ("Minimize\n3 mu_1_0 + 1 mu_1_1\n- 1 mu_2_0 + 0 mu_2_1\n+ 1 mu_00 + 2 mu_10 + 1 mu_01 + 0 mu_11\nSubject To\n"
+             "mu_1_0 + mu_1_1 = 1\nmu_2_0 + mu_2_1 = 1\nmu_00 + mu_10 + mu_01 + mu_11 = 1\nmu_1_0 - mu_00 - mu_01 = 0\n"
+             "mu_1_1 - mu_10 - mu_11 = 0\nmu_2_0 - mu_00 - mu_10 = 0\nmu_2_1 - mu_01 - mu_11 = 0\n")
+    for bounds, want_cpu, want_gpu in (("", 1.0, 1.0), ("Bounds\n mu_2_1 = 0\n", 2.0, 2.0), ("Bounds\n mu_2_1 = 0\n mu_1_1 = 0\n", 3.0, 2.4853887428038)):
+        ilp = parse_lp(chain + bounds + "End\n")
+        col = to_bdd_collection(ilp)
+        cpu, gpu = Oracle(col, np.array(ilp.objective), "double"), CudaRuleOracle(col, np.array(ilp.objective), "double")
+        for _ in range(200):
+            cpu.iteration()
+            gpu.iteration(0.5)
+        assert abs(cpu.lower_bound() + ilp.constant - want_cpu) <= 1e-6
+        assert abs(gpu.lower_bound() + ilp.constant - want_gpu) <= 1e-6
