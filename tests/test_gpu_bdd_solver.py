@@ -290,7 +290,7 @@ def test_bounds_fixations_known_answers(front_end, tmp_path):
     else:
         with pytest.raises(Exception, match="nonlinear"):
             if front_end == "python":
-                bdd_solver(bad, quiet=True)
+                bdd_solver(bad, quiet=True).solve()
             else:
                 from bdd_amd import bdd_solver_py
-                bdd_solver_py.bdd_solver(bad, quiet=True)
+                bdd_solver_py.bdd_solver(bad, quiet=True).solve()
