@@ -115,6 +115,7 @@ SIGNATURES = {
     "bddmma_layout_copy": (_I, [_V, _I, _V]),
     "bddmma_layout_res2_records": (_I, [_V, _I, _V, _V, _V]),
     "bddmma_layout_stream_records": (_I, [_V, _I, _V, _V, _V]),
+    "bddmma_layout_seg_exchange": (_I, [_V, _I, _I, _V, _V, _V, _V]),
 }
 
 # every symbol include/bdd_ilp.h declares (host-side input stage)

@@ -68,6 +68,11 @@ struct SolverT final : SolverBase {
     uint32_t wpb = 1;
     bool entry_by_var = false;  // entries ordered by (variable, bdd): exchange = k_exchange_byvar
     bool exch_small = false, exch_medium = false;
+    // exchange as a fixed schedule (kernels.hpp: k_exchange_seg; layout.hpp: SegExchange) where every bin fits it
+    bool use_seg = false;
+    uint32_t *d_seg_bin = nullptr, *d_seg_thr = nullptr;
+    uint16_t* d_seg_perm = nullptr;
+    uint32_t seg_lds = 0, seg_tile_off = 0, seg_cnt_off = 0, seg_groups = 0;
     bool big = false;  // some array reaches 4 GiB (or variant_flags bit 14, for the tests): kernels.hpp DevPtrs::big
     uint32_t opts_variant = 0;  // bddmma_options.variant_flags (A/B switches of kernel variants)
     uint32_t n_cus = 256, lds_cu = 160 * 1024;  // hipDeviceProp of `device` (init)
@@ -370,6 +375,35 @@ struct SolverT final : SolverBase {
         nt_potentials = (sizeof(REAL) == 8 && dev_bytes > (640ull << 20) && (opts_variant & 4u) == 0) ? 1u : 0u;
         exch_small = vars_per_bin <= EXS_MAX_VARS_PER_BIN;  // 256-thread workgroups (kernels.hpp: EXS_*)
         exch_medium = !exch_small && vars_per_bin <= EXM_MAX_VARS_PER_BIN;  // 512-thread workgroups (EXM_*)
+        // `deterministic`: the scheduled reduction (kernels.hpp: k_exchange_seg; no atomics, fixed order) where every bin fits its tables
+        // and the LDS — runs of <= 32 entries per thread, differences + pairs + counts of a bin in LDS —, else (or with variant_flags
+        // bit 17) the per-variable gathers k_delta_gather + k_exchange_bcast.  Both sum in (variable, bdd) order: bit-equal results.
+        if (deterministic && !entry_by_var && !big && !(opts_variant & 0x20000u)) {
+            const uint32_t T = exch_small ? EXS_THREADS : exch_medium ? EXM_THREADS : EX_THREADS;
+            SegExchange SE;
+            build_seg_exchange(L, T, (uint32_t)sizeof(REAL), SE);
+            constexpr uint32_t VEC = 16 / sizeof(REAL);
+            if (SE.ok && SE.max_groups <= 4 && SE.max_entries <= (uint64_t)SEG_MAXL * T * VEC) {
+                const uint32_t Z = (SE.max_entries + VEC - 1) / VEC * VEC;
+                seg_tile_off = ((Z + 1) * (uint32_t)sizeof(REAL) + 15u) & ~15u;
+                seg_cnt_off = seg_tile_off + SE.max_slots * 2u * (uint32_t)sizeof(REAL);
+                seg_lds = (seg_cnt_off + SE.max_slots * 2u + 15u) & ~15u;
+                if (seg_lds + 1024 <= lds_cu) {
+                    if ((rc = upload(&d_seg_bin, SE.bin))) return rc;
+                    if ((rc = upload(&d_seg_perm, SE.perm))) return rc;
+                    if ((rc = upload(&d_seg_thr, SE.thr))) return rc;
+                    use_seg = true;
+                    seg_groups = SE.max_groups;
+#define SET_SEG_G(T_, G_)                                             \
+    SET_DYN((k_exchange_seg<REAL, T_, G_, false>), seg_lds);          \
+    SET_DYN((k_exchange_seg<REAL, T_, G_, true>), seg_lds)
+#define SET_SEG(T_) switch (seg_groups) { case 1: SET_SEG_G(T_, 1); break; case 2: SET_SEG_G(T_, 2); break; case 3: SET_SEG_G(T_, 3); break; default: SET_SEG_G(T_, 4); break; }
+                    if (exch_small) { SET_SEG(EXS_THREADS) } else if (exch_medium) { SET_SEG(EXM_THREADS) } else { SET_SEG(EX_THREADS) }
+#undef SET_SEG
+#undef SET_SEG_G
+                }
+            }
+        }
 #undef SET_DYN
         // resident sweeps: chosen when every narrow pack fits its wave's LDS slice and the instance is small enough that the streaming
         // kernels are latency-bound (few waves per SIMD); resident_sweeps = 1 turns them off, = 2 forces them on
@@ -710,11 +744,26 @@ struct SolverT final : SolverBase {
             hipLaunchKernelGGL((k_exchange_byvar<REAL>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr, d_delta_lay,
                                (uint32_t)n_vars, (uint32_t)n_layers, gate(), rstep);
             delta_var_valid = false;
-        } else if (deterministic) {
+        } else if (deterministic && !use_seg) {
             hipLaunchKernelGGL((k_delta_gather<REAL, true>), dim3(cdiv(n_vars, 256)), dim3(256), 0, stream, d_mm_binned, d_var_ptr,
                                d_vpos, d_delta_var, (uint32_t)n_vars, gate());
             launch_bcast(d_delta_var, d_delta_lay, gate(), rstep);
             delta_var_valid = true;
+        } else if (use_seg) {
+#define LAUNCH_SEG(T_, RUN_)                                                                                                                        \
+    switch (seg_groups) { case 1: LAUNCH_SEG_G(T_, 1, RUN_); break; case 2: LAUNCH_SEG_G(T_, 2, RUN_); break; case 3: LAUNCH_SEG_G(T_, 3, RUN_); break; default: LAUNCH_SEG_G(T_, 4, RUN_); break; }
+#define LAUNCH_SEG_G(T_, G_, RUN_)                                                                                                                  \
+    hipLaunchKernelGGL((k_exchange_seg<REAL, T_, G_, RUN_>), dim3(n_bins + ((RUN_) && rstep.ctl != nullptr ? 1u : 0u)), dim3(T_), seg_lds, stream, d_mm_binned, \
+                       reinterpret_cast<const uint4*>(d_seg_bin), gate().stop, gate().iter, reinterpret_cast<const uint4*>(d_seg_perm),              \
+                       reinterpret_cast<const uint2*>(d_seg_thr), seg_tile_off, seg_cnt_off, d_delta_lay, rstep)
+#define LAUNCH_SEG_R(T_) do { if (run_stop) { LAUNCH_SEG(T_, true) } else { LAUNCH_SEG(T_, false) } } while (0)
+            if (exch_small) LAUNCH_SEG_R(EXS_THREADS);
+            else if (exch_medium) LAUNCH_SEG_R(EXM_THREADS);
+            else LAUNCH_SEG_R(EX_THREADS);
+#undef LAUNCH_SEG_R
+#undef LAUNCH_SEG
+#undef LAUNCH_SEG_G
+            delta_var_valid = false;
         } else {
             // All three sizes run the lean form since round 3 (kernels.hpp: EXV_* = 7: scalar-offset entry addressing, one predicated atomic per
             // entry; its 16-byte store hazard is guarded): 10.5 M nodes 124.1 -> 122.1 us per iteration (float), 236.0 -> 232.4 (double);

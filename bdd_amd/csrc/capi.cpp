@@ -817,6 +817,19 @@ int bddmma_layout_res2_records(const bddmma_layout* l, int real_size, uint32_t* 
     return BDDMMA_OK;
 }
 
+int bddmma_layout_seg_exchange(const bddmma_layout* l, int threads, int real_size, uint32_t* info, uint32_t* bin, uint16_t* perm, uint32_t* thr)
+{
+    if (!l || !info || (real_size != 4 && real_size != 8) || threads <= 0) return BDDMMA_ERR_INVALID_ARGUMENT;
+    SegExchange S;
+    build_seg_exchange(l->L, (uint32_t)threads, (uint32_t)real_size, S);
+    info[0] = S.ok ? 1u : 0u; info[1] = (uint32_t)S.bin.size(); info[2] = (uint32_t)S.perm.size(); info[3] = (uint32_t)S.thr.size();
+    info[4] = S.max_entries; info[5] = S.max_slots; info[6] = S.max_groups;
+    if (bin && !S.bin.empty()) std::memcpy(bin, S.bin.data(), S.bin.size() * sizeof(uint32_t));
+    if (perm && !S.perm.empty()) std::memcpy(perm, S.perm.data(), S.perm.size() * sizeof(uint16_t));
+    if (thr && !S.thr.empty()) std::memcpy(thr, S.thr.data(), S.thr.size() * sizeof(uint32_t));
+    return BDDMMA_OK;
+}
+
 int bddmma_layout_stream_records(const bddmma_layout* l, int real_size, uint32_t* info, uint32_t* words, uint32_t* rec_off)
 {
     if (!l || !info || (real_size != 4 && real_size != 8)) return BDDMMA_ERR_INVALID_ARGUMENT;

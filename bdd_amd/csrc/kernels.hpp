@@ -3253,6 +3253,142 @@ __global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __re
         return;
 }
 
+// The binned exchange as a fixed schedule instead of LDS atomics (layout.hpp: struct SegExchange has the idea and the tables; round 5).
+// One workgroup per bin, as k_exchange_reduce:
+//   1. every load the workgroup needs is issued at once and depends on nothing but the bin's 16-byte header: the bin's deferred differences
+//      (16-byte coalesced loads -> LDS, entry order), the thread's run (entry offsets of its positions, <= SEG_MAX_RUN u16 in <= 4 registers
+//      quads) and its {end mask, first slot};
+//   2. a thread walks its run: plain LDS reads, REAL sums in (variable, bdd) order — the order and the arithmetic of k_delta_gather, so the
+//      result is bit-reproducible and equal to the `deterministic` path's —, at the last entry of a variable the pair and the entry count go
+//      to the variable's slot;
+//   3. the pairs are normalised (one division per value, slots spread over the threads), and every thread writes its slot numbers to its
+//      entries' places (u16, over the differences, which nobody reads any more);
+//   4. the broadcast streams entry -> slot -> pair -> delta_lay with the chunk's first entry in the scalar offset (hop_store).
+// Three barriers, no atomics, no dependent global load behind the header.
+// Measured (10.5 M nodes, float, rocprofv3 in sequence): 19.5 us per launch against the LDS-atomic kernel's 17.9 — the phases (loads 5.8 us at
+// the chip's full rate, sums 4.0, normalise + slots 2.3, broadcast 3 + 4 of drain) do not overlap any more than the atomic kernel's do
+// (profiles/r05_exchange.txt) —, so this is the `deterministic` exchange (it replaces k_delta_gather + k_exchange_bcast, two launches of
+// gathers) and the LDS atomics stay the default.
+constexpr int SEG_MAXL = 12;  // 16-byte loads of differences per thread: a bin holds <= SEG_MAXL * T * 16 / sizeof(REAL) entries
+// G: 16-byte groups of run positions per thread (the largest bin's; the tables pad every run to it) — a template parameter so that every
+// register array below is indexed by constants (with run-time group counts and early exits the arrays went to scratch memory)
+template <typename REAL, int T, int G, bool RUN = false>
+__global__ void __launch_bounds__(T) k_exchange_seg(const REAL* __restrict__ mm_binned, const uint4* __restrict__ seg_bin, const uint32_t* stop, uint32_t run_iter,
+                                                      const uint4* __restrict__ seg_perm, const uint2* __restrict__ seg_thr, uint32_t tile_off, uint32_t cnt_off,
+                                                      REAL* __restrict__ delta_lay, RunStep run = RunStep{})
+{
+    const uint32_t stop_word = (RUN && stop != nullptr) ? *stop : RUN_NOT_STOPPED;
+    if (RUN && run.ctl != nullptr && blockIdx.x == gridDim.x - 1) {  // the extra workgroup of the launch that ends a run_solver iteration (see k_exchange_reduce)
+        if (stop_word <= run_iter) return;
+        run_ctl_step(run);
+        return;
+    }
+    using P2 = typename Pair<REAL>::type;
+    constexpr uint32_t VEC = 16 / sizeof(REAL);
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    REAL* mm_lds = reinterpret_cast<REAL*>(dyn_lds);           // [entries rounded up to VEC, + 1], then the entries' slot numbers
+    uint16_t* slot_lds = reinterpret_cast<uint16_t*>(dyn_lds);
+    P2* tile = reinterpret_cast<P2*>(dyn_lds + tile_off);       // [slots] {sum of -mm over mm < 0, sum of mm over mm > 0}
+    uint16_t* cnt = reinterpret_cast<uint16_t*>(dyn_lds + cnt_off);  // [slots] entries of the slot's variable = its number of BDDs
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint4 hdr = seg_bin[b];  // first group of the bin in seg_perm, groups per thread | slots << 8, first entry, entries
+    const uint32_t slots = hdr.y >> 8, E = hdr.w;
+    mm_binned += hdr.z;
+    delta_lay += 2 * (size_t)hdr.z;
+    BDDMMA_STAMP(0x100000u + blockIdx.x * (T / 64) + (tid >> 6), 0);
+    const rsrc_t rmm = make_rsrc(mm_binned, E);
+    using u4 = decltype(__builtin_amdgcn_raw_buffer_load_b128(rmm, 0, 0, 0));
+    u4 buf[SEG_MAXL];
+#pragma unroll
+    for (int j = 0; j < SEG_MAXL; ++j)
+        if ((uint32_t)j * T * VEC < E) buf[j] = __builtin_amdgcn_raw_buffer_load_b128(rmm, ((uint32_t)j * T + tid) * 16u, 0, 0);
+    uint4 pw[G];
+    const uint4* pg = seg_perm + hdr.x + tid;
+#pragma unroll
+    for (int g = 0; g < G; ++g) pw[g] = pg[(size_t)g * T];
+    const uint2 th = seg_thr[(size_t)b * T + tid];
+    if (stop_word <= run_iter) return;  // uniform for the grid; nothing has been written yet
+#pragma unroll
+    for (int j = 0; j < SEG_MAXL; ++j) {
+        const uint32_t i = ((uint32_t)j * T + tid) * VEC;
+        if ((uint32_t)j * T * VEC < E && i < E) *reinterpret_cast<u4*>(mm_lds + i) = buf[j];
+    }
+    const uint32_t Z = (E + VEC - 1) / VEC * VEC;  // the place the positions past a run's end point at: never written above
+    if (tid == 0) mm_lds[Z] = REAL(0);
+    __syncthreads();
+    BDDMMA_STAMP(0x100000u + blockIdx.x * (T / 64) + (tid >> 6), 1);
+    const uint32_t ends = th.x;
+    // position k of the run -> entry offset
+    uint32_t pl[8 * G];
+#pragma unroll
+    for (int k = 0; k < 8 * G; ++k) {
+        const uint4 q = pw[k / 8];
+        const uint32_t w = (k % 8) / 2 == 0 ? q.x : (k % 8) / 2 == 1 ? q.y : (k % 8) / 2 == 2 ? q.z : q.w;
+        pl[k] = (k & 1) ? w >> 16 : w & 0xFFFFu;
+    }
+    uint32_t sl[8 * G];  // slot of the variable of position k (the slots are numbered along the runs)
+    {
+        // all the run's differences first (independent LDS reads in flight together), then the sums in order.  Branch-free: the sums of
+        // compute_delta (bdd_cuda_parallel_mma.cu:358-393: hi += m if m > 0, lo += -m if m < 0) as hi += max(m, 0), lo += max(-m, 0) — adding
+        // +0 changes nothing —, in k_delta_gather's order; at the last entry of a variable ((ends >> k) & 1) the pair and the count go to LDS
+        // under the lane mask and the sums restart.
+        REAL mv[8 * G];
+#pragma unroll
+        for (int k = 0; k < 8 * G; ++k) mv[k] = mm_lds[pl[k]];
+        uint32_t slot = th.y, first = 0;
+        REAL lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 8 * G; ++k) {
+            const REAL m = mv[k];
+            hi += m > REAL(0) ? m : REAL(0);
+            lo += m < REAL(0) ? -m : REAL(0);
+            sl[k] = slot;
+            const bool end = (ends >> k) & 1u;
+            if (end) {
+                P2 pr;
+                pr.x = lo;
+                pr.y = hi;
+                tile[slot] = pr;
+                cnt[slot] = (uint16_t)(k + 1 - first);
+            }
+            slot += end ? 1u : 0u;
+            first = end ? (uint32_t)(k + 1) : first;
+            lo = end ? REAL(0) : lo;
+            hi = end ? REAL(0) : hi;
+        }
+    }
+    __syncthreads();
+    BDDMMA_STAMP(0x100000u + blockIdx.x * (T / 64) + (tid >> 6), 2);
+    for (uint32_t i = tid; i < slots; i += T) {  // normalize_delta, :410-430
+        P2 pr = tile[i];
+        const REAL c = REAL(cnt[i]);
+        pr.x /= c;
+        pr.y /= c;
+        tile[i] = pr;
+    }
+#pragma unroll
+    for (int k = 0; k < 8 * G; ++k) slot_lds[pl[k]] = (uint16_t)sl[k];  // past the run's end: place Z, which no entry reads
+    __syncthreads();
+    BDDMMA_STAMP(0x100000u + blockIdx.x * (T / 64) + (tid >> 6), 3);
+    const rsrc_t rdl = make_rsrc(delta_lay, 2ull * E);
+    const uint32_t vo_p = tid * (uint32_t)sizeof(P2);
+    for (uint32_t base = 0; base < E; base += 4 * T) {
+        uint32_t sl[4];
+        P2 pr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t e = base + u * T + tid;
+            sl[u] = e < E ? slot_lds[e] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pr[u] = tile[sl[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (base + u * T < E) hop_store(pr[u], rdl, vo_p, (base + u * T) * (uint32_t)sizeof(P2));  // lanes past the bin's end: out of the descriptor's range
+    }
+    BDDMMA_STAMP(0x100000u + blockIdx.x * (T / 64) + (tid >> 6), 4);
+}
+
 // Exchange for entry arrays ordered by (variable, bdd) (layout.hpp: Exchange::entry_by_var): the entries of variable v are
 // var_ptr[v] .. var_ptr[v + 1], so compute_delta (bdd_cuda_parallel_mma.cu:358-393), normalize_delta (:410-430) and the broadcast of
 // the pair to the variable's layers are one thread per variable over a contiguous run — neighbouring threads read and write

@@ -1109,6 +1109,95 @@ void build_res2_records(const HostLayout& L, uint32_t S, uint32_t ns, uint32_t n
     out.ok = true;
 }
 
+// layout.hpp: struct SegExchange
+void build_seg_exchange(const HostLayout& L, uint32_t T, uint32_t real_size, SegExchange& out)
+{
+    const uint32_t VEC = 16 / real_size;
+    out = SegExchange();
+    const Exchange& X = L.ex;
+    const uint32_t NB = X.n_bins, VB = X.vars_per_bin;
+    if (NB == 0 || X.entry_by_var || X.vpos.size() != L.n_layers || L.var_ptr.size() != L.n_vars + 1 || T == 0 || T % 64 != 0) return;
+    out.threads = T;
+    out.bin.assign(4 * (size_t)NB, 0);
+    out.thr.assign(2 * (size_t)NB * T, 0);
+    // pass 1 (per bin, independent): the deal — which variables a thread owns, in which order — and with it the bin's group count
+    struct Deal { std::vector<uint32_t> order; uint32_t groups = 0, slots = 0; };  // order: the bin's variables with entries, thread-major
+    std::vector<Deal> deal(NB);
+    std::vector<uint32_t> thr_first((size_t)NB * T + 1, 0);  // index of a thread's first variable in its bin's order
+    std::atomic<bool> fail{false};
+    Par par;
+    par.run(NB, [&](uint64_t b0, uint64_t b1, unsigned) {
+        std::vector<uint32_t> vars, cnt_sorted;
+        std::vector<std::vector<uint32_t>> own(T);
+        for (uint64_t b = b0; b < b1; ++b) {
+            const uint32_t v0 = (uint32_t)b * VB, v1 = (uint32_t)std::min<uint64_t>(L.n_vars, (uint64_t)v0 + VB);
+            const uint32_t E = X.bin_ptr[b + 1] - X.bin_ptr[b];
+            if (L.var_ptr[v1] - L.var_ptr[v0] != E || E + VEC >= 0xFFFFu) { fail = true; return; }
+            vars.clear();
+            for (uint32_t v = v0; v < v1; ++v)
+                if (L.var_ptr[v + 1] > L.var_ptr[v]) vars.push_back(v);
+            // most entries first (ties: by variable), dealt 0 .. T-1, T-1 .. 0, 0 .. T-1, ...
+            std::stable_sort(vars.begin(), vars.end(), [&](uint32_t a, uint32_t c) { return L.var_ptr[a + 1] - L.var_ptr[a] > L.var_ptr[c + 1] - L.var_ptr[c]; });
+            for (auto& o : own) o.clear();
+            for (size_t i = 0; i < vars.size(); ++i) {
+                const uint32_t round = (uint32_t)(i / T), pos = (uint32_t)(i % T);
+                own[(round & 1u) ? T - 1 - pos : pos].push_back(vars[i]);
+            }
+            Deal& D = deal[b];
+            D.order.reserve(vars.size());
+            uint32_t longest = 0;
+            for (uint32_t t = 0; t < T; ++t) {
+                thr_first[b * T + t] = (uint32_t)D.order.size();
+                uint32_t run = 0;
+                for (uint32_t v : own[t]) { D.order.push_back(v); run += L.var_ptr[v + 1] - L.var_ptr[v]; }
+                longest = std::max(longest, run);
+            }
+            if (longest > SEG_MAX_RUN) { fail = true; return; }
+            D.groups = (longest + 7) / 8;
+            D.slots = (uint32_t)vars.size();
+        }
+    }, 1);
+    if (fail) { out = SegExchange(); return; }
+    uint64_t first = 0;
+    for (uint32_t b = 0; b < NB; ++b) out.max_groups = std::max(out.max_groups, deal[b].groups);
+    for (uint32_t b = 0; b < NB; ++b) deal[b].groups = out.max_groups;  // every run padded to the longest bin's groups (k_exchange_seg<.., G>)
+    for (uint32_t b = 0; b < NB; ++b) {
+        const uint32_t E = X.bin_ptr[b + 1] - X.bin_ptr[b];
+        out.bin[4 * (size_t)b + 0] = (uint32_t)first;
+        if (deal[b].slots >= (1u << 24)) { out = SegExchange(); return; }
+        out.bin[4 * (size_t)b + 1] = deal[b].groups | (deal[b].slots << 8);
+        out.bin[4 * (size_t)b + 2] = X.bin_ptr[b];
+        out.bin[4 * (size_t)b + 3] = E;
+        first += (uint64_t)deal[b].groups * T;
+        out.max_entries = std::max(out.max_entries, E);
+        out.max_slots = std::max(out.max_slots, deal[b].slots);
+        out.max_groups = std::max(out.max_groups, deal[b].groups);
+    }
+    if (first * 16 >= (1ull << 32)) { out = SegExchange(); return; }
+    out.perm.assign((size_t)first * 8, 0);
+    // pass 2: the runs
+    par.run(NB, [&](uint64_t b0, uint64_t b1, unsigned) {
+        for (uint64_t b = b0; b < b1; ++b) {
+            const Deal& D = deal[b];
+            const uint32_t e0 = X.bin_ptr[b], E = X.bin_ptr[b + 1] - e0, G = D.groups;
+            uint16_t* pb = &out.perm[(size_t)out.bin[4 * b] * 8];
+            for (uint32_t t = 0; t < T; ++t) {
+                const uint32_t i0 = thr_first[b * T + t], i1 = t + 1 < T ? thr_first[b * T + t + 1] : (uint32_t)D.order.size();
+                uint32_t k = 0, ends = 0;
+                for (uint32_t i = i0; i < i1; ++i) {
+                    const uint32_t v = D.order[i];
+                    for (uint32_t q = L.var_ptr[v]; q < L.var_ptr[v + 1]; ++q, ++k) pb[((size_t)(k / 8) * T + t) * 8 + k % 8] = (uint16_t)(X.vpos[q] - e0);
+                    ends |= 1u << (k - 1);
+                }
+                for (; k < G * 8; ++k) pb[((size_t)(k / 8) * T + t) * 8 + k % 8] = (uint16_t)((E + VEC - 1) / VEC * VEC);  // holds 0 (k_exchange_seg)
+                out.thr[2 * ((size_t)b * T + t) + 0] = ends;
+                out.thr[2 * ((size_t)b * T + t) + 1] = i0;  // slots are numbered along `order`
+            }
+        }
+    }, 1);
+    out.ok = true;
+}
+
 // layout.hpp: struct StreamRecords
 void build_stream_records(const HostLayout& L, uint32_t S, StreamRecords& out)
 {

@@ -284,6 +284,31 @@ struct LinComb {
 };
 constexpr int LINCOMB_MAX = 8;
 
+// ---- exchange without LDS atomics (kernels.hpp: k_exchange_seg; round 5) ---------------------------------------------------------------
+// The binned exchange reduces a bin's deferred differences per variable with one LDS float atomic per entry — 7 of the launch's 19 us at
+// 10.5 M nodes, at a rate (about one lane per clock) that neither conflict-free addresses nor integer adds change (profiles/
+// r04_exchange_stamps.txt).  The structure is static, so the reduction can be a fixed schedule instead: the variables of a bin are dealt to
+// the workgroup's threads (largest first, boustrophedon, so every thread gets the same number of entries to within one or two), a thread's
+// entries — those of its variables, one variable after the other, (variable, bdd) order inside — are its RUN, and all it needs is where
+// they are: `perm`, the entry offsets (inside the bin) of the positions of its run.  The kernel copies the bin's differences to LDS with
+// coalesced loads, every thread walks its run with plain LDS reads and sums each variable in the order of the deterministic path
+// (k_delta_gather), writes the pair to the variable's SLOT (slots are numbered along the runs), and writes the slot number back to its
+// entries' LDS places; the broadcast then streams entry -> slot -> pair.  No atomics, no dependent global loads, fixed summation order.
+//   bin  [4 per bin]                first 16-byte group of the bin in `perm`, groups (of 8 positions) per thread | slots << 8, first entry, entries
+//   perm [8 per (bin, group, thread)]  u16 entry offsets, thread-minor: group g of thread t is the 16 bytes at (first + g * threads + t);
+//                                   past the end of a run: the bin's entry count rounded up to 16 bytes of REAL (an LDS place that holds 0)
+//   thr  [2 per (bin, thread)]      bit k set: position k of the run is the last entry of its variable; the thread's first slot
+struct SegExchange {
+    bool ok = false;
+    uint32_t threads = 0;
+    uint32_t max_entries = 0, max_slots = 0, max_groups = 0;  // largest bin
+    std::vector<uint32_t> bin;
+    std::vector<uint16_t> perm;
+    std::vector<uint32_t> thr;
+};
+constexpr uint32_t SEG_MAX_RUN = 32;  // positions per thread: bits of the end mask
+void build_seg_exchange(const HostLayout& L, uint32_t threads, uint32_t real_size, SegExchange& out);
+
 // What the automatic layout rules and the kernel selection need to know about the chip (bddmma_create reads it from hipDeviceProp:
 // query_chip, bdd_mma_hip.hip; the defaults are MI355X and are what the CPU-side layout entry points use).
 struct ChipInfo {

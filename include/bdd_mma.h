@@ -69,7 +69,8 @@ typedef struct bddmma_options {
     uint32_t pack_width;       /* max #nodes of one hop inside a wave-sized BDD pack: 64, 128 (default) or 256 */
     uint32_t wide_pack_width;  /* max #nodes of one hop inside a workgroup-sized pack whose frontier lives in LDS (default 2048; <= 2048 for
                                   F64, <= 4096 for F32); BDDs with wider layers use the same kernels with the frontier in global memory */
-    uint32_t deterministic;    /* 1: delta accumulation by per-variable gather (bit-reproducible) */
+    uint32_t deterministic;    /* 1: the per-variable delta sums in a fixed order — (variable, bdd), the CPU solver's — instead of LDS atomics:
+                                  bit-reproducible; one launch like the default exchange, ~10 % slower than it at 10 M nodes */
     uint32_t vars_per_bin;     /* variables per exchange bin, <= 9728 (16 B of LDS accumulators each); default: ~V/256 rounded, 1024..9728 */
     uint32_t stage_cap;        /* max layers of one stage group of a narrow pack (default 640) */
     uint32_t waves_per_block;  /* narrow packs swept by one workgroup with cooperative staging: 1, 2, 4 or 8 (default 4) */
@@ -98,7 +99,9 @@ typedef struct bddmma_options {
                                   bit 15: the L-BFGS direction as its own pass (default: formed inside the projection's first pass where that is staged
                                           and all packs are narrow)
                                   bit 16: the streaming sweeps of the narrow packs find their pack and their staging range through the hop / group /
-                                          round tables (default: from the resident headers where every pack has one stage group) */
+                                          round tables (default: from the resident headers where every pack has one stage group)
+                                  bit 17: `deterministic` exchanges by per-variable gathers (two launches) also where the one-launch fixed schedule
+                                          k_exchange_seg fits (same sums, same order: bit-equal results) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
                                   instance (NOTES.md section 6: the sweeps are bound by instructions issued, not by latency), kept for experiments */
@@ -324,6 +327,10 @@ int bddmma_layout_copy(const bddmma_layout* l, int which, void* out);
 int bddmma_layout_res2_records(const bddmma_layout* l, int real_size, uint32_t* info, uint32_t* words, uint32_t* rec_off);
 /* The same for the records of the second-generation streaming sweeps (csrc/layout.hpp: StreamRecords): info[0] = usable, [1] = words. */
 int bddmma_layout_stream_records(const bddmma_layout* l, int real_size, uint32_t* info, uint32_t* words, uint32_t* rec_off);
+/* The schedule of the atomic-free exchange (csrc/layout.hpp: SegExchange) for workgroups of `threads` and values of real_size bytes:
+ * info[0] = usable, [1] = 32-bit words of `bin` (4 per bin), [2] = 16-bit words of `perm`, [3] = 32-bit words of `thr` (2 per bin and
+ * thread), [4] / [5] / [6] = entries / slots / groups of the largest bin.  The arrays may be NULL to query sizes. */
+int bddmma_layout_seg_exchange(const bddmma_layout* l, int threads, int real_size, uint32_t* info, uint32_t* bin, uint16_t* perm, uint32_t* thr);
 
 #ifdef __cplusplus
 }

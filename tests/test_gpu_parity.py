@@ -409,6 +409,34 @@ def test_deterministic_mode_is_bit_reproducible_and_agrees():
     np.testing.assert_array_equal(s.get_delta(), d)
 
 
+@pytest.mark.parametrize("precision", ["float", "double"])
+@pytest.mark.parametrize("opts", [dict(), dict(vars_per_bin=64), dict(vars_per_bin=1500), dict(vars_per_bin=3000, pack_width=64), dict(waves_per_block=2, pack_width=256)])
+def test_deterministic_exchange_one_launch_equals_the_gathers_bit_for_bit(precision, opts):
+    """`deterministic`: k_exchange_seg (one launch, fixed schedule in LDS; layout.hpp: SegExchange) and k_delta_gather + k_exchange_bcast
+    (variant_flags bit 17) add the same numbers in the same (variable, bdd) order, 256 / 512 / 1024 threads per bin, with every pass and
+    with the CPU oracle's order: bounds, deltas and arc costs agree bit for bit over iterations; in double the oracle's bound too."""
+    from oracle.oracle import Oracle
+    col, costs = random_set_cover(4000, 3500, 7, seed=11)
+    one = bdd_hip_parallel_mma(col, costs, precision=precision, deterministic=True, **opts)
+    two = bdd_hip_parallel_mma(col, costs, precision=precision, deterministic=True, variant_flags=0x20000, **opts)
+    o = Oracle(col, costs, precision)
+    for it in range(6):
+        one.iteration(); two.iteration(); o.iteration()
+        assert one.lower_bound() == two.lower_bound()
+        np.testing.assert_array_equal(one.get_delta(), two.get_delta())
+        if precision == "double":
+            assert abs(one.lower_bound() - o.lower_bound()) <= 1e-11 * abs(o.lower_bound())
+    for a, b in zip(one.get_solver_costs(), two.get_solver_costs()):
+        np.testing.assert_array_equal(a, b)
+    # explicit passes (forward_mm / backward_mm with a delta vector) and run_solver go through the same exchange
+    d1, d2 = np.zeros(2 * one.nr_variables(), one.value_type), np.zeros(2 * two.nr_variables(), two.value_type)
+    one.forward_mm(0.5, d1); two.forward_mm(0.5, d2)
+    np.testing.assert_array_equal(d1, d2)
+    from bdd_amd.solver import run_solver
+    r1, r2 = run_solver(one, max_iter=25, tolerance=0.0, improvement_slope=0.0), run_solver(two, max_iter=25, tolerance=0.0, improvement_slope=0.0)
+    assert r1["iterations"] == r2["iterations"] == 25 and r1["lb_final"] == r2["lb_final"]
+
+
 def test_dual_ops_vs_numpy():
     col, costs = random_set_cover(500, 400, 6, seed=2)
     s = bdd_hip_parallel_mma(col, costs, precision="double")

@@ -587,3 +587,86 @@ def test_stream_records_restate_the_node_words(real_size, pack_width):
     r3 = w3.reshape(-1, 4)
     real = (r3[:, 3] & 0x80000000) == 0
     assert ((r3[real, 3] >> 8) & 63).max() >= 3          # nodes at position >= 3 of their layer exist
+
+
+def seg_exchange(lay, threads, real_size):
+    info = np.zeros(8, np.uint32)
+    capi.check(lay.L.bddmma_layout_seg_exchange(lay.h, threads, real_size, info.ctypes.data_as(C.c_void_p), None, None, None), None)
+    b, p, t = np.zeros(max(int(info[1]), 1), np.uint32), np.zeros(max(int(info[2]), 1), np.uint16), np.zeros(max(int(info[3]), 1), np.uint32)
+    capi.check(lay.L.bddmma_layout_seg_exchange(lay.h, threads, real_size, info.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                                p.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p)), None)
+    return bool(info[0]), b[: info[1]].reshape(-1, 4), p[: info[2]], t[: info[3]].reshape(-1, 2), info[4:7].tolist()
+
+
+@pytest.mark.parametrize("threads,real_size,vars_per_bin", [(256, 4, 64), (256, 8, 128), (512, 4, 0), (1024, 8, 192)])
+def test_seg_exchange_schedule_is_the_per_variable_gather(threads, real_size, vars_per_bin):
+    """layout.hpp: SegExchange — the fixed schedule of k_exchange_seg, executed here in numpy exactly as the kernel walks it, gives the
+    per-variable sums of k_delta_gather (same entries, same order), every entry gets its variable's slot, and the runs are balanced."""
+    from bdd_amd.instances import random_set_cover
+    col, _ = random_set_cover(900, 700, 6, seed=5)
+    lay = Layout(col, vars_per_bin=vars_per_bin)
+    ok, hdr, perm, thr, (max_e, max_s, max_g) = seg_exchange(lay, threads, real_size)
+    assert ok and hdr.shape[0] == lay.n_bins and thr.shape[0] == lay.n_bins * threads
+    VEC = 16 // real_size
+    rng = np.random.Generator(np.random.PCG64(3))
+    mm = rng.standard_normal(lay.n_layers).astype(np.float32 if real_size == 4 else np.float64)
+    mm[rng.random(lay.n_layers) < 0.2] = 0
+    dt = mm.dtype.type
+    seen = np.zeros(lay.n_layers, np.int64)
+    pairs_by_entry = np.zeros((lay.n_layers, 2), mm.dtype)
+    for b in range(lay.n_bins):
+        first, gy, e0, E = (int(x) for x in hdr[b])
+        groups, slots = gy & 0xFF, gy >> 8
+        assert e0 == int(lay.bin_ptr[b]) and E == int(lay.bin_ptr[b + 1]) - e0 and groups <= 4
+        Z = (E + VEC - 1) // VEC * VEC
+        lds = np.zeros(Z + 1, mm.dtype); lds[:E] = mm[e0:e0 + E]
+        tile, cnt, slot_of = np.zeros((slots, 2), mm.dtype), np.zeros(slots, np.int64), np.full(Z + 1, -1, np.int64)
+        runs = []
+        for t in range(threads):
+            ends, slot = int(thr[b * threads + t][0]), int(thr[b * threads + t][1])
+            p = np.concatenate([perm[(first + g * threads + t) * 8:(first + g * threads + t) * 8 + 8] for g in range(groups)]).astype(np.int64) if groups else np.zeros(0, np.int64)
+            run_len = ends.bit_length()
+            assert np.all(p[run_len:] == Z) and np.all(p[:run_len] < E)
+            runs.append(run_len)
+            lo, hi, n = dt(0), dt(0), 0
+            for k in range(groups * 8):
+                m = lds[p[k]]
+                if m > 0:
+                    hi = dt(hi + m)
+                elif m < 0:
+                    lo = dt(lo + -m)
+                n += 1
+                if (ends >> k) & 1:
+                    tile[slot] = (lo, hi); cnt[slot] = n; slot += 1
+                    lo, hi, n = dt(0), dt(0), 0
+                if k < run_len:
+                    slot_of[p[k]] = int(thr[b * threads + t][1]) + bin(ends & ((1 << k) - 1)).count("1")
+            seen[e0 + p[:run_len]] += 1
+        assert np.all(cnt > 0) and np.all(slot_of[:E] >= 0)
+        tile = (tile / cnt[:, None].astype(mm.dtype)).astype(mm.dtype)
+        pairs_by_entry[e0:e0 + E] = tile[slot_of[:E]]
+        # balance: no run is longer than the mean by more than the largest variable
+        nz = [r for r in runs if r]
+        per_var = np.diff(lay.var_ptr.astype(np.int64))[b * lay.vars_per_bin:(b + 1) * lay.vars_per_bin]
+        assert max(runs) <= -(-E // threads) + int(per_var.max()) and max(runs) <= 32 and (not nz or len(nz) == min(threads, int((per_var > 0).sum())))
+    assert np.all(seen == 1)                                   # every entry is in exactly one run
+    # the reference of the schedule: k_delta_gather's sum per variable in (variable, bdd) order, then the broadcast
+    for v in range(lay.n_vars):
+        k0, k1 = int(lay.var_ptr[v]), int(lay.var_ptr[v + 1])
+        lo, hi = dt(0), dt(0)
+        for e in lay.vpos[k0:k1]:
+            m = mm[e]
+            if m > 0:
+                hi = dt(hi + m)
+            elif m < 0:
+                lo = dt(lo + -m)
+        if k1 > k0:
+            want = np.array([lo / dt(k1 - k0), hi / dt(k1 - k0)], mm.dtype)
+            assert np.array_equal(pairs_by_entry[lay.vpos[k0:k1]], np.tile(want, (k1 - k0, 1)))
+
+
+def test_seg_exchange_refuses_what_it_cannot_hold():
+    from bdd_amd.instances import random_set_cover
+    col, _ = random_set_cover(40, 400, 6, seed=1)              # 60 entries per variable: runs of more than 32 with 64 threads per 64 variables
+    assert not seg_exchange(Layout(col, vars_per_bin=64), 64, 4)[0]
+    assert not seg_exchange(Layout(col, exchange_by_variable=2), 256, 4)[0]
