@@ -100,6 +100,7 @@ SIGNATURES = {
     "bddmma_lbfgs_get_state": (_I, [_V, C.POINTER(LbfgsState)]),
     "bddmma_perturb_primal_costs": (_I, [_V, _V, _D, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), _V, _V, _V]),
     "bddmma_run_solver": (_I, [_V, _V, _U64, _D, _D, _D, _I, C.POINTER(RunResult)]),
+    "bddmma_run_solver_host_loop": (_I, [_V, _V, _U64, _D, _D, _D, _I, C.POINTER(RunResult)]),
     "bddmma_incremental_mm_agreement_rounding": (_I, [_V, _V, _D, _D, _U64, _U64, C.c_uint32, _I, _V, C.POINTER(_I)]),
     "bddmma_save": (_I, [_V, C.c_char_p]),
     "bddmma_load": (_I, [C.POINTER(_V), _I, C.c_char_p]),

@@ -59,7 +59,11 @@ int bddmma_create(bddmma_solver** out, int precision, int device, const bddmma_i
     if (!out) return BDDMMA_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     try {
+#ifdef BDDMMA_EXPERIMENTAL  // make EXPERIMENTAL=1: phase timings of the construction on stderr (tools/construct_time.py)
         static const bool timing = std::getenv("BDDMMA_LAYOUT_TIMING") != nullptr;
+#else
+        constexpr bool timing = false;
+#endif
         auto t_last = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) {
             if (!timing) return;
@@ -248,17 +252,10 @@ int bddmma_gradient_step(bddmma_solver* s, const void* g, double step, int on_de
     return guarded(s, [&](SolverBase* b) { return g ? b->gradient_step(g, step, on_device) : BDDMMA_ERR_INVALID_ARGUMENT; });
 }
 
-// BDDMMA_SEQUENTIAL_RUN_SOLVER=1 keeps the reference's literal loop (iteration, lower_bound, tests on the host) for the plain solver
-// too: the twin the device-resident loop is tested against.
-static bool sequential_run_solver()
-{
-    const char* e = std::getenv("BDDMMA_SEQUENTIAL_RUN_SOLVER");
-    return e && e[0] == '1';
-}
-
-// run_solver, include/run_solver_util.h:10-77
-int bddmma_run_solver(bddmma_solver* s, bddmma_lbfgs* lbfgs, uint64_t max_iter, double tolerance,
-                      double improvement_slope, double time_limit, int verbose, bddmma_run_result* res)
+// run_solver, include/run_solver_util.h:10-77.  host_loop: the reference's literal loop (iteration, lower_bound, tests on the host) for the
+// plain solver too — bddmma_run_solver_host_loop, the twin the device-resident loop is tested against.
+static int run_solver_impl(bddmma_solver* s, bddmma_lbfgs* lbfgs, uint64_t max_iter, double tolerance, double improvement_slope, double time_limit,
+                           int verbose, bddmma_run_result* res, bool host_loop)
 {
     return guarded(s, [&](SolverBase* b) {
         if (improvement_slope < 0.0 || improvement_slope >= 1.0 || time_limit < 0.0 || tolerance < 0.0) {
@@ -267,7 +264,7 @@ int bddmma_run_solver(bddmma_solver* s, bddmma_lbfgs* lbfgs, uint64_t max_iter, 
         }
         // plain MMA: the loop runs with its termination tests on the device (no host round trip per iteration); the L-BFGS wrapper
         // decides its steps on the host anyway and keeps the sequential loop below
-        if (!lbfgs && !sequential_run_solver()) return b->run_plain(max_iter, tolerance, improvement_slope, time_limit, verbose, res);
+        if (!lbfgs && !host_loop) return b->run_plain(max_iter, tolerance, improvement_slope, time_limit, verbose, res);
         const auto t0 = std::chrono::steady_clock::now();
         auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
         double lb_initial;
@@ -300,6 +297,16 @@ int bddmma_run_solver(bddmma_solver* s, bddmma_lbfgs* lbfgs, uint64_t max_iter, 
         }
         return BDDMMA_OK;
     });
+}
+int bddmma_run_solver(bddmma_solver* s, bddmma_lbfgs* lbfgs, uint64_t max_iter, double tolerance, double improvement_slope, double time_limit,
+                      int verbose, bddmma_run_result* res)
+{
+    return run_solver_impl(s, lbfgs, max_iter, tolerance, improvement_slope, time_limit, verbose, res, false);
+}
+int bddmma_run_solver_host_loop(bddmma_solver* s, bddmma_lbfgs* lbfgs, uint64_t max_iter, double tolerance, double improvement_slope,
+                                double time_limit, int verbose, bddmma_run_result* res)
+{
+    return run_solver_impl(s, lbfgs, max_iter, tolerance, improvement_slope, time_limit, verbose, res, true);
 }
 
 // perturb_primal_costs (incremental_mm_agreement_rounding_cuda.cu:262-331).  The cost update goes through the solver type the

@@ -25,4100 +25,11 @@
 
 #include "layout.hpp"
 
-namespace bddmma {
-
-enum : int { FWD_PLAIN = 0, FWD_SOLVE = 1, FWD_SOLUTION = 2 };
-enum : int { BWD_PLAIN = 0, BWD_SOLVE = 1, BWD_MARGINALS = 2 };
-
-template <typename REAL>
-struct DevPtrs {
-    const uint32_t* nwords;  // narrow node words: distinct pack sequences, pack p's at PackDev::pack_word_off[p]
-    uint32_t n_nwords;
-    const uint64_t* wwords;  // wide node words, indexed by slot - wide_slot_base
-    uint32_t wide_slot_base;
-    REAL* F;                 // cost from root, per slot
-    REAL* T;                 // cost from terminal, per slot
-    REAL* lohi;              // per layer: {lo, hi} arc costs, interleaved
-    // variable <-> layer exchange arrays in binned entry order (layout.hpp, struct Exchange)
-    const REAL* delta_lay;   // 2 REAL per entry: {delta_lo, delta_hi} of the entry's variable (normalised)
-    REAL* mm_binned;         // 1 REAL per entry: deferred min-marginal difference of the entry's layer
-    const uint32_t* lpos;    // per layer: entry index
-    const uint32_t* cs_entry;  // cooperative staging: staged item -> entry
-    const uint16_t* cs_slot;   // cooperative staging: staged item -> LDS slot
-    uint32_t n_slots;        // element counts (buffer descriptors of the narrow kernels)
-    uint32_t n_layers;
-    uint32_t n_narrow_layers;
-    double* lb_partial;      // per pack (narrow packs first, then wide)
-    REAL* x_layer;           // BWD_SOLVE: net_solver_costs x = (hi' - lo') + mm (bdd_cuda_parallel_mma.cu:432-463) in layer order, formed by the sweep itself
-                             // from the new arc costs and the deferred difference (nullptr: not wanted; SolverT::lbfgs_views)
-    REAL* mm0_out;           // BWD_MARGINALS outputs, per layer
-    REAL* mm1_out;
-    char* sol_out;           // FWD_SOLUTION output, per layer
-    // Device-resident run_solver (run_ctl_step): when the termination test of run_solver_util.h:56-73 has fired on the device, the
-    // launches of the iterations the host had already queued return at once.  nullptr outside run_solver (one scalar compare of a
-    // kernel argument); otherwise one scalar load per launch.  *stop = number of iterations after which the loop ended (UINT32_MAX
-    // while it runs); run_iter = index of the iteration this launch belongs to.  A launch is skipped when *stop <= run_iter, so the
-    // launch that latches the word (it belongs to iteration *stop - 1) can never skip part of its own grid — with a plain flag the
-    // workgroups dispatched after workgroup 0 had latched it returned without doing their share of the exchange.
-    const uint32_t* stop;
-    uint32_t run_iter;
-    uint32_t big;            // an entry- or slot-indexed array reaches 4 GiB: the staging transfers use 64-bit addresses (stage_load / stage_flush)
-};
-struct RunGate {  // the same pair for the kernels that do not take a DevPtrs
-    const uint32_t* stop = nullptr;
-    uint32_t iter = 0;
-};
-constexpr uint32_t RUN_NOT_STOPPED = 0xFFFFFFFFu;
-
-__device__ __forceinline__ bool run_stopped(const RunGate& g) { return g.stop != nullptr && *g.stop <= g.iter; }
-// The sweep kernels test the word together with their first uniform exit: the pointer is a kernel argument, so outside run_solver
-// (nullptr) the test is one more scalar compare on values the kernel loads anyway — no extra dependent round trip at its start.
-#define BDDMMA_EXIT_IF(done_cond, dev)                                     \
-    {                                                                      \
-        const bool done_ = (done_cond);                                    \
-        if (done_ | ((dev).stop != nullptr)) {                             \
-            if (done_ || *(dev).stop <= (dev).run_iter) return;            \
-        }                                                                  \
-    }
-
-struct PackDev {
-    const uint32_t* pack_hop_ptr;
-    const uint32_t* hop_node_off;
-    const uint32_t* hop_layer_off;
-    const uint8_t* pack_steps;
-    const uint16_t* hop_root;        // narrow packs: per (pack, hop) record the local slot of a BDD root below the pack's first hop, or NO_ROOT (layout.hpp)
-    const uint32_t* pack_word_off;   // narrow packs: first word of the pack's (shared) word sequence
-    const uint32_t* pack_group_ptr;  // narrow packs: stage groups
-    const uint32_t* grp_layer_off;
-    const uint32_t* grp_hop_end;
-    const uint32_t* quad_round_ptr;  // cooperative staging rounds of each quad of packs
-    const uint32_t* cs_ptr;          // first staged item of each (quad, round)
-    uint32_t stage_cap;
-    uint32_t seg_off;  // byte offset of the seg_min2 scratch (128 REALs per wave) inside the dynamic LDS
-    uint32_t n_packs;
-    uint32_t lb_base;  // index of this set's first pack in lb_partial
-    uint32_t nt_potentials;  // streaming narrow sweeps, double: store F / T non-temporally (see hop_store)
-    uint32_t xcd_chunk;      // block_to_pack: workgroups per chunk of the XCD-interleaved map (0: contiguous eighths)
-    // narrow packs, streaming sweeps: the resident headers (layout.hpp: struct Resident — 8 words per pack, 4 per quad) where they hold for the
-    // whole set (one stage group per pack, one round per quad, no staggered packs), else null: a wave then has its pack's hop / slot / layer /
-    // word ranges and its quad's range of the staging tables after ONE round trip instead of two dependent ones each
-    const uint32_t* hdr_pack;
-    const uint32_t* hdr_quad;
-};
-
-// -DBDDMMA_STAMPS (tools/build_variant.sh): per-wave s_memrealtime stamps at the phase boundaries of the small-instance kernels, for
-// the latency budget of profiles/r03_1m_latency.txt.  Stamp i of slot s is taken after everything issued before it has arrived
-// (s_waitcnt 0), so the differences are the phases' durations on that wave.  Not compiled into the shipped library.
-#ifdef BDDMMA_STAMPS
-__device__ unsigned long long* g_bddmma_stamps = nullptr;
-#define BDDMMA_STAMP(slot, idx)                                                                              \
-    do {                                                                                                     \
-        if (g_bddmma_stamps != nullptr) {                                                                    \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
-            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); /* 100 MHz */                     \
-            if ((threadIdx.x & 63) == 0) g_bddmma_stamps[(size_t)(slot) * 8 + (idx)] = t_;                   \
-        }                                                                                                    \
-    } while (0)
-#else
-#define BDDMMA_STAMP(slot, idx) do { } while (0)
-#endif
-
-template <typename REAL> struct Pair;
-template <> struct Pair<float> { using type = float2; };
-template <> struct Pair<double> { using type = double2; };
-
-template <typename REAL> __device__ __forceinline__ REAL inf_v();
-template <> __device__ __forceinline__ float inf_v<float>() { return __builtin_huge_valf(); }
-template <> __device__ __forceinline__ double inf_v<double>() { return __builtin_huge_val(); }
-
-__device__ __forceinline__ float rmin(float a, float b) { return __builtin_fminf(a, b); }
-__device__ __forceinline__ double rmin(double a, double b) { return __builtin_fmin(a, b); }
-__device__ __forceinline__ bool rfinite(float a) { return __builtin_isfinite(a); }
-__device__ __forceinline__ bool rfinite(double a) { return __builtin_isfinite(a); }
-
-// mm = omega * (m1 - m0), or 0 unless both minima are finite (bdd_cuda_parallel_mma.cu:36-39).  Branch-free: with `&&` the compiler
-// built two nested exec regions with a skip branch around one subtraction.
-template <typename REAL>
-__device__ __forceinline__ REAL mm_diff(REAL m0, REAL m1, REAL omega)
-{
-    const bool fin = (int)rfinite(m0) & (int)rfinite(m1);
-    const REAL t = omega * (m1 - m0);
-    return fin ? t : REAL(0);
-}
-// min(x, 0) and min(-x, 0) of a min-marginal difference (never NaN).  One instruction; __builtin_fminf on a value that went through a
-// select costs a v_max x, x canonicalisation first.
-__device__ __forceinline__ float min0(float x)
-{
-    float r;
-    asm("v_min_f32_e64 %0, %1, 0" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ float min0_neg(float x)
-{
-    float r;
-    asm("v_min_f32_e64 %0, -%1, 0" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ double min0(double x) { return rmin(x, 0.0); }
-__device__ __forceinline__ double min0_neg(double x) { return rmin(-x, 0.0); }
-
-template <typename REAL>
-__device__ __forceinline__ void lds_min(REAL* p, REAL v)
-{
-    __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_min_f32 / ds_min_f64
-}
-
-// (Measured and dropped: the forward frontier as order-preserving integers with ds_min_u32 / ds_min_u64 instead of ds_min_f32 / f64 —
-// same speed on every benchmark, so the float LDS minimum is not what makes the forward pushes slower than the backward gathers.)
-// frontier minimum of the workgroup-per-pack kernels: LDS (ds_min) or, for huge packs whose frontier does not fit
-// in LDS, global scratch memory (L2 atomic; a CAS loop where the hardware has no float minimum)
-template <bool GLOBAL, typename REAL>
-__device__ __forceinline__ void frontier_min(REAL* p, REAL v)
-{
-    if (GLOBAL) __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// values other waves of the workgroup produced with frontier_min: huge packs read them from L2 (the atomics do not
-// update this CU's vector L1)
-template <bool GLOBAL, typename REAL>
-__device__ __forceinline__ REAL frontier_load(const REAL* p)
-{
-    if (GLOBAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-
-// XCD-aware block -> pack map: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md).  XCD x gets chunks of `chunk`
-// consecutive workgroups' packs — chunk x, x + 8, x + 16, ... — so that neighbouring packs, which share variables in structured
-// problems, sit behind the same 4 MiB L2, while every XCD sees every part of the pack sequence: instances that mix constraint
-// families (cheap 10-hop covering packs, expensive 30-hop knapsack packs; packs are ordered by family) had all their expensive packs
-// on one or two XCDs when each XCD owned one contiguous eighth (chunk = 0: that map, kept for A/B runs, variant_flags bit 7).
-// The grid is a multiple of 8 * chunk workgroups (the launcher rounds up; surplus workgroups exit at once).
-__device__ __forceinline__ uint32_t block_to_pack(uint32_t bid, uint32_t n_packs, uint32_t chunk)
-{
-    if (chunk == 0) {
-        const uint32_t per = (n_packs + 7u) >> 3;
-        return (bid & 7u) * per + (bid >> 3);
-    }
-    const uint32_t x = bid & 7u, i = bid >> 3;
-    return ((i / chunk) * 8u + x) * chunk + i % chunk;
-}
-
-// ---- per-layer min across the lanes of a layer ---------------------------------------------------
-// A layer occupies `len` consecutive lanes starting `pos` lanes below the current one (fields of the
-// node word).  Result: min over the layer, in every lane of the layer.
-__device__ __forceinline__ float dpp_from_next(float v)  // lane i <- lane i+1 (v_mov_b32_dpp wave_shl:1)
-{
-    const int x = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x130, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float dpp_from_prev(float v)  // lane i <- lane i-1 (wave_shr:1)
-{
-    const int x = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x138, 0xF, 0xF, false));
-}
-__device__ __forceinline__ double dpp_from_next(double v)
-{
-    const long long x = __builtin_bit_cast(long long, v);
-    const int lo = (int)x, hi = (int)(x >> 32);
-    const unsigned int l2 = (unsigned int)__builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xF, 0xF, false);
-    const unsigned int h2 = (unsigned int)__builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
-    return __builtin_bit_cast(double, ((unsigned long long)h2 << 32) | l2);
-}
-#ifndef BDDMMA_SEG_FOLD_F32
-#define BDDMMA_SEG_FOLD_F32 2
-#endif
-template <typename REAL>
-constexpr int SEG_FOLD_STEPS = sizeof(REAL) == 4 ? BDDMMA_SEG_FOLD_F32 : 1;  // see seg_min2
-template <int CTRL>
-__device__ __forceinline__ float dpp_row(float v)  // DPP move with control CTRL (row_shl:n = 0x100 + n); lanes without a source keep their value
-{
-    const int x = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false));
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_row(double v)
-{
-    const long long x = __builtin_bit_cast(long long, v);
-    const int lo = (int)x, hi = (int)(x >> 32);
-    const unsigned int l2 = (unsigned int)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    const unsigned int h2 = (unsigned int)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-    return __builtin_bit_cast(double, ((unsigned long long)h2 << 32) | l2);
-}
-__device__ __forceinline__ double dpp_from_prev(double v)
-{
-    const long long x = __builtin_bit_cast(long long, v);
-    const int lo = (int)x, hi = (int)(x >> 32);
-    const unsigned int l2 = (unsigned int)__builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xF, 0xF, false);
-    const unsigned int h2 = (unsigned int)__builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xF, 0xF, false);
-    return __builtin_bit_cast(double, ((unsigned long long)h2 << 32) | l2);
-}
-
-// Wider layers: every lane folds its two values into the layer's LDS slots with ds_min (slot = lane of the layer's head, unique inside
-// the 64-lane group) and reads the result back — 6 LDS instructions and 3 dependent LDS round trips whatever the width.  The first
-// version did ceil(log2(width)) __shfl_down halving steps + a __shfl broadcast per value: 14 ds_bpermute in 7 dependent round trips and
-// ~75 VALU for 64-wide layers, which made packs of knapsack-like BDDs instruction- and latency-bound (185 VALU per wave and hop).
-// sM: 128 REALs of LDS owned by this wave ([0, 64) for a, [64, 128) for b); a wave's LDS operations execute in order, so only the
-// compiler needs the fences.
-__device__ __forceinline__ void seg_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// layers of 1 or 2 nodes (simplex / covering / cardinality-1 rows): the head takes the minimum with its right neighbour, the second
-// node copies the head's result — DPP moves, no LDS crossbar traffic.  A 2-node layer never straddles the 64-lane group.
-__device__ __forceinline__ void seg_pair_min(double& a, double& b, uint32_t pos, uint32_t len)
-{
-    const double a2 = dpp_from_next(a), b2 = dpp_from_next(b);
-    if (pos == 0 && len == 2) {
-        a = rmin(a, a2);
-        b = rmin(b, b2);
-    }
-    const double a1 = dpp_from_prev(a), b1 = dpp_from_prev(b);
-    if (pos == 1) {
-        a = a1;
-        b = b1;
-    }
-}
-// float: the minimum with the DPP-shifted operand is one instruction (v_min_f32_dpp).  Through the builtins the compiler emits
-// v_mov_b32_dpp, two v_max x, x canonicalisations and v_min per value (it cannot see that a moved float is canonical): 16 VALU per lane
-// group and hop instead of 8.  s_nop 1: a DPP operand written by the preceding VALU instruction needs two wait states, and the hazard
-// recogniser does not look into inline assembly.  The DPP ops run with all lanes enabled (a source lane masked out by EXEC would
-// count as invalid); the selects apply the layer structure.
-__device__ __forceinline__ void seg_pair_min(float& a, float& b, uint32_t pos, uint32_t len)
-{
-    float ta, tb;
-    asm volatile("s_nop 1\n\t"
-                 "v_min_f32_dpp %0, %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_min_f32_dpp %1, %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf"
-                 : "=&v"(ta), "=&v"(tb)
-                 : "v"(a), "v"(b));
-    const bool head2 = pos == 0 && len == 2;
-    a = head2 ? ta : a;
-    b = head2 ? tb : b;
-    asm volatile("s_nop 1\n\t"
-                 "v_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mov_b32_dpp %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf"
-                 : "=&v"(ta), "=&v"(tb)
-                 : "v"(a), "v"(b));
-    a = pos == 1 ? ta : a;
-    b = pos == 1 ? tb : b;
-}
-// One fold step: a, b <- min with the values SH lanes up the row where `same` holds.  float: v_min_f32_dpp takes the shifted operand
-// directly (through the builtins the compiler emits v_mov, v_mov_dpp, two v_max canonicalisations and v_min per value: 14 instead of 5
-// VALU per step); s_nop 1: a DPP operand written by the preceding VALU instruction needs two wait states (see seg_pair_min).  Lanes
-// without a source lane keep an undefined destination, which `same` (false there) never selects.
-template <int SH>
-__device__ __forceinline__ void seg_fold_step(float& a, float& b, bool same)
-{
-    float ta, tb;
-#define BDDMMA_FOLD_ASM(N)                                                        \
-    asm("s_nop 1\n\t"                                                             \
-        "v_min_f32_dpp %0, %2, %2 row_shl:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
-        "v_min_f32_dpp %1, %3, %3 row_shl:" #N " row_mask:0xf bank_mask:0xf"       \
-        : "=&v"(ta), "=&v"(tb)                                                     \
-        : "v"(a), "v"(b))
-    static_assert(SH == 1 || SH == 2 || SH == 4, "row_shl:1 / 2 / 4");
-    if (SH == 1) BDDMMA_FOLD_ASM(1);
-    else if (SH == 2) BDDMMA_FOLD_ASM(2);
-    else BDDMMA_FOLD_ASM(4);
-#undef BDDMMA_FOLD_ASM
-    a = same ? ta : a;
-    b = same ? tb : b;
-}
-template <int SH>
-__device__ __forceinline__ void seg_fold_step(double& a, double& b, bool same)
-{
-    const double an = dpp_row<0x100 + SH>(a), bn = dpp_row<0x100 + SH>(b);
-    a = same ? rmin(a, an) : a;
-    b = same ? rmin(b, bn) : b;
-}
-// The same fold for the wide packs, whose lanes know their layer's index in the hop (`key`: equal for the consecutive lanes of a layer;
-// inactive lanes pass a key no layer has) instead of a position: returns true in the lanes that must issue the LDS atomics.
-template <typename REAL>
-__device__ __forceinline__ bool seg_fold_by_key(REAL& a, REAL& b, uint32_t key, int lane)
-{
-    constexpr int K = SEG_FOLD_STEPS<REAL>;
-    constexpr uint32_t G = 1u << K;
-#define BDDMMA_SEG_STEP(SH)                                                                                                \
-    {                                                                                                                      \
-        const uint32_t kn = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x100 + SH, 0xF, 0xF, false);      \
-        seg_fold_step<SH>(a, b, kn == key);   /* past the row: kn = ~key */                                                \
-    }
-    BDDMMA_SEG_STEP(1)
-    if (K >= 2) BDDMMA_SEG_STEP(2)
-    if (K >= 3) BDDMMA_SEG_STEP(4)
-#undef BDDMMA_SEG_STEP
-    const uint32_t kp = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x111, 0xF, 0xF, false);  // row_shr:1: lane i <- lane i - 1
-    return ((uint32_t)lane & (G - 1u)) == 0u || kp != key;
-}
-template <typename REAL>
-__device__ __forceinline__ void seg_min2(REAL& a, REAL& b, int lane, uint32_t pos, uint32_t len, int steps, REAL* sM)
-{
-    if (steps <= 1) {
-        seg_pair_min(a, b, pos, len);
-        return;
-    }
-#ifdef BDDMMA_EXP_NOSEG  // timing experiment only (wrong results): what the LDS segmented minimum costs
-    seg_pair_min(a, b, pos, len);
-    return;
-#endif
-    const REAL INF = inf_v<REAL>();
-    const uint32_t head = (uint32_t)lane - pos;
-    sM[lane] = INF;
-    sM[64 + lane] = INF;
-    seg_fence();
-    // Before LDS: the lanes of a layer fold their values with K DPP steps (row_shl 1, 2: lane i takes lane i + 2^j of its 16-lane row if
-    // that lane belongs to the same layer, i.e. its position is pos + 2^j), so lane i holds the minimum over the next 2^K lanes of its
-    // layer and row, and only every 2^K-th lane of a layer plus the first lane of each row issue the atomics.  All lanes of a layer hit ONE
-    // address, which LDS serialises: at 10 M knapsack nodes the solve sweeps were LDS-bound (57 % busy, half of it these conflicts).
-    // Measured there (it/s float / double): K = 0: 3 730 / 2 940, 1: 4 140 / 3 230, 2: 4 220 / 3 170, 3: 4 050 / 3 080, 4: 3 830 / 2 950
-    // (measured with the builtin form of the step, ~14 VALU in float; the sweeps are VALU-bound next) -> K = 2 in float, 1 in double.
-    {
-        constexpr int K = SEG_FOLD_STEPS<REAL>;
-        constexpr uint32_t G = 1u << K;
-#define BDDMMA_SEG_STEP(SH)                                                                                               \
-    {                                                                                                                     \
-        const uint32_t pn = (uint32_t)__builtin_amdgcn_update_dpp((int)pos, (int)pos, 0x100 + SH, 0xF, 0xF, false);    \
-        seg_fold_step<SH>(a, b, pn == pos + SH);   /* past the row: pn = pos */                                           \
-    }
-        BDDMMA_SEG_STEP(1)
-        if (K >= 2) BDDMMA_SEG_STEP(2)
-        if (K >= 3) BDDMMA_SEG_STEP(4)
-#undef BDDMMA_SEG_STEP
-        if ((pos & (G - 1u)) == 0u || ((uint32_t)lane & 15u) == 0u) {
-            __hip_atomic_fetch_min(&sM[head], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_min(&sM[64 + head], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    seg_fence();
-    a = sM[head];
-    b = sM[64 + head];
-    seg_fence();  // the next group's reset must not overtake these reads
-}
-
-// ---- buffer-descriptor memory ops ---------------------------------------------------------------
-// Every per-lane predicate of the narrow kernels is folded into the byte offset of a raw buffer op: an
-// offset past the descriptor's size makes the hardware drop the lane (loads return 0, stores are
-// discarded).  With `if (active) x = p[i]` hipcc emits an exec-masked branch per access; the waitcnt
-// pass then cannot count the outstanding loads and falls back to s_waitcnt vmcnt(0), which drains
-// every prefetch in flight (seen in the ISA of the first pipelined version).  Branch-free buffer ops
-// keep the instruction stream straight-line, so the waits become counted vmcnt(N).
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-constexpr uint32_t OOB = 0xFFFFFFFFu;
-#ifndef BDDMMA_LD_AUX
-#define BDDMMA_LD_AUX 0
-#endif
-#ifndef BDDMMA_ST_AUX
-#define BDDMMA_ST_AUX 0
-#endif
-
-template <typename T>
-__device__ __forceinline__ rsrc_t make_rsrc(const T* p, uint64_t n_elems)
-{
-    const uint64_t bytes = n_elems * sizeof(T);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p), 0, (uint32_t)(bytes > 0xFFFFFFFEull ? 0xFFFFFFFEull : bytes), 0x00020000);
-}
-__device__ __forceinline__ uint32_t bload_u32(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, BDDMMA_LD_AUX); }
-__device__ __forceinline__ uint32_t bload_u16(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0); }
-__device__ __forceinline__ void bload(float& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, BDDMMA_LD_AUX)); }
-__device__ __forceinline__ void bload(double& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, BDDMMA_LD_AUX)); }
-__device__ __forceinline__ void bload(float2& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, BDDMMA_LD_AUX)); }
-__device__ __forceinline__ void bload(double2& v, rsrc_t r, uint32_t off) { v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); }
-__device__ __forceinline__ void bstore(float v, rsrc_t r, uint32_t off) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0, BDDMMA_ST_AUX); }
-__device__ __forceinline__ void bstore(double v, rsrc_t r, uint32_t off)
-{
-    using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, off, 0, BDDMMA_ST_AUX);
-}
-__device__ __forceinline__ void bstore(float2 v, rsrc_t r, uint32_t off)
-{
-    using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, off, 0, BDDMMA_ST_AUX);
-}
-__device__ __forceinline__ void bstore(double2 v, rsrc_t r, uint32_t off)
-{
-    using u4 = decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, off, 0, 0);
-}
-
-template <typename REAL>
-struct NarrowRs {
-    rsrc_t words, T, F, lohi, cse, css, dlay, mm;
-    const uint32_t* cse_p;  // the staging tables as plain pointers (stage_load rebases them to its round)
-    const uint16_t* css_p;
-    const REAL* dlay_p;  // the entry arrays as plain pointers: instances whose arrays reach 4 GiB address them with 64 bits (DevPtrs::big)
-    REAL* mm_p;
-    bool big;
-    __device__ __forceinline__ explicit NarrowRs(const DevPtrs<REAL>& d)
-    {
-        cse_p = d.cs_entry;
-        css_p = d.cs_slot;
-        dlay_p = d.delta_lay;
-        mm_p = d.mm_binned;
-        big = d.big != 0;
-        words = make_rsrc(d.nwords, d.n_nwords);
-        T = make_rsrc(d.T, d.n_slots);
-        F = make_rsrc(d.F, d.n_slots);
-        lohi = make_rsrc(d.lohi, 2ull * d.n_layers);
-        cse = make_rsrc(d.cs_entry, d.n_narrow_layers);
-        css = make_rsrc(d.cs_slot, d.n_narrow_layers);
-        dlay = make_rsrc(d.delta_lay, 2ull * d.n_layers);
-        mm = make_rsrc(d.mm_binned, d.n_layers);
-    }
-    // {lo, hi} from the pack's first layer on (see HopWindow: layer indices in the sweeps are relative to it)
-    __device__ __forceinline__ void rebase_layers(const DevPtrs<REAL>& d, uint32_t l0) { lohi = make_rsrc(d.lohi + 2 * (size_t)l0, 2ull * (d.n_layers - l0)); }
-};
-
-// Cooperative stage transfer between the entry arrays and LDS: the WPB waves of a workgroup sweep WPB
-// consecutive packs; in every round they load the delta pairs of their packs' stage groups together.
-// Staged items are sorted by entry index, so consecutive threads touch consecutive entries — runs of
-// (bin, quad) instead of (bin, pack) length — and scatter them to the owning wave's LDS slots.  The
-// (entry, slot) pairs stay in registers for the write-back of the min-marginal differences.
-constexpr int STAGE_ITERS = 10;  // stage_cap <= 64 * STAGE_ITERS
-
-// (two halves, so that a kernel that knows its round's item range early — resident headers — can have the tables on their way while it sets
-// up its pipeline: stage_load_tables issues the table loads, stage_load_pairs the dependent pair loads and the scatter into LDS)
-template <typename REAL, int WPB>
-__device__ __forceinline__ void stage_load_tables(uint32_t (&e)[STAGE_ITERS], uint32_t (&sl)[STAGE_ITERS], const NarrowRs<REAL>& rs, uint32_t c0, uint32_t cnt,
-                                                  uint32_t tid)
-{
-    // (the round's range of the staging tables, rebased: item offsets stay small whatever the tables' size)
-    const rsrc_t rce = make_rsrc(rs.cse_p + c0, cnt), rcs = make_rsrc(rs.css_p + c0, cnt);
-#pragma unroll
-    for (int u = 0; u < STAGE_ITERS; ++u) {
-        const uint32_t i = 64 * WPB * u + tid;
-        e[u] = bload_u32(rce, i * 4u);   // past the round: dropped
-        sl[u] = bload_u16(rcs, i * 2u);
-    }
-}
-template <typename REAL, int WPB>
-__device__ __forceinline__ void stage_load_pairs(typename Pair<REAL>::type* sD, const uint32_t (&e)[STAGE_ITERS], const uint32_t (&sl)[STAGE_ITERS],
-                                                 const NarrowRs<REAL>& rs, uint32_t cnt, uint32_t tid)
-{
-    using P2 = typename Pair<REAL>::type;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        P2 v[STAGE_ITERS / 2];
-        if (rs.big) {  // uniform: 64-bit addresses (entry * 8 or 16 bytes does not fit the 32-bit buffer offset); unused slots read entry 0
-#pragma unroll
-            for (int u = 0; u < STAGE_ITERS / 2; ++u) {
-                const int k = half * (STAGE_ITERS / 2) + u;
-                const uint32_t i = 64 * WPB * k + tid;
-                v[u] = reinterpret_cast<const P2*>(rs.dlay_p)[i < cnt ? e[k] : 0u];
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < STAGE_ITERS / 2; ++u) {
-                const int k = half * (STAGE_ITERS / 2) + u;
-                const uint32_t i = 64 * WPB * k + tid;
-                bload(v[u], rs.dlay, i < cnt ? e[k] * (uint32_t)sizeof(P2) : OOB);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < STAGE_ITERS / 2; ++u) {
-            const int k = half * (STAGE_ITERS / 2) + u;
-            const uint32_t i = 64 * WPB * k + tid;
-            if (i < cnt) sD[sl[k]] = v[u];
-        }
-    }
-}
-template <typename REAL, int WPB>
-__device__ __forceinline__ void stage_load(typename Pair<REAL>::type* sD, uint32_t (&e)[STAGE_ITERS], uint32_t (&sl)[STAGE_ITERS],
-                                           const NarrowRs<REAL>& rs, uint32_t c0, uint32_t cnt, uint32_t tid)
-{
-    stage_load_tables<REAL, WPB>(e, sl, rs, c0, cnt, tid);
-    stage_load_pairs<REAL, WPB>(sD, e, sl, rs, cnt, tid);
-}
-
-template <typename REAL, int WPB>
-__device__ __forceinline__ void stage_flush(const typename Pair<REAL>::type* sD, const uint32_t (&e)[STAGE_ITERS],
-                                            const uint32_t (&sl)[STAGE_ITERS], const NarrowRs<REAL>& rs, uint32_t cnt, uint32_t tid)
-{
-    if (rs.big) {
-#pragma unroll
-        for (int u = 0; u < STAGE_ITERS; ++u) {
-            const uint32_t i = 64 * WPB * u + tid;
-            if (i < cnt) rs.mm_p[e[u]] = sD[sl[u]].x;
-        }
-        return;
-    }
-#pragma unroll
-    for (int u = 0; u < STAGE_ITERS; ++u) {
-        const uint32_t i = 64 * WPB * u + tid;
-        const REAL m = sD[i < cnt ? sl[u] : 0].x;
-        bstore(m, rs.mm, i < cnt ? e[u] * (uint32_t)sizeof(REAL) : OOB);
-    }
-}
-
-// =============================================================================================
-// narrow packs: one wavefront per pack, R groups of 64 slots per hop, no barriers
-// =============================================================================================
-// Window of per-hop offsets kept in LDS.  Reading pk.hop_node_off[q] inside the hop loop compiles to a
-// *vector* global load followed by s_waitcnt vmcnt(0): it serialises two extra memory round trips per
-// hop and drains every prefetch in flight.  Instead 64 consecutive offsets are fetched with one
-// coalesced load and read back with (broadcast) LDS reads, which are counted by lgkmcnt only.
-// Ordering point for LDS traffic of ONE wave.  The LDS unit executes a wave's DS instructions in order,
-// so a wave that only consumes what it wrote itself needs no hardware barrier — only the compiler must not
-// move LDS accesses across this point.  (In a one-wave workgroup __syncthreads() compiles to the same;
-// with several waves per workgroup it would be a real s_barrier per hop.)
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-constexpr uint32_t HOP_WIN = 64;
-#ifndef BDDMMA_HOP_UNROLL
-#define BDDMMA_HOP_UNROLL 2
-#endif
-constexpr int HOP_UNROLL = BDDMMA_HOP_UNROLL;  // hops per trip of the narrow kernels' hop loops (see k_fwd_narrow)
-struct HopWindow {
-    uint32_t* node;   // LDS [HOP_WIN]
-    uint32_t* layer;  // LDS [HOP_WIN]
-    uint32_t* root;   // LDS [HOP_WIN]: PackDev::hop_root of the record (NO_ROOT past the pack's last hop)
-    uint32_t base;    // record index of window slot 0
-    uint32_t q1;      // one past the pack's last hop record (offsets clamp there)
-    // Offsets are kept RELATIVE to the pack's first slot / layer (round 4): the sweeps address F, T and {lo, hi} through pointers
-    // rebased to the pack (64-bit, once per pack), so that the 32-bit byte offsets of the buffer instructions stay small whatever the
-    // arrays' size — arrays beyond 4 GiB (>= 512 M slots in double) no longer overflow them.
-    uint32_t n0, l0;  // the pack's first slot and first layer
-    __device__ __forceinline__ void fill(const PackDev& pk, uint32_t new_base, int lane)
-    {
-        base = new_base;
-        const uint32_t q = min(new_base + (uint32_t)lane, q1);
-        node[lane] = pk.hop_node_off[q] - n0;
-        layer[lane] = pk.hop_layer_off[q] - l0;
-        root[lane] = new_base + (uint32_t)lane < q1 ? (uint32_t)pk.hop_root[q] : (uint32_t)NO_ROOT;
-        wave_sync();
-    }
-    // root slot of hop q (below the pack's first hop), NO_ROOT if no BDD starts there
-    __device__ __forceinline__ uint32_t root_of(uint32_t q) const
-    {
-        return __builtin_amdgcn_readfirstlane(root[min(q, q1) - base]);
-    }
-    __device__ __forceinline__ uint32_t node_off(uint32_t q) const
-    {
-        return __builtin_amdgcn_readfirstlane(node[min(q, q1) - base]);
-    }
-    __device__ __forceinline__ uint32_t layer_off(uint32_t q) const
-    {
-        return __builtin_amdgcn_readfirstlane(layer[min(q, q1) - base]);
-    }
-};
-
-// Per-hop register sets of the software pipeline.  A wave's hop is a chain of dependent memory round
-// trips (node words -> layer costs -> LDS), and with <= 32 waves per CU the sweep was latency-bound
-// (SQ_WAIT_ANY 80 % of wave cycles, 3.9 TB/s).  All addresses of later hops are plain streams, so the
-// words of hop q+2 and the layer data / potentials of hop q+1 are requested while hop q is computed.
-template <typename REAL, int R>
-struct HopLayer {
-    typename Pair<REAL>::type c[R];  // {lo, hi}
-    uint32_t lg[R];                  // global layer index of the lane's node
-};
-
-__device__ __forceinline__ uint32_t nw_pos(uint32_t w) { return (w >> NW_POS_SHIFT) & NW_FIELD6; }
-__device__ __forceinline__ uint32_t nw_lidx(uint32_t w) { return (w >> NW_LIDX_SHIFT) & NW_FIELD6; }  // layer index inside the lane group
-__device__ __forceinline__ uint32_t nw_len(uint32_t w) { return (w & NW_TWO) ? 2u : 0u; }  // only "is it a two-node layer" is stored
-__device__ __forceinline__ bool nw_head(uint32_t w) { return (w & (NW_PAD | (NW_FIELD6 << NW_POS_SHIFT))) == 0; }
-
-__device__ __forceinline__ void hop_load(float2& v, rsrc_t rh, uint32_t voff, uint32_t soff)
-{
-    v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rh, voff, soff, BDDMMA_LD_AUX));
-}
-__device__ __forceinline__ void hop_load(double2& v, rsrc_t rh, uint32_t voff, uint32_t soff)
-{
-    v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rh, voff, soff, 0));
-}
-template <typename REAL, int R>
-__device__ __forceinline__ void load_layer(HopLayer<REAL, R>& L, const uint32_t (&w)[R], uint32_t lbase, const NarrowRs<REAL>& rs)
-{
-    using P2 = typename Pair<REAL>::type;
-    uint32_t base = lbase;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t li = nw_lidx(w[r]);
-        L.lg[r] = base + li;
-        // the group's first layer goes into the scalar offset; padding lanes (index 0) read that layer's pair and ignore it
-        hop_load(L.c[r], rs.lohi, li * (uint32_t)sizeof(P2), base * (uint32_t)sizeof(P2));
-        if (r + 1 < R) base += (uint32_t)__popcll(__ballot(nw_head(w[r])));  // layers of this lane group
-    }
-}
-
-// One hop's slice [nb, nb + n) of a slot-indexed array.  A lane addresses it with its constant byte offset j * sizeof(T); the slice's
-// start goes into the scalar offset of the buffer instruction and the descriptor ends where the slice ends, so the lanes past the
-// hop's last slot drop out by themselves: no per-lane address arithmetic or select in the hop (3 VALU per access before).  (gfx950
-// range-checks voffset + soffset against num_records — measured: with num_records = the slice's length every lane was dropped.)
-template <typename T>
-__device__ __forceinline__ rsrc_t hop_rsrc(const T* base, uint32_t nb, uint32_t n)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (nb + n) * (uint32_t)sizeof(T), 0x00020000);
-}
-template <int R>
-__device__ __forceinline__ void load_words(uint32_t (&w)[R], const uint32_t* words, uint32_t nb, uint32_t n, int lane)
-{
-    constexpr uint32_t PADW = nw_pad_word(64 * R);
-    const rsrc_t rh = hop_rsrc(words, nb, n);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t j = lane + 64 * r;
-        const uint32_t x = __builtin_amdgcn_raw_buffer_load_b32(rh, j * 4u, nb * 4u, BDDMMA_LD_AUX);
-        w[r] = (j < n) ? x : PADW;
-    }
-}
-__device__ __forceinline__ void hop_load(float& v, rsrc_t rh, uint32_t voff, uint32_t soff)
-{
-    v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, voff, soff, BDDMMA_LD_AUX));
-}
-__device__ __forceinline__ void hop_load(double& v, rsrc_t rh, uint32_t voff, uint32_t soff)
-{
-    v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rh, voff, soff, BDDMMA_LD_AUX));
-}
-// Cache policy of the potentials' stores (the F / T streams of a streaming sweep).  Double-precision instances whose arrays exceed the
-// Infinity Cache several times store them non-temporally (aux bit 1 = nt; PackDev::nt_potentials, chosen by the solver from the
-// instance's footprint): the 152 MB a sweep writes there no longer displace the arc costs and exchange arrays before the next launch
-// reads them — 10.5 M nodes 3 930 -> 4 095 it/s, row size 32: 3 310 -> 3 485 (A/B on one box).  Instances that fit the cache lose with
-// it (4.2 M nodes: 10 170 -> 9 070), and so does float at every size (10.5 M: 8 290 -> 7 090 it/s — the 4-byte hop slices end in partial
-// lines, which the cached path merges with the next hop's store), hence the run-time switch and double only.
-#ifndef BDDMMA_ST_FT_AUX_F32
-#define BDDMMA_ST_FT_AUX_F32 BDDMMA_ST_AUX
-#endif
-__device__ __forceinline__ void hop_store(float v, rsrc_t rh, uint32_t voff, uint32_t soff)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rh, voff, soff, BDDMMA_ST_FT_AUX_F32);
-}
-template <int AUX = BDDMMA_ST_AUX>
-__device__ __forceinline__ void hop_store(double v, rsrc_t rh, uint32_t voff, uint32_t soff)
-{
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rh, 0, 0, 0)), v), rh, voff, soff, AUX);
-}
-// values of the hop's slots; lanes past the last slot read 0
-template <typename REAL, int R>
-__device__ __forceinline__ void load_vals(REAL (&v)[R], const REAL* src, uint32_t nb, uint32_t n, int lane)
-{
-    const rsrc_t rh = hop_rsrc(src, nb, n);
-#pragma unroll
-    for (int r = 0; r < R; ++r) hop_load(v[r], rh, (lane + 64 * r) * (uint32_t)sizeof(REAL), nb * (uint32_t)sizeof(REAL));
-}
-// ... and the store of one value per slot of the hop (padding slots inside the hop included: nothing reads them)
-template <int R>
-__device__ __forceinline__ void store_vals(const float (&v)[R], float* dst, uint32_t nb, uint32_t n, int lane, uint32_t /*nt*/)
-{
-    const rsrc_t rh = hop_rsrc(dst, nb, n);
-#pragma unroll
-    for (int r = 0; r < R; ++r) hop_store(v[r], rh, (lane + 64 * r) * 4u, nb * 4u);
-}
-template <int R>
-__device__ __forceinline__ void store_vals(const double (&v)[R], double* dst, uint32_t nb, uint32_t n, int lane, uint32_t nt)
-{
-    const rsrc_t rh = hop_rsrc(dst, nb, n);
-    if (nt) {  // uniform (a kernel argument)
-#pragma unroll
-        for (int r = 0; r < R; ++r) hop_store<2>(v[r], rh, (lane + 64 * r) * 8u, nb * 8u);
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) hop_store<>(v[r], rh, (lane + 64 * r) * 8u, nb * 8u);
-    }
-}
-
-#ifndef BDDMMA_LOOKAHEAD
-#define BDDMMA_LOOKAHEAD 1
-#endif
-// SEG = false: no pack of the launch has a layer wider than two nodes — the segmented minimum is the DPP pair, its LDS variant and the
-// per-lane-group branch on the pack's step count are compiled out.
-template <typename REAL, int R, int MODE, int WPB, int LA = BDDMMA_LOOKAHEAD, bool SEG = true>
-__device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t block_id)
-{
-    constexpr int W = 64 * R;
-    constexpr bool NEED_T = (MODE != FWD_PLAIN);
-    using P2 = typename Pair<REAL>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    P2* sD = reinterpret_cast<P2*>(dyn_lds);  // staged {delta_lo, delta_hi} of the workgroup's stage groups; .x is overwritten by mm
-    // per wave; +2: constant sink entries at index TOP = W (cost-from-terminal 0) and BOT = W + 1 (+inf);
-    // for sF they are dummy push targets, so sink children need no branch
-    __shared__ REAL sF_[WPB][2][W + 2];
-    __shared__ REAL sT_[WPB][2][W + 2];  // costs-from-terminal of the next hop, written one hop ahead (double buffer)
-    __shared__ unsigned char sAct_[WPB][2][MODE == FWD_SOLUTION ? W + 2 : 1];
-    __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN], sOffR_[WPB][HOP_WIN];
-    const uint32_t tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int lane = tid & 63;
-    // per-wave scratch of the segmented minimum (seg_min2): behind the rest of the dynamic LDS, only reserved when a pack has layers
-    // wider than two nodes (pk.seg_off; never dereferenced otherwise)
-    REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
-    auto& sF = sF_[wave];
-    auto& sT = sT_[wave];
-    auto& sAct = sAct_[wave];
-    const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(block_id, n_quads, pk.xcd_chunk);
-    BDDMMA_EXIT_IF(quad >= n_quads, d)  // uniform for the workgroup
-    const uint32_t p = quad * WPB + wave;
-    const bool has_pack = p < pk.n_packs;  // the last quad may be partial: such a wave only helps staging
-    const bool hdr = pk.hdr_pack != nullptr;  // uniform: resident headers (PackDev::hdr_pack)
-    const uint32_t* const hp = hdr ? pk.hdr_pack + 8 * (size_t)(has_pack ? p : 0) : nullptr;
-    const uint32_t q0 = !has_pack ? 0 : (hdr ? hp[4] : pk.pack_hop_ptr[p]);
-    const uint32_t q1 = !has_pack ? 0 : (hdr ? q0 + (hp[5] & 0xFFFFu) : pk.pack_hop_ptr[p + 1]);
-    const uint32_t c0_h = (hdr && MODE == FWD_SOLVE) ? pk.hdr_quad[4 * (size_t)quad] : 0, cnt_h = (hdr && MODE == FWD_SOLVE) ? pk.hdr_quad[4 * (size_t)quad + 1] : 0;
-    const int steps = SEG ? (has_pack ? pk.pack_steps[p] : 0) : 1;
-    const REAL INF = inf_v<REAL>();
-    const uint32_t slot_first = !has_pack ? 0 : (hdr ? hp[0] : pk.hop_node_off[q0]), l0 = !has_pack ? 0 : (hdr ? hp[2] : pk.hop_layer_off[q0]);  // the pack's first slot / layer: everything below is relative to them (HopWindow)
-    NarrowRs<REAL> rs(d);
-    rs.rebase_layers(d, l0);
-    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    if (hdr && MODE == FWD_SOLVE) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
-    REAL* const Tp = d.T + slot_first;
-    REAL* const Fp = d.F + slot_first;
-    const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
-    (void)lohi_p;
-    // hop_node_off / hop_layer_off have one entry past the last hop of the last pack, so index q1 is
-    // always readable; offsets beyond q1 are clamped (those hops have no nodes for this pack)
-    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1, slot_first, l0};
-    auto off = [&](uint32_t q) { return hw.node_off(q); };
-    // word address of slot s of this pack = s + wd (the pack's words live in a sequence shared by all packs of its structure)
-    const uint32_t wd = !has_pack ? 0 : (hdr ? hp[6] : pk.pack_word_off[p]);  // (slot offsets are relative to the pack's first slot)
-    // Software pipeline with a look-ahead of D hops: at the start of hop q the wave holds the node words of hops q .. q+2D-1, the
-    // costs-from-terminal of hops q+2 .. q+D+1 (those of hop q+1 are already in LDS) and the layer data of hops q .. q+D-1; during hop q
-    // it requests the words of hop q+2D, T of hop q+D+2 and — from the words of hop q+D, which were requested D hops ago — the layer
-    // data of hop q+D.  Every request has D hop times to arrive.  o[i] = first slot of hop q+i (uniform); the newest offset and the
-    // layer offset of the next hop are read from the LDS window one hop before they are used, in the hop's single batch of LDS reads.
-    constexpr int D = LA;
-    uint32_t o[2 * D + 3];
-    uint32_t lcur = 0;  // first layer of hop q+D
-    uint32_t wr[2 * D + 1][R];
-    REAL tr[D + 1][R];
-    HopLayer<REAL, R> Lr[D + 1];
-#pragma unroll
-    for (int i = 0; i < 2 * D + 3; ++i) o[i] = 0;
-    if (has_pack) {
-        hw.fill(pk, q0, lane);
-#pragma unroll
-        for (int i = 0; i < 2 * D + 3; ++i) o[i] = off(q0 + i);
-        lcur = hw.layer_off(q0 + D);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t j = lane + 64 * r;
-            sF[0][j] = (j < o[1] - o[0]) ? REAL(0) : INF;  // every slot of hop 0 is a root (flush_costs_from_root)
-            if (MODE == FWD_SOLUTION) sAct[0][j] = (j < o[1] - o[0]) ? 1 : 0;
-        }
-        if (lane < 4) sT[lane >> 1][W + (lane & 1)] = (lane & 1) ? INF : REAL(0);
-#pragma unroll
-        for (int i = 0; i < 2 * D; ++i) load_words<R>(wr[i], d.nwords, o[i] + wd, o[i + 1] - o[i], lane);   // none past the last hop
-        if (NEED_T) {
-            REAL t1[R];
-            load_vals<REAL, R>(t1, Tp, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
-#pragma unroll
-            for (int i = 0; i < D; ++i) load_vals<REAL, R>(tr[i], Tp, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t j = lane + 64 * r;
-                if (j < o[2] - o[1]) sT[0][j] = t1[r];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < D; ++i) load_layer<REAL, R>(Lr[i], wr[i], hw.layer_off(q0 + i), rs);
-        wave_sync();
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2 * D; ++i)
-#pragma unroll
-            for (int r = 0; r < R; ++r) wr[i][r] = nw_pad_word(64 * R);
-    }
-    int cur = 0;
-    uint32_t q = q0;
-    uint32_t rt = NO_ROOT;  // root slot of hop q when a BDD starts there (staggered packs); the first hop's roots are set up above
-    const uint32_t g0 = (MODE == FWD_SOLVE && has_pack && !hdr) ? pk.pack_group_ptr[p] : 0;
-    const uint32_t ng = (MODE == FWD_SOLVE && has_pack) ? (hdr ? 1u : pk.pack_group_ptr[p + 1] - g0) : 0;
-    const uint32_t r0 = (MODE == FWD_SOLVE && !hdr) ? pk.quad_round_ptr[quad] : 0;
-    const uint32_t n_rounds = (MODE == FWD_SOLVE && !hdr) ? pk.quad_round_ptr[quad + 1] - r0 : 1;
-    P2* sDw = sD + (size_t)wave * pk.stage_cap;  // this wave's slots of the staging area
-    for (uint32_t k = 0; k < n_rounds; ++k) {
-        uint32_t gl0 = 0, cnt = 0, qe = q1;
-        if (MODE == FWD_SOLVE) {
-            if (hdr) {
-                cnt = cnt_h;
-                stage_load_pairs<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
-            } else {
-                const uint32_t c0 = pk.cs_ptr[r0 + k];
-                cnt = pk.cs_ptr[r0 + k + 1] - c0;
-                stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
-            }
-            if (hdr) {
-                qe = has_pack ? q1 : q;  // one group: the whole pack
-            } else if (k < ng) {
-                gl0 = pk.grp_layer_off[g0 + k] - l0;
-                qe = pk.grp_hop_end[g0 + k];
-            } else {
-                qe = q;  // this pack has no k-th group: no hops in this round
-            }
-            if (WPB > 1) __syncthreads(); else wave_sync();
-        }
-        // One hop of the pack.  The loop below executes HOP_UNROLL of them per trip: the compiler drains all outstanding
-        // memory operations at the loop header (s_waitcnt vmcnt(0), which also waits for the stores of the hop just
-        // finished), so the chain "wait, LDS round trips, stores" is paid once per trip; inside a trip the waits are
-        // counted and the pipeline-register rotation is renamed away.  Latency-bound cases gain most: sweeps of
-        // 100-variable rows -10 % (solve) / -22 % (plain), the 1 M-node benchmark -6 %; the saturated 10.5 M one +-1 %.
-        // One hop of the pack.  A wave's hop used to be a chain of ~9 dependent LDS round trips (offsets, frontier, T set-up -> gather,
-        // staged pairs, per 64-lane group in turn), ~130 cycles each: with few waves per SIMD that chain, not HBM, set the hop time.
-        // Now everything a hop reads from LDS — the frontier, the children's costs-from-terminal (written one hop ahead), the staged
-        // pairs, the next hop's offsets — is one batch of reads for all R groups, followed by the arithmetic, followed by the writes.
-        auto hop = [&]() {
-            if (q + 2 * D + 3 >= hw.base + HOP_WIN && hw.base + HOP_WIN <= q1) hw.fill(pk, q, lane);
-            const uint32_t nb = o[0];
-            const uint32_t n3 = o[3] - o[2];  // slots of hop q+2
-            // ---- global prefetch
-            load_words<R>(wr[2 * D], d.nwords, o[2 * D] + wd, o[2 * D + 1] - o[2 * D], lane);
-            if (NEED_T) load_vals<REAL, R>(tr[D], Tp, o[D + 2], o[D + 3] - o[D + 2], lane);
-            load_layer<REAL, R>(Lr[D], wr[D], lcur, rs);  // all padding past the last hop: no loads
-            uint32_t (&wa)[R] = wr[0];
-            HopLayer<REAL, R>& La = Lr[0];
-            // ---- the hop's LDS reads, one batch
-            REAL f[R], tl[R], th[R];
-            P2 dd[R];
-            bool on_path[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t j = lane + 64 * r;
-                const uint32_t w = wa[r];
-                const bool act = !(w & NW_PAD);
-                const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
-                f[r] = sF[cur][j];
-                if (j == rt) f[r] = REAL(0);  // a BDD that starts at this hop: its root has no parents (flush_costs_from_root)
-                if (NEED_T) {
-                    tl[r] = sT[cur][lo_i];  // sinks: [W] = 0, [W+1] = +inf
-                    th[r] = sT[cur][hi_i];
-                }
-                if (MODE == FWD_SOLVE) dd[r] = sDw[act ? La.lg[r] - gl0 : 0];  // staging index: position of the layer inside its group
-                if (MODE == FWD_SOLUTION) on_path[r] = act && (sAct[cur][j] || j == rt);
-            }
-            const uint32_t o_new = off(q + 2 * D + 3);
-            const uint32_t l_next = hw.layer_off(q + D + 1);
-            const uint32_t rt_next = hw.root_of(q + 1);
-            // ---- set-up of the next hop's buffers (nothing above depends on it)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t j = lane + 64 * r;
-                if (NEED_T && j < n3) sT[cur ^ 1][j] = tr[0][r];  // T of hop q+2, gathered by hop q+1
-                sF[cur ^ 1][j] = INF;
-                if (MODE == FWD_SOLUTION) sAct[cur ^ 1][j] = 0;
-            }
-            wave_sync();
-            // ---- arithmetic
-            REAL nlo[R], nhi[R], mmv[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t w = wa[r];
-                const bool act = !(w & NW_PAD);
-                const REAL lc = La.c[r].x, hc = La.c[r].y;
-                nlo[r] = lc;
-                nhi[r] = hc;
-                if (MODE == FWD_SOLVE) {
-                    REAL m0 = act ? (f[r] + lc) + tl[r] : INF;
-                    REAL m1 = act ? (f[r] + hc) + th[r] : INF;
-                    seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
-                    const REAL mm = mm_diff(m0, m1, omega);
-                    mmv[r] = mm;
-                    nlo[r] = (lc + min0(mm)) + dd[r].x;
-                    nhi[r] = (hc + min0_neg(mm)) + dd[r].y;
-                }
-            }
-            // ---- writes: staged min-marginal differences, pushes into the next frontier, global stores
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t j = lane + 64 * r;
-                const uint32_t w = wa[r];
-                const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
-                if (MODE == FWD_SOLVE) {
-                    const bool head = nw_head(w);
-                    P2 nc;
-                    nc.x = nlo[r];
-                    nc.y = nhi[r];
-                    // the offset goes through an opaque register: otherwise the compiler folds the select into the `if (head)` below and
-                    // emits the store twice, in two out-of-line blocks (four taken branches per lane group and hop)
-                    uint32_t soff = head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB;
-                    asm volatile("" : "+v"(soff));
-                    bstore(nc, rs.lohi, soff);
-                    if (head) sDw[La.lg[r] - gl0].x = mmv[r];  // every lane of the layer has read its pair above (same wave, in order)
-                }
-                if (MODE == FWD_SOLUTION) {
-                    // compute_bdd_sol_func, bdd_cuda_base.cu:1103-1137 (with the `< 0` fix of SURVEY.md §8)
-                    if (on_path[r]) {
-                        const REAL hi_path = f[r] + (th[r] + La.c[r].y);  // backward_step_with_path_costs, :633-640
-                        const REAL lo_path = f[r] + (tl[r] + La.c[r].x);
-                        const bool take_lo = (hi_path - lo_path) > 0;
-                        d.sol_out[l0 + La.lg[r]] = take_lo ? 0 : 1;
-                        sAct[cur ^ 1][take_lo ? lo_i : hi_i] = 1;  // sink entries are dummies
-                    }
-                }
-                // Pushes into the sinks (and from padding lanes, whose children are BOT) have no reader: they are masked out.  As plain
-                // pushes into two dummy entries they were the slowest instructions of the sweep — same-address LDS atomics serialise
-                // at 20-100 cycles per lane (measured with half-empty packs: +0.56 us per hop for 64 such lane-ops), and in a pack of
-                // equal rows every lane's last hop pushes into a sink.
-                // (Branch-free: a masked lane "pushes" +inf into its own slot j — a no-op on a distinct address.  As `if (child < W)` the
-                // compiler moved every push out of line, two taken branches each.)
-                const bool plo = lo_i < (uint32_t)W, phi = hi_i < (uint32_t)W;
-                lds_min(&sF[cur ^ 1][plo ? lo_i : j], plo ? f[r] + nlo[r] : INF);
-                lds_min(&sF[cur ^ 1][phi ? hi_i : j], phi ? f[r] + nhi[r] : INF);
-            }
-            // (the argmin-path sweep leaves the stored costs-from-root alone: nothing reads them after it, and it is 38 MB of the ~120 MB the
-            // sweep moves at 10.5 M nodes)
-            if (MODE != FWD_SOLUTION) store_vals<R>(f, Fp, nb, o[1] - o[0], lane, pk.nt_potentials);
-            wave_sync();
-            cur ^= 1;
-            // ---- rotate the pipeline registers
-#pragma unroll
-            for (int i = 0; i < 2 * D + 2; ++i) o[i] = o[i + 1];
-            o[2 * D + 2] = o_new;
-            lcur = l_next;
-            rt = rt_next;
-#pragma unroll
-            for (int i = 0; i < 2 * D; ++i)
-#pragma unroll
-                for (int r = 0; r < R; ++r) wr[i][r] = wr[i + 1][r];
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                Lr[i] = Lr[i + 1];
-                if (NEED_T) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) tr[i][r] = tr[i + 1][r];
-                }
-            }
-            ++q;
-        };
-        while (q + HOP_UNROLL <= qe) {
-#pragma unroll
-            for (int u = 0; u < HOP_UNROLL; ++u) hop();
-        }
-        while (q < qe) hop();
-        if (MODE == FWD_SOLVE) {
-            if (WPB > 1) __syncthreads(); else wave_sync();
-            stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);  // min-marginal differences of the round -> entry array
-            if (WPB > 1) __syncthreads();                        // the next round overwrites the staging area
-        }
-    }
-}
-
-template <typename REAL, int R, int MODE, int WPB, bool SEG = true>
-__global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
-{
-    fwd_narrow_body<REAL, R, MODE, WPB, BDDMMA_LOOKAHEAD, SEG>(d, pk, omega, blockIdx.x);
-}
-
-template <typename REAL, int R, int MODE, int WPB, int LA = BDDMMA_LOOKAHEAD, bool SEG = true>
-__device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t block_id)
-{
-    constexpr int W = 64 * R;
-    constexpr bool NEED_F = (MODE != BWD_PLAIN);
-    using P2 = typename Pair<REAL>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    P2* sD = reinterpret_cast<P2*>(dyn_lds);
-    __shared__ REAL sT_[WPB][2][W + 2];  // per wave; +2: sink entries TOP = W (0) and BOT = W + 1 (+inf)
-    __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN], sOffR_[WPB][HOP_WIN];
-    const uint32_t tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int lane = tid & 63;
-    // per-wave scratch of the segmented minimum (seg_min2): behind the rest of the dynamic LDS, only reserved when a pack has layers
-    // wider than two nodes (pk.seg_off; never dereferenced otherwise)
-    REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
-    auto& sT = sT_[wave];
-    const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(block_id, n_quads, pk.xcd_chunk);
-    BDDMMA_EXIT_IF(quad >= n_quads, d)
-    const uint32_t p = quad * WPB + wave;
-    const bool has_pack = p < pk.n_packs;
-    const bool hdr = pk.hdr_pack != nullptr;  // uniform: resident headers (PackDev::hdr_pack)
-    const uint32_t* const hp = hdr ? pk.hdr_pack + 8 * (size_t)(has_pack ? p : 0) : nullptr;
-    const uint32_t q0 = !has_pack ? 0 : (hdr ? hp[4] : pk.pack_hop_ptr[p]);
-    const uint32_t q1 = !has_pack ? 0 : (hdr ? q0 + (hp[5] & 0xFFFFu) : pk.pack_hop_ptr[p + 1]);
-    const uint32_t c0_h = (hdr && MODE == BWD_SOLVE) ? pk.hdr_quad[4 * (size_t)quad] : 0, cnt_h = (hdr && MODE == BWD_SOLVE) ? pk.hdr_quad[4 * (size_t)quad + 1] : 0;
-    const int steps = SEG ? (has_pack ? pk.pack_steps[p] : 0) : 1;
-    const REAL INF = inf_v<REAL>();
-    const uint32_t slot_first = !has_pack ? 0 : (hdr ? hp[0] : pk.hop_node_off[q0]), l0 = !has_pack ? 0 : (hdr ? hp[2] : pk.hop_layer_off[q0]);  // the pack's first slot / layer: everything below is relative to them (HopWindow)
-    NarrowRs<REAL> rs(d);
-    rs.rebase_layers(d, l0);
-    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    if (hdr && MODE == BWD_SOLVE) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
-    REAL* const Tp = d.T + slot_first;
-    REAL* const Fp = d.F + slot_first;
-    const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
-    (void)lohi_p;
-    const rsrc_t rxl = make_rsrc(d.x_layer != nullptr ? d.x_layer + l0 : d.x_layer, d.x_layer != nullptr ? d.n_layers - l0 : 0u);  // DevPtrs::x_layer, from the pack's first layer on
-    (void)rxl;
-    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1, slot_first, l0};
-    double lb_stag = 0.0;  // costs-to-terminal of the roots below the pack's first hop (staggered packs), for the lower bound
-    // node range of hop q; hops below q0 (pipeline run-off) are empty
-    auto nb_of = [&](uint32_t q) { return hw.node_off(q); };
-    const uint32_t wd = !has_pack ? 0 : (hdr ? hp[6] : pk.pack_word_off[p]);  // (slot offsets are relative to the pack's first slot)  // see k_fwd_narrow
-    // Software pipeline with a look-ahead of D hops, mirrored from k_fwd_narrow: before hop q is processed (q counts down) the wave
-    // holds the node words of hops q .. q-2D+1, the costs-from-root of hops q .. q-D and the layer data of hops q .. q-D+1; during the hop
-    // it requests the words of hop q-2D, F of hop q-D-1 and the layer data of hop q-D.  o[i] = first slot of hop q+1-i (hops below q0
-    // are empty: their offset is the one of q0); the offsets the next hop needs are read one hop ahead, in the hop's LDS batch.
-    constexpr int D = LA;
-    uint32_t o[2 * D + 2];
-    uint32_t lcur = 0;  // first layer of hop q-D
-    uint32_t wr[2 * D + 1][R];
-    REAL fr[D + 2][R];
-    HopLayer<REAL, R> Lr[D + 1];
-#pragma unroll
-    for (int i = 0; i < 2 * D + 2; ++i) o[i] = 0;
-    uint32_t q = q1;
-    if (has_pack) {
-        if (lane < 4) sT[lane >> 1][W + (lane & 1)] = (lane & 1) ? INF : REAL(0);
-        hw.fill(pk, q1 + 1 > q0 + HOP_WIN ? q1 + 1 - HOP_WIN : q0, lane);  // window ends at record q1
-        // state of the first hop, q = q1-1: o[i] = nb_of(q1 - i)
-#pragma unroll
-        for (int i = 0; i < 2 * D + 2; ++i) o[i] = nb_of(q1 >= q0 + i ? q1 - i : q0);
-        lcur = hw.layer_off(q1 >= q0 + D + 1 ? q1 - 1 - D : q0);
-#pragma unroll
-        for (int i = 0; i < 2 * D; ++i) load_words<R>(wr[i], d.nwords, o[i + 1] + wd, o[i] - o[i + 1], lane);  // hop q1-1-i (none below q0)
-        if (NEED_F) {
-#pragma unroll
-            for (int i = 0; i < D + 1; ++i) load_vals<REAL, R>(fr[i], Fp, o[i + 1], o[i] - o[i + 1], lane);   // F of hop q1-1-i
-        }
-#pragma unroll
-        for (int i = 0; i < D; ++i) load_layer<REAL, R>(Lr[i], wr[i], hw.layer_off(q1 >= q0 + i + 1 ? q1 - 1 - i : q0), rs);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2 * D; ++i)
-#pragma unroll
-            for (int r = 0; r < R; ++r) wr[i][r] = nw_pad_word(64 * R);
-    }
-    int cur = 0;
-    const uint32_t g0 = (MODE == BWD_SOLVE && has_pack && !hdr) ? pk.pack_group_ptr[p] : 0;
-    const uint32_t ng = (MODE == BWD_SOLVE && has_pack) ? (hdr ? 1u : pk.pack_group_ptr[p + 1] - g0) : 0;
-    const uint32_t r0 = (MODE == BWD_SOLVE && !hdr) ? pk.quad_round_ptr[quad] : 0;
-    const uint32_t n_rounds = (MODE == BWD_SOLVE && !hdr) ? pk.quad_round_ptr[quad + 1] - r0 : 1;
-    P2* sDw = sD + (size_t)wave * pk.stage_cap;
-    for (uint32_t k = n_rounds; k-- > 0;) {  // same rounds as the forward sweep, in reverse
-        uint32_t gl0 = 0, cnt = 0, qs = q0;
-        if (MODE == BWD_SOLVE) {
-            if (hdr) {
-                cnt = cnt_h;
-                stage_load_pairs<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
-            } else {
-                const uint32_t c0 = pk.cs_ptr[r0 + k];
-                cnt = pk.cs_ptr[r0 + k + 1] - c0;
-                stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
-            }
-            if (hdr) {
-                qs = has_pack ? q0 : q;  // one group: the whole pack
-            } else if (k < ng) {
-                gl0 = pk.grp_layer_off[g0 + k] - l0;
-                qs = (k == 0) ? q0 : pk.grp_hop_end[g0 + k - 1];
-            } else {
-                qs = q;  // no k-th group in this pack
-            }
-            if (WPB > 1) __syncthreads(); else wave_sync();
-        }
-        auto hop = [&]() {  // see k_fwd_narrow: one batch of LDS reads, the arithmetic, the writes
-            --q;
-            // o[i] = nb_of(q + 1 - i), i <= 2D+1; the next hop adds nb_of(q - 1 - 2D) and the first layer of hop q - 1 - D
-            if (q < hw.base + 2 * D + 1 && hw.base > q0) hw.fill(pk, q + 1 > q0 + HOP_WIN ? q + 1 - HOP_WIN : q0, lane);
-            const uint32_t nb = o[1];
-            // ---- prefetch: words of hop q-2D, F of hop q-D-1, layer data of hop q-D
-            load_words<R>(wr[2 * D], d.nwords, o[2 * D + 1] + wd, o[2 * D] - o[2 * D + 1], lane);
-            if (NEED_F) load_vals<REAL, R>(fr[D + 1], Fp, o[D + 2], o[D + 1] - o[D + 2], lane);
-            load_layer<REAL, R>(Lr[D], wr[D], lcur, rs);  // all padding below the first hop: no loads
-            uint32_t (&wa)[R] = wr[0];
-            REAL (&fa)[R] = fr[0];
-            HopLayer<REAL, R>& La = Lr[0];
-            // ---- LDS reads
-            REAL tl[R], th[R];
-            P2 dd[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t w = wa[r];
-                const bool act = !(w & NW_PAD);
-                const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
-                tl[r] = sT[cur][lo_i];  // sinks: [W] = 0, [W+1] = +inf
-                th[r] = sT[cur][hi_i];
-                if (MODE == BWD_SOLVE) dd[r] = sDw[act ? La.lg[r] - gl0 : 0];
-            }
-            const uint32_t o_new = (q >= q0 + 2 * D + 1) ? nb_of(q - 1 - 2 * D) : o[2 * D + 1];
-            const uint32_t l_next = hw.layer_off(q >= q0 + D + 1 ? q - 1 - D : q0);
-            const uint32_t rt = q > q0 ? hw.root_of(q) : (uint32_t)NO_ROOT;  // the first hop's roots are summed behind the loop
-            // ---- arithmetic
-            REAL t[R], nlo[R], nhi[R], mmv[R], lp[R], hp[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t w = wa[r];
-                const bool act = !(w & NW_PAD);
-                const REAL lc = La.c[r].x, hc = La.c[r].y;
-                if (MODE == BWD_SOLVE) {
-                    REAL m0 = act ? (fa[r] + lc) + tl[r] : INF;
-                    REAL m1 = act ? (fa[r] + hc) + th[r] : INF;
-                    seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
-                    const REAL mm = mm_diff(m0, m1, omega);
-                    mmv[r] = mm;
-                    nlo[r] = (lc + min0(mm)) + dd[r].x;
-                    nhi[r] = (hc + min0_neg(mm)) + dd[r].y;
-                    t[r] = rmin(nhi[r] + th[r], nlo[r] + tl[r]);
-                } else {
-                    const REAL ch = th[r] + hc, cl = tl[r] + lc;  // backward_step, bdd_cuda_base.cu:646-667
-                    t[r] = rmin(ch, cl);
-                    if (MODE == BWD_MARGINALS) {
-                        lp[r] = act ? fa[r] + cl : INF;  // backward_step_with_path_costs, :633-641
-                        hp[r] = act ? fa[r] + ch : INF;
-                        seg_min2(lp[r], hp[r], lane, nw_pos(w), nw_len(w), steps, sM);
-                    }
-                }
-            }
-            // ---- writes
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t j = lane + 64 * r;
-                const uint32_t w = wa[r];
-                const bool act = !(w & NW_PAD);
-                if (MODE == BWD_SOLVE) {
-                    const bool head = nw_head(w);
-                    P2 nc;
-                    nc.x = nlo[r];
-                    nc.y = nhi[r];
-                    uint32_t soff = head ? La.lg[r] * (uint32_t)sizeof(P2) : OOB;  // see k_fwd_narrow
-                    asm volatile("" : "+v"(soff));
-                    bstore(nc, rs.lohi, soff);
-                    if (head) sDw[La.lg[r] - gl0].x = mmv[r];
-                    if (d.x_layer != nullptr) {  // uniform: net_solver_costs in layer order for an L-BFGS wrapper, straight from the hop (as a pass over the staging
-                        // area behind the round it cost 13 us of a 41 us sweep at 10.5 M nodes, tools/xlayer_cost.py)
-                        uint32_t xoff = head ? La.lg[r] * (uint32_t)sizeof(REAL) : OOB;
-                        asm volatile("" : "+v"(xoff));
-                        bstore((nhi[r] - nlo[r]) + mmv[r], rxl, xoff);
-                    }
-                }
-                if (MODE == BWD_MARGINALS) {
-                    if (nw_head(w)) {
-                        d.mm0_out[l0 + La.lg[r]] = lp[r];
-                        d.mm1_out[l0 + La.lg[r]] = hp[r];
-                    }
-                }
-                if (act) sT[cur ^ 1][j] = t[r];
-                if (j == rt) lb_stag += (double)t[r];
-            }
-            store_vals<R>(t, Tp, nb, o[0] - o[1], lane, pk.nt_potentials);
-            wave_sync();
-            cur ^= 1;
-#pragma unroll
-            for (int i = 0; i < 2 * D + 1; ++i) o[i] = o[i + 1];
-            o[2 * D + 1] = o_new;
-            lcur = l_next;
-#pragma unroll
-            for (int i = 0; i < 2 * D; ++i)
-#pragma unroll
-                for (int r = 0; r < R; ++r) wr[i][r] = wr[i + 1][r];
-#pragma unroll
-            for (int i = 0; i < D; ++i) Lr[i] = Lr[i + 1];
-            if (NEED_F) {
-#pragma unroll
-                for (int i = 0; i < D + 1; ++i)
-#pragma unroll
-                    for (int r = 0; r < R; ++r) fr[i][r] = fr[i + 1][r];
-            }
-        };
-        while (q >= qs + HOP_UNROLL) {
-#pragma unroll
-            for (int u = 0; u < HOP_UNROLL; ++u) hop();
-        }
-        while (q > qs) hop();
-        if (MODE == BWD_SOLVE) {
-            if (WPB > 1) __syncthreads(); else wave_sync();
-            stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
-            if (WPB > 1) __syncthreads();
-        }
-    }
-    if (!has_pack) return;
-    // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251)
-    const uint32_t n0 = nb_of(q0 + 1) - nb_of(q0);
-    double s = lb_stag;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t j = lane + 64 * r;
-        if (j < n0) s += (double)sT[cur][j];
-    }
-    for (int off2 = 32; off2 > 0; off2 >>= 1) s += __shfl_down(s, off2);
-    if (lane == 0) d.lb_partial[pk.lb_base + p] = s;
-}
-
-template <typename REAL, int R, int MODE, int WPB, bool SEG = true>
-__global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
-{
-    bwd_narrow_body<REAL, R, MODE, WPB, BDDMMA_LOOKAHEAD, SEG>(d, pk, omega, blockIdx.x);
-}
-
-// =============================================================================================
-// narrow packs, resident sweeps: the whole pack is copied to LDS in one round trip, then swept out of LDS
-// =============================================================================================
-// The streaming kernels above walk a pack with a software pipeline that is two hops deep: enough when 5 waves per SIMD hide the
-// rest of the memory latency (the 10 M-node benchmark), but a small or medium instance has ~1 wave per SIMD, and then every hop
-// waits for memory it asked for two hops ago, after a start-up chain of 7-8 dependent round trips (pack tables, hop offsets, words,
-// layer costs, staging tables, delta pairs).  Packs are short — tens of hops — so here a wave fetches EVERYTHING its pack needs at
-// once: the pack's node words, opposite-direction potentials and arc costs are contiguous in memory, so they arrive as a few 1 KiB
-// direct-to-LDS copies (global_load_lds_dwordx4, no staging registers) issued back to back from one 32-byte header; the hop loop
-// then runs out of LDS with no loads at all.  Three dependent round trips per sweep (header; bulk copies + staging tables; delta
-// pairs) instead of ~8 + one per two hops.  Same arithmetic, same order, same results as k_fwd_narrow / k_bwd_narrow.
-struct ResDev {
-    const uint32_t* pack_hdr;  // layout.hpp: struct Resident
-    const uint32_t* quad_hdr;
-    uint32_t ns;               // node slots reserved per wave in LDS (multiple of 256: whole 1 KiB pieces)
-    uint32_t nl;               // layers reserved per wave in LDS (multiple of 128)
-};
-// What a resident sweep needs for its FIRST loads comes as leading plain kernel arguments: with -mllvm -amdgpu-kernarg-preload-count the
-// command processor hands the first 16 dwords of plain (non-struct) arguments over in SGPRs at wave launch, so the header loads do not wait
-// for the kernarg segment's own round trip (measured on the exchange, whose arguments are all plain: 4.4 -> 4.15 us at 1.05 M nodes).
-// The stop word of the device-resident run_solver is among them: its load is issued at once and tested when the headers have arrived (no
-// side effect happens before), instead of a dependent round trip in front of everything else.
-#define RES_LEADING_ARGS const uint32_t* __restrict__ res_pack_hdr, const uint32_t* __restrict__ res_quad_hdr, uint32_t res_ns, uint32_t res_nl, \
-                         uint32_t res_n_packs, uint32_t res_xcd_chunk, const uint32_t* res_stop, uint32_t res_run_iter
-typedef __attribute__((address_space(3))) void* lds_vptr_t;
-typedef __attribute__((address_space(1))) const void* glb_vptr_t;
-
-// One wave copies `bytes` (rounded up to whole 1 KiB pieces) from global memory to LDS: lane l of piece k moves the 16 bytes at
-// src + 1024 k + 16 l to dst + 1024 k + 16 l.  dst is wave-uniform and 16-byte aligned; the source only needs 4-byte alignment.
-// Reads up to 1008 bytes past the range: device allocations are padded by 1 KiB (SolverT::dalloc).
-__device__ __forceinline__ void wave_copy_to_lds(const void* src, void* dst, uint32_t bytes, int lane)
-{
-    const unsigned char* g = reinterpret_cast<const unsigned char*>(src) + lane * 16;
-    unsigned char* l = reinterpret_cast<unsigned char*>(dst);
-    for (uint32_t o = 0; o < bytes; o += 1024)
-        __builtin_amdgcn_global_load_lds((glb_vptr_t)(g + o), (lds_vptr_t)(l + o), 16, 0, 0);
-}
-__host__ __device__ inline uint32_t res_wave_bytes(uint32_t real_size, uint32_t ns, uint32_t nl)
-{
-    return ns * 4u + (ns + 4u) * real_size + nl * 2u * real_size;  // words | potentials + 2 sink entries (+2 pad) | {lo, hi}
-}
-
-template <typename REAL, int R, int WPB>
-__global__ void __launch_bounds__(64 * WPB) k_fwd_res(RES_LEADING_ARGS, DevPtrs<REAL> d, PackDev pk, REAL omega)
-{
-    const ResDev rd{res_pack_hdr, res_quad_hdr, res_ns, res_nl};
-    constexpr int W = 64 * R;
-    using P2 = typename Pair<REAL>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    __shared__ REAL sF_[WPB][2][W + 2];  // frontier: cost from root of the current / next hop; [W], [W + 1]: dummy push targets of sink children
-    __shared__ uint32_t sOffN_[WPB][64], sOffL_[WPB][64];
-    const uint32_t tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int lane = tid & 63;
-    // per-wave scratch of the segmented minimum (seg_min2): behind the rest of the dynamic LDS, only reserved when a pack has layers
-    // wider than two nodes (pk.seg_off; never dereferenced otherwise)
-    REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
-    auto& sF = sF_[wave];
-    uint32_t* sOffN = sOffN_[wave];
-    uint32_t* sOffL = sOffL_[wave];
-    const uint32_t n_quads = (res_n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(blockIdx.x, n_quads, res_xcd_chunk);
-    if (quad >= n_quads) return;
-    const uint32_t stop_word = res_stop != nullptr ? *res_stop : RUN_NOT_STOPPED;  // tested below, with the headers
-    const uint32_t p = quad * WPB + wave;
-    const bool has_pack = p < res_n_packs;
-    BDDMMA_STAMP(p, 0);
-    // dynamic LDS: [staged {delta_lo, delta_hi} / mm: WPB * stage_cap pairs][per wave: words | T of every slot | {lo, hi} of every layer]
-    P2* sD = reinterpret_cast<P2*>(dyn_lds);
-    P2* sDw = sD + (size_t)wave * pk.stage_cap;
-    const uint32_t wave_off = WPB * pk.stage_cap * (uint32_t)sizeof(P2) + (uint32_t)wave * res_wave_bytes(sizeof(REAL), rd.ns, rd.nl);
-    uint32_t* sW = reinterpret_cast<uint32_t*>(dyn_lds + wave_off);
-    REAL* sTa = reinterpret_cast<REAL*>(dyn_lds + wave_off + rd.ns * 4u);
-    P2* sC = reinterpret_cast<P2*>(dyn_lds + wave_off + rd.ns * 4u + (rd.ns + 4u) * (uint32_t)sizeof(REAL));
-    // ---- round trip 1: the headers
-    const uint32_t* hp = rd.pack_hdr + 8 * (size_t)(has_pack ? p : 0);
-    const uint32_t slot0 = hp[0], layer0 = hp[2], q0 = hp[4], woff = hp[6];
-    const uint32_t nslots = has_pack ? hp[1] : 0, nlayers = has_pack ? hp[3] : 0, nh = has_pack ? (hp[5] & 0xFFFFu) : 0;
-    const int steps = (int)(hp[5] >> 16);
-    const uint32_t c0 = rd.quad_hdr[4 * (size_t)quad], cnt = rd.quad_hdr[4 * (size_t)quad + 1];
-    if (stop_word <= res_run_iter) return;  // run_solver has stopped (uniform for the grid): nothing has been written yet
-    const REAL INF = inf_v<REAL>();
-    const NarrowRs<REAL> rs(d);
-    BDDMMA_STAMP(p, 1);
-    // ---- round trip 2: the whole pack -> LDS, hop offsets, staging tables; round trip 3 (inside stage_load): the delta pairs
-    wave_copy_to_lds(d.nwords + woff, sW, nslots * 4u, lane);
-    wave_copy_to_lds(d.T + slot0, sTa, nslots * (uint32_t)sizeof(REAL), lane);
-    wave_copy_to_lds(d.lohi + 2 * (size_t)layer0, sC, nlayers * (uint32_t)sizeof(P2), lane);
-    {
-        const uint32_t q = q0 + min((uint32_t)lane, nh);
-        const uint32_t on = pk.hop_node_off[q], ol = pk.hop_layer_off[q];
-        sOffN[lane] = on - slot0;
-        sOffL[lane] = ol - layer0;
-    }
-    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the direct-to-LDS copies have landed
-    if (lane < 2) sTa[rd.ns + lane] = lane == 0 ? REAL(0) : INF;  // sink entries: cost to terminal 0 (top) / +inf (bot)
-    wave_sync();
-    uint32_t nb = 0, ne = __builtin_amdgcn_readfirstlane(sOffN[1]);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t j = lane + 64 * r;
-        sF[0][j] = (j < ne) ? REAL(0) : INF;  // every slot of hop 0 is a root (flush_costs_from_root)
-    }
-    if (WPB > 1) __syncthreads(); else wave_sync();
-    BDDMMA_STAMP(p, 2);
-    int cur = 0;
-    for (uint32_t h = 0; h < nh; ++h) {
-        const uint32_t ne2 = __builtin_amdgcn_readfirstlane(sOffN[min(h + 2, nh)]);
-        const uint32_t n = ne - nb;
-        uint32_t lb = __builtin_amdgcn_readfirstlane(sOffL[h]);
-        REAL f[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t j = lane + 64 * r;
-            sF[cur ^ 1][j] = INF;
-            f[r] = sF[cur][j];
-        }
-        wave_sync();
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t j = lane + 64 * r;
-            constexpr uint32_t PADW = nw_pad_word(W);
-            const uint32_t w = j < n ? sW[nb + j] : PADW;
-            const bool act = !(w & NW_PAD);
-            const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
-            // layer index inside the pack = layers of the hops and lane groups before + the word's index inside its lane group
-            const uint32_t ll = act ? lb + nw_lidx(w) : 0u;
-            lb += (uint32_t)__popcll(__ballot(nw_head(w)));
-            const P2 c = sC[ll];
-            const REAL tl = sTa[lo_i < (uint32_t)W ? ne + lo_i : rd.ns + (lo_i - W)];
-            const REAL th = sTa[hi_i < (uint32_t)W ? ne + hi_i : rd.ns + (hi_i - W)];
-            const P2 dd = sDw[ll];
-            REAL m0 = act ? (f[r] + c.x) + tl : INF;
-            REAL m1 = act ? (f[r] + c.y) + th : INF;
-            seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
-            const REAL mm = mm_diff(m0, m1, omega);
-            const REAL nlo = (c.x + min0(mm)) + dd.x;
-            const REAL nhi = (c.y + min0_neg(mm)) + dd.y;
-            const bool head = nw_head(w);
-            P2 nc;
-            nc.x = nlo;
-            nc.y = nhi;
-            bstore(nc, rs.lohi, head ? (layer0 + ll) * (uint32_t)sizeof(P2) : OOB);
-            if (head) sDw[ll].x = mm;  // every lane of the layer has read its pair above (same wave, in order)
-            const bool plo = lo_i < (uint32_t)W, phi = hi_i < (uint32_t)W;  // sink children and padding lanes: no-op on the own slot (see k_fwd_narrow)
-            lds_min(&sF[cur ^ 1][plo ? lo_i : j], plo ? f[r] + nlo : INF);
-            lds_min(&sF[cur ^ 1][phi ? hi_i : j], phi ? f[r] + nhi : INF);
-            bstore(f[r], rs.F, act ? (slot0 + nb + j) * (uint32_t)sizeof(REAL) : OOB);
-        }
-        wave_sync();
-        cur ^= 1;
-        nb = ne;
-        ne = ne2;
-    }
-    BDDMMA_STAMP(p, 3);
-    if (WPB > 1) __syncthreads(); else wave_sync();
-    stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);  // min-marginal differences -> entry array
-    BDDMMA_STAMP(p, 4);
-}
-
-template <typename REAL, int R, int WPB>
-__global__ void __launch_bounds__(64 * WPB) k_bwd_res(RES_LEADING_ARGS, DevPtrs<REAL> d, PackDev pk, REAL omega)
-{
-    const ResDev rd{res_pack_hdr, res_quad_hdr, res_ns, res_nl};
-    constexpr int W = 64 * R;
-    using P2 = typename Pair<REAL>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    __shared__ REAL sT_[WPB][2][W + 2];  // cost to terminal of the hop above / of this hop; [W] = 0 (top sink), [W + 1] = +inf (bot sink)
-    __shared__ uint32_t sOffN_[WPB][64], sOffL_[WPB][64];
-    const uint32_t tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int lane = tid & 63;
-    // per-wave scratch of the segmented minimum (seg_min2): behind the rest of the dynamic LDS, only reserved when a pack has layers
-    // wider than two nodes (pk.seg_off; never dereferenced otherwise)
-    REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
-    auto& sT = sT_[wave];
-    uint32_t* sOffN = sOffN_[wave];
-    uint32_t* sOffL = sOffL_[wave];
-    const uint32_t n_quads = (res_n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(blockIdx.x, n_quads, res_xcd_chunk);
-    if (quad >= n_quads) return;
-    const uint32_t stop_word = res_stop != nullptr ? *res_stop : RUN_NOT_STOPPED;  // tested below, with the headers
-    const uint32_t p = quad * WPB + wave;
-    const bool has_pack = p < res_n_packs;
-    BDDMMA_STAMP(p, 0);
-    P2* sD = reinterpret_cast<P2*>(dyn_lds);
-    P2* sDw = sD + (size_t)wave * pk.stage_cap;
-    const uint32_t wave_off = WPB * pk.stage_cap * (uint32_t)sizeof(P2) + (uint32_t)wave * res_wave_bytes(sizeof(REAL), rd.ns, rd.nl);
-    uint32_t* sW = reinterpret_cast<uint32_t*>(dyn_lds + wave_off);
-    REAL* sFa = reinterpret_cast<REAL*>(dyn_lds + wave_off + rd.ns * 4u);  // cost from root of every slot (forward sweep)
-    P2* sC = reinterpret_cast<P2*>(dyn_lds + wave_off + rd.ns * 4u + (rd.ns + 4u) * (uint32_t)sizeof(REAL));
-    const uint32_t* hp = rd.pack_hdr + 8 * (size_t)(has_pack ? p : 0);
-    const uint32_t slot0 = hp[0], layer0 = hp[2], q0 = hp[4], woff = hp[6];
-    const uint32_t nslots = has_pack ? hp[1] : 0, nlayers = has_pack ? hp[3] : 0, nh = has_pack ? (hp[5] & 0xFFFFu) : 0;
-    const int steps = (int)(hp[5] >> 16);
-    const uint32_t c0 = rd.quad_hdr[4 * (size_t)quad], cnt = rd.quad_hdr[4 * (size_t)quad + 1];
-    if (stop_word <= res_run_iter) return;  // run_solver has stopped (uniform for the grid): nothing has been written yet
-    const REAL INF = inf_v<REAL>();
-    const NarrowRs<REAL> rs(d);
-    BDDMMA_STAMP(p, 1);
-    wave_copy_to_lds(d.nwords + woff, sW, nslots * 4u, lane);
-    wave_copy_to_lds(d.F + slot0, sFa, nslots * (uint32_t)sizeof(REAL), lane);
-    wave_copy_to_lds(d.lohi + 2 * (size_t)layer0, sC, nlayers * (uint32_t)sizeof(P2), lane);
-    {
-        const uint32_t q = q0 + min((uint32_t)lane, nh);
-        const uint32_t on = pk.hop_node_off[q], ol = pk.hop_layer_off[q];
-        sOffN[lane] = on - slot0;
-        sOffL[lane] = ol - layer0;
-    }
-    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane < 4) sT[lane >> 1][W + (lane & 1)] = (lane & 1) ? INF : REAL(0);
-    if (WPB > 1) __syncthreads(); else wave_sync();
-    BDDMMA_STAMP(p, 2);
-    int cur = 0;
-    for (uint32_t h = nh; h-- > 0;) {
-        const uint32_t nb = __builtin_amdgcn_readfirstlane(sOffN[h]), ne = __builtin_amdgcn_readfirstlane(sOffN[h + 1]);
-        const uint32_t n = ne - nb;
-        uint32_t lb = __builtin_amdgcn_readfirstlane(sOffL[h]);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t j = lane + 64 * r;
-            constexpr uint32_t PADW = nw_pad_word(W);
-            const uint32_t w = j < n ? sW[nb + j] : PADW;
-            const bool act = !(w & NW_PAD);
-            const uint32_t lo_i = w & NW_CHILD_MASK, hi_i = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
-            const uint32_t ll = act ? lb + nw_lidx(w) : 0u;
-            lb += (uint32_t)__popcll(__ballot(nw_head(w)));
-            const P2 c = sC[ll];
-            const REAL fa = sFa[act ? nb + j : 0];
-            const REAL tl = sT[cur][lo_i];  // sinks: [W] = 0, [W + 1] = +inf
-            const REAL th = sT[cur][hi_i];
-            const P2 dd = sDw[ll];
-            REAL m0 = act ? (fa + c.x) + tl : INF;
-            REAL m1 = act ? (fa + c.y) + th : INF;
-            seg_min2(m0, m1, lane, nw_pos(w), nw_len(w), steps, sM);
-            const REAL mm = mm_diff(m0, m1, omega);
-            const REAL nlo = (c.x + min0(mm)) + dd.x;
-            const REAL nhi = (c.y + min0_neg(mm)) + dd.y;
-            const REAL t = rmin(nhi + th, nlo + tl);
-            const bool head = nw_head(w);
-            P2 nc;
-            nc.x = nlo;
-            nc.y = nhi;
-            bstore(nc, rs.lohi, head ? (layer0 + ll) * (uint32_t)sizeof(P2) : OOB);
-            if (head) sDw[ll] = P2{mm, nhi - nlo};  // .y: hi' - lo' for x_layer
-            if (act) sT[cur ^ 1][j] = t;
-            bstore(t, rs.T, act ? (slot0 + nb + j) * (uint32_t)sizeof(REAL) : OOB);
-        }
-        wave_sync();
-        cur ^= 1;
-    }
-    BDDMMA_STAMP(p, 3);
-    if (WPB > 1) __syncthreads(); else wave_sync();
-    stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
-    BDDMMA_STAMP(p, 4);
-    if (!has_pack) return;
-    if (d.x_layer != nullptr)
-        for (uint32_t j = lane; j < nlayers; j += 64) d.x_layer[layer0 + j] = sDw[j].y + sDw[j].x;  // (hi' - lo') + mm
-    // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251)
-    const uint32_t n0 = __builtin_amdgcn_readfirstlane(sOffN[1]);
-    double sum = 0.0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t j = lane + 64 * r;
-        if (j < n0) sum += (double)sT[cur][j];
-    }
-    for (int off2 = 32; off2 > 0; off2 >>= 1) sum += __shfl_down(sum, off2);
-    if (lane == 0) d.lb_partial[pk.lb_base + p] = sum;
-}
-
-// =============================================================================================
-// narrow packs, resident sweeps, second generation: ready-made LDS addresses per lane and hop
-// =============================================================================================
-// k_fwd_res / k_bwd_res removed the loads from the hop loop; what is left there is ~165 instructions per hop of 64 slots of which ~25 are
-// floating point — unpacking the node word, hop-local index -> LDS address, sink selects, per-hop offsets through LDS -> SGPR
-// (profiles/r04_hop_isa.txt), on a wave that is alone on its SIMD most of the time, so every instruction's latency is the hop's.
-// Here a lane's hop is one 16-byte record (layout.hpp: Res2Records) of ready-made 16-bit byte offsets into the wave's LDS region:
-// children's costs-from-terminal, push targets, the layer's cost / staging pair, the node's own slot, the store offset of the new arc
-// costs (an out-of-range offset for lanes that are not their layer's head).  Hops are dense (64 records per hop), so there are no
-// per-hop offsets at all; sink children and padding lanes need no select (constant entries / a private dummy entry per lane); all of a
-// pack's potentials sit in LDS by slot (no double-buffered frontier to reset); a two-node layer's minimum is one DPP swap of
-// neighbouring lanes (layers of two nodes start at even lanes, layout.cpp: PackBuilder::place).  Records are prefetched four hops
-// ahead (shared by all packs of a structure template: L2 hits).  Same arithmetic, same order, same results as k_fwd_res / k_bwd_res.
-// Packs of 64 slots whose layers have <= 2 nodes (SolverT::use_res2); everything else runs the first generation.
-using u4v = decltype(__builtin_amdgcn_raw_buffer_load_b128(*static_cast<const rsrc_t*>(nullptr), 0, 0, 0));
-template <typename T>
-__device__ __forceinline__ T lds_ld(const unsigned char* lds, uint32_t off) { return *reinterpret_cast<const T*>(lds + off); }
-template <typename T>
-__device__ __forceinline__ void lds_st(unsigned char* lds, uint32_t off, T v) { *reinterpret_cast<T*>(lds + off) = v; }
-
-// minimum over the two lanes of an aligned pair where `two` holds; every lane of the wave executes it (a DPP source lane that EXEC
-// masks out would count as invalid, see seg_pair_min)
-__device__ __forceinline__ void pair_min_aligned(float& a, float& b, bool two)
-{
-    float ta, tb;
-    asm volatile("s_nop 1\n\t"
-                 "v_min_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_min_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-                 : "=&v"(ta), "=&v"(tb)
-                 : "v"(a), "v"(b));
-    a = two ? ta : a;
-    b = two ? tb : b;
-}
-__device__ __forceinline__ void pair_min_aligned(double& a, double& b, bool two)
-{
-    const double a2 = dpp_row<0xB1>(a), b2 = dpp_row<0xB1>(b);  // quad_perm [1, 0, 3, 2]
-    a = two ? rmin(a, a2) : a;
-    b = two ? rmin(b, b2) : b;
-}
-// mm = omega * (m1 - m0), or 0 unless both minima are finite (bdd_cuda_parallel_mma.cu:36-39): the minima are never -inf or NaN (sums of
-// finite costs and +inf), so "both finite" is "their difference is finite" — one class test instead of two
-template <typename REAL>
-__device__ __forceinline__ REAL mm_diff1(REAL m0, REAL m1, REAL omega)
-{
-    const REAL dm = m1 - m0;
-    return rfinite(dm) ? omega * dm : REAL(0);
-}
-
-#define RES2_ARGS RES_LEADING_ARGS, const uint32_t* __restrict__ res2_rec, const uint32_t* __restrict__ res2_rec_off, uint32_t res2_n_words
-
-template <typename REAL, int WPB>
-__global__ void __launch_bounds__(64 * WPB) k_fwd_res2(RES2_ARGS, DevPtrs<REAL> d, PackDev pk, REAL omega)
-{
-    constexpr uint32_t S = sizeof(REAL);
-    using P2 = typename Pair<REAL>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    const uint32_t tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int lane = tid & 63;
-    const uint32_t n_quads = (res_n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(blockIdx.x, n_quads, res_xcd_chunk);
-    if (quad >= n_quads) return;
-    const uint32_t stop_word = res_stop != nullptr ? *res_stop : RUN_NOT_STOPPED;
-    const uint32_t p = quad * WPB + wave;
-    const bool has_pack = p < res_n_packs;
-    BDDMMA_STAMP(p, 0);
-    // dynamic LDS: [staged {delta_lo, delta_hi} / mm: WPB * stage_cap pairs][per wave: T | F | {lo, hi}] (layout.hpp: res2_*_off)
-    P2* sD = reinterpret_cast<P2*>(dyn_lds);
-    const uint32_t db = (uint32_t)wave * pk.stage_cap * (uint32_t)sizeof(P2);
-    const uint32_t wb = WPB * pk.stage_cap * (uint32_t)sizeof(P2) + (uint32_t)wave * res2_wave_bytes(S, res_ns, res_nl);
-    const uint32_t wbF = wb + res2_f_off(S, res_ns), wbC = wb + res2_c_off(S, res_ns);
-    // ---- round trip 1: the headers
-    const uint32_t* hp = res_pack_hdr + 8 * (size_t)(has_pack ? p : 0);
-    const uint32_t slot0 = hp[0], layer0 = hp[2];
-    const uint32_t nslots = has_pack ? hp[1] : 0, nlayers = has_pack ? hp[3] : 0, nh = has_pack ? (hp[5] & 0xFFFFu) : 0;
-    const uint32_t rbase = res2_rec_off[has_pack ? p : 0];
-    const uint32_t c0 = res_quad_hdr[4 * (size_t)quad], cnt = res_quad_hdr[4 * (size_t)quad + 1];
-    if (stop_word <= res_run_iter) return;  // run_solver has stopped (uniform for the grid): nothing has been written yet
-    const REAL INF = inf_v<REAL>();
-    const NarrowRs<REAL> rs(d);
-    BDDMMA_STAMP(p, 1);
-    // ---- round trip 2: costs-from-terminal and arc costs of the pack -> LDS, the first records, the staging tables; 3: the delta pairs
-    wave_copy_to_lds(d.T + slot0, dyn_lds + wb, nslots * S, lane);
-    wave_copy_to_lds(d.lohi + 2 * (size_t)layer0, dyn_lds + wbC, nlayers * (uint32_t)sizeof(P2), lane);
-    const rsrc_t rr = make_rsrc(res2_rec, res2_n_words);
-    auto ldrec = [&](uint32_t h) { return __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)lane * 16u, (rbase + h * 64u) * 16u, 0); };
-    u4v r0 = ldrec(0), r1 = ldrec(1), r2 = ldrec(2), r3 = ldrec(3), r4 = ldrec(4), r5 = ldrec(5), r6 = ldrec(6), r7 = ldrec(7);
-    if (has_pack)
-        for (uint32_t o = (uint32_t)lane; o < res_ns + 64u; o += 64u) lds_st<REAL>(dyn_lds, wbF + o * S, INF);  // costs-from-root and the dummy entries
-    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the direct-to-LDS copies have landed
-    if (has_pack) {
-        if (lane < 2) lds_st<REAL>(dyn_lds, wb + (res_ns + (uint32_t)lane) * S, lane == 0 ? REAL(0) : INF);  // sinks: cost to terminal 0 (top) / +inf (bot)
-        if (r0[3] != RES2_PAD) lds_st<REAL>(dyn_lds, wbF + (r0[2] >> 16), REAL(0));  // every node of hop 0 is a root (flush_costs_from_root)
-    }
-    if (WPB > 1) __syncthreads(); else wave_sync();
-    BDDMMA_STAMP(p, 2);
-    // the pack's slices of the arrays the hop loop stores into: offsets past their ends are dropped
-    const rsrc_t rF = make_rsrc(d.F + slot0, nslots), rC = make_rsrc(d.lohi + 2 * (size_t)layer0, 2ull * nlayers);
-    auto hop = [&](const u4v& r) {
-        const bool real = r[3] != RES2_PAD;
-        const bool two = (r[3] & 0x10000u) != 0;
-        const uint32_t ll = r[2] & 0xFFFFu, fs = r[2] >> 16;
-        const REAL f = lds_ld<REAL>(dyn_lds, wbF + fs);
-        const REAL tl = lds_ld<REAL>(dyn_lds, wb + (r[0] & 0xFFFFu)), th = lds_ld<REAL>(dyn_lds, wb + (r[0] >> 16));
-        const P2 c = lds_ld<P2>(dyn_lds, wbC + ll);
-        const P2 dd = lds_ld<P2>(dyn_lds, db + ll);
-        REAL m0 = (f + c.x) + tl, m1 = (f + c.y) + th;  // padding lanes: +inf
-        pair_min_aligned(m0, m1, two);
-        const REAL mm = mm_diff1(m0, m1, omega);
-        P2 nc;
-        nc.x = (c.x + min0(mm)) + dd.x;
-        nc.y = (c.y + min0_neg(mm)) + dd.y;
-        bstore(nc, rC, r[3] & 0xFFFFu);                        // heads only: RES2_NO_STORE lies past the pack's layers
-        if (real) lds_st<REAL>(dyn_lds, db + ll, mm);          // every lane of a layer holds the same value
-        lds_min(reinterpret_cast<REAL*>(dyn_lds + wb + (r[1] & 0xFFFFu)), f + nc.x);  // sinks / padding: the lane's own dummy entry
-        lds_min(reinterpret_cast<REAL*>(dyn_lds + wb + (r[1] >> 16)), f + nc.y);
-        bstore(f, rF, fs);                                      // padding lanes: past the pack's slots
-        wave_sync();
-    };
-    // Sixteen hops in a straight line with side exits: inside it the compiler counts the outstanding record loads and stores (s_waitcnt
-    // vmcnt(N)); at a loop header it drains them all, which would expose the L2 latency of the newest prefetch on every trip of a 4-hop loop.
-    // (records: a ring of eight, i.e. requested eight hops = several L2 round trips ahead; packs of <= 8 hops have them all before the loop)
-#define RES2_HOP(RK, HK)            \
-    hop(RK);                        \
-    RK = ldrec(h + (HK) + 8);       \
-    if (h + (HK) + 1 >= nh) break;
-    for (uint32_t h = 0; h < nh; h += 16) {
-        RES2_HOP(r0, 0) RES2_HOP(r1, 1) RES2_HOP(r2, 2) RES2_HOP(r3, 3) RES2_HOP(r4, 4) RES2_HOP(r5, 5) RES2_HOP(r6, 6) RES2_HOP(r7, 7)
-        RES2_HOP(r0, 8) RES2_HOP(r1, 9) RES2_HOP(r2, 10) RES2_HOP(r3, 11) RES2_HOP(r4, 12) RES2_HOP(r5, 13) RES2_HOP(r6, 14) RES2_HOP(r7, 15)
-    }
-    BDDMMA_STAMP(p, 3);
-    if (WPB > 1) __syncthreads(); else wave_sync();
-    stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);  // min-marginal differences -> entry array
-    BDDMMA_STAMP(p, 4);
-}
-
-template <typename REAL, int WPB>
-__global__ void __launch_bounds__(64 * WPB) k_bwd_res2(RES2_ARGS, DevPtrs<REAL> d, PackDev pk, REAL omega)
-{
-    constexpr uint32_t S = sizeof(REAL);
-    using P2 = typename Pair<REAL>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    const uint32_t tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int lane = tid & 63;
-    const uint32_t n_quads = (res_n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(blockIdx.x, n_quads, res_xcd_chunk);
-    if (quad >= n_quads) return;
-    const uint32_t stop_word = res_stop != nullptr ? *res_stop : RUN_NOT_STOPPED;
-    const uint32_t p = quad * WPB + wave;
-    const bool has_pack = p < res_n_packs;
-    BDDMMA_STAMP(p, 0);
-    P2* sD = reinterpret_cast<P2*>(dyn_lds);
-    P2* sDw = sD + (size_t)wave * pk.stage_cap;
-    const uint32_t db = (uint32_t)wave * pk.stage_cap * (uint32_t)sizeof(P2);
-    const uint32_t wb = WPB * pk.stage_cap * (uint32_t)sizeof(P2) + (uint32_t)wave * res2_wave_bytes(S, res_ns, res_nl);
-    const uint32_t wbF = wb + res2_f_off(S, res_ns), wbC = wb + res2_c_off(S, res_ns);
-    const uint32_t* hp = res_pack_hdr + 8 * (size_t)(has_pack ? p : 0);
-    const uint32_t slot0 = hp[0], layer0 = hp[2];
-    const uint32_t nslots = has_pack ? hp[1] : 0, nlayers = has_pack ? hp[3] : 0, nh = has_pack ? (hp[5] & 0xFFFFu) : 0;
-    const uint32_t rbase = res2_rec_off[has_pack ? p : 0];
-    const uint32_t c0 = res_quad_hdr[4 * (size_t)quad], cnt = res_quad_hdr[4 * (size_t)quad + 1];
-    if (stop_word <= res_run_iter) return;
-    const REAL INF = inf_v<REAL>();
-    const NarrowRs<REAL> rs(d);
-    BDDMMA_STAMP(p, 1);
-    wave_copy_to_lds(d.F + slot0, dyn_lds + wbF, nslots * S, lane);  // costs from root of every slot (forward sweep)
-    wave_copy_to_lds(d.lohi + 2 * (size_t)layer0, dyn_lds + wbC, nlayers * (uint32_t)sizeof(P2), lane);
-    const rsrc_t rr = make_rsrc(res2_rec, res2_n_words);
-    // k-th hop processed = hop nh - 1 - k of the pack; past the first hop: any record (never used)
-    auto ldrec = [&](uint32_t k) { return __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)lane * 16u, (rbase + (k < nh ? nh - 1u - k : 0u) * 64u) * 16u, 0); };
-    u4v r0 = ldrec(0), r1 = ldrec(1), r2 = ldrec(2), r3 = ldrec(3), r4 = ldrec(4), r5 = ldrec(5), r6 = ldrec(6), r7 = ldrec(7);
-    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (has_pack && lane < 2) lds_st<REAL>(dyn_lds, wb + (res_ns + (uint32_t)lane) * S, lane == 0 ? REAL(0) : INF);
-    if (WPB > 1) __syncthreads(); else wave_sync();
-    BDDMMA_STAMP(p, 2);
-    const rsrc_t rT = make_rsrc(d.T + slot0, nslots), rC = make_rsrc(d.lohi + 2 * (size_t)layer0, 2ull * nlayers);
-    auto hop = [&](const u4v& r) {
-        const bool real = r[3] != RES2_PAD;
-        const bool two = (r[3] & 0x10000u) != 0;
-        const uint32_t ll = r[2] & 0xFFFFu, fs = r[2] >> 16;
-        const REAL f = lds_ld<REAL>(dyn_lds, wbF + fs);  // padding lanes: whatever the dummy entry holds; their results go nowhere
-        const REAL tl = lds_ld<REAL>(dyn_lds, wb + (r[0] & 0xFFFFu)), th = lds_ld<REAL>(dyn_lds, wb + (r[0] >> 16));
-        const P2 c = lds_ld<P2>(dyn_lds, wbC + ll);
-        const P2 dd = lds_ld<P2>(dyn_lds, db + ll);
-        REAL m0 = (f + c.x) + tl, m1 = (f + c.y) + th;
-        pair_min_aligned(m0, m1, two);
-        const REAL mm = mm_diff1(m0, m1, omega);
-        P2 nc;
-        nc.x = (c.x + min0(mm)) + dd.x;
-        nc.y = (c.y + min0_neg(mm)) + dd.y;
-        const REAL t = rmin(nc.y + th, nc.x + tl);
-        bstore(nc, rC, r[3] & 0xFFFFu);
-        if (real) {
-            lds_st<P2>(dyn_lds, db + ll, P2{mm, nc.y - nc.x});  // .y: hi' - lo' for x_layer
-            lds_st<REAL>(dyn_lds, wb + fs, t);
-        }
-        bstore(t, rT, fs);
-        wave_sync();
-    };
-    for (uint32_t h = 0; h < nh; h += 16) {  // see k_fwd_res2; h counts the hops processed, from the pack's last hop upwards
-        RES2_HOP(r0, 0) RES2_HOP(r1, 1) RES2_HOP(r2, 2) RES2_HOP(r3, 3) RES2_HOP(r4, 4) RES2_HOP(r5, 5) RES2_HOP(r6, 6) RES2_HOP(r7, 7)
-        RES2_HOP(r0, 8) RES2_HOP(r1, 9) RES2_HOP(r2, 10) RES2_HOP(r3, 11) RES2_HOP(r4, 12) RES2_HOP(r5, 13) RES2_HOP(r6, 14) RES2_HOP(r7, 15)
-    }
-#undef RES2_HOP
-    const u4v rroot = __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)lane * 16u, rbase * 16u, 0);  // the pack's first hop again, for the bound
-    BDDMMA_STAMP(p, 3);
-    if (WPB > 1) __syncthreads(); else wave_sync();
-    stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
-    BDDMMA_STAMP(p, 4);
-    if (!has_pack) return;
-    if (d.x_layer != nullptr)
-        for (uint32_t j = lane; j < nlayers; j += 64) d.x_layer[layer0 + j] = sDw[j].y + sDw[j].x;  // (hi' - lo') + mm
-    // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251); every node of the first hop is a root
-    double lb = rroot[3] != RES2_PAD ? (double)lds_ld<REAL>(dyn_lds, wb + (rroot[2] >> 16)) : 0.0;
-    for (int off2 = 32; off2 > 0; off2 >>= 1) lb += __shfl_down(lb, off2);
-    if (lane == 0) d.lb_partial[pk.lb_base + p] = lb;
-}
-
-// =============================================================================================
-// narrow packs, streaming sweeps, second generation: the solve sweeps on per-lane records
-// =============================================================================================
-// k_fwd_narrow / k_bwd_narrow spend 136 instructions per hop and 64 slots, 72 of them VALU of which 14 are floating point
-// (profiles/r04_hop_isa.txt): on the headline instance the vector ALUs are busy half of the sweep's duration with address arithmetic.
-// These kernels are the same sweeps — same pipeline (records two hops ahead, arc costs and potentials one), same staging rounds, same
-// arithmetic in the same order — with the 4-byte node word replaced by a 16-byte record of ready-made byte offsets into the hop's LDS
-// buffers (layout.hpp: StreamRecords): no unpacking, no sink / padding selects (constant entries; a private dummy entry per lane behind
-// the frontier), the layer index inside the hop instead of a ballot count per lane group, the head-only store as an offset past the
-// hop's layers, the two-node minimum as one DPP swap.  Records of a structure template are shared by its packs (L2 hits).
-// Solve sweeps of packs whose layers have <= 2 nodes and that are not staggered (SolverT::use_narrow2); everything else: first generation.
-__device__ __forceinline__ void hop_store(float2 v, rsrc_t rh, uint32_t voff, uint32_t soff);   // defined with the exchange kernels below
-__device__ __forceinline__ void hop_store(double2 v, rsrc_t rh, uint32_t voff, uint32_t soff);
-template <int R>
-__device__ __forceinline__ void load_recs(u4v (&r)[R], rsrc_t rr, uint32_t first_rec, int lane)
-{
-#pragma unroll
-    for (int g = 0; g < R; ++g) r[g] = __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)(lane + 64 * g) * 16u, first_rec * 16u, 0);
-}
-// {lo, hi} of the lanes' layers: the layer's offset inside the hop is the record's, the hop's first layer goes into the scalar offset
-template <typename REAL, int R>
-__device__ __forceinline__ void load_costs(typename Pair<REAL>::type (&c)[R], const u4v (&r)[R], rsrc_t lohi, uint32_t lbase)
-{
-    using P2 = typename Pair<REAL>::type;
-#pragma unroll
-    for (int g = 0; g < R; ++g) hop_load(c[g], lohi, r[g][2] & 0xFFFFu, lbase * (uint32_t)sizeof(P2));
-}
-
-template <typename REAL, int R, int WPB, bool GEN, int LA = BDDMMA_LOOKAHEAD>
-__device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ srec,
-                                                 const uint32_t* __restrict__ srec_off, uint32_t srec_words, REAL omega, uint32_t block_id,
-                                                 const uint32_t* __restrict__ hdr_pack = nullptr, const uint32_t* __restrict__ hdr_quad = nullptr)
-{
-    constexpr int W = 64 * R;
-    constexpr uint32_t S = sizeof(REAL);
-    using P2 = typename Pair<REAL>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    P2* sD = reinterpret_cast<P2*>(dyn_lds);
-    __shared__ __attribute__((aligned(16))) REAL sF_[WPB][2][2 * W + 2];  // frontier of the current / next hop; [W], [W + 1] unused, [W + 2 + j]: lane slot j's dummy push target
-    __shared__ __attribute__((aligned(16))) REAL sT_[WPB][2][W + 2];      // costs-from-terminal of the next hop (written one hop ahead); [W] = 0 (top), [W + 1] = +inf (bot)
-    __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN], sOffR_[WPB][HOP_WIN];
-    const uint32_t tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int lane = tid & 63;
-    unsigned char* sFw = reinterpret_cast<unsigned char*>(&sF_[wave][0][0]);
-    unsigned char* sTw = reinterpret_cast<unsigned char*>(&sT_[wave][0][0]);
-    constexpr uint32_t F_STRIDE = (2 * W + 2) * S, T_STRIDE = (W + 2) * S;
-    const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(block_id, n_quads, pk.xcd_chunk);
-    BDDMMA_EXIT_IF(quad >= n_quads, d)
-    const uint32_t p = quad * WPB + wave;
-    const bool has_pack = p < pk.n_packs;
-    // Resident headers (layout.hpp: struct Resident; given when every pack has one stage group and every quad one round): the pack's hop /
-    // slot / layer ranges and the quad's range of the staging tables in ONE round trip — without them q0 -> {first slot, first layer} and
-    // quad -> round -> item range are two dependent round trips each, and all workgroups of a launch walk those chains at the same time
-    // (the first ~10 us of a sweep move little: profiles/r04_sweep_timeline.txt).
-    const bool hdr = hdr_pack != nullptr;  // uniform
-    const uint32_t* const hp = hdr ? hdr_pack + 8 * (size_t)(has_pack ? p : 0) : nullptr;
-    const uint32_t q0 = !has_pack ? 0 : (hdr ? hp[4] : pk.pack_hop_ptr[p]);
-    const uint32_t q1 = !has_pack ? 0 : (hdr ? q0 + (hp[5] & 0xFFFFu) : pk.pack_hop_ptr[p + 1]);
-    const uint32_t rbase = has_pack ? srec_off[p] : 0;
-    const uint32_t c0_h = hdr ? hdr_quad[4 * (size_t)quad] : 0, cnt_h = hdr ? hdr_quad[4 * (size_t)quad + 1] : 0;
-    BDDMMA_STAMP(p, 0);
-    // GEN: packs with layers wider than two nodes (LDS segmented minimum, seg_min2: per-wave scratch behind the rest of the dynamic LDS) and
-    // staggered packs (a BDD root below the pack's first hop, PackDev::hop_root)
-    const int steps = GEN ? (has_pack ? pk.pack_steps[p] : 0) : 1;
-    REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
-    const REAL INF = inf_v<REAL>();
-    const uint32_t slot_first = !has_pack ? 0 : (hdr ? hp[0] : pk.hop_node_off[q0]), l0 = !has_pack ? 0 : (hdr ? hp[2] : pk.hop_layer_off[q0]);  // the pack's first slot / layer: everything below is relative to them (HopWindow)
-    NarrowRs<REAL> rs(d);
-    rs.rebase_layers(d, l0);
-    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    if (hdr) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
-    REAL* const Tp = d.T + slot_first;
-    REAL* const Fp = d.F + slot_first;
-    const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
-    (void)lohi_p;
-    const rsrc_t rr = make_rsrc(srec, srec_words);
-    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1, slot_first, l0};
-    auto off = [&](uint32_t q) { return hw.node_off(q); };
-    constexpr int D = LA;
-    uint32_t o[2 * D + 3];
-    uint32_t lb[D + 2];  // first layer of hops q .. q + D + 1
-    u4v rc[2 * D + 1][R];
-    REAL tr[D + 1][R];
-    P2 Lr[D + 1][R];
-#pragma unroll
-    for (int i = 0; i < 2 * D + 3; ++i) o[i] = 0;
-#pragma unroll
-    for (int i = 0; i < D + 2; ++i) lb[i] = 0;
-    if (has_pack) {
-        hw.fill(pk, q0, lane);
-#pragma unroll
-        for (int i = 0; i < 2 * D + 3; ++i) o[i] = off(q0 + i);
-#pragma unroll
-        for (int i = 0; i < D + 2; ++i) lb[i] = hw.layer_off(q0 + i);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t j = lane + 64 * r;
-            lds_st<REAL>(sFw, j * S, (j < o[1] - o[0]) ? REAL(0) : INF);  // every slot of hop 0 is a root (flush_costs_from_root)
-        }
-        if (lane < 4) lds_st<REAL>(sTw, (uint32_t)(lane >> 1) * T_STRIDE + (W + (lane & 1)) * S, (lane & 1) ? INF : REAL(0));
-#pragma unroll
-        for (int i = 0; i < 2 * D; ++i) load_recs<R>(rc[i], rr, rbase + (uint32_t)i * W, lane);  // (past the last hop: some other records, never used)
-        {
-            REAL t1[R];
-            load_vals<REAL, R>(t1, Tp, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
-#pragma unroll
-            for (int i = 0; i < D; ++i) load_vals<REAL, R>(tr[i], Tp, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t j = lane + 64 * r;
-                if (j < o[2] - o[1]) lds_st<REAL>(sTw, j * S, t1[r]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < D; ++i) load_costs<REAL, R>(Lr[i], rc[i], rs.lohi, lb[i]);
-        wave_sync();
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2 * D; ++i)
-#pragma unroll
-            for (int r = 0; r < R; ++r) rc[i][r] = u4v{0u, 0u, 0u, SREC_PAD};
-    }
-    uint32_t cur = 0;
-    uint32_t q = q0;
-    uint32_t rt = NO_ROOT;  // GEN: root slot of hop q when a BDD starts there; the first hop's roots are set up above
-    const uint32_t g0 = (has_pack && !hdr) ? pk.pack_group_ptr[p] : 0;
-    const uint32_t ng = !has_pack ? 0 : (hdr ? 1u : pk.pack_group_ptr[p + 1] - g0);
-    const uint32_t r0 = hdr ? 0 : pk.quad_round_ptr[quad];
-    const uint32_t n_rounds = hdr ? 1u : pk.quad_round_ptr[quad + 1] - r0;
-    const uint32_t db = (uint32_t)wave * pk.stage_cap * (uint32_t)sizeof(P2);  // this wave's slots of the staging area
-    for (uint32_t k = 0; k < n_rounds; ++k) {
-        uint32_t gl0 = 0, cnt = 0, qe = q1;
-        {
-            if (hdr) {
-                cnt = cnt_h;
-                stage_load_pairs<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
-            } else {
-                const uint32_t c0 = pk.cs_ptr[r0 + k];
-                cnt = pk.cs_ptr[r0 + k + 1] - c0;
-                stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
-            }
-            if (hdr) {
-                qe = has_pack ? q1 : q;  // one group: the whole pack
-            } else if (k < ng) {
-                gl0 = pk.grp_layer_off[g0 + k] - l0;
-                qe = pk.grp_hop_end[g0 + k];
-            } else {
-                qe = q;  // this pack has no k-th group: no hops in this round
-            }
-            if (WPB > 1) __syncthreads(); else wave_sync();
-            BDDMMA_STAMP(p, 1);
-        }
-        auto hop = [&]() {
-            if (q + 2 * D + 3 >= hw.base + HOP_WIN && hw.base + HOP_WIN <= q1) hw.fill(pk, q, lane);
-            const uint32_t nb = o[0];
-            const uint32_t n3 = o[3] - o[2];  // slots of hop q+2
-            const uint32_t fc = cur * F_STRIDE, fn = (cur ^ 1u) * F_STRIDE, tc = cur * T_STRIDE, tn = (cur ^ 1u) * T_STRIDE;
-            const uint32_t stg = db + (lb[0] - gl0) * (uint32_t)sizeof(P2);  // the hop's first layer inside the wave's staging slots
-            // ---- global prefetch: records of hop q+2D, T of hop q+D+2, arc costs of hop q+D
-            load_recs<R>(rc[2 * D], rr, rbase + (q - q0 + 2 * D) * W, lane);
-            load_vals<REAL, R>(tr[D], Tp, o[D + 2], o[D + 3] - o[D + 2], lane);
-            load_costs<REAL, R>(Lr[D], rc[D], rs.lohi, lb[D]);
-            u4v (&ra)[R] = rc[0];
-            P2 (&La)[R] = Lr[0];
-            // ---- the hop's LDS reads, one batch
-            REAL f[R], tl[R], th[R];
-            P2 dd[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t j = lane + 64 * r;
-                f[r] = lds_ld<REAL>(sFw, fc + j * S);
-                if (GEN && j == rt) f[r] = REAL(0);  // a BDD that starts at this hop: its root has no parents (flush_costs_from_root)
-                tl[r] = lds_ld<REAL>(sTw, tc + (ra[r][0] & 0xFFFFu));  // sinks: [W] = 0, [W+1] = +inf; padding lanes: +inf
-                th[r] = lds_ld<REAL>(sTw, tc + (ra[r][0] >> 16));
-                dd[r] = lds_ld<P2>(dyn_lds, stg + (ra[r][2] & 0xFFFFu));
-            }
-            const uint32_t o_new = off(q + 2 * D + 3);
-            const uint32_t l_next = hw.layer_off(q + D + 2);
-            const uint32_t rt_next = GEN ? hw.root_of(q + 1) : (uint32_t)NO_ROOT;
-            // ---- set-up of the next hop's buffers (nothing above depends on it)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t j = lane + 64 * r;
-                if (j < n3) lds_st<REAL>(sTw, tn + j * S, tr[0][r]);  // T of hop q+2, gathered by hop q+1
-                lds_st<REAL>(sFw, fn + j * S, INF);
-            }
-            wave_sync();
-            // ---- arithmetic
-            P2 nc[R];
-            REAL mmv[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const REAL lc = La[r].x, hc = La[r].y;
-                REAL m0 = (f[r] + lc) + tl[r], m1 = (f[r] + hc) + th[r];
-                if (!GEN || steps <= 1) pair_min_aligned(m0, m1, (ra[r][3] & 1u) != 0);
-                else seg_min2(m0, m1, lane, (ra[r][3] >> 8) & 63u, 0u, steps, sM);
-                const REAL mm = mm_diff1(m0, m1, omega);
-                mmv[r] = mm;
-                nc[r].x = (lc + min0(mm)) + dd[r].x;
-                nc[r].y = (hc + min0_neg(mm)) + dd[r].y;
-            }
-            // ---- writes: new arc costs (heads), staged min-marginal differences, pushes into the next frontier, costs-from-root
-            const rsrc_t rl = hop_rsrc(reinterpret_cast<const P2*>(lohi_p), lb[0], lb[1] - lb[0]);  // ends with the hop's layers: RES2_NO_STORE is dropped
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                hop_store(nc[r], rl, ra[r][2] >> 16, lb[0] * (uint32_t)sizeof(P2));
-                if (!(ra[r][3] & SREC_PAD)) lds_st<REAL>(dyn_lds, stg + (ra[r][2] & 0xFFFFu), mmv[r]);  // every lane of a layer holds the same value
-                lds_min(reinterpret_cast<REAL*>(sFw + fn + (ra[r][1] & 0xFFFFu)), f[r] + nc[r].x);  // sinks / padding: the lane's own dummy entry
-                lds_min(reinterpret_cast<REAL*>(sFw + fn + (ra[r][1] >> 16)), f[r] + nc[r].y);
-            }
-            store_vals<R>(f, Fp, nb, o[1] - o[0], lane, pk.nt_potentials);
-            wave_sync();
-            cur ^= 1u;
-            // ---- rotate the pipeline registers
-#pragma unroll
-            for (int i = 0; i < 2 * D + 2; ++i) o[i] = o[i + 1];
-            o[2 * D + 2] = o_new;
-#pragma unroll
-            for (int i = 0; i < D + 1; ++i) lb[i] = lb[i + 1];
-            lb[D + 1] = l_next;
-            rt = rt_next;
-#pragma unroll
-            for (int i = 0; i < 2 * D; ++i)
-#pragma unroll
-                for (int r = 0; r < R; ++r) rc[i][r] = rc[i + 1][r];
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    Lr[i][r] = Lr[i + 1][r];
-                    tr[i][r] = tr[i + 1][r];
-                }
-            ++q;
-        };
-        while (q + HOP_UNROLL <= qe) {
-#pragma unroll
-            for (int u = 0; u < HOP_UNROLL; ++u) hop();
-        }
-        while (q < qe) hop();
-        {
-            BDDMMA_STAMP(p, 3);
-            if (WPB > 1) __syncthreads(); else wave_sync();
-            BDDMMA_STAMP(p, 2);
-            stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);  // min-marginal differences of the round -> entry array
-            BDDMMA_STAMP(p, 4);
-            if (WPB > 1) __syncthreads();                        // the next round overwrites the staging area
-        }
-    }
-}
-
-// register budget: the records' ring costs 18 VGPRs more than the node words' (109 / 131 instead of 92 / 123 in the forward sweep, float / double,
-// R = 2); asking for 5 / 4 waves per SIMD makes the allocator stay at 96 / 128 without spilling
-#ifndef BDDMMA_N2_WAVES
-#define BDDMMA_N2_WAVES(REAL, R) ((R) <= 2 ? (sizeof(REAL) == 4 ? 5 : 4) : 1)
-#endif
-template <typename REAL, int R, int WPB, bool GEN>
-__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N2_WAVES(REAL, R)))) k_fwd_narrow2(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ srec, const uint32_t* __restrict__ srec_off,
-                                                          uint32_t srec_words, REAL omega)
-{
-    fwd_narrow2_body<REAL, R, WPB, GEN>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x, pk.hdr_pack, pk.hdr_quad);
-}
-
-template <typename REAL, int R, int WPB, bool GEN, int LA = BDDMMA_LOOKAHEAD>
-__device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ srec,
-                                                 const uint32_t* __restrict__ srec_off, uint32_t srec_words, REAL omega, uint32_t block_id,
-                                                 const uint32_t* __restrict__ hdr_pack = nullptr, const uint32_t* __restrict__ hdr_quad = nullptr)
-{
-    constexpr int W = 64 * R;
-    constexpr uint32_t S = sizeof(REAL);
-    using P2 = typename Pair<REAL>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    P2* sD = reinterpret_cast<P2*>(dyn_lds);
-    __shared__ __attribute__((aligned(16))) REAL sT_[WPB][2][W + 2];  // per wave; +2: sink entries TOP = W (0) and BOT = W + 1 (+inf)
-    __shared__ uint32_t sOffN_[WPB][HOP_WIN], sOffL_[WPB][HOP_WIN], sOffR_[WPB][HOP_WIN];
-    const uint32_t tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int lane = tid & 63;
-    unsigned char* sTw = reinterpret_cast<unsigned char*>(&sT_[wave][0][0]);
-    constexpr uint32_t T_STRIDE = (W + 2) * S;
-    const uint32_t n_quads = (pk.n_packs + WPB - 1) / WPB;
-    const uint32_t quad = block_to_pack(block_id, n_quads, pk.xcd_chunk);
-    BDDMMA_EXIT_IF(quad >= n_quads, d)
-    const uint32_t p = quad * WPB + wave;
-    const bool has_pack = p < pk.n_packs;
-    const bool hdr = hdr_pack != nullptr;  // uniform: resident headers, see fwd_narrow2_body
-    const uint32_t* const hp = hdr ? hdr_pack + 8 * (size_t)(has_pack ? p : 0) : nullptr;
-    const uint32_t q0 = !has_pack ? 0 : (hdr ? hp[4] : pk.pack_hop_ptr[p]);
-    const uint32_t q1 = !has_pack ? 0 : (hdr ? q0 + (hp[5] & 0xFFFFu) : pk.pack_hop_ptr[p + 1]);
-    const uint32_t rbase = has_pack ? srec_off[p] : 0;
-    const uint32_t c0_h = hdr ? hdr_quad[4 * (size_t)quad] : 0, cnt_h = hdr ? hdr_quad[4 * (size_t)quad + 1] : 0;
-    BDDMMA_STAMP(p, 0);
-    const REAL INF = inf_v<REAL>();
-    const uint32_t slot_first = !has_pack ? 0 : (hdr ? hp[0] : pk.hop_node_off[q0]), l0 = !has_pack ? 0 : (hdr ? hp[2] : pk.hop_layer_off[q0]);  // the pack's first slot / layer: everything below is relative to them (HopWindow)
-    NarrowRs<REAL> rs(d);
-    rs.rebase_layers(d, l0);
-    uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    if (hdr) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
-    REAL* const Tp = d.T + slot_first;
-    REAL* const Fp = d.F + slot_first;
-    const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
-    (void)lohi_p;
-    REAL* const x_p = d.x_layer != nullptr ? d.x_layer + l0 : nullptr;  // DevPtrs::x_layer, from the pack's first layer on
-    const rsrc_t rr = make_rsrc(srec, srec_words);
-    const int steps = GEN ? (has_pack ? pk.pack_steps[p] : 0) : 1;  // see k_fwd_narrow2
-    REAL* sM = reinterpret_cast<REAL*>(dyn_lds + pk.seg_off) + wave * 128;
-    double lb_stag = 0.0;  // GEN: costs-to-terminal of the roots below the pack's first hop (staggered packs), for the lower bound
-    HopWindow hw{sOffN_[wave], sOffL_[wave], sOffR_[wave], q0, q1, slot_first, l0};
-    auto nb_of = [&](uint32_t q) { return hw.node_off(q); };
-    // pipeline mirrored from k_fwd_narrow2 (see k_bwd_narrow): before hop q is processed (q counts down) the wave holds the records of hops
-    // q .. q-2D+1, the costs-from-root of hops q .. q-D and the arc costs of hops q .. q-D+1.  o[i] = first slot of hop q+1-i,
-    // lb[i] = first layer of hop q+1-i (hops below q0: those of q0).
-    constexpr int D = LA;
-    uint32_t o[2 * D + 2];
-    uint32_t lb[D + 2];
-    u4v rc[2 * D + 1][R];
-    REAL fr[D + 2][R];
-    P2 Lr[D + 1][R];
-#pragma unroll
-    for (int i = 0; i < 2 * D + 2; ++i) o[i] = 0;
-#pragma unroll
-    for (int i = 0; i < D + 2; ++i) lb[i] = 0;
-    uint32_t q = q1;
-    // record of hop h of the pack (h may run below 0 at the pipeline's end: any record, never used)
-    auto rec_of = [&](uint32_t qq) { return rbase + (qq >= q0 ? qq - q0 : 0u) * W; };
-    if (has_pack) {
-        if (lane < 4) lds_st<REAL>(sTw, (uint32_t)(lane >> 1) * T_STRIDE + (W + (lane & 1)) * S, (lane & 1) ? INF : REAL(0));
-        hw.fill(pk, q1 + 1 > q0 + HOP_WIN ? q1 + 1 - HOP_WIN : q0, lane);  // window ends at record q1
-#pragma unroll
-        for (int i = 0; i < 2 * D + 2; ++i) o[i] = nb_of(q1 >= q0 + i ? q1 - i : q0);
-#pragma unroll
-        for (int i = 0; i < D + 2; ++i) lb[i] = hw.layer_off(q1 >= q0 + i ? q1 - i : q0);
-#pragma unroll
-        for (int i = 0; i < 2 * D; ++i) load_recs<R>(rc[i], rr, rec_of(q1 >= q0 + i + 1 ? q1 - 1 - i : q0), lane);  // hop q1-1-i
-#pragma unroll
-        for (int i = 0; i < D + 1; ++i) load_vals<REAL, R>(fr[i], Fp, o[i + 1], o[i] - o[i + 1], lane);            // F of hop q1-1-i
-#pragma unroll
-        for (int i = 0; i < D; ++i) load_costs<REAL, R>(Lr[i], rc[i], rs.lohi, lb[i + 1]);                          // hop q1-1-i starts at layer lb[i+1]
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2 * D; ++i)
-#pragma unroll
-            for (int r = 0; r < R; ++r) rc[i][r] = u4v{0u, 0u, 0u, SREC_PAD};
-    }
-    uint32_t cur = 0;
-    const uint32_t g0 = (has_pack && !hdr) ? pk.pack_group_ptr[p] : 0;
-    const uint32_t ng = !has_pack ? 0 : (hdr ? 1u : pk.pack_group_ptr[p + 1] - g0);
-    const uint32_t r0 = hdr ? 0 : pk.quad_round_ptr[quad];
-    const uint32_t n_rounds = hdr ? 1u : pk.quad_round_ptr[quad + 1] - r0;
-    P2* sDw = sD + (size_t)wave * pk.stage_cap;
-    const uint32_t db = (uint32_t)wave * pk.stage_cap * (uint32_t)sizeof(P2);
-    for (uint32_t k = n_rounds; k-- > 0;) {  // same rounds as the forward sweep, in reverse
-        uint32_t gl0 = 0, cnt = 0, qs = q0;
-        {
-            if (hdr) {
-                cnt = cnt_h;
-                stage_load_pairs<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
-            } else {
-                const uint32_t c0 = pk.cs_ptr[r0 + k];
-                cnt = pk.cs_ptr[r0 + k + 1] - c0;
-                stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
-            }
-            if (hdr) {
-                qs = has_pack ? q0 : q;  // one group: the whole pack
-            } else if (k < ng) {
-                gl0 = pk.grp_layer_off[g0 + k] - l0;
-                qs = (k == 0) ? q0 : pk.grp_hop_end[g0 + k - 1];
-            } else {
-                qs = q;  // no k-th group in this pack
-            }
-            if (WPB > 1) __syncthreads(); else wave_sync();
-            BDDMMA_STAMP(p, 1);
-        }
-        auto hop = [&]() {
-            --q;
-            if (q < hw.base + 2 * D + 1 && hw.base > q0) hw.fill(pk, q + 1 > q0 + HOP_WIN ? q + 1 - HOP_WIN : q0, lane);
-            const uint32_t nb = o[1];
-            const uint32_t tc = cur * T_STRIDE, tn = (cur ^ 1u) * T_STRIDE;
-            const uint32_t stg = db + (lb[1] - gl0) * (uint32_t)sizeof(P2);  // hop q starts at layer lb[1]
-            // ---- prefetch: records of hop q-2D, F of hop q-D-1, arc costs of hop q-D
-            load_recs<R>(rc[2 * D], rr, rec_of(q >= q0 + 2 * D ? q - 2 * D : q0), lane);
-            load_vals<REAL, R>(fr[D + 1], Fp, o[D + 2], o[D + 1] - o[D + 2], lane);
-            load_costs<REAL, R>(Lr[D], rc[D], rs.lohi, lb[D + 1]);
-            u4v (&ra)[R] = rc[0];
-            REAL (&fa)[R] = fr[0];
-            P2 (&La)[R] = Lr[0];
-            // ---- LDS reads
-            REAL tl[R], th[R];
-            P2 dd[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                tl[r] = lds_ld<REAL>(sTw, tc + (ra[r][0] & 0xFFFFu));  // sinks: [W] = 0, [W+1] = +inf
-                th[r] = lds_ld<REAL>(sTw, tc + (ra[r][0] >> 16));
-                dd[r] = lds_ld<P2>(dyn_lds, stg + (ra[r][2] & 0xFFFFu));
-            }
-            const uint32_t o_new = (q >= q0 + 2 * D + 1) ? nb_of(q - 1 - 2 * D) : o[2 * D + 1];
-            const uint32_t l_next = hw.layer_off(q >= q0 + D + 1 ? q - 1 - D : q0);
-            const uint32_t rt = (GEN && q > q0) ? hw.root_of(q) : (uint32_t)NO_ROOT;  // the first hop's roots are summed behind the loop
-            // ---- arithmetic
-            REAL t[R], mmv[R];
-            P2 nc[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const REAL lc = La[r].x, hc = La[r].y;
-                REAL m0 = (fa[r] + lc) + tl[r], m1 = (fa[r] + hc) + th[r];
-                if (!GEN || steps <= 1) pair_min_aligned(m0, m1, (ra[r][3] & 1u) != 0);
-                else seg_min2(m0, m1, lane, (ra[r][3] >> 8) & 63u, 0u, steps, sM);
-                const REAL mm = mm_diff1(m0, m1, omega);
-                mmv[r] = mm;
-                nc[r].x = (lc + min0(mm)) + dd[r].x;
-                nc[r].y = (hc + min0_neg(mm)) + dd[r].y;
-                t[r] = rmin(nc[r].y + th[r], nc[r].x + tl[r]);
-            }
-            // ---- writes
-            const rsrc_t rl = hop_rsrc(reinterpret_cast<const P2*>(lohi_p), lb[1], lb[0] - lb[1]);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t j = lane + 64 * r;
-                hop_store(nc[r], rl, ra[r][2] >> 16, lb[1] * (uint32_t)sizeof(P2));
-                if (!(ra[r][3] & SREC_PAD)) {
-                    lds_st<REAL>(dyn_lds, stg + (ra[r][2] & 0xFFFFu), mmv[r]);
-                    lds_st<REAL>(sTw, tn + j * S, t[r]);
-                }
-                if (GEN && j == rt) lb_stag += (double)t[r];
-            }
-            if (x_p != nullptr) {  // uniform: net_solver_costs x = (hi' - lo') + mm in layer order for an L-BFGS wrapper, heads only, straight from the hop
-                // (as a pass over the staging area behind the round it cost 13 us of a 41 us sweep at 10.5 M nodes, tools/xlayer_cost.py)
-                const rsrc_t rx = hop_rsrc(x_p, lb[1], lb[0] - lb[1]);  // ends with the hop's layers: half of RES2_NO_STORE is dropped as well
-#pragma unroll
-                for (int r = 0; r < R; ++r) hop_store((nc[r].y - nc[r].x) + mmv[r], rx, (ra[r][2] >> 16) >> 1, lb[1] * S);
-            }
-            store_vals<R>(t, Tp, nb, o[0] - o[1], lane, pk.nt_potentials);
-            wave_sync();
-            cur ^= 1u;
-#pragma unroll
-            for (int i = 0; i < 2 * D + 1; ++i) o[i] = o[i + 1];
-            o[2 * D + 1] = o_new;
-#pragma unroll
-            for (int i = 0; i < D + 1; ++i) lb[i] = lb[i + 1];
-            lb[D + 1] = l_next;
-#pragma unroll
-            for (int i = 0; i < 2 * D; ++i)
-#pragma unroll
-                for (int r = 0; r < R; ++r) rc[i][r] = rc[i + 1][r];
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int r = 0; r < R; ++r) Lr[i][r] = Lr[i + 1][r];
-#pragma unroll
-            for (int i = 0; i < D + 1; ++i)
-#pragma unroll
-                for (int r = 0; r < R; ++r) fr[i][r] = fr[i + 1][r];
-        };
-        while (q >= qs + HOP_UNROLL) {
-#pragma unroll
-            for (int u = 0; u < HOP_UNROLL; ++u) hop();
-        }
-        while (q > qs) hop();
-        {
-            BDDMMA_STAMP(p, 3);
-            if (WPB > 1) __syncthreads(); else wave_sync();
-            BDDMMA_STAMP(p, 2);
-            stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
-            BDDMMA_STAMP(p, 4);
-            if (WPB > 1) __syncthreads();
-        }
-    }
-    if (!has_pack) return;
-    // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251)
-    const uint32_t n0 = nb_of(q0 + 1) - nb_of(q0);
-    double s = lb_stag;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t j = lane + 64 * r;
-        if (j < n0) s += (double)lds_ld<REAL>(sTw, cur * T_STRIDE + j * S);
-    }
-    for (int off2 = 32; off2 > 0; off2 >>= 1) s += __shfl_down(s, off2);
-    if (lane == 0) d.lb_partial[pk.lb_base + p] = s;
-}
-
-template <typename REAL, int R, int WPB, bool GEN>
-__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N2_WAVES(REAL, R)))) k_bwd_narrow2(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ srec, const uint32_t* __restrict__ srec_off,
-                                                          uint32_t srec_words, REAL omega)
-{
-    bwd_narrow2_body<REAL, R, WPB, GEN>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x, pk.hdr_pack, pk.hdr_quad);
-}
-
-// =============================================================================================
-// wide packs: one workgroup per pack; layers may span waves, so the layer min goes through LDS
-// =============================================================================================
-constexpr int WIDE_THREADS = 256;
-
-template <typename REAL>
-struct WideLds {
-    REAL* a;  // fwd: F cur/next ; bwd: T cur/next
-    REAL* b;
-    REAL* t;   // fwd: T of next hop
-    REAL* m0;  // per-layer min-marginals
-    REAL* m1;
-    REAL* lc;  // per-layer costs staged so that the in-place cost update cannot race with readers
-    REAL* hc;
-    unsigned char* act0;
-    unsigned char* act1;
-};
-
-__host__ __device__ inline size_t wide_lds_bytes(size_t real_size, uint32_t ww, bool solution)
-{
-    return 7 * real_size * ww + (solution ? 2 * ww : 0);
-}
-
-template <typename REAL>
-__device__ __forceinline__ WideLds<REAL> carve_lds(unsigned char* base, uint32_t ww)
-{
-    WideLds<REAL> l;
-    REAL* r = reinterpret_cast<REAL*>(base);
-    l.a = r; l.b = r + ww; l.t = r + 2 * ww; l.m0 = r + 3 * ww; l.m1 = r + 4 * ww; l.lc = r + 5 * ww; l.hc = r + 6 * ww;
-    l.act0 = base + 7 * sizeof(REAL) * ww;
-    l.act1 = l.act0 + ww;
-    return l;
-}
-
-// GLOBAL: the frontier arrays of pack p live at scratch + p * wide_lds_bytes(ww) in global memory (huge packs)
-template <typename REAL, int MODE, bool GLOBAL = false>
-__global__ void __launch_bounds__(WIDE_THREADS) k_fwd_wide(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww, unsigned char* scratch = nullptr)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t p = blockIdx.x;
-    BDDMMA_EXIT_IF(p >= pk.n_packs, d)
-    WideLds<REAL> s = carve_lds<REAL>(GLOBAL ? scratch + (size_t)p * wide_lds_bytes(sizeof(REAL), ww, true) : smem, ww);
-    const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
-    const REAL INF = inf_v<REAL>();
-    REAL* Fc = s.a;
-    REAL* Fn = s.b;
-    unsigned char* Ac = s.act0;
-    unsigned char* An = s.act1;
-    uint32_t nb = pk.hop_node_off[q0], ne = pk.hop_node_off[q0 + 1];
-    for (uint32_t j = tid; j < ne - nb; j += WIDE_THREADS) {
-        Fc[j] = REAL(0);
-        if (MODE == FWD_SOLUTION) Ac[j] = 1;
-    }
-    for (uint32_t q = q0; q < q1; ++q) {
-        const uint32_t n = ne - nb;
-        const bool last = (q + 1 == q1);
-        const uint32_t ne2 = last ? ne : pk.hop_node_off[q + 2];
-        const uint32_t n2 = ne2 - ne;
-        const uint32_t lbase = pk.hop_layer_off[q];
-        const uint32_t nl = pk.hop_layer_off[q + 1] - lbase;
-        for (uint32_t j = tid; j < n2; j += WIDE_THREADS) {
-            if (MODE != FWD_PLAIN) s.t[j] = d.T[ne + j];
-            Fn[j] = INF;
-            if (MODE == FWD_SOLUTION) An[j] = 0;
-        }
-        for (uint32_t l = tid; l < nl; l += WIDE_THREADS) {
-            s.m0[l] = INF;
-            s.m1[l] = INF;
-            s.lc[l] = d.lohi[2 * (size_t)(lbase + l)];
-            s.hc[l] = d.lohi[2 * (size_t)(lbase + l) + 1];
-        }
-        __syncthreads();
-        if (MODE == FWD_SOLVE) {
-            for (uint32_t j = tid; j < n; j += WIDE_THREADS) {
-                const uint64_t w = d.wwords[nb + j - d.wide_slot_base];
-                const uint32_t lo_i = (uint32_t)(w & WW_CHILD_MASK), hi_i = (uint32_t)((w >> WW_CHILD_BITS) & WW_CHILD_MASK);
-                const uint32_t l = (uint32_t)((w >> (2 * WW_CHILD_BITS)) & WW_CHILD_MASK);
-                const REAL f = frontier_load<GLOBAL>(&Fc[j]);
-                const REAL tl = lo_i == WW_BOT ? INF : (lo_i == WW_TOP ? REAL(0) : s.t[lo_i]);
-                const REAL th = hi_i == WW_BOT ? INF : (hi_i == WW_TOP ? REAL(0) : s.t[hi_i]);
-                frontier_min<GLOBAL>(&s.m0[l], (f + s.lc[l]) + tl);
-                frontier_min<GLOBAL>(&s.m1[l], (f + s.hc[l]) + th);
-            }
-            __syncthreads();
-        }
-        for (uint32_t j = tid; j < n; j += WIDE_THREADS) {
-            const uint64_t w = d.wwords[nb + j - d.wide_slot_base];
-            const uint32_t lo_i = (uint32_t)(w & WW_CHILD_MASK), hi_i = (uint32_t)((w >> WW_CHILD_BITS) & WW_CHILD_MASK);
-            const uint32_t l = (uint32_t)((w >> (2 * WW_CHILD_BITS)) & WW_CHILD_MASK);
-            const REAL f = frontier_load<GLOBAL>(&Fc[j]);
-            REAL nlo = s.lc[l], nhi = s.hc[l];
-            if (MODE == FWD_SOLVE) {
-                const REAL m0 = frontier_load<GLOBAL>(&s.m0[l]), m1 = frontier_load<GLOBAL>(&s.m1[l]);
-                const uint32_t e = d.lpos[lbase + l];
-                const REAL mm = mm_diff(m0, m1, omega);
-                nlo = (nlo + min0(mm)) + d.delta_lay[2 * (size_t)e];
-                nhi = (nhi + min0_neg(mm)) + d.delta_lay[2 * (size_t)e + 1];
-                if (w & WW_HEAD) {
-                    d.lohi[2 * (size_t)(lbase + l)] = nlo;
-                    d.lohi[2 * (size_t)(lbase + l) + 1] = nhi;
-                    d.mm_binned[e] = mm;
-                }
-            } else if (MODE == FWD_SOLUTION) {
-                if (Ac[j]) {
-                    const REAL tl = lo_i == WW_BOT ? INF : (lo_i == WW_TOP ? REAL(0) : s.t[lo_i]);
-                    const REAL th = hi_i == WW_BOT ? INF : (hi_i == WW_TOP ? REAL(0) : s.t[hi_i]);
-                    const REAL hi_path = f + (th + nhi);
-                    const REAL lo_path = f + (tl + nlo);
-                    const bool take_lo = (hi_path - lo_path) > 0;
-                    d.sol_out[lbase + l] = take_lo ? 0 : 1;
-                    const uint32_t c = take_lo ? lo_i : hi_i;
-                    if (c < WW_TOP) An[c] = 1;
-                }
-            }
-            if (lo_i < WW_TOP) frontier_min<GLOBAL>(&Fn[lo_i], f + nlo);
-            if (hi_i < WW_TOP) frontier_min<GLOBAL>(&Fn[hi_i], f + nhi);
-            d.F[nb + j] = f;
-        }
-        __syncthreads();
-        REAL* tmp = Fc; Fc = Fn; Fn = tmp;
-        unsigned char* ta = Ac; Ac = An; An = ta;
-        nb = ne;
-        ne = ne2;
-    }
-}
-
-template <typename REAL, int MODE, bool GLOBAL = false>
-__global__ void __launch_bounds__(WIDE_THREADS) k_bwd_wide(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww, unsigned char* scratch = nullptr)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ double red[WIDE_THREADS / 64];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t p = blockIdx.x;
-    BDDMMA_EXIT_IF(p >= pk.n_packs, d)
-    WideLds<REAL> s = carve_lds<REAL>(GLOBAL ? scratch + (size_t)p * wide_lds_bytes(sizeof(REAL), ww, true) : smem, ww);
-    const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
-    const REAL INF = inf_v<REAL>();
-    REAL* Tc = s.a;  // T of hop q+1
-    REAL* Tn = s.b;  // T of hop q (being written)
-    for (uint32_t q = q1; q-- > q0;) {
-        const uint32_t nb = pk.hop_node_off[q], ne = pk.hop_node_off[q + 1];
-        const uint32_t n = ne - nb;
-        const uint32_t lbase = pk.hop_layer_off[q];
-        const uint32_t nl = pk.hop_layer_off[q + 1] - lbase;
-        for (uint32_t l = tid; l < nl; l += WIDE_THREADS) {
-            s.m0[l] = INF;
-            s.m1[l] = INF;
-            s.lc[l] = d.lohi[2 * (size_t)(lbase + l)];
-            s.hc[l] = d.lohi[2 * (size_t)(lbase + l) + 1];
-        }
-        __syncthreads();
-        if (MODE != BWD_PLAIN) {
-            for (uint32_t j = tid; j < n; j += WIDE_THREADS) {
-                const uint64_t w = d.wwords[nb + j - d.wide_slot_base];
-                const uint32_t lo_i = (uint32_t)(w & WW_CHILD_MASK), hi_i = (uint32_t)((w >> WW_CHILD_BITS) & WW_CHILD_MASK);
-                const uint32_t l = (uint32_t)((w >> (2 * WW_CHILD_BITS)) & WW_CHILD_MASK);
-                const REAL f = d.F[nb + j];
-                const REAL tl = lo_i == WW_BOT ? INF : (lo_i == WW_TOP ? REAL(0) : Tc[lo_i]);
-                const REAL th = hi_i == WW_BOT ? INF : (hi_i == WW_TOP ? REAL(0) : Tc[hi_i]);
-                if (MODE == BWD_SOLVE) {
-                    frontier_min<GLOBAL>(&s.m0[l], (f + s.lc[l]) + tl);
-                    frontier_min<GLOBAL>(&s.m1[l], (f + s.hc[l]) + th);
-                } else {
-                    frontier_min<GLOBAL>(&s.m0[l], f + (tl + s.lc[l]));
-                    frontier_min<GLOBAL>(&s.m1[l], f + (th + s.hc[l]));
-                }
-            }
-            __syncthreads();
-        }
-        for (uint32_t j = tid; j < n; j += WIDE_THREADS) {
-            const uint64_t w = d.wwords[nb + j - d.wide_slot_base];
-            const uint32_t lo_i = (uint32_t)(w & WW_CHILD_MASK), hi_i = (uint32_t)((w >> WW_CHILD_BITS) & WW_CHILD_MASK);
-            const uint32_t l = (uint32_t)((w >> (2 * WW_CHILD_BITS)) & WW_CHILD_MASK);
-            const REAL tl = lo_i == WW_BOT ? INF : (lo_i == WW_TOP ? REAL(0) : Tc[lo_i]);
-            const REAL th = hi_i == WW_BOT ? INF : (hi_i == WW_TOP ? REAL(0) : Tc[hi_i]);
-            REAL t;
-            if (MODE == BWD_SOLVE) {
-                const REAL m0 = frontier_load<GLOBAL>(&s.m0[l]), m1 = frontier_load<GLOBAL>(&s.m1[l]);
-                const uint32_t e = d.lpos[lbase + l];
-                const REAL mm = mm_diff(m0, m1, omega);
-                const REAL nlo = (s.lc[l] + min0(mm)) + d.delta_lay[2 * (size_t)e];
-                const REAL nhi = (s.hc[l] + min0_neg(mm)) + d.delta_lay[2 * (size_t)e + 1];
-                t = rmin(nhi + th, nlo + tl);
-                if (w & WW_HEAD) {
-                    d.lohi[2 * (size_t)(lbase + l)] = nlo;
-                    d.lohi[2 * (size_t)(lbase + l) + 1] = nhi;
-                    d.mm_binned[e] = mm;
-                    if (d.x_layer != nullptr) d.x_layer[lbase + l] = (nhi - nlo) + mm;
-                }
-            } else {
-                t = rmin(th + s.hc[l], tl + s.lc[l]);
-                if (MODE == BWD_MARGINALS && (w & WW_HEAD)) {
-                    d.mm0_out[lbase + l] = frontier_load<GLOBAL>(&s.m0[l]);
-                    d.mm1_out[lbase + l] = frontier_load<GLOBAL>(&s.m1[l]);
-                }
-            }
-            Tn[j] = t;
-            d.T[nb + j] = t;
-        }
-        __syncthreads();
-        REAL* tmp = Tc; Tc = Tn; Tn = tmp;
-    }
-    const uint32_t n0 = pk.hop_node_off[q0 + 1] - pk.hop_node_off[q0];
-    double acc = 0.0;
-    for (uint32_t j = tid; j < n0; j += WIDE_THREADS) acc += (double)Tc[j];
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
-    __syncthreads();
-    if (tid == 0) {
-        double t = 0.0;
-        for (int i = 0; i < WIDE_THREADS / 64; ++i) t += red[i];
-        d.lb_partial[pk.lb_base + p] = t;
-    }
-}
-
-// =============================================================================================
-// wide packs, LDS frontier: register-resident rewrite of the workgroup-per-pack sweeps
-// =============================================================================================
-// One workgroup of T = blockDim.x threads (a multiple of 64, <= 1024) sweeps one wide pack; thread `tid` owns the nodes
-// tid + i * T, i < NPT, of every hop (NPT = 1 for packs up to 1024 nodes per hop), so everything a node needs between the
-// min-marginal phase and the update phase stays in registers and the node words are read once per hop.
-//   * global loads are branch-free raw buffer ops issued three hops ahead (words, potentials), two hops ahead (the layer's
-//     entry index, which needs the word) and one hop ahead (arc costs, delta pair), so a hop never waits for memory it asked
-//     for in the same hop;
-//   * the per-layer minimum goes through LDS (ds_min per node into the layer's slot: layers may span wavefronts);
-//   * two workgroup barriers per hop in the solve / marginal modes (after the minima, after the pushes), one in the plain and
-//     solution modes (three rotating frontier buffers make the second one unnecessary);
-//   * sink children are ordinary LDS indices (ww = cost-to-terminal 0 / dummy push target, ww + 1 = +inf), as in the narrow kernels.
-// The old k_*_wide kernels above remain for huge packs (frontier in global memory).
-__host__ __device__ inline size_t wide2_lds_bytes(size_t real_size, uint32_t ww, bool solution)
-{
-    return 8 * real_size * (size_t)(ww + 2) + (solution ? 3 * (size_t)(ww + 2) : 0);
-}
-constexpr uint64_t WW_PAD_WORD = WW_BOT | (WW_BOT << WW_CHILD_BITS);  // inactive lane: children = bot sink, layer 0, not a head
-
-template <typename REAL>
-struct WideRs {
-    rsrc_t words, T, F, lohi, lpos, dlay, mm;
-    __device__ __forceinline__ explicit WideRs(const DevPtrs<REAL>& d)
-    {
-        words = make_rsrc(d.wwords, (uint64_t)d.n_slots - d.wide_slot_base);
-        T = make_rsrc(d.T, d.n_slots);
-        F = make_rsrc(d.F, d.n_slots);
-        lohi = make_rsrc(d.lohi, 2ull * d.n_layers);
-        lpos = make_rsrc(d.lpos, d.n_layers);
-        dlay = make_rsrc(d.delta_lay, 2ull * d.n_layers);
-        mm = make_rsrc(d.mm_binned, d.n_layers);
-    }
-};
-__device__ __forceinline__ uint64_t bload_u64(rsrc_t r, uint32_t off)
-{
-    const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
-    return ((uint64_t)v[1] << 32) | (uint64_t)v[0];
-}
-__device__ __forceinline__ uint32_t ww_child(uint32_t c, uint32_t ww) { return c >= (uint32_t)WW_TOP ? ww + (c - (uint32_t)WW_TOP) : c; }
-__device__ __forceinline__ uint32_t ww_lo(uint64_t w, uint32_t ww) { return ww_child((uint32_t)(w & WW_CHILD_MASK), ww); }
-__device__ __forceinline__ uint32_t ww_hi(uint64_t w, uint32_t ww) { return ww_child((uint32_t)((w >> WW_CHILD_BITS) & WW_CHILD_MASK), ww); }
-__device__ __forceinline__ uint32_t ww_layer(uint64_t w) { return (uint32_t)((w >> (2 * WW_CHILD_BITS)) & WW_CHILD_MASK); }
-
-template <int NPT>
-__device__ __forceinline__ void wide_load_words(uint64_t (&w)[NPT], rsrc_t words, uint32_t wb, uint32_t n, uint32_t tid, uint32_t T)
-{
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        const uint32_t j = tid + i * T;
-        const uint64_t x = bload_u64(words, j < n ? (wb + j) * 8u : OOB);
-        w[i] = j < n ? x : WW_PAD_WORD;
-    }
-}
-template <typename REAL, int NPT>
-__device__ __forceinline__ void wide_load_vals(REAL (&v)[NPT], rsrc_t src, uint32_t nb, uint32_t n, uint32_t tid, uint32_t T)
-{
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        const uint32_t j = tid + i * T;
-        bload(v[i], src, j < n ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
-    }
-}
-
-template <typename REAL, int MODE, int NPT>
-__device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t ww, uint32_t p)
-{
-    using P2 = typename Pair<REAL>::type;
-    constexpr bool NEED_T = (MODE != FWD_PLAIN);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x, T = blockDim.x;
-    BDDMMA_EXIT_IF(p >= pk.n_packs, d)
-    const uint32_t S = ww + 2;
-    // All LDS arrays are addressed as lds[offset + index] with integer offsets that rotate from hop to hop: with rotating POINTERS the
-    // compiler loses the address space and emits flat loads / a flat compare-and-swap loop for the float minimum (seen in the ISA).
-    REAL* const lds = reinterpret_cast<REAL*>(smem);           // 8 arrays of S values: F x3, T, minima x4
-    unsigned char* const ldsA = smem + 8 * sizeof(REAL) * S;   // 3 arrays of S flags (solution mode)
-    // T of the next hop.  Solve mode: one buffer, rewritten in phase B (its readers are behind the phase-A barrier).  Solution mode has
-    // no such barrier, so it alternates between two buffers (the second one is the space of the minima, unused there).
-    const uint32_t oT0 = 3 * S, oT1 = MODE == FWD_SOLUTION ? 4 * S : 3 * S;
-    const uint32_t oM0 = 4 * S, oM1 = 6 * S;  // minima of lo / hi: [oM0 + cur * S + l], [oM1 + cur * S + l]
-    const REAL INF = inf_v<REAL>();
-    const WideRs<REAL> rs(d);
-    const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
-    auto noff = [&](uint32_t q) { return pk.hop_node_off[min(q, q1)]; };
-    auto loff = [&](uint32_t q) { return pk.hop_layer_off[min(q, q1)]; };
-    const uint32_t wsb = d.wide_slot_base;
-    // node / layer offsets of hops q .. q+4 / q .. q+3
-    uint32_t nv[5], lv[4];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) nv[i] = noff(q0 + i);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lv[i] = loff(q0 + i);
-    // ---- prologue: three dependent round trips, once per pack
-    uint64_t W0[NPT], W1[NPT], W2[NPT];
-    wide_load_words<NPT>(W0, rs.words, nv[0] - wsb, nv[1] - nv[0], tid, T);
-    wide_load_words<NPT>(W1, rs.words, nv[1] - wsb, nv[2] - nv[1], tid, T);
-    wide_load_words<NPT>(W2, rs.words, nv[2] - wsb, nv[3] - nv[2], tid, T);
-    REAL T1[NPT], T2[NPT];
-    if (NEED_T) {
-        wide_load_vals<REAL, NPT>(T1, rs.T, nv[1], nv[2] - nv[1], tid, T);
-        wide_load_vals<REAL, NPT>(T2, rs.T, nv[2], nv[3] - nv[2], tid, T);
-    }
-    uint32_t E0[NPT], E1[NPT];
-    P2 C0[NPT], D0[NPT];
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        const uint32_t j = tid + i * T;
-        const bool a0 = j < nv[1] - nv[0], a1 = j < nv[2] - nv[1];
-        bload(C0[i], rs.lohi, a0 ? (lv[0] + ww_layer(W0[i])) * (uint32_t)sizeof(P2) : OOB);
-        E0[i] = E1[i] = 0;
-        if (MODE == FWD_SOLVE) {
-            E0[i] = bload_u32(rs.lpos, a0 ? (lv[0] + ww_layer(W0[i])) * 4u : OOB);
-            E1[i] = bload_u32(rs.lpos, a1 ? (lv[1] + ww_layer(W1[i])) * 4u : OOB);
-        }
-    }
-    if (MODE == FWD_SOLVE) {
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) bload(D0[i], rs.dlay, (tid + i * T) < nv[1] - nv[0] ? E0[i] * (uint32_t)sizeof(P2) : OOB);
-    }
-    // LDS: roots, empty next frontiers, T of hop q0+1, empty minima
-    for (uint32_t j = tid; j < S; j += T) {
-        lds[j] = j < nv[1] - nv[0] ? REAL(0) : INF;  // every node of hop 0 is a root (flush_costs_from_root)
-        lds[S + j] = INF;
-        lds[2 * S + j] = INF;
-        if (MODE == FWD_SOLVE) { lds[oM0 + j] = INF; lds[oM0 + S + j] = INF; lds[oM1 + j] = INF; lds[oM1 + S + j] = INF; }
-        if (MODE == FWD_SOLUTION) { ldsA[j] = j < nv[1] - nv[0] ? 1 : 0; ldsA[S + j] = 0; ldsA[2 * S + j] = 0; }
-    }
-    if (NEED_T) {
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const uint32_t j = tid + i * T;
-            if (j < nv[2] - nv[1]) lds[oT0 + j] = T1[i];
-        }
-        if (tid < 4) lds[((tid >> 1) ? oT1 : oT0) + ww + (tid & 1)] = (tid & 1) ? INF : REAL(0);
-    }
-    __syncthreads();
-    uint32_t fc = 0, cur = 0;  // frontier buffer fc: current, (fc+1)%3: next, (fc+2)%3: being cleared for the hop after
-    // staggered wide packs: slot of the BDD that starts at hop q (below the pack's first hop), read two hops ahead like the offsets
-    auto root_at = [&](uint32_t q) -> uint32_t { return (q > q0 && q < q1) ? (uint32_t)pk.hop_root[q] : (uint32_t)NO_ROOT; };
-    uint32_t rt0 = NO_ROOT, rt1 = root_at(q0 + 1);
-    for (uint32_t q = q0; q < q1; ++q) {
-        const uint32_t rt2 = root_at(q + 2);
-        const uint32_t n = nv[1] - nv[0];
-        const uint32_t oFc = fc * S, oFn = (fc == 2 ? 0 : fc + 1) * S, oFx = (fc == 0 ? 2 : fc - 1) * S;
-        const uint32_t oT = cur ? oT1 : oT0, oTn = cur ? oT0 : oT1;
-        const uint32_t oMa = oM0 + cur * S, oMb = oM1 + cur * S, oMa_n = oM0 + (cur ^ 1) * S, oMb_n = oM1 + (cur ^ 1) * S;
-        // ---- prefetch (consumed in later hops): words / T of hop q+3, entry indices of hop q+2, arc costs and delta pairs of hop q+1
-        uint64_t W3[NPT];
-        REAL T3[NPT];
-        uint32_t E2[NPT];
-        P2 C1[NPT], D1[NPT];
-        const uint32_t nv5 = noff(q + 5), lv4 = loff(q + 4);
-        wide_load_words<NPT>(W3, rs.words, nv[3] - wsb, nv[4] - nv[3], tid, T);
-        if (NEED_T) wide_load_vals<REAL, NPT>(T3, rs.T, nv[3], nv[4] - nv[3], tid, T);
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const uint32_t j = tid + i * T;
-            const bool a1 = j < nv[2] - nv[1], a2 = j < nv[3] - nv[2];
-            bload(C1[i], rs.lohi, a1 ? (lv[1] + ww_layer(W1[i])) * (uint32_t)sizeof(P2) : OOB);
-            E2[i] = 0;
-            if (MODE == FWD_SOLVE) {
-                E2[i] = bload_u32(rs.lpos, a2 ? (lv[2] + ww_layer(W2[i])) * 4u : OOB);
-                bload(D1[i], rs.dlay, a1 ? E1[i] * (uint32_t)sizeof(P2) : OOB);
-            }
-        }
-        // ---- phase A: per-layer minima of the two min-marginals
-        REAL f[NPT], tl[NPT], th[NPT];
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const uint32_t j = tid + i * T;
-            const bool act = j < n;
-            f[i] = act ? lds[oFc + j] : INF;
-            if (j == rt0) f[i] = REAL(0);  // a BDD that starts at this hop: its root has no parents (flush_costs_from_root)
-            if (NEED_T) {
-                tl[i] = lds[oT + ww_lo(W0[i], ww)];
-                th[i] = lds[oT + ww_hi(W0[i], ww)];
-            }
-            if (MODE == FWD_SOLVE) {
-                const uint32_t l = ww_layer(W0[i]);
-                REAL a = (f[i] + C0[i].x) + tl[i], b = (f[i] + C0[i].y) + th[i];
-                const bool lead = seg_fold_by_key(a, b, act ? l : 0xFFFFFFFFu, (int)(tid & 63u));
-                if (act && lead) {  // inactive lanes have nothing to contribute (and would all hit one address)
-                    lds_min(&lds[oMa + l], a);
-                    lds_min(&lds[oMb + l], b);
-                }
-            }
-        }
-        if (MODE == FWD_SOLVE) __syncthreads();
-        // ---- phase B: cost update, pushes into the next frontier
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const uint32_t j = tid + i * T;
-            const bool act = j < n;
-            const uint64_t w = W0[i];
-            const uint32_t l = ww_layer(w), lo_i = ww_lo(w, ww), hi_i = ww_hi(w, ww);
-            REAL nlo = C0[i].x, nhi = C0[i].y;
-            if (MODE == FWD_SOLVE) {
-                const REAL m0 = lds[oMa + l], m1 = lds[oMb + l];
-                const REAL mm = mm_diff(m0, m1, omega);
-                nlo = (nlo + min0(mm)) + D0[i].x;
-                nhi = (nhi + min0_neg(mm)) + D0[i].y;
-                const bool head = act && (w & WW_HEAD);
-                P2 nc;
-                nc.x = nlo;
-                nc.y = nhi;
-                bstore(nc, rs.lohi, head ? (lv[0] + l) * (uint32_t)sizeof(P2) : OOB);
-                bstore(mm, rs.mm, head ? E0[i] * (uint32_t)sizeof(REAL) : OOB);
-            } else if (MODE == FWD_SOLUTION) {
-                if (act && (ldsA[oFc + j] || j == rt0)) {
-                    const REAL hi_path = f[i] + (th[i] + nhi);  // backward_step_with_path_costs, bdd_cuda_base.cu:633-640
-                    const REAL lo_path = f[i] + (tl[i] + nlo);
-                    const bool take_lo = (hi_path - lo_path) > 0;
-                    d.sol_out[lv[0] + l] = take_lo ? 0 : 1;
-                    ldsA[oFn + (take_lo ? lo_i : hi_i)] = 1;  // sink entries are dummies
-                }
-            }
-            const bool plo = lo_i < ww, phi = hi_i < ww;  // sink children and inactive lanes: no-op on a slot of their own (see k_fwd_narrow)
-            if (act) {
-                lds_min(&lds[oFn + (plo ? lo_i : j)], plo ? f[i] + nlo : INF);
-                lds_min(&lds[oFn + (phi ? hi_i : j)], phi ? f[i] + nhi : INF);
-            }
-            if (MODE != FWD_SOLUTION) bstore(f[i], rs.F, act ? (nv[0] + j) * (uint32_t)sizeof(REAL) : OOB);
-        }
-        // set-up of later hops: the frontier after next is cleared, T of hop q+2 goes to LDS (phase A of the next hop reads it),
-        // the minima of hop q+1 are reset
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const uint32_t j = tid + i * T;
-            if (j < nv[3] - nv[2]) {
-                lds[oFx + j] = INF;
-                if (MODE == FWD_SOLUTION) ldsA[oFx + j] = 0;
-                if (NEED_T) lds[oTn + j] = T2[i];
-            }
-        }
-        if (MODE == FWD_SOLVE) {
-            const uint32_t nl1 = lv[2] - lv[1];
-            for (uint32_t l = tid; l < nl1; l += T) { lds[oMa_n + l] = INF; lds[oMb_n + l] = INF; }
-        }
-        __syncthreads();
-        // rotate
-        fc = fc == 2 ? 0 : fc + 1;
-        cur ^= 1;
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            W0[i] = W1[i]; W1[i] = W2[i]; W2[i] = W3[i];
-            E0[i] = E1[i]; E1[i] = E2[i];
-            C0[i] = C1[i];
-            if (MODE == FWD_SOLVE) D0[i] = D1[i];
-            if (NEED_T) T2[i] = T3[i];
-        }
-        nv[0] = nv[1]; nv[1] = nv[2]; nv[2] = nv[3]; nv[3] = nv[4]; nv[4] = nv5;
-        lv[0] = lv[1]; lv[1] = lv[2]; lv[2] = lv[3]; lv[3] = lv4;
-        rt0 = rt1; rt1 = rt2;
-    }
-}
-
-template <typename REAL, int MODE, int NPT>
-__global__ void __launch_bounds__(1024) k_fwd_wide2(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
-{
-    fwd_wide2_body<REAL, MODE, NPT>(d, pk, omega, ww, blockIdx.x);
-}
-
-template <typename REAL, int MODE, int NPT>
-__device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t ww, uint32_t p)
-{
-    using P2 = typename Pair<REAL>::type;
-    constexpr bool NEED_F = (MODE != BWD_PLAIN);
-    constexpr bool NEED_M = (MODE != BWD_PLAIN);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ double red[16];
-    const uint32_t tid = threadIdx.x, T = blockDim.x;
-    BDDMMA_EXIT_IF(p >= pk.n_packs, d)
-    const uint32_t S = ww + 2;
-    REAL* const lds = reinterpret_cast<REAL*>(smem);  // integer offsets instead of rotating pointers, see k_fwd_wide2
-    const uint32_t oM0 = 4 * S, oM1 = 6 * S;
-    const REAL INF = inf_v<REAL>();
-    const WideRs<REAL> rs(d);
-    const uint32_t q0 = pk.pack_hop_ptr[p], q1 = pk.pack_hop_ptr[p + 1];
-    const uint32_t wsb = d.wide_slot_base;
-    // hop h below the current one: node range [nb(h), nb(h+1)), empty below q0
-    auto nb_of = [&](int64_t h) { return pk.hop_node_off[h < (int64_t)q0 ? q0 : (uint32_t)h]; };
-    auto cnt_of = [&](int64_t h) { return h < (int64_t)q0 ? 0u : pk.hop_node_off[h + 1] - pk.hop_node_off[h]; };
-    auto lb_of = [&](int64_t h) { return pk.hop_layer_off[h < (int64_t)q0 ? q0 : (uint32_t)h]; };
-    auto nl_of = [&](int64_t h) { return h < (int64_t)q0 ? 0u : pk.hop_layer_off[h + 1] - pk.hop_layer_off[h]; };
-    int64_t q = (int64_t)q1 - 1;
-    // ---- prologue
-    uint64_t W0[NPT], W1[NPT], W2[NPT];
-    REAL F0[NPT], F1[NPT], F2[NPT];
-    wide_load_words<NPT>(W0, rs.words, nb_of(q) - wsb, cnt_of(q), tid, T);
-    wide_load_words<NPT>(W1, rs.words, nb_of(q - 1) - wsb, cnt_of(q - 1), tid, T);
-    wide_load_words<NPT>(W2, rs.words, nb_of(q - 2) - wsb, cnt_of(q - 2), tid, T);
-    if (NEED_F) {
-        wide_load_vals<REAL, NPT>(F0, rs.F, nb_of(q), cnt_of(q), tid, T);
-        wide_load_vals<REAL, NPT>(F1, rs.F, nb_of(q - 1), cnt_of(q - 1), tid, T);
-        wide_load_vals<REAL, NPT>(F2, rs.F, nb_of(q - 2), cnt_of(q - 2), tid, T);
-    }
-    uint32_t E0[NPT], E1[NPT];
-    P2 C0[NPT], D0[NPT];
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        const uint32_t j = tid + i * T;
-        const bool a0 = j < cnt_of(q), a1 = j < cnt_of(q - 1);
-        bload(C0[i], rs.lohi, a0 ? (lb_of(q) + ww_layer(W0[i])) * (uint32_t)sizeof(P2) : OOB);
-        E0[i] = E1[i] = 0;
-        if (MODE == BWD_SOLVE) {
-            E0[i] = bload_u32(rs.lpos, a0 ? (lb_of(q) + ww_layer(W0[i])) * 4u : OOB);
-            E1[i] = bload_u32(rs.lpos, a1 ? (lb_of(q - 1) + ww_layer(W1[i])) * 4u : OOB);
-        }
-    }
-    if (MODE == BWD_SOLVE) {
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) bload(D0[i], rs.dlay, (tid + i * T) < cnt_of(q) ? E0[i] * (uint32_t)sizeof(P2) : OOB);
-    }
-    for (uint32_t j = tid; j < S; j += T) {
-        if (NEED_M) { lds[oM0 + j] = INF; lds[oM0 + S + j] = INF; lds[oM1 + j] = INF; lds[oM1 + S + j] = INF; }
-    }
-    if (tid < 4) lds[(tid >> 1) * S + ww + (tid & 1)] = (tid & 1) ? INF : REAL(0);
-    __syncthreads();
-    uint32_t tc = 0, cur = 0;  // T buffer tc: hop q+1 (children), tc^1: hop q (being written)
-    // staggered wide packs: the root that sits at hop q below the pack's first hop contributes its cost-to-terminal to the lower bound
-    auto root_at = [&](int64_t h) -> uint32_t { return h > (int64_t)q0 ? (uint32_t)pk.hop_root[h] : (uint32_t)NO_ROOT; };
-    uint32_t rt0 = root_at(q), rt1 = root_at(q - 1);
-    double lb_stag = 0.0;
-    for (; q >= (int64_t)q0; --q) {
-        const uint32_t rt2 = root_at(q - 2);
-        const uint32_t n = cnt_of(q), nb = nb_of(q), lb = lb_of(q);
-        const uint32_t oTc = tc * S, oTn = (tc ^ 1) * S;
-        const uint32_t oMa = oM0 + cur * S, oMb = oM1 + cur * S, oMa_n = oM0 + (cur ^ 1) * S, oMb_n = oM1 + (cur ^ 1) * S;
-        // ---- prefetch: words / F of hop q-3, entry indices of hop q-2, arc costs and delta pairs of hop q-1
-        uint64_t W3[NPT];
-        REAL F3[NPT];
-        uint32_t E2[NPT];
-        P2 C1[NPT], D1[NPT];
-        const uint32_t c1 = cnt_of(q - 1), c2 = cnt_of(q - 2), c3 = cnt_of(q - 3);
-        const uint32_t lb1 = lb_of(q - 1), lb2 = lb_of(q - 2);
-        wide_load_words<NPT>(W3, rs.words, nb_of(q - 3) - wsb, c3, tid, T);
-        if (NEED_F) wide_load_vals<REAL, NPT>(F3, rs.F, nb_of(q - 3), c3, tid, T);
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const uint32_t j = tid + i * T;
-            bload(C1[i], rs.lohi, j < c1 ? (lb1 + ww_layer(W1[i])) * (uint32_t)sizeof(P2) : OOB);
-            E2[i] = 0;
-            if (MODE == BWD_SOLVE) {
-                E2[i] = bload_u32(rs.lpos, j < c2 ? (lb2 + ww_layer(W2[i])) * 4u : OOB);
-                bload(D1[i], rs.dlay, j < c1 ? E1[i] * (uint32_t)sizeof(P2) : OOB);
-            }
-        }
-        // ---- phase A
-        REAL tl[NPT], th[NPT];
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const uint32_t j = tid + i * T;
-            const bool act = j < n;
-            tl[i] = lds[oTc + ww_lo(W0[i], ww)];
-            th[i] = lds[oTc + ww_hi(W0[i], ww)];
-            if (NEED_M) {
-                const uint32_t l = ww_layer(W0[i]);
-                REAL a, b;
-                if (MODE == BWD_SOLVE) {
-                    a = (F0[i] + C0[i].x) + tl[i];
-                    b = (F0[i] + C0[i].y) + th[i];
-                } else {  // backward_step_with_path_costs, bdd_cuda_base.cu:633-641
-                    a = F0[i] + (tl[i] + C0[i].x);
-                    b = F0[i] + (th[i] + C0[i].y);
-                }
-                const bool lead = seg_fold_by_key(a, b, act ? l : 0xFFFFFFFFu, (int)(tid & 63u));
-                if (act && lead) {
-                    lds_min(&lds[oMa + l], a);
-                    lds_min(&lds[oMb + l], b);
-                }
-            }
-        }
-        if (NEED_M) __syncthreads();
-        // ---- phase B
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const uint32_t j = tid + i * T;
-            const bool act = j < n;
-            const uint64_t w = W0[i];
-            const uint32_t l = ww_layer(w);
-            const bool head = act && (w & WW_HEAD);
-            REAL t;
-            if (MODE == BWD_SOLVE) {
-                const REAL m0 = lds[oMa + l], m1 = lds[oMb + l];
-                const REAL mm = mm_diff(m0, m1, omega);
-                const REAL nlo = (C0[i].x + min0(mm)) + D0[i].x;
-                const REAL nhi = (C0[i].y + min0_neg(mm)) + D0[i].y;
-                t = rmin(nhi + th[i], nlo + tl[i]);
-                P2 nc;
-                nc.x = nlo;
-                nc.y = nhi;
-                bstore(nc, rs.lohi, head ? (lb + l) * (uint32_t)sizeof(P2) : OOB);
-                bstore(mm, rs.mm, head ? E0[i] * (uint32_t)sizeof(REAL) : OOB);
-                if (d.x_layer != nullptr && head) d.x_layer[lb + l] = (nhi - nlo) + mm;
-            } else {
-                t = rmin(th[i] + C0[i].y, tl[i] + C0[i].x);  // backward_step, bdd_cuda_base.cu:646-667
-                if (MODE == BWD_MARGINALS && head) {
-                    d.mm0_out[lb + l] = lds[oMa + l];
-                    d.mm1_out[lb + l] = lds[oMb + l];
-                }
-            }
-            if (act) lds[oTn + j] = t;
-            if (j == rt0) lb_stag += (double)t;
-            bstore(t, rs.T, act ? (nb + j) * (uint32_t)sizeof(REAL) : OOB);
-        }
-        if (NEED_M) {
-            const uint32_t nl1 = nl_of(q - 1);
-            for (uint32_t l = tid; l < nl1; l += T) { lds[oMa_n + l] = INF; lds[oMb_n + l] = INF; }
-        }
-        __syncthreads();
-        tc ^= 1;
-        cur ^= 1;
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            W0[i] = W1[i]; W1[i] = W2[i]; W2[i] = W3[i];
-            if (NEED_F) { F0[i] = F1[i]; F1[i] = F2[i]; F2[i] = F3[i]; }
-            E0[i] = E1[i]; E1[i] = E2[i];
-            C0[i] = C1[i];
-            if (MODE == BWD_SOLVE) D0[i] = D1[i];
-        }
-        rt0 = rt1; rt1 = rt2;
-    }
-    // lower bound contribution of this pack (bdd_cuda_base.cu:1243-1251)
-    const uint32_t n0 = pk.hop_node_off[q0 + 1] - pk.hop_node_off[q0];
-    double acc = lb_stag;
-    for (uint32_t j = tid; j < n0; j += T) acc += (double)lds[tc * S + j];
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
-    __syncthreads();
-    if (tid == 0) {
-        double t = 0.0;
-        for (uint32_t i = 0; i < T / 64; ++i) t += red[i];
-        d.lb_partial[pk.lb_base + p] = t;
-    }
-}
-
-template <typename REAL, int MODE, int NPT>
-__global__ void __launch_bounds__(1024) k_bwd_wide2(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
-{
-    bwd_wide2_body<REAL, MODE, NPT>(d, pk, omega, ww, blockIdx.x);
-}
-
-// Instances with narrow AND wide packs: one launch for both.  The first n_wide workgroups sweep one wide pack each (they are the
-// long pole, so they start first), the rest are the narrow launch unchanged; the workgroup size is the narrow one (64 * WPB threads,
-// NPT = nodes of a wide hop per thread).  Sequential launches add their times (61 us = 36 + 20 + boundary on the knapsack
-// benchmark), a second stream costs more in event fork / join than it returns; inside one grid the two kinds of workgroups simply
-// share the CUs.
-// (the narrow part stays first generation: instances with wide packs are general linear rows, whose BDDs share no structure templates, and
-// per-lane records that are not shared cost four times the node words' bytes — 40 000 knapsack rows, 10 M nodes: sweeps 73 / 73 us with
-// node words, 91 / 110 us with records, profiles/r04_widebench.txt)
-template <typename REAL, int R, int WPB, int NPT>
-__global__ void __launch_bounds__(64 * WPB) k_fwd_mixed(DevPtrs<REAL> d, PackDev pkn, PackDev pkw, REAL omega, uint32_t ww)
-{
-    const uint32_t nw8 = (pkw.n_packs + 7u) & ~7u;  // a multiple of 8, so that the narrow workgroups keep their XCD-aware block -> pack map
-    if (blockIdx.x < nw8) fwd_wide2_body<REAL, FWD_SOLVE, NPT>(d, pkw, omega, ww, blockIdx.x);
-    else fwd_narrow_body<REAL, R, FWD_SOLVE, WPB>(d, pkn, omega, blockIdx.x - nw8);
-}
-template <typename REAL, int R, int WPB, int NPT>
-__global__ void __launch_bounds__(64 * WPB) k_bwd_mixed(DevPtrs<REAL> d, PackDev pkn, PackDev pkw, REAL omega, uint32_t ww)
-{
-    const uint32_t nw8 = (pkw.n_packs + 7u) & ~7u;
-    if (blockIdx.x < nw8) bwd_wide2_body<REAL, BWD_SOLVE, NPT>(d, pkw, omega, ww, blockIdx.x);
-    else bwd_narrow_body<REAL, R, BWD_SOLVE, WPB>(d, pkn, omega, blockIdx.x - nw8);
-}
-
-// =============================================================================================
-// small elementwise / per-variable kernels
-// =============================================================================================
-
-// Device-resident run_solver (include/run_solver_util.h:40-73).  The reference's loop is iteration(); lower_bound(); three tests on the
-// bound — a host round trip per iteration that leaves the GPU idle between the reduce kernel and the next forward sweep (119 -> 135 us
-// per iteration at 10.5 M nodes, 33 -> 47 us at 1 M).  Here workgroup 0 of the exchange launch that ends an iteration also reduces the per-pack bounds the
-// backward sweep has just written and runs the tests, in the reference's order and in the same double arithmetic, and latches `stop`:
-// the launches of the iterations the host queued ahead see it and return (DevPtrs::stop), so the solver state is exactly the one
-// after the iteration that met the criterion.  No extra launch, no synchronisation; the host only watches `RunHost` (pinned) for
-// the bounds to print and for the end.  The wall-clock limit stays a host test.
-constexpr uint32_t RUN_RING = 64;
-struct RunCtl {  // device memory
-    double lb_initial, lb_first, lb_post, tolerance, slope;
-    double time_limit;   // seconds since the start of run_solver (run_solver_util.h:45-55); tested on the device's constant 100 MHz clock
-    uint64_t t0;         // s_memrealtime at the start of the run (minus what the host had already spent), set by k_run_begin
-    uint64_t iter;
-    uint32_t stop, reason;
-};
-constexpr double RUN_TICKS_PER_SECOND = 1e8;  // s_memrealtime
-static __global__ void k_run_begin(RunCtl* ctl, uint64_t host_ticks_so_far)
-{
-    ctl->t0 = __builtin_amdgcn_s_memrealtime() - host_ticks_so_far;
-}
-struct RunHost {  // pinned host memory, written by the device
-    uint64_t state;       // (iterations whose bound has been published) | (stop reason << 56): one word, so the host never sees half an update
-    double lb[RUN_RING];  // bound after iteration i at [i % RUN_RING]
-};
-struct RunStep {  // argument of the launch that ends an iteration (ctl == nullptr: nothing to do)
-    const double* part;  // per-pack lower bounds
-    uint32_t n;
-    RunCtl* ctl;
-    RunHost* host;
-};
-// Executed by every thread of ONE workgroup of 256, 512 or 1024 threads.  The sum has the shape and order of k_lb_reduce (1024
-// threads: 16 waves of strided partial sums, an in-wave tree, the 16 results added in order) whatever the workgroup size, so the
-// published bound equals lower_bound() bit for bit.
-__device__ __forceinline__ void run_ctl_step(const RunStep& r)
-{
-    __shared__ double run_red[16];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    // the control block is read while the partial sums are on their way (one round trip instead of two)
-    RunCtl c{};
-    if (threadIdx.x == 0) c = *r.ctl;
-    for (uint32_t vw = wave; vw < 16; vw += nw) {
-        double acc = 0.0;
-        uint32_t i = vw * 64 + lane;
-        for (; i + 7 * 1024u < r.n; i += 8 * 1024u) {  // eight loads in flight, additions in the plain loop's order (see k_lb_reduce)
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = r.part[i + u * 1024u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
-        }
-        for (; i < r.n; i += 1024) acc += r.part[i];
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-        if (lane == 0) run_red[vw] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    RunCtl* ctl = r.ctl;
-    double t = 0.0;
-    for (uint32_t i = 0; i < 16; ++i) t += run_red[i];
-    const uint64_t it = c.iter;
-    const double lb_prev = c.lb_post, lb_post = t;
-    const double lb_first = it == 0 ? lb_post : c.lb_first, lb_initial = c.lb_initial;
-    if (it == 0) ctl->lb_first = lb_post;
-    ctl->lb_post = lb_post;
-    ctl->iter = it + 1;
-    uint32_t reason = 0;
-    // the wall-clock limit first, as the reference tests it (:45-55) — on the device, so that no iteration queued behind the one that crossed
-    // the limit runs (the host-side test let up to window - 1 more iterations execute)
-    const double time_spent = (double)(__builtin_amdgcn_s_memrealtime() - c.t0) / RUN_TICKS_PER_SECOND;
-    if (time_spent > c.time_limit) reason = 1;
-    else if (__builtin_fabs(lb_prev - lb_post) < __builtin_fabs(c.tolerance * lb_prev)) reason = 2;           // run_solver_util.h:56-61
-    else if (__builtin_fabs(lb_prev - lb_post) < c.slope * __builtin_fabs(lb_initial - lb_first)) reason = 3;  // :62-67
-    else if (lb_post == __builtin_huge_val()) reason = 4;                                                       // :68-73
-    if (reason) { ctl->reason = reason; ctl->stop = (uint32_t)(it + 1 < (uint64_t)RUN_NOT_STOPPED ? it + 1 : (uint64_t)RUN_NOT_STOPPED - 1); }  // launches of iterations >= it + 1 are skipped
-    volatile RunHost* h = r.host;
-    h->lb[it % RUN_RING] = lb_post;
-    __threadfence_system();
-    h->state = (it + 1) | ((uint64_t)reason << 56);
-}
-
-template <typename REAL>
-__device__ __forceinline__ void lds_add(REAL* p, REAL v)
-{
-#ifdef BDDMMA_EXP_INT_ATOMIC  // timing experiment only (wrong results): the rate of the integer LDS atomic of the same width
-    using U = typename std::conditional<sizeof(REAL) == 8, unsigned long long, unsigned int>::type;
-    __hip_atomic_fetch_add(reinterpret_cast<U*>(p), __builtin_bit_cast(U, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f32 / ds_add_f64
-#endif
-}
-
-// Exchange kernel: one workgroup per bin of variables; the bin's 2*vars_per_bin accumulators live in LDS.
-//   EX_ITER : compute_delta (bdd_cuda_parallel_mma.cu:358-393) + normalize_delta (:410-430) + broadcast of the
-//             normalised pairs to the bin's entries (what the next sweep adds, :191-197); the per-variable
-//             result is also stored in delta_var (the solver's delta_lo_hi_).
-//   EX_RAW  : compute_delta only — un-normalised sums into delta_var (explicit forward_mm / backward_mm API).
-// The accumulators are ACC-typed: LDS f32 atomics (ds_add_f32) run at half the rate of ds_add_f64 on
-// gfx950 (measured: 33 us vs 16 us for the same 5 M entries), so float solvers accumulate in double
-// and round once per variable.
-enum : int { EX_ITER = 0, EX_RAW = 1 };
-constexpr int EX_THREADS = 1024;
-constexpr int EX_UNROLL = 12;  // entries per thread and chunk: a bin of <= 24576 entries is one chunk — every load of the bin in flight at once,
-                               // and the local variable indices stay in registers for the broadcast (no second round trip)
-constexpr int EX_NPT = 19;     // 2 * vars_per_bin <= EX_NPT * EX_THREADS
-// Small instances (few hundred bins of 1024 threads would leave most CUs idle and pay 16-wave barriers for a handful of entries per
-// thread): the same kernel with 256-thread workgroups over bins of <= 1024 variables.
-constexpr int EXS_THREADS = 256;
-constexpr int EXS_UNROLL = 12;
-constexpr int EXS_NPT = 8;
-constexpr uint32_t EXS_MAX_VARS_PER_BIN = EXS_THREADS * EXS_NPT / 2;
-// Bins of <= 2048 variables: 512-thread workgroups.  The 1024-thread kernel holds ~100 VGPRs per lane, i.e. ONE workgroup per CU, so
-// with more bins than CUs its workgroups run in rounds, each paying the whole latency chain (bin range -> loads -> accumulate ->
-// normalise -> broadcast); two 512-thread workgroups per CU overlap one bin's broadcast with the other's loads.
-constexpr int EXM_THREADS = 512;
-constexpr int EXM_UNROLL = 12;
-constexpr int EXM_NPT = 8;
-constexpr uint32_t EXM_MAX_VARS_PER_BIN = EXM_THREADS * EXM_NPT / 2;
-
-// (Round 2 shelved a version of this kernel with scalar-offset entry addressing and one predicated atomic per entry because about 1 % of the
-// differential fuzz runs came out with 1e-7 errors when several processes shared the GPU.  Root cause, found in round 3 by bisecting the
-// rewrite's three ingredients (EXV_* below) under that load: a hardware write-data hazard of 16-byte buffer stores with an SGPR soffset that
-// the compiler does not guard — see hop_store(double2) and profiles/r03_exchange_variant_rootcause.txt.  The entry LOADS by scalar offset,
-// the idiom the narrow sweeps use, were never involved.)
-// pair stores with the chunk's first entry in the scalar offset (EXV_SOFF_STORES below)
-__device__ __forceinline__ void hop_store(float2 v, rsrc_t rh, uint32_t voff, uint32_t soff)
-{
-    using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(rh, 0, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rh, voff, soff, BDDMMA_ST_AUX);
-}
-// 16-byte store with an SGPR soffset: on gfx950 a VMEM store of more than 64 bits needs one wait state before a VALU instruction
-// overwrites its data registers — also when soffset is an SGPR, which the ISA manuals exempt and the compiler therefore does not pad
-// (LLVM GCNHazardRecognizer::createsVALUHazard).  Without the s_nop 1.1 % of such pairs store the overwritten first dword
-// (tools/store_hazard.hip, profiles/r03_exchange_variant_rootcause.txt): this was the round-2 exchange rewrite's "rare 1e-7 error".
-// -DBDDMMA_REPRODUCE_STORE_HAZARD builds without it (tools/build_variant.sh), for the record only; tests/test_isa_lint.py checks the
-// built library for unpadded pairs.
-__device__ __forceinline__ void hop_store(double2 v, rsrc_t rh, uint32_t voff, uint32_t soff)
-{
-    using u4 = decltype(__builtin_amdgcn_raw_buffer_load_b128(rh, 0, 0, 0));
-    const u4 data = __builtin_bit_cast(u4, v);
-    __builtin_amdgcn_raw_buffer_store_b128(data, rh, voff, soff, 0);
-#ifndef BDDMMA_REPRODUCE_STORE_HAZARD
-    // the data registers are an input of the nop: they stay live up to it, so no VALU write of them can be scheduled between the store and
-    // the wait state (the Makefile runs tools/isa_lint.py on every build)
-    asm volatile("s_nop 0" ::"v"(data) : "memory");
-#endif
-}
-// VAR: the three ingredients of the round-2 rewrite that was shelved (see the note above), separately switchable so that the rare
-// multi-process discrepancy can be bisected (bddmma_options.variant_flags bits 3-5, 256-thread instantiation only; profiles/r03_exchange_variant_soak.txt):
-enum : int {
-    EXV_SOFF_LOADS = 1,    // entry loads: lane offset tid * size, chunk start in the scalar offset, descriptor ends at the bin's last entry
-    EXV_SOFF_STORES = 2,   // the pair broadcast addressed the same way
-    EXV_ONE_ATOMIC = 4,    // one predicated LDS atomic per entry (slot 2 v + [mm > 0], value |mm|) instead of two branches around two atomics
-};
-template <typename REAL, typename ACC, int MODE, int EX_THREADS, int EX_UNROLL, int NPT, int VAR = 0>
-__device__ __forceinline__ bool exchange_reduce_body(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
-                                                     const uint16_t* __restrict__ bvar, const int32_t* __restrict__ nbdds,
-                                                     REAL* __restrict__ delta_var, REAL* __restrict__ delta_lay,
-                                                     uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries,
-                                                     uint32_t stop_word = RUN_NOT_STOPPED, uint32_t run_iter = 0)  // false: run_solver has stopped
-{
-    using P2 = typename Pair<REAL>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    ACC* tile = reinterpret_cast<ACC*>(dyn_lds);
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    const uint32_t v0 = b * vars_per_bin;
-    const uint32_t nv = min(vars_per_bin, n_vars - v0);
-    // the bin's ranges of the entry arrays, rebased (64-bit, once): entry offsets below are relative to the bin's first entry, so the arrays
-    // may exceed the 4 GiB that a 32-bit buffer offset reaches
-    const uint32_t e0_abs = bin_ptr[b], e1_abs = bin_ptr[b + 1];
-    mm_binned += e0_abs;
-    bvar += e0_abs;
-    if (delta_lay) delta_lay += 2 * (size_t)e0_abs;
-    const uint32_t e0 = 0, e1 = e1_abs - e0_abs;
-    n_entries = e1;
-    BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 0);
-    constexpr bool SOFF_L = (VAR & EXV_SOFF_LOADS) != 0, SOFF_S = (VAR & EXV_SOFF_STORES) != 0, ONE_ATOMIC = (VAR & EXV_ONE_ATOMIC) != 0;
-    const rsrc_t rmm = make_rsrc(mm_binned, SOFF_L ? e1 : n_entries), rev = make_rsrc(bvar, SOFF_L ? e1 : n_entries);
-    const rsrc_t rnb = make_rsrc(nbdds, n_vars);
-    const uint32_t vo_m = tid * (uint32_t)sizeof(REAL), vo_v = tid * 2u, vo_p = tid * (uint32_t)sizeof(P2);
-    const bool one_chunk = (e1 - e0) <= EX_THREADS * EX_UNROLL;
-    // first chunk: every load of the workgroup is issued before anything is consumed
-    REAL m[EX_UNROLL];
-    uint32_t lv[EX_UNROLL];
-#pragma unroll
-    for (int u = 0; u < EX_UNROLL; ++u) {
-        if (SOFF_L) {
-            const uint32_t es = e0 + u * EX_THREADS;  // uniform
-            hop_load(m[u], rmm, vo_m, es * (uint32_t)sizeof(REAL));  // past the bin: 0 -> no contribution
-            lv[u] = __builtin_amdgcn_raw_buffer_load_b16(rev, vo_v, es * 2u, 0);
-        } else {
-            const uint32_t e = e0 + tid + u * EX_THREADS;
-            bload(m[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);  // out of range: 0 -> no contribution
-            lv[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
-        }
-    }
-    BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 1);  // (waits for the first chunk here: the kernel itself does not)
-    if (stop_word <= run_iter) return false;  // uniform for the grid; nothing has been written yet
-    // number of BDDs of the variables this thread normalises (needed only after the accumulation)
-    int nb[NPT];
-    if (MODE == EX_ITER) {
-#pragma unroll
-        for (int k = 0; k < NPT; ++k) {
-            const uint32_t i = tid + k * EX_THREADS;
-            nb[k] = (int)bload_u32(rnb, i < 2 * nv ? (v0 + (i >> 1)) * 4u : OOB);
-        }
-    }
-    for (uint32_t i = tid; i < 2 * nv; i += EX_THREADS) tile[i] = ACC(0);
-    __syncthreads();
-    // bins larger than one chunk: the loads of chunk c+1 are in flight while chunk c is accumulated
-    constexpr uint32_t CH = EX_THREADS * EX_UNROLL;
-    auto load_chunk = [&](REAL (&mm_)[EX_UNROLL], uint32_t (&lv_)[EX_UNROLL], uint32_t start) {
-#pragma unroll
-        for (int u = 0; u < EX_UNROLL; ++u) {
-            if (SOFF_L) {
-                const uint32_t es = start + u * EX_THREADS;
-                hop_load(mm_[u], rmm, vo_m, es * (uint32_t)sizeof(REAL));
-                lv_[u] = __builtin_amdgcn_raw_buffer_load_b16(rev, vo_v, es * 2u, 0);
-            } else {
-                const uint32_t e = start + tid + u * EX_THREADS;
-                bload(mm_[u], rmm, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
-                lv_[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
-            }
-        }
-    };
-    auto accumulate = [&](const REAL (&mm_)[EX_UNROLL], const uint32_t (&lv_)[EX_UNROLL]) {
-#pragma unroll
-        for (int u = 0; u < EX_UNROLL; ++u) {
-            if (ONE_ATOMIC) {
-                const REAL mv = mm_[u];
-                const uint32_t slot = 2 * lv_[u] + (mv > 0 ? 1u : 0u);
-                if (mv != 0) lds_add(&tile[slot], ACC(mv > 0 ? mv : -mv));
-            } else {
-                if (mm_[u] > 0) lds_add(&tile[2 * lv_[u] + 1], ACC(mm_[u]));
-                else if (mm_[u] < 0) lds_add(&tile[2 * lv_[u]], ACC(-mm_[u]));
-            }
-        }
-    };
-    {
-        REAL mc[EX_UNROLL];
-        uint32_t lc[EX_UNROLL];
-        uint32_t cs = e0 + CH;  // start of the next chunk (uniform)
-        bool have = cs < e1;
-        if (have) load_chunk(mc, lc, cs);
-        accumulate(m, lv);
-        while (have) {
-            REAL mn[EX_UNROLL];
-            uint32_t ln[EX_UNROLL];
-            const uint32_t ns = cs + CH;
-            const bool more = ns < e1;
-            if (more) load_chunk(mn, ln, ns);
-            accumulate(mc, lc);
-            if (!more) break;
-#pragma unroll
-            for (int u = 0; u < EX_UNROLL; ++u) { mc[u] = mn[u]; lc[u] = ln[u]; }
-            cs = ns;
-        }
-    }
-    __syncthreads();
-    BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 2);
-#pragma unroll
-    for (int k = 0; k < NPT; ++k) {
-        const uint32_t i = tid + k * EX_THREADS;
-        if (i < 2 * nv) {
-            REAL x = REAL(tile[i]);
-            if (MODE == EX_ITER) {
-                x = nb[k] > 0 ? x / REAL(nb[k]) : REAL(0);
-                tile[i] = ACC(x);
-            }
-            // EX_ITER leaves delta_var alone when the solver passes nullptr: the hot loop only needs the broadcast pairs,
-            // and the per-variable copy (8 MB at V = 1 M) is rebuilt on demand by k_delta_var_from_lay
-            if (MODE != EX_ITER || delta_var) delta_var[2 * (size_t)v0 + i] = x;
-        }
-    }
-    if (MODE != EX_ITER) return true;
-    __syncthreads();
-    BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 3);
-    const rsrc_t rdl = make_rsrc(delta_lay, 2ull * (SOFF_S ? e1 : n_entries));
-#pragma unroll
-    for (int u = 0; u < EX_UNROLL; ++u) {  // first chunk: the local variable indices are still in registers
-        const uint32_t e = e0 + tid + u * EX_THREADS;
-        P2 pr;
-        pr.x = REAL(tile[2 * lv[u]]);
-        pr.y = REAL(tile[2 * lv[u] + 1]);
-        if (SOFF_S) hop_store(pr, rdl, vo_p, (e0 + u * EX_THREADS) * (uint32_t)sizeof(P2));
-        else bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
-    }
-    BDDMMA_STAMP(0x100000u + blockIdx.x * (EX_THREADS / 64) + (tid >> 6), 4);
-    if (one_chunk) return true;
-    for (uint32_t base = e0 + EX_THREADS * EX_UNROLL + tid; (SOFF_L || SOFF_S) ? base - tid < e1 : base < e1; base += EX_THREADS * EX_UNROLL) {
-        uint32_t lv2[EX_UNROLL];
-#pragma unroll
-        for (int u = 0; u < EX_UNROLL; ++u) {
-            const uint32_t e = base + u * EX_THREADS;
-            if (SOFF_L) lv2[u] = __builtin_amdgcn_raw_buffer_load_b16(rev, vo_v, (e - tid) * 2u, 0);
-            else lv2[u] = bload_u16(rev, e < e1 ? e * 2u : OOB);
-        }
-#pragma unroll
-        for (int u = 0; u < EX_UNROLL; ++u) {
-            const uint32_t e = base + u * EX_THREADS;
-            P2 pr;
-            pr.x = REAL(tile[2 * lv2[u]]);
-            pr.y = REAL(tile[2 * lv2[u] + 1]);
-            if (SOFF_S) hop_store(pr, rdl, vo_p, (e - tid) * (uint32_t)sizeof(P2));
-            else bstore(pr, rdl, e < e1 ? e * (uint32_t)sizeof(P2) : OOB);
-        }
-    }
-    return true;
-}
-
-// The launch: `stop` (device-resident run_solver, DevPtrs::stop) makes it return at once when the termination test has fired; `run`
-// (only on the launch that ends an iteration) makes workgroup 0 reduce the lower bound and run the tests after its bin is done —
-// behind the body, where no register of the exchange is live any more (the 1024-thread double instantiation sits at its 128-VGPR limit).
-// RUN = false is the kernel every other caller launches: `stop` and `run` are not looked at, the code is the body alone.
-template <typename REAL, typename ACC, int MODE, int EX_THREADS = bddmma::EX_THREADS, int EX_UNROLL = bddmma::EX_UNROLL, int NPT = bddmma::EX_NPT,
-          bool RUN = false, int VAR = 0>
-__global__ void __launch_bounds__(EX_THREADS) k_exchange_reduce(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ bin_ptr,
-                                                                  const uint16_t* __restrict__ bvar, const uint32_t* stop, uint32_t run_iter,
-                                                                  uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries,
-                                                                  const int32_t* __restrict__ nbdds, REAL* __restrict__ delta_var,
-                                                                  REAL* __restrict__ delta_lay, RunStep run = RunStep{})
-{
-    // argument order: what the first loads need comes first (the first 16 dwords of plain arguments are preloaded into SGPRs, see
-    // RES_LEADING_ARGS); the stop word's load is issued at once and tested inside the body when the first chunk's loads are in flight
-    const uint32_t stop_word = (RUN && stop != nullptr) ? *stop : RUN_NOT_STOPPED;
-    // The launch that ends an iteration of run_solver has one workgroup more than bins: it adds up the per-pack bounds the backward sweep
-    // has left and runs the termination tests while the others work on their bins (as the tail of workgroup 0, behind its bin, the
-    // reduction's dependent round trips were the end of the launch: run_solver at 1.05 M nodes 36.3 -> 35.6 us per iteration with the stop
-    // word's load overlapped, -> 33.3 us with the extra workgroup, the plain loop being 32.0; 10.5 M nodes 125.1 -> 122.3 us).
-    if (RUN && run.ctl != nullptr && blockIdx.x == gridDim.x - 1) {  // uniform
-        if (stop_word <= run_iter) return;
-        run_ctl_step(run);
-        return;
-    }
-    if (!exchange_reduce_body<REAL, ACC, MODE, EX_THREADS, EX_UNROLL, NPT, VAR>(mm_binned, bin_ptr, bvar, nbdds, delta_var, delta_lay, vars_per_bin,
-                                                                                 n_vars, n_entries, stop_word, RUN ? run_iter : 0u))
-        return;
-}
-
-// The binned exchange as a fixed schedule instead of LDS atomics (layout.hpp: struct SegExchange has the idea and the tables; round 5).
-// One workgroup per bin, as k_exchange_reduce:
-//   1. every load the workgroup needs is issued at once and depends on nothing but the bin's 16-byte header: the bin's deferred differences
-//      (16-byte coalesced loads -> LDS, entry order), the thread's run (entry offsets of its positions, <= SEG_MAX_RUN u16 in <= 4 registers
-//      quads) and its {end mask, first slot};
-//   2. a thread walks its run: plain LDS reads, REAL sums in (variable, bdd) order — the order and the arithmetic of k_delta_gather, so the
-//      result is bit-reproducible and equal to the `deterministic` path's —, at the last entry of a variable the pair and the entry count go
-//      to the variable's slot;
-//   3. the pairs are normalised (one division per value, slots spread over the threads), and every thread writes its slot numbers to its
-//      entries' places (u16, over the differences, which nobody reads any more);
-//   4. the broadcast streams entry -> slot -> pair -> delta_lay with the chunk's first entry in the scalar offset (hop_store).
-// Three barriers, no atomics, no dependent global load behind the header.
-// Measured (10.5 M nodes, float, rocprofv3 in sequence): 19.5 us per launch against the LDS-atomic kernel's 17.9 — the phases (loads 5.8 us at
-// the chip's full rate, sums 4.0, normalise + slots 2.3, broadcast 3 + 4 of drain) do not overlap any more than the atomic kernel's do
-// (profiles/r05_exchange.txt) —, so this is the `deterministic` exchange (it replaces k_delta_gather + k_exchange_bcast, two launches of
-// gathers) and the LDS atomics stay the default.
-constexpr int SEG_MAXL = 12;  // 16-byte loads of differences per thread: a bin holds <= SEG_MAXL * T * 16 / sizeof(REAL) entries
-// G: 16-byte groups of run positions per thread (the largest bin's; the tables pad every run to it) — a template parameter so that every
-// register array below is indexed by constants (with run-time group counts and early exits the arrays went to scratch memory)
-template <typename REAL, int T, int G, bool RUN = false>
-__global__ void __launch_bounds__(T) k_exchange_seg(const REAL* __restrict__ mm_binned, const uint4* __restrict__ seg_bin, const uint32_t* stop, uint32_t run_iter,
-                                                      const uint4* __restrict__ seg_perm, const uint2* __restrict__ seg_thr, uint32_t tile_off, uint32_t cnt_off,
-                                                      REAL* __restrict__ delta_lay, RunStep run = RunStep{})
-{
-    const uint32_t stop_word = (RUN && stop != nullptr) ? *stop : RUN_NOT_STOPPED;
-    if (RUN && run.ctl != nullptr && blockIdx.x == gridDim.x - 1) {  // the extra workgroup of the launch that ends a run_solver iteration (see k_exchange_reduce)
-        if (stop_word <= run_iter) return;
-        run_ctl_step(run);
-        return;
-    }
-    using P2 = typename Pair<REAL>::type;
-    constexpr uint32_t VEC = 16 / sizeof(REAL);
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    REAL* mm_lds = reinterpret_cast<REAL*>(dyn_lds);           // [entries rounded up to VEC, + 1], then the entries' slot numbers
-    uint16_t* slot_lds = reinterpret_cast<uint16_t*>(dyn_lds);
-    P2* tile = reinterpret_cast<P2*>(dyn_lds + tile_off);       // [slots] {sum of -mm over mm < 0, sum of mm over mm > 0}
-    uint16_t* cnt = reinterpret_cast<uint16_t*>(dyn_lds + cnt_off);  // [slots] entries of the slot's variable = its number of BDDs
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    const uint4 hdr = seg_bin[b];  // first group of the bin in seg_perm, groups per thread | slots << 8, first entry, entries
-    const uint32_t slots = hdr.y >> 8, E = hdr.w;
-    mm_binned += hdr.z;
-    delta_lay += 2 * (size_t)hdr.z;
-    BDDMMA_STAMP(0x100000u + blockIdx.x * (T / 64) + (tid >> 6), 0);
-    const rsrc_t rmm = make_rsrc(mm_binned, E);
-    using u4 = decltype(__builtin_amdgcn_raw_buffer_load_b128(rmm, 0, 0, 0));
-    u4 buf[SEG_MAXL];
-#pragma unroll
-    for (int j = 0; j < SEG_MAXL; ++j)
-        if ((uint32_t)j * T * VEC < E) buf[j] = __builtin_amdgcn_raw_buffer_load_b128(rmm, ((uint32_t)j * T + tid) * 16u, 0, 0);
-    uint4 pw[G];
-    const uint4* pg = seg_perm + hdr.x + tid;
-#pragma unroll
-    for (int g = 0; g < G; ++g) pw[g] = pg[(size_t)g * T];
-    const uint2 th = seg_thr[(size_t)b * T + tid];
-    if (stop_word <= run_iter) return;  // uniform for the grid; nothing has been written yet
-#pragma unroll
-    for (int j = 0; j < SEG_MAXL; ++j) {
-        const uint32_t i = ((uint32_t)j * T + tid) * VEC;
-        if ((uint32_t)j * T * VEC < E && i < E) *reinterpret_cast<u4*>(mm_lds + i) = buf[j];
-    }
-    const uint32_t Z = (E + VEC - 1) / VEC * VEC;  // the place the positions past a run's end point at: never written above
-    if (tid == 0) mm_lds[Z] = REAL(0);
-    __syncthreads();
-    BDDMMA_STAMP(0x100000u + blockIdx.x * (T / 64) + (tid >> 6), 1);
-    const uint32_t ends = th.x;
-    // position k of the run -> entry offset
-    uint32_t pl[8 * G];
-#pragma unroll
-    for (int k = 0; k < 8 * G; ++k) {
-        const uint4 q = pw[k / 8];
-        const uint32_t w = (k % 8) / 2 == 0 ? q.x : (k % 8) / 2 == 1 ? q.y : (k % 8) / 2 == 2 ? q.z : q.w;
-        pl[k] = (k & 1) ? w >> 16 : w & 0xFFFFu;
-    }
-    uint32_t sl[8 * G];  // slot of the variable of position k (the slots are numbered along the runs)
-    {
-        // all the run's differences first (independent LDS reads in flight together), then the sums in order.  Branch-free: the sums of
-        // compute_delta (bdd_cuda_parallel_mma.cu:358-393: hi += m if m > 0, lo += -m if m < 0) as hi += max(m, 0), lo += max(-m, 0) — adding
-        // +0 changes nothing —, in k_delta_gather's order; at the last entry of a variable ((ends >> k) & 1) the pair and the count go to LDS
-        // under the lane mask and the sums restart.
-        REAL mv[8 * G];
-#pragma unroll
-        for (int k = 0; k < 8 * G; ++k) mv[k] = mm_lds[pl[k]];
-        uint32_t slot = th.y, first = 0;
-        REAL lo = 0, hi = 0;
-#pragma unroll
-        for (int k = 0; k < 8 * G; ++k) {
-            const REAL m = mv[k];
-            hi += m > REAL(0) ? m : REAL(0);
-            lo += m < REAL(0) ? -m : REAL(0);
-            sl[k] = slot;
-            const bool end = (ends >> k) & 1u;
-            if (end) {
-                P2 pr;
-                pr.x = lo;
-                pr.y = hi;
-                tile[slot] = pr;
-                cnt[slot] = (uint16_t)(k + 1 - first);
-            }
-            slot += end ? 1u : 0u;
-            first = end ? (uint32_t)(k + 1) : first;
-            lo = end ? REAL(0) : lo;
-            hi = end ? REAL(0) : hi;
-        }
-    }
-    __syncthreads();
-    BDDMMA_STAMP(0x100000u + blockIdx.x * (T / 64) + (tid >> 6), 2);
-    for (uint32_t i = tid; i < slots; i += T) {  // normalize_delta, :410-430
-        P2 pr = tile[i];
-        const REAL c = REAL(cnt[i]);
-        pr.x /= c;
-        pr.y /= c;
-        tile[i] = pr;
-    }
-#pragma unroll
-    for (int k = 0; k < 8 * G; ++k) slot_lds[pl[k]] = (uint16_t)sl[k];  // past the run's end: place Z, which no entry reads
-    __syncthreads();
-    BDDMMA_STAMP(0x100000u + blockIdx.x * (T / 64) + (tid >> 6), 3);
-    const rsrc_t rdl = make_rsrc(delta_lay, 2ull * E);
-    const uint32_t vo_p = tid * (uint32_t)sizeof(P2);
-    for (uint32_t base = 0; base < E; base += 4 * T) {
-        uint32_t sl[4];
-        P2 pr[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t e = base + u * T + tid;
-            sl[u] = e < E ? slot_lds[e] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pr[u] = tile[sl[u]];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (base + u * T < E) hop_store(pr[u], rdl, vo_p, (base + u * T) * (uint32_t)sizeof(P2));  // lanes past the bin's end: out of the descriptor's range
-    }
-    BDDMMA_STAMP(0x100000u + blockIdx.x * (T / 64) + (tid >> 6), 4);
-}
-
-// Exchange for entry arrays ordered by (variable, bdd) (layout.hpp: Exchange::entry_by_var): the entries of variable v are
-// var_ptr[v] .. var_ptr[v + 1], so compute_delta (bdd_cuda_parallel_mma.cu:358-393), normalize_delta (:410-430) and the broadcast of
-// the pair to the variable's layers are one thread per variable over a contiguous run — neighbouring threads read and write
-// neighbouring addresses, there are no LDS accumulators and no barriers, and the sum has the fixed order of the reduce_by_key variant
-// the reference keeps commented out (:395-407).  One dependent round trip (var_ptr) before the values instead of the binned kernel's
-// chain of loads, LDS atomics and three workgroup barriers: 3.5 us instead of 9.7 us at 1 M nodes.
-template <typename REAL>
-__global__ void __launch_bounds__(256) k_exchange_byvar(const REAL* __restrict__ mm, const uint32_t* __restrict__ var_ptr,
-                                                          REAL* __restrict__ delta_lay, uint32_t n_vars, uint32_t n_entries,
-                                                          RunGate gate = RunGate{}, RunStep run = RunStep{})
-{
-    if (run_stopped(gate)) return;
-    if (run.ctl != nullptr && blockIdx.x == 0) run_ctl_step(run);
-    using P2 = typename Pair<REAL>::type;
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    const rsrc_t rvp = make_rsrc(var_ptr, (uint64_t)n_vars + 1), rmm = make_rsrc(mm, n_entries), rdl = make_rsrc(delta_lay, 2ull * n_entries);
-    const uint32_t k0 = bload_u32(rvp, v < n_vars ? v * 4u : OOB), k1 = bload_u32(rvp, v < n_vars ? (v + 1) * 4u : OOB);
-    const uint32_t n = k1 - k0;  // 0 for threads past the last variable and for variables in no BDD
-    constexpr int J = 8;         // values requested together; variables in more BDDs continue one by one
-    REAL m[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) bload(m[j], rmm, (uint32_t)j < n ? (k0 + j) * (uint32_t)sizeof(REAL) : OOB);  // dropped: 0
-    REAL lo = 0, hi = 0;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        if (m[j] > 0) hi += m[j];
-        else if (m[j] < 0) lo += -m[j];
-    }
-    for (uint32_t j = J; j < n; ++j) {
-        REAL x;
-        bload(x, rmm, (k0 + j) * (uint32_t)sizeof(REAL));
-        if (x > 0) hi += x;
-        else if (x < 0) lo += -x;
-    }
-    if (n == 0) return;
-    P2 pr;
-    pr.x = lo / REAL(n);
-    pr.y = hi / REAL(n);
-#pragma unroll
-    for (int j = 0; j < J; ++j) bstore(pr, rdl, (uint32_t)j < n ? (k0 + j) * (uint32_t)sizeof(P2) : OOB);
-    for (uint32_t j = J; j < n; ++j) bstore(pr, rdl, (k0 + j) * (uint32_t)sizeof(P2));
-}
-
-// Exchange, step B: broadcast the per-variable pairs to every entry (what the next sweep adds to the
-// arc costs, bdd_cuda_parallel_mma.cu:191-197).  Entries of one bin are contiguous, so the pairs of
-// vars_per_bin consecutive variables are re-read from L1/L2 while the writes stream out coalesced.
-// Four entries per thread: one 16-byte index load, four independent pair gathers, 16-byte stores.
-template <typename REAL>
-__global__ void __launch_bounds__(256) k_exchange_bcast(const REAL* __restrict__ delta_var, const uint32_t* __restrict__ evar,
-                                                          REAL* __restrict__ delta_lay, uint32_t n_entries, uint32_t n_vars,
-                                                          RunGate gate = RunGate{}, RunStep run = RunStep{})
-{
-    if (run_stopped(gate)) return;
-    // the deterministic exchange is two launches (k_delta_gather, this one): the tests latch `stop` in the LAST launch of the iteration
-    if (run.ctl != nullptr && blockIdx.x == 0) run_ctl_step(run);
-    using P2 = typename Pair<REAL>::type;
-    const uint32_t e = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
-    if (e >= n_entries) return;
-    const rsrc_t rdv = make_rsrc(delta_var, 2ull * n_vars);
-    uint32_t v[4];
-    if (e + 4 <= n_entries) {
-        const uint4 vv = *reinterpret_cast<const uint4*>(evar + e);
-        v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; v[3] = vv.w;
-    } else {
-        for (int u = 0; u < 4; ++u) v[u] = e + u < n_entries ? evar[e + u] : 0xFFFFFFFFu;
-    }
-    P2 pr[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) bload(pr[u], rdv, v[u] != 0xFFFFFFFFu ? v[u] * (uint32_t)sizeof(P2) : OOB);
-    P2* out = reinterpret_cast<P2*>(delta_lay) + e;
-    if (e + 4 <= n_entries) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) out[u] = pr[u];
-    } else {
-        for (int u = 0; u < 4; ++u)
-            if (e + u < n_entries) out[u] = pr[u];
-    }
-}
-
-template <typename REAL>
-__global__ void k_normalize_delta(REAL* __restrict__ delta, const int32_t* __restrict__ nbdds, uint32_t n2)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n2) return;
-    const int nb = nbdds[i >> 1];
-    if (nb > 0) delta[i] /= REAL(nb);
-}
-
-// Deterministic alternative to the LDS atomics of k_exchange: per-variable gather over the
-// (variable,bdd)-sorted entry list (the reduce_by_key variant commented out at bdd_cuda_parallel_mma.cu:395-407).
-template <typename REAL, bool NORMALIZE>
-__global__ void k_delta_gather(const REAL* __restrict__ mm_binned, const uint32_t* __restrict__ var_ptr,
-                               const uint32_t* __restrict__ vpos, REAL* __restrict__ delta_var, uint32_t n_vars,
-                               RunGate gate = RunGate{})
-{
-    if (run_stopped(gate)) return;
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_vars) return;
-    REAL lo = 0, hi = 0;
-    const uint32_t k0 = var_ptr[v], k1 = var_ptr[v + 1];
-    for (uint32_t k = k0; k < k1; ++k) {
-        const REAL m = mm_binned[vpos[k]];
-        if (m > 0) hi += m;
-        else if (m < 0) lo += -m;
-    }
-    if (NORMALIZE && k1 > k0) {
-        lo /= REAL(k1 - k0);
-        hi /= REAL(k1 - k0);
-    }
-    delta_var[2 * (size_t)v] = lo;
-    delta_var[2 * (size_t)v + 1] = hi;
-}
-
-// delta_var[v] = the pair broadcast to the entries of v (any of them; 0 for a variable in no BDD)
-template <typename REAL>
-__global__ void k_delta_var_from_lay(const REAL* __restrict__ delta_lay, const uint32_t* __restrict__ var_ptr,
-                                     const uint32_t* __restrict__ vpos, REAL* __restrict__ delta_var, uint32_t n_vars)
-{
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_vars) return;
-    const uint32_t k0 = var_ptr[v], k1 = var_ptr[v + 1];
-    const size_t e = k1 > k0 ? vpos[k0] : 0;
-    delta_var[2 * (size_t)v] = k1 > k0 ? delta_lay[2 * e] : REAL(0);
-    delta_var[2 * (size_t)v + 1] = k1 > k0 ? delta_lay[2 * e + 1] : REAL(0);
-}
-
-// binned entry order <-> internal layer order (rare elementwise ops, checkpointing)
-template <typename REAL>
-__global__ void k_entries_to_layers(const REAL* __restrict__ binned, const uint32_t* __restrict__ lpos, REAL* __restrict__ out, uint32_t n)
-{
-    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < n) out[l] = binned[lpos[l]];
-}
-template <typename REAL>
-__global__ void k_layers_to_entries(const REAL* __restrict__ in, const uint32_t* __restrict__ lpos, REAL* __restrict__ binned, uint32_t n)
-{
-    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < n) binned[lpos[l]] = in[l];
-}
-
-// set_vars_costs_func (bdd_cuda_base.cu:457-474).  Quotient and sum are formed in double and rounded
-// once to REAL, as the reference CPU solver does (bdd_parallel_mma_base.cpp:640,651,674-677).
-// Two steps.  As one kernel every layer gathered its variable's BDD count and both cost entries itself: three random reads per layer
-// over 4-8 MB arrays, 935 MB of sector traffic for 5 M layers (126 us).  Now k_cost_quotients reads the caller's
-// vectors once, coalesced, and leaves {c_lo / n, c_hi / n} per variable as one 16-byte record; the per-layer pass makes ONE gather.
-// Flags per record: bit 0 / 1 = the side is SET to 0 (variable past the end of a shorter vector, :465-469).
-struct CostQuot {
-    double lo, hi;
-};
-template <typename TIN>
-__global__ void k_cost_quotients(CostQuot* __restrict__ q, uint8_t* __restrict__ flags, const int32_t* __restrict__ nbdds, const TIN* __restrict__ c_lo, uint64_t n_lo,
-                                 const TIN* __restrict__ c_hi, uint64_t n_hi, uint32_t n_vars)
-{
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_vars) return;
-    const double nb = (double)nbdds[v];
-    CostQuot r;
-    r.lo = (n_lo && v < n_lo) ? (double)c_lo[v] / nb : 0.0;
-    r.hi = (n_hi && v < n_hi) ? (double)c_hi[v] / nb : 0.0;
-    q[v] = r;
-    flags[v] = (uint8_t)(((n_lo && v >= n_lo) ? 1 : 0) | ((n_hi && v >= n_hi) ? 2 : 0));
-}
-template <typename REAL>
-__global__ void k_update_costs(REAL* __restrict__ lohi, const int32_t* __restrict__ var, const CostQuot* __restrict__ q, const uint8_t* __restrict__ flags,
-                               uint32_t do_lo, uint32_t do_hi, uint32_t n_layers)
-{
-    using P2 = typename Pair<REAL>::type;
-    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= n_layers) return;
-    const int v = var[l];
-    const CostQuot d = q[v];
-    const uint32_t f = flags[v];
-    P2 c = reinterpret_cast<P2*>(lohi)[l];
-    if (do_lo) c.x = (f & 1u) ? REAL(0) : REAL((double)c.x + d.lo);
-    if (do_hi) c.y = (f & 2u) ? REAL(0) : REAL((double)c.y + d.hi);
-    reinterpret_cast<P2*>(lohi)[l] = c;
-}
-
-template <typename REAL>
-__global__ void k_set_cost(REAL* __restrict__ hi, const uint32_t* __restrict__ var_layers, uint32_t k0, uint32_t k1, REAL c)
-{
-    const uint32_t k = k0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < k1) hi[2 * (size_t)var_layers[k]] += c;
-}
-
-// Deterministic fixed-shape reduction of the per-pack partial lower bounds.
-// `seq_out` (pinned host memory, may be null): receives `seq` after the bound has been written — the host polls it instead of waiting for
-// the stream (an interrupt-driven wait was measured to leave the GPU idle for 26 us per bound read in the L-BFGS loop, tools/gaps.sh).
-static __global__ void k_lb_reduce(const double* __restrict__ part, uint32_t n, double* __restrict__ out, uint64_t* seq_out = nullptr, uint64_t seq = 0)
-{
-    __shared__ double red[16];
-    double acc = 0.0;
-    // a thread's partial sums eight at a time: their loads are in flight together, the additions keep the order of the plain loop (as a
-    // plain loop every element was a dependent round trip: 4.7 us per launch for the 7 813 packs of the 10.5 M-node instance)
-    uint32_t i = threadIdx.x;
-    for (; i + 7 * blockDim.x < n; i += 8 * blockDim.x) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = part[i + u * blockDim.x];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
-    }
-    for (; i < n; i += blockDim.x) acc += part[i];
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (uint32_t i = 0; i < blockDim.x / 64; ++i) t += red[i];
-        *out = t;
-        if (seq_out != nullptr) {
-            __threadfence_system();
-            *reinterpret_cast<volatile uint64_t*>(seq_out) = seq;
-        }
-    }
-}
-
-template <typename REAL>
-__global__ void k_lb_per_bdd(const REAL* __restrict__ T, const uint32_t* __restrict__ root_slot, REAL* __restrict__ out, uint32_t nb)
-{
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nb) out[b] = T[root_slot[b]];
-}
-
-// compute_net_costs_func (bdd_cuda_parallel_mma.cu:432-446)
-template <typename REAL>
-__global__ void k_net_costs(const REAL* __restrict__ lo, const REAL* __restrict__ hi, const REAL* __restrict__ mm_binned,
-                            const uint32_t* __restrict__ lpos, REAL* __restrict__ out, uint32_t n)
-{
-    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < n) out[l] = hi[2 * (size_t)l] - lo[2 * (size_t)l] + mm_binned[lpos[l]];
-}
-
-// distribute_deffered_mm_diff_func (bdd_cuda_base.cu:1396-1414) + the zero-fill of :1427
-template <typename REAL>
-__global__ void k_distribute_delta(REAL* __restrict__ lo, REAL* __restrict__ hi, REAL* __restrict__ mm_binned,
-                                   const uint32_t* __restrict__ lpos, uint32_t n)
-{
-    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= n) return;
-    const uint32_t e = lpos[l];
-    const REAL m = mm_binned[e];
-    if (m > 0) hi[2 * (size_t)l] += m;
-    else lo[2 * (size_t)l] -= m;
-    mm_binned[e] = REAL(0);
-}
-
-// add_scaled_product_func (bdd_cuda_parallel_mma.h:54-60)
-template <typename REAL>
-__global__ void k_gradient_step(REAL* __restrict__ hi, const REAL* __restrict__ g, REAL step, uint32_t n)
-{
-    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < n) hi[2 * (size_t)l] = hi[2 * (size_t)l] + step * g[l];
-}
-
-// make_dual_feasible (bdd_cuda_base.cu:1261-1303): g[l] -= (sum over layers of var) / nr_bdds(var)
-template <typename REAL>
-__global__ void k_make_dual_feasible(REAL* __restrict__ g, const uint32_t* __restrict__ var_ptr,
-                                     const uint32_t* __restrict__ var_layers, uint32_t n_vars)
-{
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_vars) return;
-    const uint32_t k0 = var_ptr[v], k1 = var_ptr[v + 1];
-    if (k1 == k0) return;
-    // the layers of a variable are scattered over the whole vector: issue the first MAXR gathers together
-    // instead of one dependent round trip per layer (same summation order as the plain loop)
-    constexpr int MAXR = 8;
-    uint32_t idx[MAXR];
-    REAL val[MAXR];
-#pragma unroll
-    for (int u = 0; u < MAXR; ++u) idx[u] = k0 + u < k1 ? var_layers[k0 + u] : 0u;
-#pragma unroll
-    for (int u = 0; u < MAXR; ++u) val[u] = k0 + u < k1 ? g[idx[u]] : REAL(0);
-    REAL s = 0;
-#pragma unroll
-    for (int u = 0; u < MAXR; ++u) s += val[u];
-    for (uint32_t k = k0 + MAXR; k < k1; ++k) s += g[var_layers[k]];
-    const REAL q = s / REAL(k1 - k0);
-#pragma unroll
-    for (int u = 0; u < MAXR; ++u)
-        if (k0 + u < k1) g[idx[u]] = val[u] - q;
-    for (uint32_t k = k0 + MAXR; k < k1; ++k) g[var_layers[k]] -= q;
-}
-
-// The two halves of make_dual_feasible for a vector that is only ever applied as a cost update (the L-BFGS direction): the
-// per-variable means are gathered once (no scattered write-back of the projected vector) ...
-template <typename REAL>
-__global__ void k_projection_means(const REAL* __restrict__ g, const uint32_t* __restrict__ var_ptr, const uint32_t* __restrict__ var_layers,
-                                   REAL* __restrict__ q, uint32_t n_vars)
-{
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_vars) return;
-    const uint32_t k0 = var_ptr[v], k1 = var_ptr[v + 1];
-    if (k1 == k0) { q[v] = REAL(0); return; }
-    constexpr int MAXR = 8;
-    uint32_t idx[MAXR];
-    REAL val[MAXR];
-#pragma unroll
-    for (int u = 0; u < MAXR; ++u) idx[u] = k0 + u < k1 ? var_layers[k0 + u] : 0u;
-#pragma unroll
-    for (int u = 0; u < MAXR; ++u) val[u] = k0 + u < k1 ? g[idx[u]] : REAL(0);
-    REAL s = 0;
-#pragma unroll
-    for (int u = 0; u < MAXR; ++u) s += val[u];
-    for (uint32_t k = k0 + MAXR; k < k1; ++k) s += g[var_layers[k]];
-    q[v] = s / REAL(k1 - k0);   // same summation order and quotient as k_make_dual_feasible
-}
-// ... and subtracted where the step is applied: hi += step * (g[l] - q[var(l)]), the value k_make_dual_feasible + k_gradient_step produce
-template <typename REAL>
-__global__ void k_gradient_step_projected(REAL* __restrict__ hi, const REAL* __restrict__ g, const REAL* __restrict__ q,
-                                          const uint32_t* __restrict__ layer_var, REAL step, uint32_t n)
-{
-    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= n) return;
-    const REAL gp = g[l] - q[layer_var[l]];
-    hi[2 * (size_t)l] = hi[2 * (size_t)l] + step * gp;
-}
-
-// ---- make_dual_feasible of a device vector through the staging tables (the L-BFGS direction at large sizes) ------------------------
-// As gathers (k_projection_means + k_gradient_step_projected) the layer <-> variable coupling costs a random access per layer in
-// each direction: 63 us for the means and 44 us per trial step at 5 M layers (profiles/r03_lbfgs_time_to_bound.txt), ~30 us of each
-// being the gather.  The sweeps do the same coupling through the (entry, slot) staging tables in runs of consecutive entries, and the
-// exchange reduces per variable in LDS.  The same three steps for any layer-ordered vector:
-//   k_stage_transpose<.., 0> : layers -> entries   (a quad's waves copy their stage group to LDS, the items stream it out by entry)
-//   k_project_entries        : per bin: sums per variable in LDS (double accumulators), x_e -= sum / nr_bdds(var), in place
-//   k_stage_transpose<.., 1> : entries -> layers   (the reverse), optionally applying the first gradient step on the way
-// after which every trial step is the plain streaming k_gradient_step.  Layers of wide / huge packs have no staging tables: they go
-// through lpos (k_layers_to_entries / k_entries_to_layers on their range).
-template <typename REAL, int WPB, int TO_LAYERS>
-__global__ void __launch_bounds__(64 * WPB) k_stage_transpose(const REAL* __restrict__ in, REAL* __restrict__ out, PackDev pk,
-                                                               const uint32_t* __restrict__ cs_entry, const uint16_t* __restrict__ cs_slot,
-                                                               uint32_t n_narrow_layers, uint32_t n_layers, REAL* __restrict__ lohi, REAL step)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    REAL* sD = reinterpret_cast<REAL*>(dyn_lds);
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t quad = blockIdx.x;
-    const uint32_t p = quad * WPB + wave;
-    const bool has_pack = p < pk.n_packs;
-    const uint32_t g0 = has_pack ? pk.pack_group_ptr[p] : 0;
-    const uint32_t ng = has_pack ? pk.pack_group_ptr[p + 1] - g0 : 0;
-    const uint32_t r0 = pk.quad_round_ptr[quad], n_rounds = pk.quad_round_ptr[quad + 1] - r0;
-    const rsrc_t rse = make_rsrc(cs_entry, n_narrow_layers), rss = make_rsrc(cs_slot, n_narrow_layers);
-    const rsrc_t rin = make_rsrc(in, n_layers), rout = make_rsrc(out, n_layers), rlh = make_rsrc(lohi, 2ull * n_layers);
-    REAL* sDw = sD + (size_t)wave * pk.stage_cap;
-    for (uint32_t k = 0; k < n_rounds; ++k) {
-        const uint32_t c0 = pk.cs_ptr[r0 + k], cnt = pk.cs_ptr[r0 + k + 1] - c0;
-        uint32_t gl0 = 0, gn = 0;
-        if (k < ng) {
-            gl0 = pk.grp_layer_off[g0 + k];
-            gn = pk.grp_layer_off[g0 + k + 1] - gl0;
-        }
-        uint32_t e[STAGE_ITERS], sl[STAGE_ITERS];
-#pragma unroll
-        for (int u = 0; u < STAGE_ITERS; ++u) {
-            const uint32_t i = 64 * WPB * u + tid;
-            e[u] = bload_u32(rse, i < cnt ? (c0 + i) * 4u : OOB);
-            sl[u] = bload_u16(rss, i < cnt ? (c0 + i) * 2u : OOB);
-        }
-        if (!TO_LAYERS) {
-            REAL x[STAGE_ITERS];
-#pragma unroll
-            for (int u = 0; u < STAGE_ITERS; ++u) {
-                const uint32_t i = lane + 64 * u;
-                bload(x[u], rin, i < gn ? (gl0 + i) * (uint32_t)sizeof(REAL) : OOB);
-            }
-#pragma unroll
-            for (int u = 0; u < STAGE_ITERS; ++u) {
-                const uint32_t i = lane + 64 * u;
-                if (i < gn) sDw[i] = x[u];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < STAGE_ITERS; ++u) {
-                const uint32_t i = 64 * WPB * u + tid;
-                const REAL v = sD[i < cnt ? sl[u] : 0];
-                bstore(v, rout, i < cnt ? e[u] * (uint32_t)sizeof(REAL) : OOB);
-            }
-            __syncthreads();  // the next round overwrites the staging area
-        } else {
-            REAL v[STAGE_ITERS];
-#pragma unroll
-            for (int u = 0; u < STAGE_ITERS; ++u) {
-                const uint32_t i = 64 * WPB * u + tid;
-                bload(v[u], rin, i < cnt ? e[u] * (uint32_t)sizeof(REAL) : OOB);
-            }
-#pragma unroll
-            for (int u = 0; u < STAGE_ITERS; ++u) {
-                const uint32_t i = 64 * WPB * u + tid;
-                if (i < cnt) sD[sl[u]] = v[u];
-            }
-            __syncthreads();
-            // the group's layers are contiguous: values out, and hi += step * x on whole {lo, hi} pairs (lo rewritten unchanged: full-width
-            // stores instead of every other word), all loads of the group in flight together
-            using P2 = typename Pair<REAL>::type;
-            P2 c[STAGE_ITERS];
-            if (lohi != nullptr) {
-#pragma unroll
-                for (int u = 0; u < STAGE_ITERS; ++u) {
-                    const uint32_t i = lane + 64 * u;
-                    bload(c[u], rlh, i < gn ? (gl0 + i) * (uint32_t)sizeof(P2) : OOB);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < STAGE_ITERS; ++u) {
-                const uint32_t i = lane + 64 * u;
-                const REAL x = sDw[i < gn ? i : 0];
-                bstore(x, rout, i < gn ? (gl0 + i) * (uint32_t)sizeof(REAL) : OOB);
-                if (lohi != nullptr) {
-                    c[u].y = c[u].y + step * x;   // k_gradient_step
-                    bstore(c[u], rlh, i < gn ? (gl0 + i) * (uint32_t)sizeof(P2) : OOB);
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// k_stage_transpose<..., 0> whose input is not an array but a linear combination of stored vectors evaluated on the fly (layout.hpp:
-// LinComb — the L-BFGS direction q = g + sum cy y + sum cs s of lbfgs.hip, same operations in the same order as its k_lb_direction):
-// the direction goes straight from the history into the staging area and leaves in entry order, instead of being written in layer
-// order by one pass and read back by the next (2 x 20 / 40 MB and a launch at 5 M layers).  A lane forms four consecutive layers per trip —
-// 16-byte loads of the REAL vectors, 4-byte loads of the char vectors, as the wrapper's own passes — starting at the multiple of 4 at or
-// below the group's first layer; what falls outside the group is computed and dropped.
-typedef uint32_t lc_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint64_t lc_u64x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void lc_ld4(float (&v)[4], const float* p)
-{
-    const lc_u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const lc_u32x4*>(p));
-    const uint32_t w[4] = {x.x, x.y, x.z, x.w};  // (__builtin_bit_cast straight from a vector element was seen to take element 0 for every one)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(float, w[i]);
-}
-__device__ __forceinline__ void lc_ld4(double (&v)[4], const double* p)
-{
-    const lc_u64x2 a = __builtin_nontemporal_load(reinterpret_cast<const lc_u64x2*>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const lc_u64x2*>(p) + 1);
-    const uint64_t w[4] = {a.x, a.y, b.x, b.y};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(double, w[i]);
-}
-template <typename REAL, int WPB, int NS>  // NS = 0: lc.ns vectors, known at run time only
-__global__ void __launch_bounds__(64 * WPB) k_stage_lincomb(LinComb lc, REAL* __restrict__ out, PackDev pk, const uint32_t* __restrict__ cs_entry,
-                                                             const uint16_t* __restrict__ cs_slot, uint32_t n_narrow_layers, uint32_t n_layers)
-{
-    constexpr int NK = NS > 0 ? NS : LINCOMB_MAX;
-    const int ns = NS > 0 ? NS : lc.ns;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    REAL* sD = reinterpret_cast<REAL*>(dyn_lds);
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t quad = blockIdx.x;
-    const uint32_t p = quad * WPB + wave;
-    const bool has_pack = p < pk.n_packs;
-    const uint32_t g0 = has_pack ? pk.pack_group_ptr[p] : 0;
-    const uint32_t ng = has_pack ? pk.pack_group_ptr[p + 1] - g0 : 0;
-    const uint32_t r0 = pk.quad_round_ptr[quad], n_rounds = pk.quad_round_ptr[quad + 1] - r0;
-    const rsrc_t rse = make_rsrc(cs_entry, n_narrow_layers), rss = make_rsrc(cs_slot, n_narrow_layers);
-    const rsrc_t rout = make_rsrc(out, n_layers);
-    REAL* sDw = sD + (size_t)wave * pk.stage_cap;
-    const REAL* sk[NK];
-    const char* yk[NK];
-    double cy[NK], cs[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const uint32_t ps = k < ns ? lc.order[k] : 0u;
-        sk[k] = reinterpret_cast<const REAL*>(lc.S) + (size_t)ps * lc.slot;
-        yk[k] = lc.Y + (size_t)ps * lc.slot;
-        cy[k] = k < ns ? lc.cy[ps] : 0.0;
-        cs[k] = k < ns ? lc.cs[ps] : 0.0;
-    }
-    for (uint32_t k = 0; k < n_rounds; ++k) {
-        const uint32_t c0 = pk.cs_ptr[r0 + k], cnt = pk.cs_ptr[r0 + k + 1] - c0;
-        uint32_t gl0 = 0, gn = 0;
-        if (k < ng) {
-            gl0 = pk.grp_layer_off[g0 + k];
-            gn = pk.grp_layer_off[g0 + k + 1] - gl0;
-        }
-        uint32_t e[STAGE_ITERS], sl[STAGE_ITERS];
-#pragma unroll
-        for (int u = 0; u < STAGE_ITERS; ++u) {
-            const uint32_t i = 64 * WPB * u + tid;
-            e[u] = bload_u32(rse, i < cnt ? (c0 + i) * 4u : OOB);
-            sl[u] = bload_u16(rss, i < cnt ? (c0 + i) * 2u : OOB);
-        }
-        const uint32_t a0 = gl0 & ~3u;
-        const uint32_t nch = gn ? (gl0 + gn - a0 + 3u) / 4u : 0u;
-        for (uint32_t c = lane; c < nch; c += 64) {
-            const size_t j = (size_t)a0 + 4 * (size_t)c;
-            const uint32_t g4 = *reinterpret_cast<const uint32_t*>(lc.g + j);
-            uint32_t y4[NK];
-            REAL s4[NK][4];
-#pragma unroll
-            for (int h = 0; h < NK; ++h)
-                if (h < ns) {
-                    y4[h] = *reinterpret_cast<const uint32_t*>(yk[h] + j);
-                    lc_ld4(s4[h], sk[h] + j);
-                }
-#pragma unroll
-            for (int el = 0; el < 4; ++el) {
-                double q = (double)(char)(signed char)((g4 >> (8 * el)) & 0xFFu);
-#pragma unroll
-                for (int h = 0; h < NK; ++h)
-                    if (h < ns) q += cy[h] * (double)(char)(signed char)((y4[h] >> (8 * el)) & 0xFFu);
-#pragma unroll
-                for (int h = 0; h < NK; ++h)
-                    if (h < ns) q += cs[h] * (double)s4[h][el];
-                const uint32_t li = (uint32_t)(j + el) - gl0;  // (wraps below the group's first layer)
-                if (li < gn) sDw[li] = REAL(q);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < STAGE_ITERS; ++u) {
-            const uint32_t i = 64 * WPB * u + tid;
-            const REAL v = sD[i < cnt ? sl[u] : 0];
-            bstore(v, rout, i < cnt ? e[u] * (uint32_t)sizeof(REAL) : OOB);
-        }
-        __syncthreads();  // the next round overwrites the staging area
-    }
-}
-
-// One workgroup per bin of variables (the exchange's bins and its u16 local variable indices): x_e -= (sum over the entries of the
-// variable) / nr_bdds(variable).  The sum is accumulated in double by LDS atomics and rounded to REAL once, then divided in REAL as
-// k_make_dual_feasible does.
-template <typename REAL, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_project_entries(REAL* __restrict__ x, const uint32_t* __restrict__ bin_ptr, const uint16_t* __restrict__ bvar,
-                                                               const int32_t* __restrict__ nbdds, uint32_t vars_per_bin, uint32_t n_vars, uint32_t n_entries)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    double* tile = reinterpret_cast<double*>(dyn_lds);
-    constexpr int U = 8;
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    const uint32_t v0 = b * vars_per_bin;
-    const uint32_t nv = min(vars_per_bin, n_vars - v0);
-    const uint32_t e0 = bin_ptr[b], e1 = bin_ptr[b + 1];
-    const rsrc_t rx = make_rsrc(x, n_entries), rv = make_rsrc(bvar, n_entries);
-    for (uint32_t i = tid; i < nv; i += THREADS) tile[i] = 0.0;
-    __syncthreads();
-    for (uint32_t base = e0; base < e1; base += THREADS * U) {
-        REAL m[U];
-        uint32_t lv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t e = base + tid + u * THREADS;
-            bload(m[u], rx, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
-            lv[u] = bload_u16(rv, e < e1 ? e * 2u : OOB);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t e = base + tid + u * THREADS;
-            if (e < e1) lds_add(&tile[lv[u]], (double)m[u]);
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < nv; i += THREADS) {
-        const int nb = nbdds[v0 + i];
-        const REAL s = REAL(tile[i]);
-        tile[i] = nb > 0 ? (double)(s / REAL(nb)) : 0.0;
-    }
-    __syncthreads();
-    for (uint32_t base = e0; base < e1; base += THREADS * U) {
-        REAL m[U];
-        uint32_t lv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t e = base + tid + u * THREADS;
-            bload(m[u], rx, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
-            lv[u] = bload_u16(rv, e < e1 ? e * 2u : OOB);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t e = base + tid + u * THREADS;
-            bstore(m[u] - REAL(tile[lv[u]]), rx, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
-        }
-    }
-}
-
-// compute_primal_objective_vec (bdd_cuda_base.cu:1352-1362)
-template <typename REAL>
-__global__ void k_primal_objective(const REAL* __restrict__ lo, const REAL* __restrict__ hi, const uint32_t* __restrict__ var_ptr,
-                                   const uint32_t* __restrict__ var_layers, REAL* __restrict__ out, uint32_t n_vars)
-{
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_vars) return;
-    REAL s = 0;
-    for (uint32_t k = var_ptr[v]; k < var_ptr[v + 1]; ++k) s += hi[2 * (size_t)var_layers[k]] - lo[2 * (size_t)var_layers[k]];
-    out[v] = s;
-}
-
-// ---- primal rounding by cost perturbation (incremental_mm_agreement_rounding_cuda.cu) -----------------
-// One thread per variable over its (variable,bdd)-sorted layers: sign agreement of the min-marginal
-// differences (mm_diff_direction_func :29-41, fill_mm_type_func :43-65), their sums (compute_mm_sums
-// :110-134) and the cost perturbation of mm_types_transform (:136-205, only_perturb_inconsistent = false).
-// counts[0..3] = #one, #zero, #equal, #inconsistent.  The reference draws its random numbers from
-// thrust::default_random_engine discarded by thread id (:177-181); here a counter-based hash of
-// (variable, round, seed) — statistically equivalent, not bit-identical.
-__device__ __forceinline__ float hash_uniform(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x165667B1u) * 0xC2B2AE3Du;
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return (float)(x >> 8) * (1.0f / 16777216.0f);  // [0, 1)
-}
-
-template <typename REAL>
-__global__ void k_round_perturb(const REAL* __restrict__ mm0, const REAL* __restrict__ mm1, const uint32_t* __restrict__ var_ptr,
-                                const uint32_t* __restrict__ var_layers, REAL* __restrict__ cost_delta_0, REAL* __restrict__ cost_delta_1,
-                                char* __restrict__ sol, uint32_t* __restrict__ counts, uint32_t n_vars, double delta, uint32_t round,
-                                uint32_t seed)
-{
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_vars) return;
-    int dmin = 2, dmax = -2;
-    REAL s0 = 0, s1 = 0;
-    for (uint32_t k = var_ptr[v]; k < var_ptr[v + 1]; ++k) {
-        const REAL a = mm0[var_layers[k]], b = mm1[var_layers[k]];
-        // mm_diff_direction_func (:29-41): `mm_0 + 1e-6 <= mm_1` with a double literal, i.e. compared in double
-        const int dir = ((double)a + 1e-6 <= (double)b) ? -1 : (((double)b + 1e-6 <= (double)a) ? 1 : 0);
-        dmin = min(dmin, dir);
-        dmax = max(dmax, dir);
-        s0 += a;
-        s1 += b;
-    }
-    int type;  // 0 one, 1 zero, 2 equal, 3 inconsistent
-    if (dmin == 2) type = 1;            // variable in no BDD: any value is consistent, take 0
-    else if (dmin > 0) type = 0;
-    else if (dmax < 0) type = 1;
-    else if (dmin == 0 && dmax == 0) type = 2;
-    else type = 3;
-    atomicAdd(&counts[type], 1u);
-    sol[v] = type == 0 ? 1 : 0;
-    REAL c0 = 0, c1 = 0;
-    if (type == 0) c0 = REAL(delta);
-    else if (type == 1) c1 = REAL(delta);
-    else {
-        const float r = (2.0f * hash_uniform(v, round, seed) - 1.0f) * (float)delta;  // U(-delta, delta)
-        const REAL mag = REAL(fabsf(r) * delta);
-        if (type == 2) {
-            if (r < 0.0f) c0 = mag; else c1 = mag;
-        } else {
-            if (s0 < s1) c1 = mag; else c0 = mag;
-        }
-    }
-    cost_delta_0[v] = c0;
-    cost_delta_1[v] = c1;
-}
-
-template <typename T>
-__global__ void k_gather(const T* __restrict__ in, const uint32_t* __restrict__ idx, T* __restrict__ out, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[idx[i]];
-}
-
-static __global__ void k_gather_var(const int32_t* __restrict__ in, const uint32_t* __restrict__ idx, int32_t* __restrict__ out, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[idx[i]];
-}
-
-// dst[i * ds] = src[i * ss]   (interleaved {lo,hi} array <-> the API's separate cost vectors)
-template <typename T>
-__global__ void k_strided_copy(T* __restrict__ dst, uint32_t ds, const T* __restrict__ src, uint32_t ss, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[(size_t)i * ds] = src[(size_t)i * ss];
-}
-
-template <typename T>
-__global__ void k_fill(T* __restrict__ p, T v, uint64_t n)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
-// STREAM triad a = b + s*c (COPY: a = b): the measured HBM ceilings bench.py quotes next to the sweeps.  One 16-byte vector per
-// thread, no loop: a one-shot grid keeps every CU's memory queue full for the whole launch and reaches the 6.3-6.7 TB/s of
-// MI355X_MICROARCH.md, where the persistent grid-stride version of rounds 1-2 (4 vectors per thread and trip, non-temporal) stayed at
-// 5.1-5.3 TB/s — below what the solver's own sweeps sustain, i.e. not a ceiling (VERDICT r2 #4b).  profiles/r01_stream_ceiling.txt has
-// the variants.
-typedef float stream_v4 __attribute__((ext_vector_type(4)));
-template <bool COPY>
-static __global__ void __launch_bounds__(256) k_stream(stream_v4* __restrict__ a, const stream_v4* __restrict__ b,
-                                                       const stream_v4* __restrict__ c, float s, uint64_t n4)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    stream_v4 x = b[i];
-    if (!COPY) x += s * c[i];
-    a[i] = x;
-}
-
-// L-BFGS vector helpers (lbfgs_impl.h two-loop recursion; thrust::inner_product / transform there)
-template <typename TA, typename TB>
-__global__ void k_dot(const TA* __restrict__ a, const TB* __restrict__ b, double* __restrict__ partial, uint32_t n)
-{
-    __shared__ double red[4];
-    double acc = 0.0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += (double)a[i] * (double)b[i];
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (uint32_t i = 0; i < blockDim.x / 64; ++i) t += red[i];
-        partial[blockIdx.x] = t;
-    }
-}
-
-// y[i] += alpha * x[i]   (x may be char-typed: the subgradient history, lbfgs.h:60)
-template <typename REAL, typename TX>
-__global__ void k_axpy(REAL* __restrict__ y, const TX* __restrict__ x, REAL alpha, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] += alpha * REAL(x[i]);
-}
-
-template <typename REAL>
-__global__ void k_scale(REAL* __restrict__ y, REAL alpha, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] *= alpha;
-}
-
-// out[i] = a[i] - b[i]
-template <typename TO, typename TA>
-__global__ void k_diff(TO* __restrict__ out, const TA* __restrict__ a, const TA* __restrict__ b, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = TO(a[i] - b[i]);
-}
-
-}  // namespace bddmma
+// The kernels by family (round 5: one 4 000-line header before); order matters — each part uses what the ones before it define.
+#include "kernels/common.hpp"
+#include "kernels/narrow.hpp"
+#include "kernels/resident.hpp"
+#include "kernels/narrow2.hpp"
+#include "kernels/wide.hpp"
+#include "kernels/exchange.hpp"
+#include "kernels/elementwise.hpp"

@@ -219,7 +219,11 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
 {
     L = HostLayout();
     // BDDMMA_LAYOUT_TIMING=1: phase times on stderr
+#ifdef BDDMMA_EXPERIMENTAL  // make EXPERIMENTAL=1
     static const bool timing = std::getenv("BDDMMA_LAYOUT_TIMING") != nullptr;
+#else
+    constexpr bool timing = false;
+#endif
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!timing) return;
@@ -1160,7 +1164,8 @@ void build_seg_exchange(const HostLayout& L, uint32_t T, uint32_t real_size, Seg
     if (fail) { out = SegExchange(); return; }
     uint64_t first = 0;
     for (uint32_t b = 0; b < NB; ++b) out.max_groups = std::max(out.max_groups, deal[b].groups);
-    for (uint32_t b = 0; b < NB; ++b) deal[b].groups = out.max_groups;  // every run padded to the longest bin's groups (k_exchange_seg<.., G>)
+    out.max_groups = out.max_groups <= 2 ? 2 : 4;  // the two instantiations of k_exchange_seg<.., G>
+    for (uint32_t b = 0; b < NB; ++b) deal[b].groups = out.max_groups;  // every run padded to it
     for (uint32_t b = 0; b < NB; ++b) {
         const uint32_t E = X.bin_ptr[b + 1] - X.bin_ptr[b];
         out.bin[4 * (size_t)b + 0] = (uint32_t)first;

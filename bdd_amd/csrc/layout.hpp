@@ -310,7 +310,7 @@ constexpr uint32_t SEG_MAX_RUN = 32;  // positions per thread: bits of the end m
 void build_seg_exchange(const HostLayout& L, uint32_t threads, uint32_t real_size, SegExchange& out);
 
 // What the automatic layout rules and the kernel selection need to know about the chip (bddmma_create reads it from hipDeviceProp:
-// query_chip, bdd_mma_hip.hip; the defaults are MI355X and are what the CPU-side layout entry points use).
+// query_chip, solver_base.hip; the defaults are MI355X and are what the CPU-side layout entry points use).
 struct ChipInfo {
     uint32_t n_cus = 256;
     uint32_t lds_bytes = 160 * 1024;  // per CU

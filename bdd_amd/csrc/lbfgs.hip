@@ -725,8 +725,12 @@ struct Lbfgs final : bddmma_lbfgs {
         step_size = p.init_step_size;
         int rc;
         if (p.history_size >= SC_DOT) { err = "history size must be < 32"; return BDDMMA_ERR_INVALID_ARGUMENT; }
+#ifdef BDDMMA_EXPERIMENTAL  // make EXPERIMENTAL=1: the two-loop passes (the form histories > LB_MAXS take) for short histories too
         const char* two_loop = std::getenv("BDDMMA_LBFGS_TWO_LOOP");
         gram = p.history_size <= LB_MAXS && !(two_loop && two_loop[0] == '1');
+#else
+        gram = p.history_size <= LB_MAXS;
+#endif
         // (the char vectors are read four at a time up to the next multiple of 4 past the last layer: k_stage_lincomb)
         if ((rc = alloc(&prev_x, n)) || (rc = alloc(&dir, n)) || (rc = alloc(&prev_g, (size_t)n + 64)) || (rc = alloc(&cur_g, (size_t)n + 64))) return rc;
         if (gram) {

@@ -30,6 +30,7 @@ struct SolverBase {
     LayoutScalars lay_scalars{};
     bddmma_options saved_opts{};
     virtual int download_layout(HostLayout& H) = 0;  // rebuilds a HostLayout from what the device holds
+    virtual int init_from_layout(const HostLayout& L, const bddmma_options* opts) = 0;  // device buffers + upload (create_solver)
 
     // profiling: one hipEvent pair per launch group on `stream`
     bool profiling = false;        // hipEvent pairs are recorded for every `prof_stride`-th iteration only: an event
@@ -51,7 +52,7 @@ struct SolverBase {
     virtual int lower_bound_fetch(int slot, double* lb) = 0;
     virtual int lower_bound_per_bdd(void* out, int on_device) = 0;
     virtual int iteration(double omega) = 0;
-    // run_solver (include/run_solver_util.h:10-77) around iteration(): termination tests on the device, see bdd_mma_hip.hip
+    // run_solver (include/run_solver_util.h:10-77) around iteration(): termination tests on the device, see solver_impl.hpp
     virtual int run_plain(uint64_t max_iter, double tolerance, double slope, double time_limit, int verbose, bddmma_run_result* res) = 0;
     virtual int forward_mm(double omega, void* delta, int on_device) = 0;
     virtual int backward_mm(double omega, void* delta, int on_device) = 0;

@@ -1,11 +1,11 @@
-// bdd_mma_hip.hip — solver object + C-ABI (include/bdd_mma.h) of the MI355X-native
-// parallel deferred min-marginal-averaging solver.  gfx950 only; there is no CPU fallback:
-// every compute entry point fails with BDDMMA_ERR_DEVICE when no HIP device is usable.
+// solver_impl.hpp — the solver object behind the C-ABI (include/bdd_mma.h): template SolverT<REAL>, instantiated once per precision in its
+// own translation unit (solver_f32.hip / solver_f64.hip, so that the two compile side by side; solver_base.hip has the precision-free part).
+// gfx950 only; there is no CPU fallback: every compute entry point fails with BDDMMA_ERR_DEVICE when no HIP device is usable.
 //
 // Mirrors LPMP::bdd_cuda_parallel_mma<REAL> / bdd_cuda_base<REAL>
 // (reference: src/bdd_solver/bdd_cuda_parallel_mma.cu, src/bdd_solver/bdd_cuda_base.cu).
+#pragma once
 #include <hip/hip_runtime.h>
-
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -17,7 +17,6 @@
 #include <string>
 #include <thread>
 #include <vector>
-
 #include "../../include/bdd_mma.h"
 #include "kernels.hpp"
 #include "layout.hpp"
@@ -25,7 +24,6 @@
 
 namespace bddmma {
 
-thread_local std::string g_create_error;
 
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
@@ -142,8 +140,8 @@ struct SolverT final : SolverBase {
     // the streaming sweeps of the narrow packs start from the resident headers where those hold (one stage group per pack, one round per quad, no
     // staggered packs; layout.hpp: struct Resident) — variant_flags bit 16: from the hop / group / round tables as before
     bool res_hdr_ok = false;
-    const uint32_t* n2_hdr_pack() const { return (res_hdr_ok && !(opts_variant & 0x10000u)) ? d_pack_hdr : nullptr; }
-    const uint32_t* n2_hdr_quad() const { return (res_hdr_ok && !(opts_variant & 0x10000u)) ? d_quad_hdr : nullptr; }
+    const uint32_t* n2_hdr_pack() const { return res_hdr_ok ? d_pack_hdr : nullptr; }
+    const uint32_t* n2_hdr_quad() const { return res_hdr_ok ? d_quad_hdr : nullptr; }
     uint32_t srec_words = 0;
     uint32_t huge_pack_width = 0;
     unsigned char* d_huge_scratch = nullptr;  // frontier arrays of the huge packs (global memory instead of LDS)
@@ -217,6 +215,7 @@ struct SolverT final : SolverBase {
         return BDDMMA_OK;
     }
 
+    int init_from_layout(const HostLayout& L, const bddmma_options* opts) override { return init(L, opts); }
     int init(const HostLayout& L, const bddmma_options* opts)
     {
         HIPCHK(hipSetDevice(device));
@@ -367,12 +366,10 @@ struct SolverT final : SolverBase {
         SET_DYN((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_ITER>), exch_lds);
         SET_DYN((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_RAW>), exch_lds);
         SET_DYN((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, true>), exch_lds);  // run_plain()'s instantiation
-        SET_DYN((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, false, 7>), exch_lds);
-        SET_DYN((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_ITER, EX_THREADS, EX_UNROLL, EX_NPT, true, 7>), exch_lds);
         opts_variant = opts ? opts->variant_flags : 0u;
         mixed_fwd = (opts_variant & 2u) == 0;
         // measured in double: 7.1 M nodes (490 MB resident) lose 12 % with non-temporal potentials, 10.5 M (720 MB) gain 4 %
-        nt_potentials = (sizeof(REAL) == 8 && dev_bytes > (640ull << 20) && (opts_variant & 4u) == 0) ? 1u : 0u;
+        nt_potentials = (sizeof(REAL) == 8 && dev_bytes > (640ull << 20)) ? 1u : 0u;
         exch_small = vars_per_bin <= EXS_MAX_VARS_PER_BIN;  // 256-thread workgroups (kernels.hpp: EXS_*)
         exch_medium = !exch_small && vars_per_bin <= EXM_MAX_VARS_PER_BIN;  // 512-thread workgroups (EXM_*)
         // `deterministic`: the scheduled reduction (kernels.hpp: k_exchange_seg; no atomics, fixed order) where every bin fits its tables
@@ -397,7 +394,7 @@ struct SolverT final : SolverBase {
 #define SET_SEG_G(T_, G_)                                             \
     SET_DYN((k_exchange_seg<REAL, T_, G_, false>), seg_lds);          \
     SET_DYN((k_exchange_seg<REAL, T_, G_, true>), seg_lds)
-#define SET_SEG(T_) switch (seg_groups) { case 1: SET_SEG_G(T_, 1); break; case 2: SET_SEG_G(T_, 2); break; case 3: SET_SEG_G(T_, 3); break; default: SET_SEG_G(T_, 4); break; }
+#define SET_SEG(T_) if (seg_groups <= 2) { SET_SEG_G(T_, 2); } else { SET_SEG_G(T_, 4); }
                     if (exch_small) { SET_SEG(EXS_THREADS) } else if (exch_medium) { SET_SEG(EXM_THREADS) } else { SET_SEG(EX_THREADS) }
 #undef SET_SEG
 #undef SET_SEG_G
@@ -500,10 +497,6 @@ struct SolverT final : SolverBase {
             // instance (25 000 rows of 18 variables, 15 M nodes): packs of 512 / 1024 slots with one node per thread 1 823 / 1 662 it/s, with
             // two 2 158 / 2 205, with four (1024 slots) 1 936
             wide_threads = std::min<uint32_t>(1024, std::max<uint32_t>(64, ((wide_pack_width + 1) / 2 + 63) / 64 * 64));
-            if (const char* e = std::getenv("BDDMMA_WIDE_THREADS")) {  // experiments: another workgroup size (<= 4 nodes per thread)
-                const uint32_t t = (uint32_t)std::atoi(e) / 64 * 64;
-                if (t >= 64 && t <= 1024 && (wide_pack_width + t - 1) / t <= 4) wide_threads = t;
-            }
             wide_npt = (wide_pack_width + wide_threads - 1) / wide_threads;
             wide_npt = wide_npt <= 1 ? 1 : (wide_npt <= 2 ? 2 : 4);
             wide_lds = (uint32_t)wide2_lds_bytes(sizeof(REAL), wide_pack_width, true);
@@ -567,7 +560,7 @@ struct SolverT final : SolverBase {
     // constraint families); homogeneous instances keep the contiguous map, which measured 1-3 % faster there (neighbouring packs share
     // more L2 lines).  variant_flags bit 7 forces the contiguous map, bit 8 the interleaved one.
     uint32_t xcd_chunk_auto = 0;
-    uint32_t xcd_chunk() const { return (opts_variant & 0x80u) ? 0u : ((opts_variant & 0x100u) ? 32u : xcd_chunk_auto); }
+    uint32_t xcd_chunk() const { return xcd_chunk_auto; }
     uint32_t narrow_grid(uint32_t n_quads) const
     {
         const uint32_t c = xcd_chunk();
@@ -751,7 +744,7 @@ struct SolverT final : SolverBase {
             delta_var_valid = true;
         } else if (use_seg) {
 #define LAUNCH_SEG(T_, RUN_)                                                                                                                        \
-    switch (seg_groups) { case 1: LAUNCH_SEG_G(T_, 1, RUN_); break; case 2: LAUNCH_SEG_G(T_, 2, RUN_); break; case 3: LAUNCH_SEG_G(T_, 3, RUN_); break; default: LAUNCH_SEG_G(T_, 4, RUN_); break; }
+    if (seg_groups <= 2) { LAUNCH_SEG_G(T_, 2, RUN_); } else { LAUNCH_SEG_G(T_, 4, RUN_); }
 #define LAUNCH_SEG_G(T_, G_, RUN_)                                                                                                                  \
     hipLaunchKernelGGL((k_exchange_seg<REAL, T_, G_, RUN_>), dim3(n_bins + ((RUN_) && rstep.ctl != nullptr ? 1u : 0u)), dim3(T_), seg_lds, stream, d_mm_binned, \
                        reinterpret_cast<const uint4*>(d_seg_bin), gate().stop, gate().iter, reinterpret_cast<const uint4*>(d_seg_perm),              \
@@ -765,36 +758,14 @@ struct SolverT final : SolverBase {
 #undef LAUNCH_SEG_G
             delta_var_valid = false;
         } else {
-            // All three sizes run the lean form since round 3 (kernels.hpp: EXV_* = 7: scalar-offset entry addressing, one predicated atomic per
-            // entry; its 16-byte store hazard is guarded): 10.5 M nodes 124.1 -> 122.1 us per iteration (float), 236.0 -> 232.4 (double);
-            // 1.05 M nodes 4.7 -> 4.4 us per launch.  variant_flags bit 6 selects the round-2 form (0), bits 3-5 any combination for the
-            // 256-thread kernel (the bisection of profiles/r03_exchange_variant_rootcause.txt).
-#define LAUNCH_EX(T_, U_, N_, RUN_, V_)                                                                                                              \
-    hipLaunchKernelGGL((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_ITER, T_, U_, N_, RUN_, V_>), dim3(n_bins + ((RUN_) && rstep.ctl != nullptr ? 1u : 0u)), dim3(T_), exch_lds, stream, d_mm_binned, d_bin_ptr, \
+#define LAUNCH_EX(T_, U_, N_, RUN_)                                                                                                                  \
+    hipLaunchKernelGGL((k_exchange_reduce<REAL, BDDMMA_EX_ACC, EX_ITER, T_, U_, N_, RUN_>), dim3(n_bins + ((RUN_) && rstep.ctl != nullptr ? 1u : 0u)), dim3(T_), exch_lds, stream, d_mm_binned, d_bin_ptr, \
                        d_bvar, gate().stop, gate().iter, vars_per_bin, (uint32_t)n_vars, (uint32_t)n_layers, d_nbdds, (REAL*)nullptr, d_delta_lay, rstep)
-#define LAUNCH_EX_RV(T_, U_, N_)                                                                        \
-    do {                                                                                                \
-        if (opts_variant & 0x40u) {                                                                     \
-            if (run_stop) LAUNCH_EX(T_, U_, N_, true, 0); else LAUNCH_EX(T_, U_, N_, false, 0);         \
-        } else {                                                                                        \
-            if (run_stop) LAUNCH_EX(T_, U_, N_, true, 7); else LAUNCH_EX(T_, U_, N_, false, 7);         \
-        }                                                                                               \
-    } while (0)
-            if (exch_medium) LAUNCH_EX_RV(EXM_THREADS, EXM_UNROLL, EXM_NPT);
-            else if (exch_small && !run_stop && !(opts_variant & 0x40u) && ((opts_variant >> 3) & 7u)) {
-                switch ((opts_variant >> 3) & 7u) {
-                    case 1: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 1); break;
-                    case 2: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 2); break;
-                    case 3: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 3); break;
-                    case 4: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 4); break;
-                    case 5: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 5); break;
-                    case 6: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 6); break;
-                    default: LAUNCH_EX(EXS_THREADS, EXS_UNROLL, EXS_NPT, false, 7); break;
-                }
-            }
-            else if (exch_small) LAUNCH_EX_RV(EXS_THREADS, EXS_UNROLL, EXS_NPT);
-            else LAUNCH_EX_RV(EX_THREADS, EX_UNROLL, EX_NPT);
-#undef LAUNCH_EX_RV
+#define LAUNCH_EX_R(T_, U_, N_) do { if (run_stop) LAUNCH_EX(T_, U_, N_, true); else LAUNCH_EX(T_, U_, N_, false); } while (0)
+            if (exch_medium) LAUNCH_EX_R(EXM_THREADS, EXM_UNROLL, EXM_NPT);
+            else if (exch_small) LAUNCH_EX_R(EXS_THREADS, EXS_UNROLL, EXS_NPT);
+            else LAUNCH_EX_R(EX_THREADS, EX_UNROLL, EX_NPT);
+#undef LAUNCH_EX_R
 #undef LAUNCH_EX
             delta_var_valid = false;
         }
@@ -1611,126 +1582,5 @@ struct SolverT final : SolverBase {
         return BDDMMA_OK;
     }
 };
-
-// ---------------------------------------------------------------------------------------------
-int SolverBase::synchronize()
-{
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamSynchronize(stream));
-    return BDDMMA_OK;
-}
-
-void SolverBase::prof_begin(int kclass)
-{
-    if (!profiling || !prof_active) return;
-    if (ev_used == ev_pool.size()) {
-        hipEvent_t a, b;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { profiling = false; return; }
-        ev_pool.push_back({a, b});
-        ev_class.push_back(kclass);
-    }
-    ev_class[ev_used] = kclass;
-    (void)hipEventRecord(ev_pool[ev_used].first, stream);
-}
-void SolverBase::prof_end(int)
-{
-    if (!profiling || !prof_active) return;
-    (void)hipEventRecord(ev_pool[ev_used].second, stream);
-    ++ev_used;
-}
-int SolverBase::set_profiling(int on)
-{
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamSynchronize(stream));
-    profiling = on != 0;
-    prof_stride = on > 0 ? (uint32_t)on : 1;
-    prof_iter = 0;
-    prof_active = profiling;
-    ev_used = 0;
-    return BDDMMA_OK;
-}
-int SolverBase::get_profile(bddmma_profile* out)
-{
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamSynchronize(stream));
-    std::memset(out, 0, sizeof(*out));
-    for (size_t i = 0; i < ev_used; ++i) {
-        float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
-        out->launches[ev_class[i]]++;
-        out->total_ms[ev_class[i]] += ms;
-    }
-    return BDDMMA_OK;
-}
-int SolverBase::time_iterations(double omega, uint64_t n, double* ms)
-{
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipEventRecord(ev_t0, stream));
-    for (uint64_t i = 0; i < n; ++i) {
-        int rc = iteration(omega);
-        if (rc) return rc;
-    }
-    HIPCHK(hipEventRecord(ev_t1, stream));
-    HIPCHK(hipEventSynchronize(ev_t1));
-    float f = 0.f;
-    HIPCHK(hipEventElapsedTime(&f, ev_t0, ev_t1));
-    *ms = f;
-    return BDDMMA_OK;
-}
-
-int device_count()
-{
-    int count = 0;
-    return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
-}
-
-int query_chip(int device, ChipInfo* out, std::string& err)
-{
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return BDDMMA_OK;  // create_solver reports it; defaults meanwhile
-    hipDeviceProp_t prop;
-    const hipError_t e = hipGetDeviceProperties(&prop, device);
-    if (e != hipSuccess) { err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return BDDMMA_ERR_DEVICE; }
-    if (prop.multiProcessorCount > 0) out->n_cus = (uint32_t)prop.multiProcessorCount;
-    if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) out->lds_bytes = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
-    return BDDMMA_OK;
-}
-
-int create_solver(SolverBase** out, int precision, int device, const HostLayout& L, const bddmma_options* opts, std::string& err)
-{
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count == 0) {
-        err = std::string("no HIP device available (") + (e == hipSuccess ? "device count 0" : hipGetErrorString(e)) +
-              "); this library has no CPU fallback";
-        return BDDMMA_ERR_DEVICE;
-    }
-    if (device < 0 || device >= count) {
-        err = "device index out of range";
-        return BDDMMA_ERR_INVALID_ARGUMENT;
-    }
-    std::unique_ptr<SolverBase> s;
-    int rc;
-    if (precision == BDDMMA_F32) {
-        auto* t = new SolverT<float>();
-        s.reset(t);
-        t->precision = precision; t->device = device;
-        rc = t->init(L, opts);
-    } else if (precision == BDDMMA_F64) {
-        auto* t = new SolverT<double>();
-        s.reset(t);
-        t->precision = precision; t->device = device;
-        rc = t->init(L, opts);
-    } else {
-        err = "precision must be BDDMMA_F32 or BDDMMA_F64";
-        return BDDMMA_ERR_INVALID_ARGUMENT;
-    }
-    if (rc) {
-        err = s->err;
-        return rc;
-    }
-    *out = s.release();
-    return BDDMMA_OK;
-}
 
 }  // namespace bddmma

@@ -385,13 +385,14 @@ class bdd_hip_lbfgs:
 
 
 def run_solver(solver, max_iter=1000, tolerance=1e-6, improvement_slope=1e-9, time_limit=3600.0, verbose=False,
-               lbfgs: bdd_hip_lbfgs = None):
-    """run_solver<SOLVER>() of include/run_solver_util.h:10-77 (executed inside the library)."""
+               lbfgs: bdd_hip_lbfgs = None, host_loop: bool = False):
+    """run_solver<SOLVER>() of include/run_solver_util.h:10-77 (executed inside the library).  host_loop: the reference's literal loop
+    (a host round trip for the bound every iteration) instead of the device-resident one; same result."""
     L = capi.lib()
     res = capi.RunResult()
     base = solver.solver if isinstance(solver, bdd_hip_lbfgs) else solver
     lb = solver if isinstance(solver, bdd_hip_lbfgs) else lbfgs
-    capi.check(L.bddmma_run_solver(base._h, lb._h if lb else None, int(max_iter), float(tolerance),
+    capi.check((L.bddmma_run_solver_host_loop if host_loop else L.bddmma_run_solver)(base._h, lb._h if lb else None, int(max_iter), float(tolerance),
                                    float(improvement_slope), float(time_limit), 1 if verbose else 0, C.byref(res)), base._h)
     return dict(iterations=int(res.iterations), lb_initial=res.lb_initial, lb_final=res.lb_final,
                 seconds=res.seconds, stop_reason=int(res.stop_reason))

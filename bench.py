@@ -28,7 +28,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "HBM3E peak BW")
-KERNEL_SOURCES = ("bdd_amd/csrc/kernels.hpp", "bdd_amd/csrc/bdd_mma_hip.hip", "bdd_amd/csrc/layout.cpp")
+KERNEL_SOURCES = ("bdd_amd/csrc/kernels.hpp", "bdd_amd/csrc/kernels/common.hpp", "bdd_amd/csrc/kernels/narrow.hpp", "bdd_amd/csrc/kernels/resident.hpp",
+                  "bdd_amd/csrc/kernels/narrow2.hpp", "bdd_amd/csrc/kernels/wide.hpp", "bdd_amd/csrc/kernels/exchange.hpp",
+                  "bdd_amd/csrc/kernels/elementwise.hpp", "bdd_amd/csrc/solver_impl.hpp", "bdd_amd/csrc/layout.cpp")
 
 
 def sweep_bytes(sizes, R):

@@ -81,27 +81,21 @@ typedef struct bddmma_options {
                                   per variable over a contiguous run: deterministic, no LDS accumulators, a shorter exchange launch; but
                                   the sweeps' accesses to the entry arrays lose their locality (slower overall on every instance
                                   measured).  Default (0 / 1): binned order */
-    uint32_t variant_flags;    /* switches between equivalent code paths, for A/B measurements and the differential tests (default 0):
-                                  bit 0: narrow and wide backward sweeps as two launches (default: one, k_bwd_mixed)
-                                  bit 1: narrow and wide forward sweeps as two launches (default: one, k_fwd_mixed)
-                                  bit 2: no non-temporal stores of the potentials (default: on for double instances above 640 MB)
-                                  bits 3-5: 256-thread exchange kernel with this combination of {1: scalar-offset entry loads, 2: scalar-offset
-                                            pair stores, 4: one predicated LDS atomic per entry} instead of all three (the default)
-                                  bit 6: the round-2 exchange kernels (none of the three), every bin size
-                                  bit 7 / bit 8: narrow workgroups mapped to XCDs in contiguous eighths / in interleaved chunks of 32
-                                                 (default: interleaved when the eighths' hop counts differ by more than 10 %)
+    uint32_t variant_flags;    /* TEST HOOKS, default 0.  Every bit forces a code path of the shipped library that the automatic rules choose on
+                                  other shapes or sizes, so that the differential tests reach it on small instances; none changes results
+                                  beyond floating-point summation order.  (The A/B-only switches of rounds 2-4 — bits 2-8 and 16 — are gone:
+                                  the paths they selected were deleted or are selected by rule alone; those bits are ignored.)
+                                  bit 0 / bit 1: narrow and wide backward / forward sweeps as two launches (rule: one launch, k_*_mixed, except
+                                                 where the wide share is large)
                                   bit 9 / bit 10: make_dual_feasible of the L-BFGS direction through the staging tables / by gathers
-                                                  (default: staged from 500 000 layers on)
-                                  bit 11: resident sweeps of the first generation only (node words in LDS; default: per-lane records, k_fwd_res2)
-                                  bit 12: streaming solve sweeps of the first generation only (default: per-lane records where packs share them)
+                                                  (rule: staged from 500 000 layers on)
+                                  bit 11: first-generation resident sweeps (rule: packs of 128 / 256 slots or layers wider than two nodes)
+                                  bit 12: first-generation streaming solve sweeps (rule: packs that share no records; float above 16 M slots)
                                   bit 13: per-lane records for the streaming solve sweeps also where packs do not share them
-                                  bit 14: the staging transfers with 64-bit addresses, as for arrays of 4 GiB and more (no resident sweeps)
-                                  bit 15: the L-BFGS direction as its own pass (default: formed inside the projection's first pass where that is staged
-                                          and all packs are narrow)
-                                  bit 16: the streaming sweeps of the narrow packs find their pack and their staging range through the hop / group /
-                                          round tables (default: from the resident headers where every pack has one stage group)
-                                  bit 17: `deterministic` exchanges by per-variable gathers (two launches) also where the one-launch fixed schedule
-                                          k_exchange_seg fits (same sums, same order: bit-equal results) */
+                                  bit 14: staging transfers with 64-bit addresses (rule: arrays of 4 GiB and more)
+                                  bit 15: the L-BFGS direction as its own pass (rule: wide packs present, or the projection by gathers)
+                                  bit 17: `deterministic` exchanges by per-variable gathers, two launches (rule: bins that do not fit the
+                                          one-launch schedule k_exchange_seg; same sums, same order: bit-equal results) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
                                   instance (NOTES.md section 6: the sweeps are bound by instructions issued, not by latency), kept for experiments */
@@ -261,6 +255,10 @@ typedef struct bddmma_run_result {
 } bddmma_run_result;
 int bddmma_run_solver(bddmma_solver* s, bddmma_lbfgs* lbfgs_or_null, uint64_t max_iter, double tolerance,
                       double improvement_slope, double time_limit, int verbose, bddmma_run_result* res);
+/* The same loop literally as the reference writes it — iteration(); lower_bound() with a host round trip; the tests on the host — for the
+ * plain solver too (with an L-BFGS wrapper both entry points run this loop).  Same iteration count, same state, same bound. */
+int bddmma_run_solver_host_loop(bddmma_solver* s, bddmma_lbfgs* lbfgs_or_null, uint64_t max_iter, double tolerance,
+                                double improvement_slope, double time_limit, int verbose, bddmma_run_result* res);
 
 /* ---- primal rounding (src/bdd_solver/incremental_mm_agreement_rounding_cuda.cu:333-372) ------------------
  * incremental_mm_agreement_rounding_cuda(s, init_delta, delta_growth_rate, num_itr_lb, verbose, num_rounds):

@@ -1,6 +1,6 @@
-"""run_solver (include/run_solver_util.h:10-77) with its termination tests on the device (bdd_mma_hip.hip: run_plain,
+"""run_solver (include/run_solver_util.h:10-77) with its termination tests on the device (solver_impl.hpp: run_plain,
 kernels.hpp: k_lb_reduce_ctl) against the reference's sequential loop — iteration(); lower_bound(); tests — restated here
-in Python on a twin solver, and against the library's own sequential loop (BDDMMA_SEQUENTIAL_RUN_SOLVER=1)."""
+in Python on a twin solver, and against the library's own sequential loop (bddmma_run_solver_host_loop)."""
 import math
 import os
 
@@ -68,13 +68,9 @@ def test_device_resident_loop_equals_the_sequential_loop(precision, case):
 def test_default_exchange_and_the_librarys_own_sequential_loop():
     col, costs = random_set_cover(4000, 3000, 10, seed=5)
     results = []
-    for env in ("0", "1"):
-        os.environ["BDDMMA_SEQUENTIAL_RUN_SOLVER"] = env
-        try:
-            s = bdd_hip_parallel_mma(col, costs, precision="double")
-            results.append(run_solver(s, max_iter=300, tolerance=1e-5, improvement_slope=0.0, time_limit=1e9))
-        finally:
-            os.environ.pop("BDDMMA_SEQUENTIAL_RUN_SOLVER", None)
+    for host_loop in (False, True):
+        s = bdd_hip_parallel_mma(col, costs, precision="double")
+        results.append(run_solver(s, max_iter=300, tolerance=1e-5, improvement_slope=0.0, time_limit=1e9, host_loop=host_loop))
     a, b = results
     assert a["stop_reason"] == b["stop_reason"] == 2 and a["iterations"] == b["iterations"] < 300
     assert abs(a["lb_final"] - b["lb_final"]) <= 1e-12 * abs(b["lb_final"])  # LDS-atomic order only

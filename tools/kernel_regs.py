@@ -3,7 +3,7 @@ import re, subprocess, sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pat = sys.argv[1] if len(sys.argv) > 1 else ""
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function",
-       "-Rpass-analysis=kernel-resource-usage", "-c", "bdd_mma_hip.hip", "-o", "/tmp/kernel_regs.o"] + sys.argv[2:]
+       "-Rpass-analysis=kernel-resource-usage", "-c", "solver_f32.hip" if "--double" not in sys.argv else "solver_f64.hip", "-o", "/tmp/kernel_regs.o"] + sys.argv[2:]
 out = subprocess.run(cmd, cwd=os.path.join(root, "bdd_amd", "csrc"), capture_output=True, text=True).stderr
 cur = None
 rows = {}

@@ -22,7 +22,7 @@ for pid in "${pids[@]}"; do wait "$pid"; done
 t1=$(date +%s)
 {
     echo "soak $TAG: $P fuzz processes x $REPS repeats x 40 seeds + $P x $LOOPS loops of tests/test_gpu_run_solver.py, concurrently on one GPU; $((t1 - t0)) s; env: $*"
-    echo "kernel sources: $(cat bdd_amd/csrc/kernels.hpp bdd_amd/csrc/bdd_mma_hip.hip bdd_amd/csrc/layout.cpp | sha256sum | cut -c1-16)"
+    echo "kernel sources: $(cat bdd_amd/csrc/kernels.hpp bdd_amd/csrc/kernels/*.hpp bdd_amd/csrc/solver_impl.hpp bdd_amd/csrc/layout.cpp | sha256sum | cut -c1-16)"
     grep -h "failures in" "$OUT"/fuzz_*.txt
     grep -h "^FAIL" "$OUT"/fuzz_*.txt | head -40
     echo "run_solver loops (one line per pytest run):"
