@@ -11,7 +11,8 @@ i=0
 while read -r pmc; do
   [ -z "$pmc" ] && continue
   i=$((i+1))
-  rocprofv3 --pmc $pmc --output-format csv -d $out/p$i -o pmc -- python tools/hbm_diag.py "$@" > /dev/null 2> $out/p$i.err
+  # (a counter set the hardware cannot collect makes rocprofv3 abort and then hang in its signal handler: never without a timeout)
+  timeout 300 rocprofv3 --pmc $pmc --output-format csv -d $out/p$i -o pmc -- python tools/hbm_diag.py "$@" > /dev/null 2> $out/p$i.err
 done <<'PMC'
 TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum
 TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum
@@ -21,7 +22,7 @@ TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TC
 TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_TAG_STALL_sum TCC_BUBBLE_sum TCC_IB_STALL_sum
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_WAVES
 TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum
-TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE
+TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum
 FETCH_SIZE WRITE_SIZE
 PMC
