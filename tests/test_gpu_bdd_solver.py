@@ -202,6 +202,38 @@ def test_eight_slot_rehearsal_on_one_gpu(tmp_path):
     assert len({round(r["lower_bound"], 6) for r in rows[:8]}) == 8
 
 
+def test_eight_full_size_instances_share_one_gpu():
+    """configs[4] at its own size: eight DIFFERENT 10.5 M-node instances (seeds 12345-12352) built and iterated by the farm's eight host
+    threads, all on the one GPU of this box (3.7 GB resident).  What an 8-GPU node would run per device is exactly one of these slots; here
+    the eight share the chip, so the aggregate rate is about ONE device's rate — the test pins that nothing in the farm degrades at this
+    size (memory, shared layout threads, eight enqueue threads): every slot's bound equals the bound a lone solver reaches on that seed,
+    and the aggregate stays above half of the lone solver's rate."""
+    import os
+    from bdd_amd.instances import random_set_cover_mt
+    from bdd_amd.solver import bdd_hip_parallel_mma
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bdd_amd", "csrc", "bdd_solver_cl")
+    out = subprocess.run([exe, "--bench-set-cover", "1000000", "500000", "10", "--iterations", "60", "--warmup", "20", "--seeds", "12345-12352",
+                          "--devices", "0,0,0,0,0,0,0,0", "--precision", "float"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 9 and rows[8]["instances"] == 8 and all(r["ok"] for r in rows[:8])
+    assert sorted(r["seed"] for r in rows[:8]) == list(range(12345, 12353))
+    assert len({round(r["lower_bound"], 3) for r in rows[:8]}) == 8
+    lone_rate = None
+    for seed in (12345, 12352):
+        col, costs = random_set_cover_mt(1_000_000, 500_000, 10, seed=seed)
+        s = bdd_hip_parallel_mma(col, costs, precision="float")
+        s.iterations(20)
+        ms = s.time_iterations(60)
+        lone_rate = 60 / ms * 1e3
+        lb = s.lower_bound()
+        row = next(r for r in rows[:8] if r["seed"] == seed)
+        assert abs(row["lower_bound"] - lb) <= 1e-5 * abs(lb), (seed, row["lower_bound"], lb)
+        del s
+    assert rows[8]["aggregate_iterations_per_second"] > 0.5 * lone_rate, (rows[8], lone_rate)
+
+
 def test_export_keys_of_both_drivers(tmp_path):
     """"export bdd lp" / "export bdd graph" (bdd_solver.cpp:400-410, :432-462) through the C++ driver and the Python driver: the same files,
     equal to what the collection's own emitters give (tests/test_exports.py pins those on the reference's output)."""
