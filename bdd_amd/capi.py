@@ -62,6 +62,7 @@ SIGNATURES = {
     "bddmma_nr_bdd_nodes": (_U64, [_V]),
     "bddmma_nr_hops": (_U64, [_V]),
     "bddmma_nr_packs": (_U64, [_V]),
+    "bddmma_solve_sweep_kind": (_I, [_V]),
     "bddmma_precision": (_I, [_V]),
     "bddmma_device": (_I, [_V]),
     "bddmma_num_bdds_per_var": (_I, [_V, _V]),
@@ -116,6 +117,7 @@ SIGNATURES = {
     "bddmma_layout_copy": (_I, [_V, _I, _V]),
     "bddmma_layout_res2_records": (_I, [_V, _I, _V, _V, _V]),
     "bddmma_layout_stream_records": (_I, [_V, _I, _V, _V, _V]),
+    "bddmma_layout_layer_records": (_I, [_V, _I, _V, _V, _V]),
     "bddmma_layout_seg_exchange": (_I, [_V, _I, _I, _V, _V, _V, _V]),
 }
 

@@ -130,6 +130,7 @@ uint64_t bddmma_nr_layers(const bddmma_solver* s) { return s && s->impl ? s->imp
 uint64_t bddmma_nr_bdd_nodes(const bddmma_solver* s) { return s && s->impl ? s->impl->n_input_nodes : 0; }
 uint64_t bddmma_nr_hops(const bddmma_solver* s) { return s && s->impl ? s->impl->n_hops : 0; }
 uint64_t bddmma_nr_packs(const bddmma_solver* s) { return s && s->impl ? s->impl->n_packs_narrow + s->impl->n_packs_wide : 0; }
+int bddmma_solve_sweep_kind(const bddmma_solver* s) { return s && s->impl ? s->impl->solve_sweep_kind : -1; }
 int bddmma_precision(const bddmma_solver* s) { return s && s->impl ? s->impl->precision : -1; }
 int bddmma_device(const bddmma_solver* s) { return s && s->impl ? s->impl->device : -1; }
 uint64_t bddmma_device_bytes(const bddmma_solver* s) { return s && s->impl ? s->impl->dev_bytes : 0; }
@@ -842,6 +843,17 @@ int bddmma_layout_stream_records(const bddmma_layout* l, int real_size, uint32_t
     if (!l || !info || (real_size != 4 && real_size != 8)) return BDDMMA_ERR_INVALID_ARGUMENT;
     StreamRecords R;
     build_stream_records(l->L, (uint32_t)real_size, R);
+    info[0] = R.ok ? 1u : 0u; info[1] = (uint32_t)R.rec.size();
+    if (words && !R.rec.empty()) std::memcpy(words, R.rec.data(), R.rec.size() * sizeof(uint32_t));
+    if (rec_off && !R.rec_off.empty()) std::memcpy(rec_off, R.rec_off.data(), R.rec_off.size() * sizeof(uint32_t));
+    return BDDMMA_OK;
+}
+
+int bddmma_layout_layer_records(const bddmma_layout* l, int real_size, uint32_t* info, uint32_t* words, uint32_t* rec_off)
+{
+    if (!l || !info || (real_size != 4 && real_size != 8)) return BDDMMA_ERR_INVALID_ARGUMENT;
+    LayerRecords R;
+    build_layer_records(l->L, (uint32_t)real_size, R);
     info[0] = R.ok ? 1u : 0u; info[1] = (uint32_t)R.rec.size();
     if (words && !R.rec.empty()) std::memcpy(words, R.rec.data(), R.rec.size() * sizeof(uint32_t));
     if (rec_off && !R.rec_off.empty()) std::memcpy(rec_off, R.rec_off.data(), R.rec_off.size() * sizeof(uint32_t));

@@ -30,6 +30,7 @@
 #include "kernels/narrow.hpp"
 #include "kernels/resident.hpp"
 #include "kernels/narrow2.hpp"
+#include "kernels/narrow3.hpp"
 #include "kernels/wide.hpp"
 #include "kernels/exchange.hpp"
 #include "kernels/elementwise.hpp"

@@ -166,8 +166,10 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
             const uint32_t stg = db + (lb[0] - gl0) * (uint32_t)sizeof(P2);  // the hop's first layer inside the wave's staging slots
             // ---- global prefetch: records of hop q+2D, T of hop q+D+2, arc costs of hop q+D
             load_recs<R>(rc[2 * D], rr, rbase + (q - q0 + 2 * D) * W, lane);
+#ifndef BDDMMA_EXP_NO_HOP_LOADS  // timing experiments only (wrong results): the hop loop without its streams from / to global memory
             load_vals<REAL, R>(tr[D], Tp, o[D + 2], o[D + 3] - o[D + 2], lane);
             load_costs<REAL, R>(Lr[D], rc[D], rs.lohi, lb[D]);
+#endif
             u4v (&ra)[R] = rc[0];
             P2 (&La)[R] = Lr[0];
             // ---- the hop's LDS reads, one batch
@@ -211,12 +213,16 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
             const rsrc_t rl = hop_rsrc(reinterpret_cast<const P2*>(lohi_p), lb[0], lb[1] - lb[0]);  // ends with the hop's layers: RES2_NO_STORE is dropped
 #pragma unroll
             for (int r = 0; r < R; ++r) {
+#ifndef BDDMMA_EXP_NO_HOP_STORES
                 hop_store(nc[r], rl, ra[r][2] >> 16, lb[0] * (uint32_t)sizeof(P2));
+#endif
                 if (!(ra[r][3] & SREC_PAD)) lds_st<REAL>(dyn_lds, stg + (ra[r][2] & 0xFFFFu), mmv[r]);  // every lane of a layer holds the same value
                 lds_min(reinterpret_cast<REAL*>(sFw + fn + (ra[r][1] & 0xFFFFu)), f[r] + nc[r].x);  // sinks / padding: the lane's own dummy entry
                 lds_min(reinterpret_cast<REAL*>(sFw + fn + (ra[r][1] >> 16)), f[r] + nc[r].y);
             }
+#ifndef BDDMMA_EXP_NO_HOP_STORES
             store_vals<R>(f, Fp, nb, o[1] - o[0], lane, pk.nt_potentials);
+#endif
             wave_sync();
             cur ^= 1u;
             // ---- rotate the pipeline registers

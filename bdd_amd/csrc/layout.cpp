@@ -1259,6 +1259,68 @@ void build_stream_records(const HostLayout& L, uint32_t S, StreamRecords& out)
     out.ok = true;
 }
 
+void build_layer_records(const HostLayout& L, uint32_t S, LayerRecords& out)
+{
+    out = LayerRecords();
+    const PackSet& N = L.narrow;
+    const uint32_t P = N.n_packs(), W = L.pack_width;
+    if (P == 0 || W != 128 || L.narrow_word_off.size() != P || N.hop_root.size() + 1 != N.hop_node_off.size()) return;
+    if ((uint64_t)(W + 128u) * S >= LREC_NO_STORE) return;
+    for (uint16_t r : N.hop_root)
+        if (r != NO_ROOT) return;  // staggered packs
+    out.rec_off.assign(P, 0);
+    std::unordered_map<uint32_t, uint32_t> seen;  // word offset of a structure template -> its first record
+    for (uint32_t p = 0; p < P; ++p) {
+        if (N.pack_steps[p] > 1) { out = LayerRecords(); return; }  // a layer wider than two nodes
+        const uint32_t q0 = N.pack_hop_ptr[p], q1 = N.pack_hop_ptr[p + 1], nh = q1 - q0;
+        const uint32_t s0 = N.hop_node_off[q0];
+        const auto it = seen.find(L.narrow_word_off[p]);
+        if (it != seen.end()) { out.rec_off[p] = it->second; continue; }
+        const uint64_t first = out.rec.size() / 4;
+        if ((first + (uint64_t)nh * 64) * 16 >= (1ull << 31)) { out = LayerRecords(); return; }
+        seen.emplace(L.narrow_word_off[p], (uint32_t)first);
+        out.rec_off[p] = (uint32_t)first;
+        out.rec.resize(out.rec.size() + (size_t)nh * 64 * 4);
+        uint32_t* r = &out.rec[(size_t)first * 4];
+        const uint32_t* words = &L.narrow_words_unique[L.narrow_word_off[p]];
+        for (uint32_t h = 0; h < nh; ++h, r += 64 * 4) {
+            const uint32_t nb = N.hop_node_off[q0 + h] - s0, n = N.hop_node_off[q0 + h + 1] - N.hop_node_off[q0 + h];
+            const uint32_t nl = N.hop_layer_off[q0 + h + 1] - N.hop_layer_off[q0 + h];
+            if (n > W || nl > 64) { out = LayerRecords(); return; }
+            for (uint32_t l = 0; l < 64; ++l) {  // idle lanes
+                const uint32_t bot = (W + 2 * l + 1) * S;
+                r[4 * l + 0] = r[4 * l + 1] = bot | (bot << 16);
+                r[4 * l + 2] = (W + 2 * l) * S;
+                r[4 * l + 3] = LREC_NO_STORE | (LREC_NO_STORE << 16);
+            }
+            uint32_t l = 0;  // hop-local layer index = heads before this slot = the lane
+            for (uint32_t j = 0; j < n; ++j) {
+                const uint32_t w = words[nb + j];
+                if (w & NW_PAD) continue;
+                const uint32_t pos = (w >> NW_POS_SHIFT) & NW_FIELD6;
+                const uint32_t lo = w & NW_CHILD_MASK, hi = (w >> NW_CHILD_BITS) & NW_CHILD_MASK;
+                auto child = [&](uint32_t c, uint32_t lane) { return (c < W ? c : W + 2 * lane + (c - W)) * S; };  // W = TOP, W + 1 = BOT (nw_pad_word)
+                if (pos == 0) {
+                    if (l >= nl) { out = LayerRecords(); return; }
+                    r[4 * l + 0] = child(lo, l) | (child(hi, l) << 16);
+                    r[4 * l + 2] = (j * S) | (LREC_REAL << 16);
+                    r[4 * l + 3] = (j * S) | (LREC_NO_STORE << 16);
+                    ++l;
+                } else {
+                    // second node of the layer whose head is the slot before (two-node layers are placed in neighbouring slots)
+                    if (pos != 1 || l == 0 || !(w & NW_TWO) || (r[4 * (l - 1) + 2] & 0xFFFFu) != (j - 1) * S) { out = LayerRecords(); return; }
+                    const uint32_t k = l - 1;
+                    r[4 * k + 1] = child(lo, k) | (child(hi, k) << 16);
+                    r[4 * k + 2] |= LREC_TWO << 16;
+                    r[4 * k + 3] = (r[4 * k + 3] & 0xFFFFu) | ((j * S) << 16);
+                }
+            }
+            if (l != nl) { out = LayerRecords(); return; }
+        }
+    }
+    out.ok = true;
+}
+
 void set_layout_threads(unsigned n) { g_layout_threads.store(n, std::memory_order_relaxed); }
 void set_thread_layout_threads(unsigned n) { t_layout_threads = n; }
 

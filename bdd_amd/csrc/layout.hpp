@@ -267,6 +267,31 @@ struct StreamRecords {
 };
 void build_stream_records(const HostLayout& L, uint32_t real_size, StreamRecords& out);
 
+// ---- records of the streaming sweeps, third generation (kernels/narrow3.hpp: k_fwd_narrow3 / k_bwd_narrow3; round 5) ---------------------
+// A lane per LAYER instead of a lane per node.  Round 5's measurements (profiles/r05_hbm_only.txt) showed the streaming solve sweeps bound
+// by what a hop costs in issue slots and in bytes through the CU's vector-memory path (5 KB per wave and hop, 2 KB of them records),
+// not by HBM: with the hop's global loads AND stores removed a sweep still took 65 % of its time.  In packs whose layers have at most two
+// nodes a lane that owns a whole layer (its one or two nodes sit in neighbouring slots, layout.cpp: PackBuilder::place) does every
+// per-layer step once instead of once per node — arc costs, staged pair, the difference, the new costs, their store — needs no
+// cross-lane minimum, reads and writes {lo, hi} and the staged values at lane * size (contiguous, no offsets from a record), and one
+// 16-byte record per lane and hop instead of two:
+//   .x  node a: lo child | hi child << 16     byte offsets into a hop buffer of W + 128 values: a child's hop-local slot index * S; the
+//   .y  node b: lo child | hi child << 16     sinks are per-lane entries behind the slots, (W + 2 lane) S = TOP and (W + 2 lane + 1) S = BOT —
+//                                             constants 0 / +inf in the costs-from-terminal buffers, dummy push targets in the frontier
+//                                             buffers, so ONE offset serves the gather and the push (one-node layers / idle lanes: b -> BOT)
+//   .z  slot of node a (hop-local) * S | flags << 16     flags bit 0: the layer has two nodes (b = a + 1), bit 1: the lane has a layer
+//   .w  store offset of a's potential | b's << 16        slot * S inside the hop's slice, LREC_NO_STORE (past any slice: dropped) otherwise
+// 64 records per hop (dense), shared by the packs of a structure template.  Usable where every hop of every narrow pack has <= 64 layers of
+// <= 2 nodes, packs are 128 slots wide and none is staggered; everything else keeps the second / first generation.
+constexpr uint32_t LREC_NO_STORE = 0xFFF0u;
+constexpr uint32_t LREC_TWO = 1u, LREC_REAL = 2u;
+struct LayerRecords {
+    bool ok = false;
+    std::vector<uint32_t> rec;      // 4 words per record
+    std::vector<uint32_t> rec_off;  // [narrow packs] first record of the pack
+};
+void build_layer_records(const HostLayout& L, uint32_t real_size, LayerRecords& out);
+
 // A per-layer vector given as a linear combination of stored ones (the L-BFGS direction, lbfgs.hip: q = g + sum_k cy[order[k]] Y[order[k]]
 // + sum_k cs[order[k]] S[order[k]], accumulated in double in that order and rounded to REAL once): what the wrapper hands to
 // SolverBase::projection_means_lincomb so that the direction is formed inside the first pass of its projection instead of being written

@@ -17,6 +17,7 @@ struct SolverBase {
     hipStream_t stream = nullptr;
     std::string err;
     uint64_t n_vars = 0, n_bdds = 0, n_layers = 0, n_hops = 0, n_input_nodes = 0, n_slots = 0;
+    int solve_sweep_kind = 0;  // bddmma_solve_sweep_kind (include/bdd_mma.h): which kernels run the narrow packs' solve sweeps
     uint32_t pack_width = 0, wide_pack_width = 0, wide_slot_base = 0;
     uint64_t dev_bytes = 0;
     bool fwd_valid = false, bwd_valid = false;  // forward_state_valid_ / backward_state_valid_ (bdd_cuda_base.h:205-206)

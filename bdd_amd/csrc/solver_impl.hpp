@@ -143,6 +143,10 @@ struct SolverT final : SolverBase {
     const uint32_t* n2_hdr_pack() const { return res_hdr_ok ? d_pack_hdr : nullptr; }
     const uint32_t* n2_hdr_quad() const { return res_hdr_ok ? d_quad_hdr : nullptr; }
     uint32_t srec_words = 0;
+    // streaming solve sweeps, third generation: a lane per layer (kernels/narrow3.hpp: k_fwd_narrow3 / k_bwd_narrow3)
+    bool use_narrow3 = false;
+    uint32_t *d_lrec = nullptr, *d_lrec_off = nullptr;
+    uint32_t lrec_words = 0;
     uint32_t huge_pack_width = 0;
     unsigned char* d_huge_scratch = nullptr;  // frontier arrays of the huge packs (global memory instead of LDS)
 
@@ -491,6 +495,33 @@ struct SolverT final : SolverBase {
                 for (uint16_t r : L.narrow.hop_root) narrow_gen = narrow_gen || r != NO_ROOT;
             }
         }
+        // streaming solve sweeps, third generation (kernels/narrow3.hpp): a lane per LAYER — packs of 128 slots whose layers have <= 2 nodes and whose
+        // hops have <= 64 layers, started from the resident headers (one stage group per pack, one round per quad, no staggered packs), records
+        // shared like the second generation's.  At every size: what it saves — issue slots and bytes through the CU's vector-memory path — is what
+        // bounds the sweeps with or without the caches' help (profiles/r05_hbm_only.txt).  variant_flags bit 18: second / first generation instead.
+        if (nb_.n_packs && !use_res && !wb_.n_packs && !hb_.n_packs && !narrow_seg && res_hdr_ok && pack_width == 128 && (L.ex.waves_per_block == 4 || L.ex.waves_per_block == 8) &&
+            !(opts && (opts->variant_flags & 0x41000u))) {
+            LayerRecords LR;
+            build_layer_records(L, sizeof(REAL), LR);
+            const uint32_t n3_static = L.ex.waves_per_block * (4 * (128 + 128) * (uint32_t)sizeof(REAL) + 3 * 64 * 4);
+            const bool forced = opts && (opts->variant_flags & 0x2000u);
+            // ... and while the instance is small enough for the Infinity Cache to matter (same-box A/B against what the rules chose before,
+            // tools/ab_n3.sh, it/s float / double: 4.2 M nodes 16 150 / 11 660 against 15 380 / 10 770; 10.5 M 8 850 / 4 390 against 8 530 /
+            // 4 290; 21 M 3 480 / 1 838 against 3 555 / 1 879; 42 M 1 604 / 888 against 1 638 / 913): beyond, a shorter hop loop only
+            // lengthens the staging phase of the same waves (profiles/r05_hbm_only.txt) and the eight-pack first / second generation stay ahead
+            const bool shared = forced || (LR.rec.size() * sizeof(uint32_t) <= (uint64_t)L.narrow_slots * sizeof(REAL) / 2 && n_slots <= 16'000'000ull);
+            if (LR.ok && shared && stage_lds + n3_static <= lds_cu - 1024) {
+                if ((rc = upload(&d_lrec, LR.rec))) return rc;
+                if ((rc = upload(&d_lrec_off, LR.rec_off))) return rc;
+                lrec_words = (uint32_t)LR.rec.size();
+                use_narrow3 = true;
+#define SET_N3(W_)                                                                                                                              \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_narrow3<REAL, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds)); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_narrow3<REAL, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
+                if (L.ex.waves_per_block == 4) { SET_N3(4) } else { SET_N3(8) }
+#undef SET_N3
+            }
+        }
         if (wb_.n_packs) {
             // one workgroup per wide pack, thread t owns the nodes t + i * wide_threads of a hop (kernels.hpp: k_fwd_wide2)
             // two nodes of a hop per thread: half the wavefronts at the hop's two barriers and two independent chains per lane.  Wide-only
@@ -525,6 +556,8 @@ struct SolverT final : SolverBase {
                 mixed_lds = std::max(narrow_dyn, wide_lds);
             }
         }
+        solve_sweep_kind = !nb_.n_packs ? BDDMMA_SWEEPS_NONE : mixed ? BDDMMA_SWEEPS_MIXED : (use_res && use_res2) ? BDDMMA_SWEEPS_RESIDENT2 : use_res ? BDDMMA_SWEEPS_RESIDENT1
+                           : use_narrow3 ? BDDMMA_SWEEPS_STREAMING3 : use_narrow2 ? BDDMMA_SWEEPS_STREAMING2 : BDDMMA_SWEEPS_STREAMING1;
         HIPCHK(hipStreamSynchronize(stream));
         return BDDMMA_OK;
     }
@@ -615,6 +648,7 @@ struct SolverT final : SolverBase {
 #define LAUNCH_N(R_, W_)                                                                                                      \
     if (res && use_res2) hipLaunchKernelGGL((k_fwd_res2<REAL, W_>), grid, block, res2_lds, stream, rd.pack_hdr, rd.quad_hdr, res2_ns, res2_nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d_res2_rec, d_res2_rec_off, res2_n_words, d, pk, omega); \
     else if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
+    else if (MODE == FWD_SOLVE && use_narrow3 && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_fwd_narrow3<REAL, (W_ == 8 ? 8 : 4)>), grid, block, dyn, stream, d, pk, d_lrec, d_lrec_off, lrec_words, omega); \
     else if (MODE == FWD_SOLVE && use_narrow2 && narrow_gen) hipLaunchKernelGGL((k_fwd_narrow2<REAL, R_, W_, true>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (MODE == FWD_SOLVE && use_narrow2) hipLaunchKernelGGL((k_fwd_narrow2<REAL, R_, W_, false>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (two_node) hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_, MODE != FWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
@@ -688,6 +722,7 @@ struct SolverT final : SolverBase {
 #define LAUNCH_N(R_, W_)                                                                                                      \
     if (res && use_res2) hipLaunchKernelGGL((k_bwd_res2<REAL, W_>), grid, block, res2_lds, stream, rd.pack_hdr, rd.quad_hdr, res2_ns, res2_nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d_res2_rec, d_res2_rec_off, res2_n_words, d, pk, omega); \
     else if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
+    else if (MODE == BWD_SOLVE && use_narrow3 && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_bwd_narrow3<REAL, (W_ == 8 ? 8 : 4)>), grid, block, dyn, stream, d, pk, d_lrec, d_lrec_off, lrec_words, omega); \
     else if (MODE == BWD_SOLVE && use_narrow2 && narrow_gen) hipLaunchKernelGGL((k_bwd_narrow2<REAL, R_, W_, true>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (MODE == BWD_SOLVE && use_narrow2) hipLaunchKernelGGL((k_bwd_narrow2<REAL, R_, W_, false>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (two_node) hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_, MODE != BWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \

@@ -82,6 +82,12 @@ class bdd_hip_parallel_mma:
     def nr_bdd_nodes(self): return int(self._L.bddmma_nr_bdd_nodes(self._h))
     def nr_hops(self): return int(self._L.bddmma_nr_hops(self._h))
     def nr_packs(self): return int(self._L.bddmma_nr_packs(self._h))
+
+    SWEEP_KINDS = ("none", "mixed", "streaming1", "streaming2", "streaming3", "resident1", "resident2")
+
+    def solve_sweep_kind(self) -> str:
+        """which kernels run the narrow packs' solve sweeps (include/bdd_mma.h: BDDMMA_SWEEPS_*)"""
+        return self.SWEEP_KINDS[int(self._L.bddmma_solve_sweep_kind(self._h))]
     def device_bytes(self): return int(self._L.bddmma_device_bytes(self._h))
 
     def nr_bdds(self, var=None):

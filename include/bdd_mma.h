@@ -95,7 +95,10 @@ typedef struct bddmma_options {
                                   bit 14: staging transfers with 64-bit addresses (rule: arrays of 4 GiB and more)
                                   bit 15: the L-BFGS direction as its own pass (rule: wide packs present, or the projection by gathers)
                                   bit 17: `deterministic` exchanges by per-variable gathers, two launches (rule: bins that do not fit the
-                                          one-launch schedule k_exchange_seg; same sums, same order: bit-equal results) */
+                                          one-launch schedule k_exchange_seg; same sums, same order: bit-equal results)
+                                  bit 18: no third-generation streaming solve sweeps (a lane per layer; rule: packs of 128 slots with layers of
+                                          <= 2 nodes and <= 64 layers per hop that share their records, up to 16 M slots): the second / first
+                                          generation instead (bit 13 lifts the sharing and size conditions of the third generation too) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
                                   instance (NOTES.md section 6: the sweeps are bound by instructions issued, not by latency), kept for experiments */
@@ -141,6 +144,18 @@ uint64_t bddmma_nr_layers(const bddmma_solver* s);      /* non-terminal layers =
 uint64_t bddmma_nr_bdd_nodes(const bddmma_solver* s);   /* incl. 2 terminals per BDD, as the reference counts */
 uint64_t bddmma_nr_hops(const bddmma_solver* s);        /* length of the longest BDD */
 uint64_t bddmma_nr_packs(const bddmma_solver* s);
+/* Which kernels run the solve sweeps (forward_mm / backward_mm) of the narrow packs — chosen by rule at creation from the instance's shape and
+ * size; diagnostics for benchmarks and for the tests that must know which path they compare with the oracle. */
+enum {
+    BDDMMA_SWEEPS_NONE = 0,        /* no narrow packs (wide / huge packs only) */
+    BDDMMA_SWEEPS_MIXED = 1,       /* narrow and wide packs in one launch (k_fwd_mixed / k_bwd_mixed) */
+    BDDMMA_SWEEPS_STREAMING1 = 2,  /* streaming, node words (k_fwd_narrow / k_bwd_narrow) */
+    BDDMMA_SWEEPS_STREAMING2 = 3,  /* streaming, a 16-byte record per lane and hop (k_*_narrow2) */
+    BDDMMA_SWEEPS_STREAMING3 = 4,  /* streaming, a lane per layer (k_*_narrow3) */
+    BDDMMA_SWEEPS_RESIDENT1 = 5,   /* pack resident in LDS (k_*_res) */
+    BDDMMA_SWEEPS_RESIDENT2 = 6    /* pack resident in LDS, records (k_*_res2) */
+};
+int bddmma_solve_sweep_kind(const bddmma_solver* s);
 int bddmma_precision(const bddmma_solver* s);
 int bddmma_device(const bddmma_solver* s);
 /* nr_bdds(var): int32[nr_variables] (get_num_bdds_per_var, bdd_cuda_base.h:166) */
@@ -325,6 +340,9 @@ int bddmma_layout_copy(const bddmma_layout* l, int which, void* out);
 int bddmma_layout_res2_records(const bddmma_layout* l, int real_size, uint32_t* info, uint32_t* words, uint32_t* rec_off);
 /* The same for the records of the second-generation streaming sweeps (csrc/layout.hpp: StreamRecords): info[0] = usable, [1] = words. */
 int bddmma_layout_stream_records(const bddmma_layout* l, int real_size, uint32_t* info, uint32_t* words, uint32_t* rec_off);
+/* ... and the per-layer records of the third-generation streaming sweeps (csrc/layout.hpp: LayerRecords; 64 records of 4 words per hop):
+ * info[0] = usable (packs of 128 slots, layers of <= 2 nodes, <= 64 layers per hop, no staggered packs), [1] = number of 32-bit words. */
+int bddmma_layout_layer_records(const bddmma_layout* l, int real_size, uint32_t* info, uint32_t* words, uint32_t* rec_off);
 /* The schedule of the atomic-free exchange (csrc/layout.hpp: SegExchange) for workgroups of `threads` and values of real_size bytes:
  * info[0] = usable, [1] = 32-bit words of `bin` (4 per bin), [2] = 16-bit words of `perm`, [3] = 32-bit words of `thr` (2 per bin and
  * thread), [4] / [5] / [6] = entries / slots / groups of the largest bin.  The arrays may be NULL to query sizes. */

@@ -705,6 +705,75 @@ def test_full_size_wide_packs_only_vs_oracle():
     np.testing.assert_allclose(sd.lower_bound_per_bdd(), o.lower_bound_per_bdd(), rtol=1e-9, atol=1e-8)
 
 
+# ---------------------------------------------------------------- third-generation streaming sweeps: a lane per layer
+@pytest.mark.parametrize("precision", ["double", "float"])
+@pytest.mark.parametrize("wpb", [4, 8])
+@pytest.mark.parametrize("shape", ["cover10", "mixed_short"])
+def test_lane_per_layer_sweeps_vs_oracle_and_second_generation(precision, wpb, shape):
+    """k_fwd_narrow3 / k_bwd_narrow3 (kernels/narrow3.hpp) forced on small instances (streaming sweeps, records although the packs share
+    none): delta per pass and bound per iteration against the oracle; arc costs, deferred differences and bound bit for bit against the
+    second-generation kernels (same arithmetic in the same order); covering and simplex rows of 2-10 variables in one pack (one- and
+    two-node layers side by side, ragged pack ends)."""
+    rng = np.random.Generator(np.random.PCG64({"cover10": 5, "mixed_short": 6}[shape]))
+    col = BddCollection()
+    V = 500
+    if shape == "cover10":
+        for _ in range(1500):
+            col.add_covering(np.sort(rng.choice(V, size=10, replace=False)))
+    else:
+        for _ in range(1500):
+            k = int(rng.integers(2, 11))
+            (col.add_covering if rng.random() < 0.5 else col.add_simplex)(np.sort(rng.choice(V, size=k, replace=False)))
+    costs = rng.normal(0, 3, col.nr_variables()).round(3)
+    # (deterministic: the exchange adds in a fixed order, so that "bit for bit" is a statement about the sweeps)
+    opts = dict(precision=precision, pack_width=128, waves_per_block=wpb, resident_sweeps=1, deterministic=True)
+    s3 = bdd_hip_parallel_mma(col, costs, variant_flags=0x2000, **opts)
+    s2 = bdd_hip_parallel_mma(col, costs, variant_flags=0x2000 | 0x40000, **opts)
+    # (eight packs per workgroup in double: the second generation's LDS exceeds 64 KiB and the first takes over — same arithmetic again)
+    assert s3.solve_sweep_kind() == "streaming3" and s2.solve_sweep_kind() in ("streaming2", "streaming1")
+    o = Oracle(col, costs, precision)
+    assert close(s3.lower_bound(), o.lower_bound(), precision, 10)
+    V = s3.nr_variables()
+    d3, d2, do = (np.zeros(2 * V, s3.value_type) for _ in range(3))
+    tol = dict(rtol=1e-9, atol=1e-9) if precision == "double" else dict(rtol=1e-4, atol=5e-4)
+    for it in range(8):
+        s3.forward_mm(0.5, d3); s2.forward_mm(0.5, d2); o.forward_mm(0.5, do)
+        np.testing.assert_array_equal(d3, d2)
+        np.testing.assert_allclose(d3, do, **tol)
+        s3.backward_mm(0.5, d3); s2.backward_mm(0.5, d2); o.backward_mm(0.5, do)
+        np.testing.assert_array_equal(d3, d2)
+        np.testing.assert_allclose(d3, do, **tol)
+        assert s3.lower_bound() == s2.lower_bound()
+        assert close(s3.lower_bound(), o.lower_bound(), precision, 10)
+    for a, b in zip(s3.get_solver_costs(), s2.get_solver_costs()):
+        np.testing.assert_array_equal(a, b)
+    s3.iterations(5); s2.iterations(5)
+    assert s3.lower_bound() == s2.lower_bound()
+    np.testing.assert_array_equal(s3.lower_bound_per_bdd(), s2.lower_bound_per_bdd())
+    # ... and a fresh pair against the oracle's own iteration()
+    s = bdd_hip_parallel_mma(col, costs, variant_flags=0x2000, **opts)
+    o = Oracle(col, costs, precision)
+    for _ in range(6):
+        s.iteration(); o.iteration()
+        assert close(s.lower_bound(), o.lower_bound(), precision, 10)
+
+
+def test_lane_per_layer_sweeps_are_the_rule_where_they_apply():
+    """The automatic choice: a uniform family at a streaming size takes the third generation in both precisions; rows with layers wider than
+    two nodes, 64-slot packs and variant_flags bit 18 do not."""
+    col, costs = random_set_cover(200_000, 140_000, 8, seed=3)   # 2 188 packs of 128 slots (fewer than 2 048 packs: 64-slot packs)
+    for precision in ("float", "double"):
+        s = bdd_hip_parallel_mma(col, costs, precision=precision, resident_sweeps=1)
+        assert s.solve_sweep_kind() == "streaming3", s.solve_sweep_kind()
+        o = Oracle(col, costs, precision)
+        s.iterations(3)
+        for _ in range(3):
+            o.iteration()
+        assert close(s.lower_bound(), o.lower_bound(), precision, 10)
+    assert bdd_hip_parallel_mma(col, costs, resident_sweeps=1, variant_flags=0x40000).solve_sweep_kind() == "streaming2"
+    assert bdd_hip_parallel_mma(col, costs, resident_sweeps=1, pack_width=64).solve_sweep_kind() in ("streaming2", "streaming1")
+
+
 # ---------------------------------------------------------------- long BDDs: hop-window refills and several stage groups per pack
 @pytest.mark.parametrize("precision", ["double", "float"])
 @pytest.mark.parametrize("variant", [0, 0x2000])   # 0x2000: the second-generation streaming sweeps (per-lane records) although these packs share none
@@ -965,7 +1034,7 @@ def test_randomised_instances_and_layout_options_vs_oracle(seed):
     opts = dict(pack_width=pw, waves_per_block=wpb, stage_cap=max(cap, pw), vars_per_bin=int(rng.choice([0, 64, 256])),
                 wide_pack_width=int(rng.choice([0, 64, 128, 256])), keep_bdd_order=bool(rng.integers(0, 2)),
                 resident_sweeps=int(rng.choice([0, 1, 2])), exchange_by_variable=int(rng.choice([0, 0, 2])),
-                variant_flags=int(rng.choice([0, 0, 1, 2, 3])) | int(rng.choice([0, 0x800, 0x1000, 0x2000, 0x2000])) | int(rng.choice([0, 0, 0x4000]))   # 0x800 / 0x1000: first-generation resident / streaming sweeps, 0x2000: per-lane records also for unshared packs (general form), 0x4000: 64-bit staging addresses (arrays >= 4 GiB)
+                variant_flags=int(rng.choice([0, 0, 1, 2, 3])) | int(rng.choice([0, 0x800, 0x1000, 0x2000, 0x2000])) | int(rng.choice([0, 0, 0x4000])) | int(rng.choice([0, 0, 0x40000]))   # 0x800 / 0x1000: first-generation resident / streaming sweeps, 0x2000: per-lane records also for unshared packs (general form), 0x4000: 64-bit staging addresses (arrays >= 4 GiB)
                 | int(os.environ.get("BDDMMA_FUZZ_VARIANT_OR", "0")),  # the env: tools/soak.sh bisections
                 pack_fill=int(rng.choice([0, 0, pw // 2, 16])), pack_stagger=int(rng.choice([0, 1, 24, 60, 200])))
     s = bdd_hip_parallel_mma(col, costs, precision="double", **opts)

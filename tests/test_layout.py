@@ -589,6 +589,79 @@ def test_stream_records_restate_the_node_words(real_size, pack_width):
     assert ((r3[real, 3] >> 8) & 63).max() >= 3          # nodes at position >= 3 of their layer exist
 
 
+@pytest.mark.parametrize("real_size", [4, 8])
+def test_layer_records_restate_the_node_words(real_size):
+    """The records of the third-generation streaming sweeps (layout.hpp: LayerRecords): lane l of a hop owns the hop's l-th layer — its one or
+    two nodes (neighbouring slots), their children as offsets into a hop buffer with per-lane sink entries, the store offsets — against the
+    node words; and the shapes the builder must refuse."""
+    col = BddCollection()
+    rng = np.random.Generator(np.random.PCG64(23))
+    for _ in range(900):
+        k = int(rng.integers(2, 14))
+        vs = np.sort(rng.choice(600, size=k, replace=False))
+        (col.add_covering if rng.random() < 0.6 else col.add_simplex)(vs)
+    for _ in range(30):
+        col.add_simplex([int(rng.integers(0, 600))])
+    lay = Layout(col, pack_width=128)
+    info = np.zeros(5, np.uint32)
+    capi.check(lay.L.bddmma_layout_layer_records(lay.h, real_size, info.ctypes.data_as(C.c_void_p), None, None), None)
+    assert info[0] == 1
+    words, off = np.zeros(int(info[1]), np.uint32), np.zeros(lay.np_n, np.uint32)
+    capi.check(lay.L.bddmma_layout_layer_records(lay.h, real_size, info.ctypes.data_as(C.c_void_p), words.ctypes.data_as(C.c_void_p),
+                                                 off.ctypes.data_as(C.c_void_p)), None)
+    rec = words.reshape(-1, 4)
+    S, W = real_size, 128
+    N = lay.sets[0]
+    checked = two_node = 0
+    for p in range(lay.np_n):
+        q0, q1 = int(N["pack_hop_ptr"][p]), int(N["pack_hop_ptr"][p + 1])
+        s0 = int(N["hop_node_off"][q0])
+        for h in range(q1 - q0):
+            nb, ne = int(N["hop_node_off"][q0 + h]) - s0, int(N["hop_node_off"][q0 + h + 1]) - s0
+            nl = int(N["hop_layer_off"][q0 + h + 1]) - int(N["hop_layer_off"][q0 + h])
+            layers = []          # [(slot of the head, [words of the layer's nodes])] in slot order
+            for j in range(ne - nb):
+                w = int(lay.nwords[s0 + nb + j])
+                if w >> 31:
+                    continue
+                if (w >> 18) & 63 == 0:
+                    layers.append((j, [w]))
+                else:
+                    assert layers[-1][0] == j - 1 and len(layers[-1][1]) == 1      # second node: the slot behind its head
+                    layers[-1][1].append(w)
+            assert len(layers) == nl <= 64
+            for l in range(64):
+                r = [int(x) for x in rec[int(off[p]) + h * 64 + l]]
+                top, bot = (W + 2 * l) * S, (W + 2 * l + 1) * S
+                ch = lambda c: (c if c < W else W + 2 * l + (c - W)) * S
+                if l >= nl:
+                    assert r == [bot | bot << 16, bot | bot << 16, top, 0xFFF0 | 0xFFF0 << 16]
+                    continue
+                j, ws = layers[l]
+                a = ws[0]
+                assert r[0] == ch(a & 511) | ch((a >> 9) & 511) << 16
+                assert r[2] & 0xFFFF == j * S and r[2] >> 16 == (2 | (1 if len(ws) == 2 else 0))
+                if len(ws) == 2:
+                    b = ws[1]
+                    assert r[1] == ch(b & 511) | ch((b >> 9) & 511) << 16 and r[3] == (j * S) | ((j + 1) * S) << 16
+                    two_node += 1
+                else:
+                    assert r[1] == bot | bot << 16 and r[3] == (j * S) | 0xFFF0 << 16
+                checked += 1
+    assert checked > 3000 and two_node > 1000
+    # refused: other pack widths, layers wider than two nodes, staggered packs
+    for lay2 in (Layout(col, pack_width=64), Layout(col, pack_width=256)):
+        capi.check(lay2.L.bddmma_layout_layer_records(lay2.h, real_size, info.ctypes.data_as(C.c_void_p), None, None), None)
+        assert info[0] == 0
+    col3 = BddCollection()
+    for _ in range(40):
+        co = rng.integers(1, 9, size=9)
+        col3.add_linear(co, "<=", int(co.sum() // 2), np.sort(rng.choice(60, size=9, replace=False)))
+    for lay3 in (Layout(col3, pack_width=128), Layout(col3, pack_width=128, pack_stagger=24)):
+        capi.check(lay3.L.bddmma_layout_layer_records(lay3.h, real_size, info.ctypes.data_as(C.c_void_p), None, None), None)
+        assert info[0] == 0
+
+
 def seg_exchange(lay, threads, real_size):
     info = np.zeros(8, np.uint32)
     capi.check(lay.L.bddmma_layout_seg_exchange(lay.h, threads, real_size, info.ctypes.data_as(C.c_void_p), None, None, None), None)
