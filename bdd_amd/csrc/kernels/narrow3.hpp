@@ -18,8 +18,8 @@ namespace bddmma {
 // the same order as k_fwd_narrow2 / k_bwd_narrow2 (SURVEY.md §8 a'), bit-equal results.
 // Hop buffers in LDS: [0, W) the hop's slots, behind them per lane l the entries W + 2 l (TOP) and W + 2 l + 1 (BOT): constants 0 / +inf
 // in the costs-from-terminal buffers, dummy push targets in the frontier buffers.
-// Packs with one stage group and quads with one round (the resident headers, PackDev::hdr_pack), 128 slots, no staggered packs;
-// everything else: second / first generation (SolverT::use_narrow3).
+// Packs of 128 slots with <= 64 layers of <= 2 nodes per hop, none staggered; everything else: second / first generation
+// (SolverT::use_narrow3).  Stage groups, staging rounds and the start from the resident headers as in k_fwd_narrow2.
 constexpr int N3_W = 128;
 template <typename REAL>
 __device__ __forceinline__ void lds_ld2(REAL& a, REAL& b, const unsigned char* lds, uint32_t off)  // two neighbouring values (ds_read2_b32 / ds_read2_b64: 4- / 8-byte alignment)
@@ -60,19 +60,21 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
     BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
-    // one round trip: the pack's hop / slot / layer ranges and the quad's range of the staging tables (layout.hpp: struct Resident)
-    const uint32_t* const hp = pk.hdr_pack + 8 * (size_t)(has_pack ? p : 0);
-    const uint32_t q0 = has_pack ? hp[4] : 0;
-    const uint32_t q1 = has_pack ? q0 + (hp[5] & 0xFFFFu) : 0;
+    // resident headers (given when every pack has one stage group and every quad one round, see fwd_narrow2_body): the pack's hop / slot /
+    // layer ranges and the quad's range of the staging tables in one round trip
+    const bool hdr = pk.hdr_pack != nullptr;  // uniform
+    const uint32_t* const hp = hdr ? pk.hdr_pack + 8 * (size_t)(has_pack ? p : 0) : nullptr;
+    const uint32_t q0 = !has_pack ? 0 : (hdr ? hp[4] : pk.pack_hop_ptr[p]);
+    const uint32_t q1 = !has_pack ? 0 : (hdr ? q0 + (hp[5] & 0xFFFFu) : pk.pack_hop_ptr[p + 1]);
     const uint32_t rbase = has_pack ? lrec_off[p] : 0;
-    const uint32_t c0_h = pk.hdr_quad[4 * (size_t)quad], cnt = pk.hdr_quad[4 * (size_t)quad + 1];
+    const uint32_t c0_h = hdr ? pk.hdr_quad[4 * (size_t)quad] : 0, cnt_h = hdr ? pk.hdr_quad[4 * (size_t)quad + 1] : 0;
     BDDMMA_STAMP(p, 0);
     const REAL INF = inf_v<REAL>();
-    const uint32_t slot_first = has_pack ? hp[0] : 0, l0 = has_pack ? hp[2] : 0;
+    const uint32_t slot_first = !has_pack ? 0 : (hdr ? hp[0] : pk.hop_node_off[q0]), l0 = !has_pack ? 0 : (hdr ? hp[2] : pk.hop_layer_off[q0]);
     NarrowRs<REAL> rs(d);
     rs.rebase_layers(d, l0);
     uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt, tid);  // on their way while the pipeline is set up
+    if (hdr) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
     REAL* const Tp = d.T + slot_first;
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
@@ -128,9 +130,28 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
     }
     uint32_t cur = 0;
     uint32_t q = q0;
+    const uint32_t g0 = (has_pack && !hdr) ? pk.pack_group_ptr[p] : 0;
+    const uint32_t ng = !has_pack ? 0 : (hdr ? 1u : pk.pack_group_ptr[p + 1] - g0);
+    const uint32_t r0 = hdr ? 0 : pk.quad_round_ptr[quad];
+    const uint32_t n_rounds = hdr ? 1u : pk.quad_round_ptr[quad + 1] - r0;
     const uint32_t db = (uint32_t)wave * pk.stage_cap * (uint32_t)sizeof(P2);  // this wave's slots of the staging area
-    stage_load_pairs<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
-    const uint32_t qe = has_pack ? q1 : q;
+    for (uint32_t k = 0; k < n_rounds; ++k) {
+    uint32_t gl0 = 0, cnt = 0, qe = q1;
+    if (hdr) {
+        cnt = cnt_h;
+        stage_load_pairs<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
+        qe = has_pack ? q1 : q;  // one group: the whole pack
+    } else {
+        const uint32_t c0 = pk.cs_ptr[r0 + k];
+        cnt = pk.cs_ptr[r0 + k + 1] - c0;
+        stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
+        if (k < ng) {
+            gl0 = pk.grp_layer_off[g0 + k] - l0;
+            qe = pk.grp_hop_end[g0 + k];
+        } else {
+            qe = q;  // this pack has no k-th group: no hops in this round
+        }
+    }
     if (WPB > 1) __syncthreads(); else wave_sync();
     BDDMMA_STAMP(p, 1);
     auto hop = [&]() {
@@ -138,7 +159,7 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
         const uint32_t nb = o[0];
         const uint32_t n3 = o[3] - o[2];  // slots of hop q+2
         const uint32_t fc = cur * BUF, fn = (cur ^ 1u) * BUF;
-        const uint32_t stg = db + (lb[0] + (uint32_t)lane) * (uint32_t)sizeof(P2);  // the lane's layer inside the wave's staging slots
+        const uint32_t stg = db + (lb[0] - gl0 + (uint32_t)lane) * (uint32_t)sizeof(P2);  // the lane's layer inside the wave's staging slots
         // ---- global prefetch: record of hop q+2D, T of hop q+D+2, arc costs of hop q+D
         rc[2 * D] = ldrec(q - q0 + 2 * D);
 #ifndef BDDMMA_EXP_NO_HOP_LOADS
@@ -217,8 +238,10 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
     BDDMMA_STAMP(p, 3);
     if (WPB > 1) __syncthreads(); else wave_sync();
     BDDMMA_STAMP(p, 2);
-    stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);  // min-marginal differences -> entry array
+    stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);  // min-marginal differences of the round -> entry array
     BDDMMA_STAMP(p, 4);
+    if (WPB > 1 && k + 1 < n_rounds) __syncthreads();    // the next round overwrites the staging area
+    }
 }
 
 #ifndef BDDMMA_N3_WAVES
@@ -252,18 +275,19 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
     BDDMMA_EXIT_IF(quad >= n_quads, d)
     const uint32_t p = quad * WPB + wave;
     const bool has_pack = p < pk.n_packs;
-    const uint32_t* const hp = pk.hdr_pack + 8 * (size_t)(has_pack ? p : 0);
-    const uint32_t q0 = has_pack ? hp[4] : 0;
-    const uint32_t q1 = has_pack ? q0 + (hp[5] & 0xFFFFu) : 0;
+    const bool hdr = pk.hdr_pack != nullptr;  // uniform: resident headers, see fwd_narrow3_body
+    const uint32_t* const hp = hdr ? pk.hdr_pack + 8 * (size_t)(has_pack ? p : 0) : nullptr;
+    const uint32_t q0 = !has_pack ? 0 : (hdr ? hp[4] : pk.pack_hop_ptr[p]);
+    const uint32_t q1 = !has_pack ? 0 : (hdr ? q0 + (hp[5] & 0xFFFFu) : pk.pack_hop_ptr[p + 1]);
     const uint32_t rbase = has_pack ? lrec_off[p] : 0;
-    const uint32_t c0_h = pk.hdr_quad[4 * (size_t)quad], cnt = pk.hdr_quad[4 * (size_t)quad + 1];
+    const uint32_t c0_h = hdr ? pk.hdr_quad[4 * (size_t)quad] : 0, cnt_h = hdr ? pk.hdr_quad[4 * (size_t)quad + 1] : 0;
     BDDMMA_STAMP(p, 0);
     const REAL INF = inf_v<REAL>();
-    const uint32_t slot_first = has_pack ? hp[0] : 0, l0 = has_pack ? hp[2] : 0;
+    const uint32_t slot_first = !has_pack ? 0 : (hdr ? hp[0] : pk.hop_node_off[q0]), l0 = !has_pack ? 0 : (hdr ? hp[2] : pk.hop_layer_off[q0]);
     NarrowRs<REAL> rs(d);
     rs.rebase_layers(d, l0);
     uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt, tid);
+    if (hdr) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);
     REAL* const Tp = d.T + slot_first;
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
@@ -316,11 +340,28 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
         for (int i = 0; i < 2 * D; ++i) rc[i] = u4v{0u, 0u, 0u, 0u};
     }
     uint32_t cur = 0;
-    P2* sDw = sD + (size_t)wave * pk.stage_cap;
-    (void)sDw;
+    const uint32_t g0 = (has_pack && !hdr) ? pk.pack_group_ptr[p] : 0;
+    const uint32_t ng = !has_pack ? 0 : (hdr ? 1u : pk.pack_group_ptr[p + 1] - g0);
+    const uint32_t r0 = hdr ? 0 : pk.quad_round_ptr[quad];
+    const uint32_t n_rounds = hdr ? 1u : pk.quad_round_ptr[quad + 1] - r0;
     const uint32_t db = (uint32_t)wave * pk.stage_cap * (uint32_t)sizeof(P2);
-    stage_load_pairs<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
-    const uint32_t qs = has_pack ? q0 : q;
+    for (uint32_t k = n_rounds; k-- > 0;) {  // same rounds as the forward sweep, in reverse
+    uint32_t gl0 = 0, cnt = 0, qs = q0;
+    if (hdr) {
+        cnt = cnt_h;
+        stage_load_pairs<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
+        qs = has_pack ? q0 : q;  // one group: the whole pack
+    } else {
+        const uint32_t c0 = pk.cs_ptr[r0 + k];
+        cnt = pk.cs_ptr[r0 + k + 1] - c0;
+        stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
+        if (k < ng) {
+            gl0 = pk.grp_layer_off[g0 + k] - l0;
+            qs = (k == 0) ? q0 : pk.grp_hop_end[g0 + k - 1];
+        } else {
+            qs = q;  // no k-th group in this pack
+        }
+    }
     if (WPB > 1) __syncthreads(); else wave_sync();
     BDDMMA_STAMP(p, 1);
     auto hop = [&]() {
@@ -328,7 +369,7 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
         if (q < hw.base + 2 * D + 1 && hw.base > q0) hw.fill(pk, q + 1 > q0 + HOP_WIN ? q + 1 - HOP_WIN : q0, lane);
         const uint32_t nb = o[1];
         const uint32_t tc = cur * BUF, tn = (cur ^ 1u) * BUF;
-        const uint32_t stg = db + (lb[1] + (uint32_t)lane) * (uint32_t)sizeof(P2);  // hop q starts at layer lb[1]
+        const uint32_t stg = db + (lb[1] - gl0 + (uint32_t)lane) * (uint32_t)sizeof(P2);  // hop q starts at layer lb[1]
         // ---- prefetch: record of hop q-2D, costs-from-root and arc costs of hop q-D
         rc[2 * D] = ldrec(q >= q0 + 2 * D ? q - 2 * D : q0);
 #ifndef BDDMMA_EXP_NO_HOP_LOADS
@@ -403,6 +444,8 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
     BDDMMA_STAMP(p, 2);
     stage_flush<REAL, WPB>(sD, ent, esl, rs, cnt, tid);
     BDDMMA_STAMP(p, 4);
+    if (WPB > 1 && k > 0) __syncthreads();
+    }
     if (!has_pack) return;
     // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251); every slot of the first hop is a root
     const uint32_t n0 = nb_of(q0 + 1) - nb_of(q0);

@@ -496,10 +496,9 @@ struct SolverT final : SolverBase {
             }
         }
         // streaming solve sweeps, third generation (kernels/narrow3.hpp): a lane per LAYER — packs of 128 slots whose layers have <= 2 nodes and whose
-        // hops have <= 64 layers, started from the resident headers (one stage group per pack, one round per quad, no staggered packs), records
-        // shared like the second generation's.  At every size: what it saves — issue slots and bytes through the CU's vector-memory path — is what
+        // hops have <= 64 layers, no staggered packs, records shared like the second generation's.  At every size: what it saves — issue slots and bytes through the CU's vector-memory path — is what
         // bounds the sweeps with or without the caches' help (profiles/r05_hbm_only.txt).  variant_flags bit 18: second / first generation instead.
-        if (nb_.n_packs && !use_res && !wb_.n_packs && !hb_.n_packs && !narrow_seg && res_hdr_ok && pack_width == 128 && (L.ex.waves_per_block == 4 || L.ex.waves_per_block == 8) &&
+        if (nb_.n_packs && !use_res && !wb_.n_packs && !hb_.n_packs && !narrow_seg && pack_width == 128 && (L.ex.waves_per_block == 4 || L.ex.waves_per_block == 8) &&
             !(opts && (opts->variant_flags & 0x41000u))) {
             LayerRecords LR;
             build_layer_records(L, sizeof(REAL), LR);

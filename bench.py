@@ -196,6 +196,7 @@ def main():
         triad_gbs = 3 * (1 << 30) / (solver.time_kernel(6, 20) * 1e-3) / 1e9
         copy_gbs = 2 * (1 << 30) / (solver.time_kernel(7, 20) * 1e-3) / 1e9
     packs, hops, resident = solver.nr_packs(), solver.nr_hops(), solver.device_bytes()
+    sweep_kind = solver.solve_sweep_kind()
     solver.close()
     lbfgs = None
     if rank == 0 and not args.no_lbfgs:
@@ -225,6 +226,7 @@ def main():
                 "pack_width": args.pack_width or "auto (128; 64 when fewer than 2048 packs)",
                 "waves_per_block": args.wpb or "auto",
                 "packs": packs,
+                "solve_sweeps": sweep_kind,   # include/bdd_mma.h: BDDMMA_SWEEPS_* (streaming3 = a lane per layer, kernels/narrow3.hpp)
                 "hops": hops,
                 "delta_exchange": "per-variable gather (deterministic)" if args.deterministic else "binned exchange, LDS accumulators",
                 "hbm_resident_bytes": resident,
@@ -398,9 +400,13 @@ def measured_traffic(kernel, args, sfx):
         want = "k_fwd_narrow" if kernel == "forward_mm" else "k_bwd_narrow"
         real = "float" if sfx == "f32" else "double"   # one profile holds both precisions: the default bench run times both
         sweep = None
-        for name, v in d.items():   # second-generation streaming solve sweeps: <REAL, R, waves per block, GEN>
-            if isinstance(v, dict) and re.search(want + "2<" + real + r", \d+, \d+, \w+>", name):
+        for name, v in d.items():   # third-generation streaming solve sweeps (a lane per layer): <REAL, waves per block>
+            if isinstance(v, dict) and re.search(want + "3<" + real + r", \d+>", name):
                 sweep = v["hbm_bytes"]
+        if sweep is None:
+            for name, v in d.items():   # second generation: <REAL, R, waves per block, GEN>
+                if isinstance(v, dict) and re.search(want + "2<" + real + r", \d+, \d+, \w+>", name):
+                    sweep = v["hbm_bytes"]
         if sweep is None:
             for name, v in d.items():
                 m = re.search(want + "<" + real + r", \d+, (\d+), \d+(?:, \w+)?>", name)   # <REAL, R, MODE, waves per block[, SEG]>; MODE 1 = solve

@@ -708,21 +708,26 @@ def test_full_size_wide_packs_only_vs_oracle():
 # ---------------------------------------------------------------- third-generation streaming sweeps: a lane per layer
 @pytest.mark.parametrize("precision", ["double", "float"])
 @pytest.mark.parametrize("wpb", [4, 8])
-@pytest.mark.parametrize("shape", ["cover10", "mixed_short"])
+@pytest.mark.parametrize("shape", ["cover10", "mixed_short", "long"])
 def test_lane_per_layer_sweeps_vs_oracle_and_second_generation(precision, wpb, shape):
     """k_fwd_narrow3 / k_bwd_narrow3 (kernels/narrow3.hpp) forced on small instances (streaming sweeps, records although the packs share
     none): delta per pass and bound per iteration against the oracle; arc costs, deferred differences and bound bit for bit against the
     second-generation kernels (same arithmetic in the same order); covering and simplex rows of 2-10 variables in one pack (one- and
-    two-node layers side by side, ragged pack ends)."""
-    rng = np.random.Generator(np.random.PCG64({"cover10": 5, "mixed_short": 6}[shape]))
+    two-node layers side by side, ragged pack ends); packs of 70-150 hops (several stage groups per pack, staging rounds, hop-window
+    refills, no resident headers)."""
+    rng = np.random.Generator(np.random.PCG64({"cover10": 5, "mixed_short": 6, "long": 7}[shape]))
     col = BddCollection()
     V = 500
     if shape == "cover10":
         for _ in range(1500):
             col.add_covering(np.sort(rng.choice(V, size=10, replace=False)))
-    else:
+    elif shape == "mixed_short":
         for _ in range(1500):
             k = int(rng.integers(2, 11))
+            (col.add_covering if rng.random() < 0.5 else col.add_simplex)(np.sort(rng.choice(V, size=k, replace=False)))
+    else:
+        for _ in range(300):
+            k = int(rng.integers(70, 150))
             (col.add_covering if rng.random() < 0.5 else col.add_simplex)(np.sort(rng.choice(V, size=k, replace=False)))
     costs = rng.normal(0, 3, col.nr_variables()).round(3)
     # (deterministic: the exchange adds in a fixed order, so that "bit for bit" is a statement about the sweeps)
