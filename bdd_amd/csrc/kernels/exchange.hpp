@@ -91,7 +91,8 @@ __device__ __forceinline__ void run_ctl_step(const RunStep& r)
 template <typename REAL>
 __device__ __forceinline__ void lds_add(REAL* p, REAL v)
 {
-#ifdef BDDMMA_EXP_INT_ATOMIC  // timing experiment only (wrong results): the rate of the integer LDS atomic of the same width
+#ifdef BDDMMA_EXP_INT_ATOMIC  // timing experiment only (wrong results).  NOT the rate of integer atomics, as rounds 4-5 first read it: the garbage sums make
+    // every cost NaN, the sweeps then defer 0 everywhere and the exchange skips ALL its atomics — it times the exchange without accumulation (tools/exp_r05_j.sh)
     using U = typename std::conditional<sizeof(REAL) == 8, unsigned long long, unsigned int>::type;
     __hip_atomic_fetch_add(reinterpret_cast<U*>(p), __builtin_bit_cast(U, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
