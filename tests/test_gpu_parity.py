@@ -763,6 +763,54 @@ def test_lane_per_layer_sweeps_vs_oracle_and_second_generation(precision, wpb, s
         assert close(s.lower_bound(), o.lower_bound(), precision, 10)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_lane_per_layer_sweeps_fuzz(seed):
+    """Differential fuzz aimed at the third-generation sweeps (the general fuzz below rarely meets their conditions): covering / simplex /
+    at-most-one rows of 2-24 variables (packs with one and with several stage groups), random options that keep them selected — packs per
+    workgroup, bin size, BDD order, deterministic exchange, 64-bit staging addresses — both precisions against the oracle: bound per
+    iteration, min-marginals, the L-BFGS view of the backward sweep (net_solver_costs) and a primal from the argmin paths."""
+    rng = np.random.Generator(np.random.PCG64(5000 + seed))
+    V = int(rng.integers(40, 400))
+    kmax = int(rng.choice([6, 10, 24]))
+    col = BddCollection()
+    for _ in range(int(rng.integers(300, 1500))):
+        k = int(rng.integers(2, min(V, kmax) + 1))
+        vs = np.sort(rng.choice(V, size=k, replace=False))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            col.add_covering(vs)
+        elif kind == 1:
+            col.add_simplex(vs)
+        else:
+            col.add_linear(np.ones(k, int), "<=", 1, vs)
+    costs = rng.normal(0, 4, col.nr_variables()).round(3)
+    opts = dict(pack_width=128, waves_per_block=int(rng.choice([4, 8])), resident_sweeps=1, vars_per_bin=int(rng.choice([0, 64, 256])),
+                keep_bdd_order=bool(rng.integers(0, 2)), deterministic=bool(rng.integers(0, 2)),
+                variant_flags=0x2000 | int(rng.choice([0, 0x4000])))
+    for precision in ("double", "float"):
+        s = bdd_hip_parallel_mma(col, costs, precision=precision, **opts)
+        assert s.solve_sweep_kind() == "streaming3", (opts, s.solve_sweep_kind())
+        o = Oracle(col, costs, precision)
+        n_it = int(rng.integers(3, 25))
+        for _ in range(n_it):
+            s.iteration(); o.iteration()
+            assert close(s.lower_bound(), o.lower_bound(), precision, 10), (opts, precision)
+        perm = oracle_layer_perm(s, o)
+        _, mm0, mm1 = s.min_marginals_cuda(get_sorted=False)
+        omm = o.min_marginals()
+        tol = dict(rtol=1e-9, atol=1e-8) if precision == "double" else dict(rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(mm0[perm], omm[:, 0], err_msg=str(opts), **tol)
+        np.testing.assert_allclose(mm1[perm], omm[:, 1], err_msg=str(opts), **tol)
+        lo, hi, mm = s.get_solver_costs()
+        np.testing.assert_allclose(s.net_solver_costs(), (hi - lo) + mm, rtol=0, atol=1e-12 if precision == "double" else 1e-5)
+        sol = s.bdds_solution_vec()
+        bdd, v = s.get_bdd_index(), s.get_primal_variable_index()
+        for b in range(min(5, col.nr_bdds())):
+            m = bdd == b
+            x = np.zeros(col.nr_variables()); x[v[m]] = sol[m]
+            assert col.evaluate(b, x)
+
+
 def test_lane_per_layer_sweeps_are_the_rule_where_they_apply():
     """The automatic choice: a uniform family at a streaming size takes the third generation in both precisions; rows with layers wider than
     two nodes, 64-slot packs and variant_flags bit 18 do not."""
