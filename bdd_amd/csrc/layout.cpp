@@ -422,7 +422,31 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         for (size_t k = 0; k < order_n.size(); ++k) cls_of[k] = cls.emplace(bdd_shape[order_n[k]], (uint32_t)cls.size()).first->second;
         std::vector<uint32_t> idx(order_n.size());
         for (size_t k = 0; k < idx.size(); ++k) idx[k] = (uint32_t)k;
-        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cls_of[a] < cls_of[b]; });
+        // Diamond-shaped BDDs of small classes (general linear rows: every shape its own class) are chained into staggered packs below;
+        // neighbours of similar peak width chain at shorter offsets than neighbours in input order — 4 000 / 40 000 knapsack rows of 14
+        // variables: lane utilisation 0.57 -> 0.60 with at most 42 hops per pack (a window of 16-64 candidates per placement or several
+        // open packs give no more: 0.60-0.61; the chain itself ends at ~0.68).  Widest first, and all of them before the other classes:
+        // their chained packs are the longest of the launch and must not start last (behind 250 000 covering rows: 5 640 -> 5 060 it/s);
+        // classes stay together (same shape = same peak).
+        std::vector<uint32_t> cls_size(cls.size(), 0);
+        for (uint32_t c : cls_of) ++cls_size[c];
+        std::vector<uint32_t> peak_key(order_n.size(), 0);  // 0: keep the class order
+        if (!(opts && opts->keep_bdd_order == 2))
+            for (size_t k = 0; k < order_n.size(); ++k) {
+                const uint32_t b = order_n[k];
+                const uint64_t nodes = (delims[b + 1] - delims[b]) - 2, nl = bdd_lay_ptr[b + 1] - bdd_lay_ptr[b];
+                const bool diamond = bdd_maxw[b] >= 4 && nodes * 10 <= (uint64_t)bdd_maxw[b] * nl * 6;  // = PackBuilder::chainable
+                if (diamond && cls_size[cls_of[k]] < 256) peak_key[k] = bdd_maxw[b];
+            }
+        // ... and the other classes longest BDDs first (the blocks of a launch start in pack order: long packs must not start last)
+        std::vector<uint32_t> len_key(order_n.size(), 0);
+        if (!(opts && opts->keep_bdd_order == 2))
+            for (size_t k = 0; k < order_n.size(); ++k) len_key[k] = bdd_lay_ptr[order_n[k] + 1] - bdd_lay_ptr[order_n[k]];
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+            if (peak_key[a] != peak_key[b]) return peak_key[a] > peak_key[b];
+            if (len_key[a] != len_key[b]) return len_key[a] > len_key[b];
+            return cls_of[a] < cls_of[b];
+        });
         std::vector<uint32_t> grouped(order_n.size());
         order_cls.resize(order_n.size());
         for (size_t k = 0; k < idx.size(); ++k) {
@@ -619,6 +643,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
             }
         }
     }
+    // (chained wide packs in the same order — widest first — save 0.6 % of their hops and were measured 1-3 % slower: input order stays)
     form(pw, order_w);
     form(ph, order_h);
 

@@ -49,7 +49,7 @@ class bdd_hip_parallel_mma:
         instr = np.ascontiguousarray(bdd_col.instr, dtype=np.uint64)
         delims = np.ascontiguousarray(bdd_col.delims, dtype=np.uint64)
         opts = capi.Options(pack_width, wide_pack_width, 1 if deterministic else 0, vars_per_bin, stage_cap, waves_per_block)
-        opts.keep_bdd_order = 1 if keep_bdd_order else 0   # default: BDDs of equal shape are packed together
+        opts.keep_bdd_order = int(keep_bdd_order)   # 0 (default): BDDs of equal shape are packed together; 1: input order; 2: include/bdd_mma.h
         opts.resident_sweeps = int(resident_sweeps)         # 0 automatic, 1 off, 2 on
         opts.exchange_by_variable = int(exchange_by_variable)             # 2: entries by (variable, bdd)
         opts.pack_fill = int(pack_fill)

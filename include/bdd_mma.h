@@ -74,7 +74,8 @@ typedef struct bddmma_options {
     uint32_t vars_per_bin;     /* variables per exchange bin, <= 9728 (16 B of LDS accumulators each); default: ~V/256 rounded, 1024..9728 */
     uint32_t stage_cap;        /* max layers of one stage group of a narrow pack (default 640) */
     uint32_t waves_per_block;  /* narrow packs swept by one workgroup with cooperative staging: 1, 2, 4 or 8 (default 4) */
-    uint32_t keep_bdd_order;   /* 1: keep the input order of the BDDs when forming packs (default: BDDs of equal shape are grouped) */
+    uint32_t keep_bdd_order;   /* 1: keep the input order of the BDDs when forming packs (default: BDDs of equal shape are grouped, diamond-shaped
+                                  BDDs of small shape classes — general linear rows — follow widest first; 2: grouped by shape only) */
     uint32_t resident_sweeps;  /* narrow packs copied to LDS up front and swept from there: 0 automatic (when every workgroup of a sweep can
                                   be in flight at once: small / medium instances), 1 off, 2 on whenever the packs fit */
     uint32_t exchange_by_variable;  /* 2: entry arrays ordered by (variable, bdd) — the per-variable delta reduction becomes one thread

@@ -29,6 +29,7 @@ ap.add_argument("--wpb", type=int, default=0)
 ap.add_argument("--vars-per-bin", type=int, default=0)
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--stagger", type=int, default=0, help="bddmma_options.pack_stagger: 0 auto, 1 off, N: most hops of a narrow pack")
+ap.add_argument("--keep-order", type=int, default=0, dest="keep", help="bddmma_options.keep_bdd_order (2: the pack order before round 5)")
 a = ap.parse_args()
 V = a.vars or 5 * a.rows
 rng = np.random.Generator(np.random.PCG64(1))
@@ -52,6 +53,7 @@ Lh = capi.lib()
 h = C.c_void_p()
 opts = capi.Options(a.pack_width, a.wpw, 0, a.vars_per_bin, 0, a.wpb)
 opts.pack_stagger = a.stagger
+opts.keep_bdd_order = a.keep
 capi.check(Lh.bddmma_layout_create(C.byref(h), np.ascontiguousarray(col.instr).ctypes.data_as(C.c_void_p), np.ascontiguousarray(col.delims).ctypes.data_as(C.c_void_p),
                                    col.nr_bdds(), C.byref(opts)), None)
 sz = lambda w: int(Lh.bddmma_layout_size(h, w))
@@ -60,7 +62,7 @@ print(f"layout: {sz(3)} narrow packs of width {sz(16)} over {sz(7)} (pack, hop) 
 Lh.bddmma_layout_destroy(h)
 for prec in a.precision.split(","):
     R = 4 if prec == "float" else 8
-    s = bdd_hip_parallel_mma(col, costs, precision=prec, pack_width=a.pack_width, wide_pack_width=a.wpw, variant_flags=a.variant, resident_sweeps=a.res, waves_per_block=a.wpb, vars_per_bin=a.vars_per_bin, pack_stagger=a.stagger)
+    s = bdd_hip_parallel_mma(col, costs, precision=prec, pack_width=a.pack_width, wide_pack_width=a.wpw, variant_flags=a.variant, resident_sweeps=a.res, waves_per_block=a.wpb, vars_per_bin=a.vars_per_bin, pack_stagger=a.stagger, keep_bdd_order=a.keep)
     L, Vs = s.nr_layers(), s.nr_variables()
     b_iter = 2 * (12 * Nt + 2 * R * N + (5 * R + 4) * L + (8 * R + 4) * Vs)
     s.iterations(5)
