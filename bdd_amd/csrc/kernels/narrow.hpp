@@ -451,8 +451,12 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     }
 }
 
+// register budget of the float solve sweeps of 64-slot packs (general linear rows without wide packs): as the mixed kernels', wide.hpp
+#ifndef BDDMMA_N1_WAVES
+#define BDDMMA_N1_WAVES(REAL, R, MODE) ((MODE) == 1 && (R) == 1 && sizeof(REAL) == 4 ? 6 : 1)
+#endif
 template <typename REAL, int R, int MODE, int WPB, bool SEG = true>
-__global__ void __launch_bounds__(64 * WPB) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N1_WAVES(REAL, R, MODE)))) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
 {
     fwd_narrow_body<REAL, R, MODE, WPB, BDDMMA_LOOKAHEAD, SEG>(d, pk, omega, blockIdx.x);
 }
@@ -692,7 +696,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
 }
 
 template <typename REAL, int R, int MODE, int WPB, bool SEG = true>
-__global__ void __launch_bounds__(64 * WPB) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N1_WAVES(REAL, R, MODE)))) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
 {
     bwd_narrow_body<REAL, R, MODE, WPB, BDDMMA_LOOKAHEAD, SEG>(d, pk, omega, blockIdx.x);
 }

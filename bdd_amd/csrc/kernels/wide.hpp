@@ -671,15 +671,23 @@ __global__ void __launch_bounds__(1024) k_bwd_wide2(DevPtrs<REAL> d, PackDev pk,
 // (the narrow part stays first generation: instances with wide packs are general linear rows, whose BDDs share no structure templates, and
 // per-lane records that are not shared cost four times the node words' bytes — 40 000 knapsack rows, 10 M nodes: sweeps 73 / 73 us with
 // node words, 91 / 110 us with records, profiles/r04_widebench.txt)
+// Register cap of the mixed kernels (round 5; tools/exp_r05_q.sh, same-box A/B, it/s float): uncapped they hold 101-106 VGPRs = 4 waves per
+// SIMD; 96 (5 waves, no spills with 64-slot packs, 2 with 128-slot ones) and 80 (6 waves, 2-5 spills, 64-slot packs only) give 40 000
+// knapsack rows 6 580 -> 6 860 / 6 890, 30 000 + 100 000 covering rows 6 910 -> 7 210 / 7 590, 4 000 rows 17 650 -> 20 170 / 20 170;
+// 72 registers spill 15, 64 spill 70.  Double loses with every cap (40 000 rows 4 360 -> 4 110 / 2 890) and stays uncapped, as do
+// the kernels with four nodes of a wide hop per thread (149 VGPRs).
+#ifndef BDDMMA_MIXED_WAVES
+#define BDDMMA_MIXED_WAVES(REAL, R, NPT) ((NPT) == 4 ? 3 : sizeof(REAL) == 4 ? ((R) == 1 ? 6 : 5) : 4)
+#endif
 template <typename REAL, int R, int WPB, int NPT>
-__global__ void __launch_bounds__(64 * WPB) k_fwd_mixed(DevPtrs<REAL> d, PackDev pkn, PackDev pkw, REAL omega, uint32_t ww)
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_MIXED_WAVES(REAL, R, NPT)))) k_fwd_mixed(DevPtrs<REAL> d, PackDev pkn, PackDev pkw, REAL omega, uint32_t ww)
 {
     const uint32_t nw8 = (pkw.n_packs + 7u) & ~7u;  // a multiple of 8, so that the narrow workgroups keep their XCD-aware block -> pack map
     if (blockIdx.x < nw8) fwd_wide2_body<REAL, FWD_SOLVE, NPT>(d, pkw, omega, ww, blockIdx.x);
     else fwd_narrow_body<REAL, R, FWD_SOLVE, WPB>(d, pkn, omega, blockIdx.x - nw8);
 }
 template <typename REAL, int R, int WPB, int NPT>
-__global__ void __launch_bounds__(64 * WPB) k_bwd_mixed(DevPtrs<REAL> d, PackDev pkn, PackDev pkw, REAL omega, uint32_t ww)
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_MIXED_WAVES(REAL, R, NPT)))) k_bwd_mixed(DevPtrs<REAL> d, PackDev pkn, PackDev pkw, REAL omega, uint32_t ww)
 {
     const uint32_t nw8 = (pkw.n_packs + 7u) & ~7u;
     if (blockIdx.x < nw8) bwd_wide2_body<REAL, BWD_SOLVE, NPT>(d, pkw, omega, ww, blockIdx.x);
