@@ -477,8 +477,14 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
     }
 }
 
+// Register budget of the wide sweeps: 4 waves per SIMD = what a 1024-thread workgroup implies (the solve sweeps with two nodes per thread
+// hold 80 / 75 VGPRs = 6 waves).  Measured and not kept (tools/exp_r05_s.sh, 25 000 rows of 18 variables, float): 72 VGPRs (7 waves, 3-4
+// spills) 2 890 -> 2 550 it/s, 64 (8 waves, 14-17 spills) 1 420.
+#ifndef BDDMMA_WIDE2_WAVES
+#define BDDMMA_WIDE2_WAVES(REAL, MODE, NPT) 4
+#endif
 template <typename REAL, int MODE, int NPT>
-__global__ void __launch_bounds__(1024) k_fwd_wide2(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(BDDMMA_WIDE2_WAVES(REAL, MODE, NPT)))) k_fwd_wide2(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
 {
     fwd_wide2_body<REAL, MODE, NPT>(d, pk, omega, ww, blockIdx.x);
 }
@@ -658,7 +664,7 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
 }
 
 template <typename REAL, int MODE, int NPT>
-__global__ void __launch_bounds__(1024) k_bwd_wide2(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(BDDMMA_WIDE2_WAVES(REAL, MODE, NPT)))) k_bwd_wide2(DevPtrs<REAL> d, PackDev pk, REAL omega, uint32_t ww)
 {
     bwd_wide2_body<REAL, MODE, NPT>(d, pk, omega, ww, blockIdx.x);
 }
