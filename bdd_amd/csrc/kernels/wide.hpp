@@ -284,6 +284,18 @@ __device__ __forceinline__ void wide_load_vals(REAL (&v)[NPT], rsrc_t src, uint3
     }
 }
 
+// Which wide sweeps skip the node slots of a wavefront that lie past the hop's last slot (phase A below).  Measured per mode (tools/exp_r05_t.sh,
+// profiles/r05_wide_skip.txt, same box, two rounds): forward solve sweeps in float 25 000 rows of 18 variables 156 -> 147 us (2 883 -> 2 968 it/s),
+// 4 000 rows 58 -> 49.5 us (7 630 -> 8 100 it/s), rows of 16 and the knapsack benchmark +-1 %; in double rows of 18 gain 5 % and rows of 16 lose 4 %
+// (forward solve sweep 124 -> 141 us, reproducibly); plain sweeps lose 7-18 % (the branch costs them their counted waits), backward solve
+// sweeps gain on the small instance only.  The sweeps are bound by the latency of their own prefetches, whose registers the rotation at the end of
+// a hop touches (one hop of tolerance), not by instruction issue — which is why skipping three quarters of the lanes' work buys this little.
+#ifndef BDDMMA_WIDE_SKIP_FWD
+#define BDDMMA_WIDE_SKIP_FWD(REAL, MODE) ((MODE) == FWD_SOLVE && sizeof(REAL) == 4)
+#endif
+#ifndef BDDMMA_WIDE_SKIP_BWD
+#define BDDMMA_WIDE_SKIP_BWD(REAL, MODE) false
+#endif
 template <typename REAL, int MODE, int NPT>
 __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t ww, uint32_t p)
 {
@@ -357,6 +369,8 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
         if (tid < 4) lds[((tid >> 1) ? oT1 : oT0) + ww + (tid & 1)] = (tid & 1) ? INF : REAL(0);
     }
     __syncthreads();
+    const uint32_t wv0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tid);  // the wavefront's first thread (uniform)
+    constexpr bool SKIP_IDLE = BDDMMA_WIDE_SKIP_FWD(REAL, MODE);
     uint32_t fc = 0, cur = 0;  // frontier buffer fc: current, (fc+1)%3: next, (fc+2)%3: being cleared for the hop after
     // staggered wide packs: slot of the BDD that starts at hop q (below the pack's first hop), read two hops ahead like the offsets
     auto root_at = [&](uint32_t q) -> uint32_t { return (q > q0 && q < q1) ? (uint32_t)pk.hop_root[q] : (uint32_t)NO_ROOT; };
@@ -387,9 +401,13 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
             }
         }
         // ---- phase A: per-layer minima of the two min-marginals
+        // SKIP_IDLE: a wavefront whose i-th nodes all lie past the hop's last slot skips them in both phases (a scalar branch): a chained wide
+        // pack is as wide as its widest BDD and BDDs of general linear rows are diamonds — the mean hop of the 25 000-row instance fills a
+        // quarter of its 512 slots (everything the skipped code does is predicated on `act`).
         REAL f[NPT], tl[NPT], th[NPT];
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
+            if (SKIP_IDLE && !(wv0 + i * T < n)) continue;
             const uint32_t j = tid + i * T;
             const bool act = j < n;
             f[i] = act ? lds[oFc + j] : INF;
@@ -412,6 +430,7 @@ __device__ __forceinline__ void fwd_wide2_body(const DevPtrs<REAL>& d, const Pac
         // ---- phase B: cost update, pushes into the next frontier
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
+            if (SKIP_IDLE && !(wv0 + i * T < n)) continue;
             const uint32_t j = tid + i * T;
             const bool act = j < n;
             const uint64_t w = W0[i];
@@ -545,6 +564,8 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
     }
     if (tid < 4) lds[(tid >> 1) * S + ww + (tid & 1)] = (tid & 1) ? INF : REAL(0);
     __syncthreads();
+    const uint32_t wv0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tid);  // the wavefront's first thread (uniform)
+    constexpr bool SKIP_IDLE = BDDMMA_WIDE_SKIP_BWD(REAL, MODE);
     uint32_t tc = 0, cur = 0;  // T buffer tc: hop q+1 (children), tc^1: hop q (being written)
     // staggered wide packs: the root that sits at hop q below the pack's first hop contributes its cost-to-terminal to the lower bound
     auto root_at = [&](int64_t h) -> uint32_t { return h > (int64_t)q0 ? (uint32_t)pk.hop_root[h] : (uint32_t)NO_ROOT; };
@@ -578,6 +599,7 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
         REAL tl[NPT], th[NPT];
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
+            if (SKIP_IDLE && !(wv0 + i * T < n)) continue;  // no node of this wavefront in the hop: see k_fwd_wide2
             const uint32_t j = tid + i * T;
             const bool act = j < n;
             tl[i] = lds[oTc + ww_lo(W0[i], ww)];
@@ -603,6 +625,7 @@ __device__ __forceinline__ void bwd_wide2_body(const DevPtrs<REAL>& d, const Pac
         // ---- phase B
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
+            if (SKIP_IDLE && !(wv0 + i * T < n)) continue;
             const uint32_t j = tid + i * T;
             const bool act = j < n;
             const uint64_t w = W0[i];
