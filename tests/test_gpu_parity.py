@@ -785,7 +785,7 @@ def test_lane_per_layer_sweeps_fuzz(seed):
             col.add_linear(np.ones(k, int), "<=", 1, vs)
     costs = rng.normal(0, 4, col.nr_variables()).round(3)
     opts = dict(pack_width=128, waves_per_block=int(rng.choice([4, 8])), resident_sweeps=1, vars_per_bin=int(rng.choice([0, 64, 256])),
-                keep_bdd_order=bool(rng.integers(0, 2)), deterministic=bool(rng.integers(0, 2)),
+                keep_bdd_order=int(rng.integers(0, 3)), deterministic=bool(rng.integers(0, 2)),
                 variant_flags=0x2000 | int(rng.choice([0, 0x4000])))
     for precision in ("double", "float"):
         s = bdd_hip_parallel_mma(col, costs, precision=precision, **opts)

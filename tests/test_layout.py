@@ -434,6 +434,58 @@ def test_automatic_stagger_leaves_flat_rows_side_by_side():
     assert hops() == side                      # grouped by shape (closed-form packing): unchanged
 
 
+def test_packs_are_formed_longest_first():
+    """Round 5: the blocks of a launch start in pack order and a sweep ends with its last wave, so (a) diamond-shaped BDDs of small shape
+    classes (general linear rows) come first, widest peak first — neighbours of similar peak chain at shorter offsets — and (b) the other
+    classes follow longest BDDs first.  keep_bdd_order = 2 keeps the order before (classes by first appearance), 1 the input order; every
+    order decodes back to the input."""
+    from bdd_amd.instances import random_set_cover_mixed
+    col, _ = random_set_cover_mixed(6_000, 4_000, 3, 9, seed=4)           # rows of 3 ... 9 variables, interleaved at random
+    def pack_hops(lay):
+        return np.diff(lay.sets[0]["pack_hop_ptr"]).astype(int)
+    new, old = check_roundtrip(col), Layout(col, keep_bdd_order=2)
+    h_new, h_old = pack_hops(new), pack_hops(old)
+    assert np.all(h_new[1:] <= h_new[:-1]) and h_new[0] == 9 and h_new[-1] == 3         # longest packs first
+    assert not np.all(h_old[1:] <= h_old[:-1])                                         # first appearance: whatever the input starts with
+    assert sorted(h_new) == sorted(h_old) and new.narrow_slots == old.narrow_slots      # the same packs, another order
+    # general linear rows (every BDD its own shape) behind covering rows in the input: the chained packs come first, and the peak widths of
+    # the BDDs they hold do not increase from pack to pack
+    rng = np.random.Generator(np.random.PCG64(5))
+    col = BddCollection()
+    V = 400
+    for _ in range(600):
+        col.add_covering(np.sort(rng.choice(V, size=6, replace=False)))
+    rows = []
+    for _ in range(300):
+        k = 12
+        co = rng.integers(1, 30, size=k)
+        col.add_linear(co, "<=", int(co.sum() // 2), np.sort(rng.choice(V, size=k, replace=False)))
+    lay = check_roundtrip(col, pack_width=64, pack_stagger=36)
+    S = lay.sets[0]
+    hops = pack_hops(lay)
+    first_short = int(np.argmax(hops <= 6))                                            # covering rows: 6 hops
+    assert first_short > 0 and np.all(hops[:first_short] > 6) and np.all(hops[first_short:] <= 6)
+    d = col.delims.astype(np.int64)
+    ins = col.instr
+    peak = {}
+    for b in range(600, 900):                                                          # widest layer of every knapsack BDD
+        idx = ins[d[b]:d[b + 1] - 2, 2]
+        peak[b] = int(np.unique(idx, return_counts=True)[1].max())
+    narrow = {b: w for b, w in peak.items() if w <= 64}
+    first_slot = {b: int(lay.root_slot[b]) for b in narrow}                            # slots grow with the pack index
+    by_pack = sorted(narrow, key=lambda b: first_slot[b])
+    pack_of = {b: int(np.searchsorted(S["hop_node_off"][S["pack_hop_ptr"]], first_slot[b], side="right") - 1) for b in by_pack}
+    per_pack = {}
+    for b in by_pack:
+        per_pack.setdefault(pack_of[b], []).append(narrow[b])
+    maxima = [max(v) for _, v in sorted(per_pack.items())]
+    minima = [min(v) for _, v in sorted(per_pack.items())]
+    assert all(minima[i] >= maxima[i + 1] for i in range(len(maxima) - 1))             # widest first, pack by pack
+    older = Layout(col, pack_width=64, pack_stagger=36, keep_bdd_order=2)                # the order before: covering rows (first in the input) first
+    assert pack_hops(older)[0] == 6 and older.n_layers == lay.n_layers
+    # (fewer wave-hops than the order before is a statistical statement — 5.6 % on 40 000 rows, profiles/r05_pack_order_widebench.txt —, not one about 300)
+
+
 def test_large_instances_get_eight_packs_per_workgroup():
     """The entries a sweep workgroup stages per bin form one run in the entry arrays; where four packs give runs shorter than 4.5 entries
     (many bins: 105 M nodes, or here a small bin size; threshold 4.5 entries) the automatic choice is eight packs per workgroup (layout.cpp; measured +5-9 % at
