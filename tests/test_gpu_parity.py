@@ -1085,7 +1085,7 @@ def test_randomised_instances_and_layout_options_vs_oracle(seed):
     wpb = int(rng.choice([1, 2, 4, 8]))
     cap = int(rng.choice([pw, 256, 640])) if wpb < 8 else 256
     opts = dict(pack_width=pw, waves_per_block=wpb, stage_cap=max(cap, pw), vars_per_bin=int(rng.choice([0, 64, 256])),
-                wide_pack_width=int(rng.choice([0, 64, 128, 256])), keep_bdd_order=bool(rng.integers(0, 2)),
+                wide_pack_width=int(rng.choice([0, 64, 128, 256])), keep_bdd_order=int(rng.integers(0, 3)),
                 resident_sweeps=int(rng.choice([0, 1, 2])), exchange_by_variable=int(rng.choice([0, 0, 2])),
                 variant_flags=int(rng.choice([0, 0, 1, 2, 3])) | int(rng.choice([0, 0x800, 0x1000, 0x2000, 0x2000])) | int(rng.choice([0, 0, 0x4000])) | int(rng.choice([0, 0, 0x40000]))   # 0x800 / 0x1000: first-generation resident / streaming sweeps, 0x2000: per-lane records also for unshared packs (general form), 0x4000: 64-bit staging addresses (arrays >= 4 GiB)
                 | int(os.environ.get("BDDMMA_FUZZ_VARIANT_OR", "0")),  # the env: tools/soak.sh bisections
