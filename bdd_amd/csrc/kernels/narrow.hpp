@@ -451,12 +451,14 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     }
 }
 
-// register budget of the float solve sweeps of 64-slot packs (general linear rows without wide packs): as the mixed kernels', wide.hpp
+// register budget of the float solve sweeps of general linear rows without wide packs, as the mixed kernels' (wide.hpp): 80 VGPRs with 64-slot
+// packs; 96 with 128-slot packs swept one per workgroup (staggered packs; 109-122 before: 100 000 rows of 11 variables in 128-slot packs
+// 6 080 -> 7 280 it/s, tools/exp_r05_u.sh) — workgroups of four or eight packs (the large set-cover instances) keep their registers
 #ifndef BDDMMA_N1_WAVES
-#define BDDMMA_N1_WAVES(REAL, R, MODE) ((MODE) == 1 && (R) == 1 && sizeof(REAL) == 4 ? 6 : 1)
+#define BDDMMA_N1_WAVES(REAL, R, MODE, WPB) ((MODE) == 1 && sizeof(REAL) == 4 ? ((R) == 1 ? 6 : (R) == 2 && (WPB) == 1 ? 5 : 1) : 1)
 #endif
 template <typename REAL, int R, int MODE, int WPB, bool SEG = true>
-__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N1_WAVES(REAL, R, MODE)))) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N1_WAVES(REAL, R, MODE, WPB)))) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
 {
     fwd_narrow_body<REAL, R, MODE, WPB, BDDMMA_LOOKAHEAD, SEG>(d, pk, omega, blockIdx.x);
 }
@@ -696,7 +698,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
 }
 
 template <typename REAL, int R, int MODE, int WPB, bool SEG = true>
-__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N1_WAVES(REAL, R, MODE)))) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N1_WAVES(REAL, R, MODE, WPB)))) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
 {
     bwd_narrow_body<REAL, R, MODE, WPB, BDDMMA_LOOKAHEAD, SEG>(d, pk, omega, blockIdx.x);
 }

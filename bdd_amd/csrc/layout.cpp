@@ -204,7 +204,17 @@ int build_layout(const bddmma_instruction* instr, const uint64_t* delims, uint64
     if (rc == BDDMMA_OK)
         for (uint32_t p = 0; p < L.narrow.n_packs(); ++p) longest_pack = std::max(longest_pack, L.narrow.pack_hop_ptr[p + 1] - L.narrow.pack_hop_ptr[p]);
     const uint32_t few_packs = 2048u * std::min(48u, std::max(16u, longest_pack)) / 16u;
-    if (rc == BDDMMA_OK && !(opts && opts->pack_width) && L.narrow.n_packs() < few_packs && L.narrow.n_packs() > 0) {
+    // General linear rows (round 5): where the BDDs chained into staggered packs hold most of the narrow nodes, 64-slot packs at any pack
+    // count — a staggered pack is swept by a workgroup of one wave either way, a 128-slot pack is two 64-lane groups filled independently
+    // (lane utilisation 0.45-0.58 against 0.63) and twice the work per wave.  it/s float, 128 / 64 slots (tools/exp_r05_u.sh, _v.sh):
+    // 100 000 rows of 11 variables 6 080 / 7 550, 150 000 rows of 10 5 530 / 6 990; with covering rows in the majority 128 stays ahead
+    // (10 000 knapsack + 400 000 covering rows 6 920 / 6 520; 20 000 + 250 000, 47 % of the nodes: 6 570 / 6 660, double 3 470 / 3 350).
+    bool staggered = false;
+    if (rc == BDDMMA_OK)
+        for (uint16_t r : L.narrow.hop_root)
+            if (r != NO_ROOT) { staggered = true; break; }
+    const bool mostly_chained = staggered && L.diamond_nodes * 2 > L.narrow_nodes;
+    if (rc == BDDMMA_OK && !(opts && opts->pack_width) && (L.narrow.n_packs() < few_packs || mostly_chained) && L.narrow.n_packs() > 0) {
         bddmma_options o = opts ? *opts : bddmma_options{};
         o.pack_width = 64;
         HostLayout L2;
@@ -438,6 +448,11 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
                 const bool diamond = bdd_maxw[b] >= 4 && nodes * 10 <= (uint64_t)bdd_maxw[b] * nl * 6;  // = PackBuilder::chainable
                 if (diamond && cls_size[cls_of[k]] < 256) peak_key[k] = bdd_maxw[b];
             }
+        for (size_t k = 0; k < order_n.size(); ++k) {
+            const uint64_t nodes = (delims[order_n[k] + 1] - delims[order_n[k]]) - 2;
+            L.narrow_nodes += nodes;
+            if (peak_key[k]) L.diamond_nodes += nodes;
+        }
         // ... and the other classes longest BDDs first (the blocks of a launch start in pack order: long packs must not start last)
         std::vector<uint32_t> len_key(order_n.size(), 0);
         if (!(opts && opts->keep_bdd_order == 2))

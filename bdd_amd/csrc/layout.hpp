@@ -139,6 +139,7 @@ struct HostLayout {
     PackSet narrow, wide, huge;   // huge: BDDs with a layer wider than wide_pack_width (frontier in global memory)
     uint32_t huge_pack_width = 0;  // largest hop of a huge pack (0: none)
     uint32_t narrow_slots = 0;        // slots [0, narrow_slots) belong to narrow packs
+    uint64_t narrow_nodes = 0, diamond_nodes = 0;  // nodes of the narrow BDDs / of those among them that are chained into staggered packs (layout.cpp)
     std::vector<uint32_t> narrow_words;  // [narrow_slots]
     // Packs with the same structure (same BDD shapes at the same slots: every row of one constraint family) have
     // identical word sequences.  The device holds each distinct sequence once; pack p reads its words at
