@@ -169,13 +169,33 @@ struct SolverT final : SolverBase {
         if (stream) (void)hipStreamDestroy(stream);
     }
 
+    // Arena: the solver's arrays are carved out of few large allocations instead of one hipMalloc each (see arena_chunk below).
+    struct Arena { char* base = nullptr; uint64_t size = 0, used = 0; };
+    std::vector<Arena> arenas;
+    uint64_t arena_chunk = 0;   // bytes per arena allocation (0: one hipMalloc per array, as before round 5)
+    uint64_t arena_skew = 0;    // extra bytes between consecutive arrays
     template <typename T>
     int dalloc(T** p, uint64_t n)
     {
         // + 1 KiB: the resident sweeps copy in whole 1 KiB pieces and may read up to 1008 bytes past a pack's range (kernels.hpp: wave_copy_to_lds)
         const uint64_t bytes = std::max<uint64_t>(n, 1) * sizeof(T) + 1024;
-        HIPCHK(hipMalloc((void**)p, bytes));
-        allocs.push_back(*p);
+        if (arena_chunk == 0) {
+            HIPCHK(hipMalloc((void**)p, bytes));
+            allocs.push_back(*p);
+            dev_bytes += bytes;
+            return BDDMMA_OK;
+        }
+        const uint64_t need = (bytes + 4095) / 4096 * 4096 + arena_skew;
+        if (arenas.empty() || arenas.back().used + need > arenas.back().size) {
+            Arena a;
+            a.size = std::max(arenas.empty() ? arena_chunk : std::min<uint64_t>(arena_chunk, 64ull << 20), need);   // what comes after the first chunk is small
+            HIPCHK(hipMalloc((void**)&a.base, a.size));
+            allocs.push_back(a.base);
+            arenas.push_back(a);
+        }
+        Arena& a = arenas.back();
+        *p = reinterpret_cast<T*>(a.base + a.used);
+        a.used += need;
         dev_bytes += bytes;
         return BDDMMA_OK;
     }
@@ -242,6 +262,21 @@ struct SolverT final : SolverBase {
         lay_scalars = layout_scalars(L);
         if (opts) saved_opts = *opts;
         deterministic = opts && opts->deterministic;
+        {
+            // Placement (round 5, tools/placement_probe.py, profiles/r05_placement.txt).  With one hipMalloc per array the iteration rate of
+            // the SAME instance depends on where the arrays happened to land: the 10.5 M-node float instance runs at 8 810, 8 200, 7 500 or
+            // 6 960 it/s from one solver object to the next in one process (stable for the life of an object; the sweeps alone always take
+            // 38.7 / 39.8 us, inside the iteration loop 41 ... 57 us: what varies is how much of the 465 MB working set the 256 MiB Infinity
+            // Cache keeps between launches) — the "noisy boxes" of rounds 3-4.  Carved out of ONE allocation, 4 KiB-aligned back to back,
+            // the arrays gave 8 800-8 840 it/s in 40 of 40 solver objects on three boxes (a deliberate 1 MiB + 64 KiB between arrays: 8 000
+            // in 10 of 10).  Beyond the cache's reach the contiguous placement is the consistently SLOWER one (21 M nodes 3 580 against
+            // 3 590-3 800, 42 M 1 650 against 1 640-1 840 it/s), so the arena is used while the solver's arrays are expected to stay below
+            // ~640 MiB; 1 M / 4.2 M nodes and double at 4.2 M: no difference.
+            const uint64_t est = (uint64_t)n_slots * 2 * sizeof(REAL) + (uint64_t)n_layers * (5 * sizeof(REAL) + 24) + (uint64_t)n_vars * 24 +
+                                 L.narrow_words_unique.size() * 4 + L.wide_words.size() * 8;
+            const uint64_t want = est + est / 2 + est / 8 + (16ull << 20);   // ~1.6 x: measured 1.45 x on the headline instance
+            if (want <= (640ull << 20)) arena_chunk = std::max<uint64_t>(want, 32ull << 20);
+        }
         // Arrays of 4 GiB and more (>= 512 M slots or 256 M layers in double; the reference indexes nodes with int: 2^31).  The narrow sweeps
         // and the exchange address F / T / {lo, hi} and the entry arrays relative to their pack / bin (HopWindow, exchange_reduce_body) and
         // stage with 64-bit addresses then (DevPtrs::big); what still carries absolute 32-bit byte offsets is refused for such instances
