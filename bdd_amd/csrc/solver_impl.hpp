@@ -276,6 +276,12 @@ struct SolverT final : SolverBase {
                                  L.narrow_words_unique.size() * 4 + L.wide_words.size() * 8;
             const uint64_t want = est + est / 2 + est / 8 + (16ull << 20);   // ~1.6 x: measured 1.45 x on the headline instance
             if (want <= (640ull << 20)) arena_chunk = std::max<uint64_t>(want, 32ull << 20);
+#ifdef BDDMMA_EXPERIMENTAL  // make EXPERIMENTAL=1: BDDMMA_EXP_ARENA="<chunk MiB>,<bytes between arrays>" (0: one hipMalloc per array) — tools/exp_r05_aa.sh ... _ad.sh
+            if (const char* ar = std::getenv("BDDMMA_EXP_ARENA")) {
+                unsigned long long mib = 0, skew = 0;
+                if (std::sscanf(ar, "%llu,%llu", &mib, &skew) >= 1) { arena_chunk = mib << 20; arena_skew = skew; }
+            }
+#endif
         }
         // Arrays of 4 GiB and more (>= 512 M slots or 256 M layers in double; the reference indexes nodes with int: 2^31).  The narrow sweeps
         // and the exchange address F / T / {lo, hi} and the entry arrays relative to their pack / bin (HopWindow, exchange_reduce_body) and
