@@ -3,6 +3,9 @@
     python tools/placement_probe.py [N = 8] [precision = float] [V = 1000000]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bdd_amd import capi
+if os.environ.get("BDDMMA_LIB"):
+    capi.LIB_PATH = os.path.abspath(os.environ["BDDMMA_LIB"])   # experimental builds under build/
 from bdd_amd.instances import random_set_cover_mt
 from bdd_amd.solver import bdd_hip_parallel_mma
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
