@@ -389,6 +389,9 @@ constexpr uint32_t OOB = 0xFFFFFFFFu;
 #ifndef BDDMMA_ST_AUX
 #define BDDMMA_ST_AUX 0
 #endif
+#ifndef BDDMMA_LD_TAB_AUX   // the staging tables' loads (stage_load_tables): read once per sweep; see BDDMMA_LD_POT_AUX (kernels/narrow.hpp)
+#define BDDMMA_LD_TAB_AUX 0
+#endif
 
 template <typename T>
 __device__ __forceinline__ rsrc_t make_rsrc(const T* p, uint64_t n_elems)
@@ -465,8 +468,8 @@ __device__ __forceinline__ void stage_load_tables(uint32_t (&e)[STAGE_ITERS], ui
 #pragma unroll
     for (int u = 0; u < STAGE_ITERS; ++u) {
         const uint32_t i = 64 * WPB * u + tid;
-        e[u] = bload_u32(rce, i * 4u);   // past the round: dropped
-        sl[u] = bload_u16(rcs, i * 2u);
+        e[u] = __builtin_amdgcn_raw_buffer_load_b32(rce, i * 4u, 0, BDDMMA_LD_TAB_AUX);   // past the round: dropped
+        sl[u] = __builtin_amdgcn_raw_buffer_load_b16(rcs, i * 2u, 0, BDDMMA_LD_TAB_AUX);
     }
 }
 template <typename REAL, int WPB>

@@ -120,13 +120,22 @@ __device__ __forceinline__ void load_words(uint32_t (&w)[R], const uint32_t* wor
         w[r] = (j < n) ? x : PADW;
     }
 }
+// Cache policy of the potentials' loads (F / T: written by one sweep, read once by the next) — a build knob (round 5, tools/exp_r05_af.sh,
+// profiles/r05_placement.txt #7): loaded non-temporally (2) they leave more of the arrays that ARE read again in the Infinity Cache once the working
+// set is beyond its reach — double at 10.5 M nodes 4 410-4 460 -> 4 490-4 560 it/s, with the staging tables' loads (BDDMMA_LD_TAB_AUX) 4 590-4 610;
+// float at 21 M nodes 3 570-3 840 -> 3 750-3 990 — and cost 7-12 % within its reach (float at 10.5 M nodes: 8 790 -> 8 200 / 7 700).  A RUN-TIME
+// switch (a uniform branch around the loads, as the non-temporal stores have) was built and lost all of it (double 4 370-4 455 against 4 420-4 556
+// without, the branches cost the hop loop its schedule): the switch has to be a template parameter of the sweeps — next round.
+#ifndef BDDMMA_LD_POT_AUX
+#define BDDMMA_LD_POT_AUX BDDMMA_LD_AUX
+#endif
 __device__ __forceinline__ void hop_load(float& v, rsrc_t rh, uint32_t voff, uint32_t soff)
 {
-    v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, voff, soff, BDDMMA_LD_AUX));
+    v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, voff, soff, BDDMMA_LD_POT_AUX));
 }
 __device__ __forceinline__ void hop_load(double& v, rsrc_t rh, uint32_t voff, uint32_t soff)
 {
-    v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rh, voff, soff, BDDMMA_LD_AUX));
+    v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rh, voff, soff, BDDMMA_LD_POT_AUX));
 }
 // Cache policy of the potentials' stores (the F / T streams of a streaming sweep).  Double-precision instances whose arrays exceed the
 // Infinity Cache several times store them non-temporally (aux bit 1 = nt; PackDev::nt_potentials, chosen by the solver from the
