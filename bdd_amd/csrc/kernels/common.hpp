@@ -459,7 +459,7 @@ constexpr int STAGE_ITERS = 10;  // stage_cap <= 64 * STAGE_ITERS
 
 // (two halves, so that a kernel that knows its round's item range early — resident headers — can have the tables on their way while it sets
 // up its pipeline: stage_load_tables issues the table loads, stage_load_pairs the dependent pair loads and the scatter into LDS)
-template <typename REAL, int WPB>
+template <typename REAL, int WPB, int AUX = BDDMMA_LD_TAB_AUX>
 __device__ __forceinline__ void stage_load_tables(uint32_t (&e)[STAGE_ITERS], uint32_t (&sl)[STAGE_ITERS], const NarrowRs<REAL>& rs, uint32_t c0, uint32_t cnt,
                                                   uint32_t tid)
 {
@@ -468,8 +468,8 @@ __device__ __forceinline__ void stage_load_tables(uint32_t (&e)[STAGE_ITERS], ui
 #pragma unroll
     for (int u = 0; u < STAGE_ITERS; ++u) {
         const uint32_t i = 64 * WPB * u + tid;
-        e[u] = __builtin_amdgcn_raw_buffer_load_b32(rce, i * 4u, 0, BDDMMA_LD_TAB_AUX);   // past the round: dropped
-        sl[u] = __builtin_amdgcn_raw_buffer_load_b16(rcs, i * 2u, 0, BDDMMA_LD_TAB_AUX);
+        e[u] = __builtin_amdgcn_raw_buffer_load_b32(rce, i * 4u, 0, AUX);   // past the round: dropped
+        sl[u] = __builtin_amdgcn_raw_buffer_load_b16(rcs, i * 2u, 0, AUX);
     }
 }
 template <typename REAL, int WPB>
@@ -503,11 +503,11 @@ __device__ __forceinline__ void stage_load_pairs(typename Pair<REAL>::type* sD, 
         }
     }
 }
-template <typename REAL, int WPB>
+template <typename REAL, int WPB, int AUX = BDDMMA_LD_TAB_AUX>
 __device__ __forceinline__ void stage_load(typename Pair<REAL>::type* sD, uint32_t (&e)[STAGE_ITERS], uint32_t (&sl)[STAGE_ITERS],
                                            const NarrowRs<REAL>& rs, uint32_t c0, uint32_t cnt, uint32_t tid)
 {
-    stage_load_tables<REAL, WPB>(e, sl, rs, c0, cnt, tid);
+    stage_load_tables<REAL, WPB, AUX>(e, sl, rs, c0, cnt, tid);
     stage_load_pairs<REAL, WPB>(sD, e, sl, rs, cnt, tid);
 }
 

@@ -163,6 +163,27 @@ __device__ __forceinline__ void load_vals(REAL (&v)[R], const REAL* src, uint32_
 #pragma unroll
     for (int r = 0; r < R; ++r) hop_load(v[r], rh, (lane + 64 * r) * (uint32_t)sizeof(REAL), nb * (uint32_t)sizeof(REAL));
 }
+// ... with the cache policy as a template parameter (NT: non-temporal; the third-generation sweeps' instantiation for footprints beyond the Infinity
+// Cache's reach, see BDDMMA_LD_POT_AUX above)
+__device__ __forceinline__ void hop_load_nt(float& v, rsrc_t rh, uint32_t voff, uint32_t soff)
+{
+    v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, voff, soff, 2));
+}
+__device__ __forceinline__ void hop_load_nt(double& v, rsrc_t rh, uint32_t voff, uint32_t soff)
+{
+    v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rh, voff, soff, 2));
+}
+template <typename REAL, int R, bool NT>
+__device__ __forceinline__ void load_vals_p(REAL (&v)[R], const REAL* src, uint32_t nb, uint32_t n, int lane)
+{
+    if constexpr (!NT) {
+        load_vals<REAL, R>(v, src, nb, n, lane);
+    } else {
+        const rsrc_t rh = hop_rsrc(src, nb, n);
+#pragma unroll
+        for (int r = 0; r < R; ++r) hop_load_nt(v[r], rh, (lane + 64 * r) * (uint32_t)sizeof(REAL), nb * (uint32_t)sizeof(REAL));
+    }
+}
 // ... and the store of one value per slot of the hop (padding slots inside the hop included: nothing reads them)
 template <int R>
 __device__ __forceinline__ void store_vals(const float (&v)[R], float* dst, uint32_t nb, uint32_t n, int lane, uint32_t /*nt*/)

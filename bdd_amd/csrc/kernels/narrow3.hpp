@@ -37,7 +37,7 @@ __device__ __forceinline__ void pot_store(double v, rsrc_t rh, uint32_t voff, ui
     else hop_store<>(v, rh, voff, soff);
 }
 
-template <typename REAL, int WPB, int LA = BDDMMA_LOOKAHEAD>
+template <typename REAL, int WPB, bool NT = false, int LA = BDDMMA_LOOKAHEAD>
 __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ lrec,
                                                  const uint32_t* __restrict__ lrec_off, uint32_t lrec_words, REAL omega, uint32_t block_id)
 {
@@ -74,7 +74,7 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
     NarrowRs<REAL> rs(d);
     rs.rebase_layers(d, l0);
     uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    if (hdr) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
+    if (hdr) stage_load_tables<REAL, WPB, (NT ? 2 : BDDMMA_LD_TAB_AUX)>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
     REAL* const Tp = d.T + slot_first;
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
@@ -112,9 +112,9 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
         for (int i = 0; i < 2 * D; ++i) rc[i] = ldrec((uint32_t)i);  // (past the last hop: some other records, never used)
         {
             REAL t1[2];
-            load_vals<REAL, 2>(t1, Tp, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
+            load_vals_p<REAL, 2, NT>(t1, Tp, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
 #pragma unroll
-            for (int i = 0; i < D; ++i) load_vals<REAL, 2>(tr[i], Tp, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
+            for (int i = 0; i < D; ++i) load_vals_p<REAL, 2, NT>(tr[i], Tp, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const uint32_t j = lane + 64 * r;
@@ -144,7 +144,7 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
     } else {
         const uint32_t c0 = pk.cs_ptr[r0 + k];
         cnt = pk.cs_ptr[r0 + k + 1] - c0;
-        stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
+        stage_load<REAL, WPB, (NT ? 2 : BDDMMA_LD_TAB_AUX)>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
         if (k < ng) {
             gl0 = pk.grp_layer_off[g0 + k] - l0;
             qe = pk.grp_hop_end[g0 + k];
@@ -163,7 +163,7 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
         // ---- global prefetch: record of hop q+2D, T of hop q+D+2, arc costs of hop q+D
         rc[2 * D] = ldrec(q - q0 + 2 * D);
 #ifndef BDDMMA_EXP_NO_HOP_LOADS
-        load_vals<REAL, 2>(tr[D], Tp, o[D + 2], o[D + 3] - o[D + 2], lane);
+        load_vals_p<REAL, 2, NT>(tr[D], Tp, o[D + 2], o[D + 3] - o[D + 2], lane);
         hop_load(Lr[D], rs.lohi, (uint32_t)lane * (uint32_t)sizeof(P2), lb[D] * (uint32_t)sizeof(P2));
 #endif
         const u4v ra = rc[0];
@@ -247,14 +247,14 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
 #ifndef BDDMMA_N3_WAVES
 #define BDDMMA_N3_WAVES(REAL) (sizeof(REAL) == 4 ? 5 : 4)
 #endif
-template <typename REAL, int WPB>
+template <typename REAL, int WPB, bool NT = false>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N3_WAVES(REAL)))) k_fwd_narrow3(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ lrec, const uint32_t* __restrict__ lrec_off,
                                                           uint32_t lrec_words, REAL omega)
 {
-    fwd_narrow3_body<REAL, WPB>(d, pk, lrec, lrec_off, lrec_words, omega, blockIdx.x);
+    fwd_narrow3_body<REAL, WPB, NT>(d, pk, lrec, lrec_off, lrec_words, omega, blockIdx.x);
 }
 
-template <typename REAL, int WPB, int LA = BDDMMA_LOOKAHEAD>
+template <typename REAL, int WPB, bool NT = false, int LA = BDDMMA_LOOKAHEAD>
 __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ lrec,
                                                  const uint32_t* __restrict__ lrec_off, uint32_t lrec_words, REAL omega, uint32_t block_id)
 {
@@ -287,7 +287,7 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
     NarrowRs<REAL> rs(d);
     rs.rebase_layers(d, l0);
     uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    if (hdr) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);
+    if (hdr) stage_load_tables<REAL, WPB, (NT ? 2 : BDDMMA_LD_TAB_AUX)>(ent, esl, rs, c0_h, cnt_h, tid);
     REAL* const Tp = d.T + slot_first;
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
@@ -313,8 +313,13 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
     // costs-from-root of the two nodes of the lane's layer: slice of the hop [nb, nb + n), the record's store offsets (idle lanes / no second node: past the slice -> 0)
     auto ldf = [&](REAL (&f)[2], const u4v& r, uint32_t nb, uint32_t n) {
         const rsrc_t rh = hop_rsrc(Fp, nb, n);
-        hop_load(f[0], rh, r[3] & 0xFFFFu, nb * S);
-        hop_load(f[1], rh, r[3] >> 16, nb * S);
+        if constexpr (NT) {
+            hop_load_nt(f[0], rh, r[3] & 0xFFFFu, nb * S);
+            hop_load_nt(f[1], rh, r[3] >> 16, nb * S);
+        } else {
+            hop_load(f[0], rh, r[3] & 0xFFFFu, nb * S);
+            hop_load(f[1], rh, r[3] >> 16, nb * S);
+        }
     };
     const uint32_t sink = (W + 2 * (uint32_t)lane) * S;
     if (has_pack) {
@@ -354,7 +359,7 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
     } else {
         const uint32_t c0 = pk.cs_ptr[r0 + k];
         cnt = pk.cs_ptr[r0 + k + 1] - c0;
-        stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
+        stage_load<REAL, WPB, (NT ? 2 : BDDMMA_LD_TAB_AUX)>(sD, ent, esl, rs, c0, cnt, tid);
         if (k < ng) {
             gl0 = pk.grp_layer_off[g0 + k] - l0;
             qs = (k == 0) ? q0 : pk.grp_hop_end[g0 + k - 1];
@@ -459,11 +464,11 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
     if (lane == 0) d.lb_partial[pk.lb_base + p] = s;
 }
 
-template <typename REAL, int WPB>
+template <typename REAL, int WPB, bool NT = false>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N3_WAVES(REAL)))) k_bwd_narrow3(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ lrec, const uint32_t* __restrict__ lrec_off,
                                                           uint32_t lrec_words, REAL omega)
 {
-    bwd_narrow3_body<REAL, WPB>(d, pk, lrec, lrec_off, lrec_words, omega, blockIdx.x);
+    bwd_narrow3_body<REAL, WPB, NT>(d, pk, lrec, lrec_off, lrec_words, omega, blockIdx.x);
 }
 
 }  // namespace bddmma

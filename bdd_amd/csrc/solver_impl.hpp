@@ -117,6 +117,7 @@ struct SolverT final : SolverBase {
         uint32_t n_packs = 0;
     } nb_, wb_, hb_;  // narrow, wide, huge packs
     uint32_t wide_lds = 0, wide_threads = 256, wide_npt = 1;
+    bool n3_nt = false;  // third-generation sweeps: the instantiation with non-temporal loads (double beyond the Infinity Cache's reach)
     uint32_t nt_potentials = 0;  // PackDev::nt_potentials (kernels.hpp: hop_store): double, footprint several times the Infinity Cache
     bool mixed = false;      // narrow (streaming) and wide solve sweeps in one launch (kernels.hpp: k_fwd_mixed / k_bwd_mixed)
     // Measured on the knapsack benchmark (3 604 narrow + 389 wide packs): backward 44.7 -> 37.4 us in one launch.  The forward sweeps
@@ -555,10 +556,16 @@ struct SolverT final : SolverBase {
                 if ((rc = upload(&d_lrec_off, LR.rec_off))) return rc;
                 lrec_words = (uint32_t)LR.rec.size();
                 use_narrow3 = true;
-#define SET_N3(W_)                                                                                                                              \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_narrow3<REAL, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds)); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_narrow3<REAL, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
-                if (L.ex.waves_per_block == 4) { SET_N3(4) } else { SET_N3(8) }
+                // double, footprint beyond the Infinity Cache's reach (the condition of the non-temporal stores): the instantiation that LOADS what a
+                // sweep reads once — potentials, staging tables — non-temporally (profiles/r05_placement.txt #7: 10.5 M nodes +3.5 %)
+                n3_nt = sizeof(REAL) == 8 && nt_potentials != 0;
+#define SET_N3(W_, NT_)                                                                                                                              \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_narrow3<REAL, W_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds)); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_narrow3<REAL, W_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
+                if (L.ex.waves_per_block == 4) { SET_N3(4, false) } else { SET_N3(8, false) }
+                if constexpr (sizeof(REAL) == 8) {
+                    if (L.ex.waves_per_block == 4) { SET_N3(4, true) } else { SET_N3(8, true) }
+                }
 #undef SET_N3
             }
         }
@@ -688,6 +695,7 @@ struct SolverT final : SolverBase {
 #define LAUNCH_N(R_, W_)                                                                                                      \
     if (res && use_res2) hipLaunchKernelGGL((k_fwd_res2<REAL, W_>), grid, block, res2_lds, stream, rd.pack_hdr, rd.quad_hdr, res2_ns, res2_nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d_res2_rec, d_res2_rec_off, res2_n_words, d, pk, omega); \
     else if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
+    else if (MODE == FWD_SOLVE && use_narrow3 && n3_nt && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_fwd_narrow3<REAL, (W_ == 8 ? 8 : 4), sizeof(REAL) == 8>), grid, block, dyn, stream, d, pk, d_lrec, d_lrec_off, lrec_words, omega); \
     else if (MODE == FWD_SOLVE && use_narrow3 && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_fwd_narrow3<REAL, (W_ == 8 ? 8 : 4)>), grid, block, dyn, stream, d, pk, d_lrec, d_lrec_off, lrec_words, omega); \
     else if (MODE == FWD_SOLVE && use_narrow2 && narrow_gen) hipLaunchKernelGGL((k_fwd_narrow2<REAL, R_, W_, true>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (MODE == FWD_SOLVE && use_narrow2) hipLaunchKernelGGL((k_fwd_narrow2<REAL, R_, W_, false>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
@@ -762,6 +770,7 @@ struct SolverT final : SolverBase {
 #define LAUNCH_N(R_, W_)                                                                                                      \
     if (res && use_res2) hipLaunchKernelGGL((k_bwd_res2<REAL, W_>), grid, block, res2_lds, stream, rd.pack_hdr, rd.quad_hdr, res2_ns, res2_nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d_res2_rec, d_res2_rec_off, res2_n_words, d, pk, omega); \
     else if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
+    else if (MODE == BWD_SOLVE && use_narrow3 && n3_nt && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_bwd_narrow3<REAL, (W_ == 8 ? 8 : 4), sizeof(REAL) == 8>), grid, block, dyn, stream, d, pk, d_lrec, d_lrec_off, lrec_words, omega); \
     else if (MODE == BWD_SOLVE && use_narrow3 && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_bwd_narrow3<REAL, (W_ == 8 ? 8 : 4)>), grid, block, dyn, stream, d, pk, d_lrec, d_lrec_off, lrec_words, omega); \
     else if (MODE == BWD_SOLVE && use_narrow2 && narrow_gen) hipLaunchKernelGGL((k_bwd_narrow2<REAL, R_, W_, true>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (MODE == BWD_SOLVE && use_narrow2) hipLaunchKernelGGL((k_bwd_narrow2<REAL, R_, W_, false>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \

@@ -401,7 +401,7 @@ def measured_traffic(kernel, args, sfx):
         real = "float" if sfx == "f32" else "double"   # one profile holds both precisions: the default bench run times both
         sweep = None
         for name, v in d.items():   # third-generation streaming solve sweeps (a lane per layer): <REAL, waves per block>
-            if isinstance(v, dict) and re.search(want + "3<" + real + r", \d+>", name):
+            if isinstance(v, dict) and re.search(want + "3<" + real + r", \d+(?:, \w+)?>", name):   # <REAL, waves per block[, NT]>
                 sweep = v["hbm_bytes"]
         if sweep is None:
             for name, v in d.items():   # second generation: <REAL, R, waves per block, GEN>
