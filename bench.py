@@ -389,8 +389,8 @@ def measured_traffic(kernel, args, sfx):
     tag = {(1_000_000, 500_000, 10): "10m", (100_000, 50_000, 10): "1m"}.get((args.vars, args.rows, args.k))
     if tag is None or args.deterministic or args.pack_width or args.wpb or args.vars_per_bin or args.stage_cap:
         return None, None, None
-    for rnd in ("r05", "r04", "r03", "r02"):
-        rel = os.path.join("profiles", f"{rnd}_{tag}_{sfx}", "traffic.json")
+    for rnd, dsfx in [(r, x) for r in ("r05", "r04", "r03", "r02") for x in dict.fromkeys((sfx, "f32"))]:   # a round's f32 directory holds both precisions
+        rel = os.path.join("profiles", f"{rnd}_{tag}_{dsfx}", "traffic.json")
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
