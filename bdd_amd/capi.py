@@ -53,6 +53,7 @@ SIGNATURES = {
     "bddmma_create": (_I, [C.POINTER(_V), _I, _I, _V, _V, _U64, _V, _U64, C.POINTER(Options)]),
     "bddmma_destroy": (None, [_V]),
     "bddmma_device_count": (_I, []),
+    "bddmma_device_chip": (_I, [_I, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "bddmma_set_layout_threads": (_I, [_I]),
     "bddmma_set_thread_layout_threads": (_I, [_I]),
     "bddmma_last_error": (C.c_char_p, [_V]),
@@ -111,7 +112,9 @@ SIGNATURES = {
     "bddmma_time_iterations": (_I, [_V, _D, _U64, C.POINTER(_D)]),
     "bddmma_time_kernel": (_I, [_V, _I, _U64, C.POINTER(_D)]),
     "bddmma_device_bytes": (_U64, [_V]),
+    "bddmma_device_allocated_bytes": (_U64, [_V]),
     "bddmma_layout_create": (_I, [C.POINTER(_V), _V, _V, _U64, C.POINTER(Options)]),
+    "bddmma_layout_create_for_chip": (_I, [C.POINTER(_V), _V, _V, _U64, C.POINTER(Options), _I, C.c_uint32, C.c_uint32]),
     "bddmma_layout_destroy": (None, [_V]),
     "bddmma_layout_size": (_U64, [_V, _I]),
     "bddmma_layout_copy": (_I, [_V, _I, _V]),

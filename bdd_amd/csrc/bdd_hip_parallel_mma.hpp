@@ -42,7 +42,19 @@ class bdd_hip_parallel_mma {
     explicit bdd_hip_parallel_mma(const BDD_COLLECTION& bdd_col, const std::vector<double>& costs_hi = {}, int device = 0)
     {
         std::vector<bddmma_instruction> instr;
-        std::vector<uint64_t> delims(1, 0);
+        std::vector<uint64_t> delims;
+        flatten(bdd_col, instr, delims);
+        check(bddmma_create(&h_, precision, device, instr.data(), delims.data(), bdd_col.nr_bdds(), costs_hi.data(), costs_hi.size(), nullptr), nullptr);
+    }
+    // The collection's BDDs as the dense arrays bddmma_create takes (arc targets re-based from the collection's storage offsets to the
+    // dense array).  Needs no GPU: oracle/ref_driver.cpp instantiates it with the reference's own BDD::bdd_collection
+    // (include/bdd_collection/bdd_collection.h:206 `operator()(bdd_nr, offset)`) and tests/test_bdd_builders.py compares the result with
+    // the reference-side export.
+    template <typename BDD_COLLECTION>
+    static void flatten(const BDD_COLLECTION& bdd_col, std::vector<bddmma_instruction>& instr, std::vector<uint64_t>& delims)
+    {
+        instr.clear();
+        delims.assign(1, 0);
         for (size_t b = 0; b < bdd_col.nr_bdds(); ++b) {
             const size_t off = bdd_col.offset(b), base = instr.size();
             for (size_t i = 0; i < bdd_col.nr_bdd_nodes(b); ++i) {
@@ -52,7 +64,6 @@ class bdd_hip_parallel_mma {
             }
             delims.push_back(instr.size());
         }
-        check(bddmma_create(&h_, precision, device, instr.data(), delims.data(), bdd_col.nr_bdds(), costs_hi.data(), costs_hi.size(), nullptr), nullptr);
     }
     ~bdd_hip_parallel_mma() { bddmma_destroy(h_); }
     bdd_hip_parallel_mma(bdd_hip_parallel_mma&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }

@@ -102,6 +102,17 @@ int bddmma_create(bddmma_solver** out, int precision, int device, const bddmma_i
 }
 
 int bddmma_device_count(void) { return device_count(); }
+int bddmma_device_chip(int device, uint32_t* n_cus, uint32_t* lds_bytes_per_cu, uint64_t* max_resident_threads)
+{
+    if (device < 0 || device >= device_count()) { g_err = "no such HIP device"; return BDDMMA_ERR_DEVICE; }
+    ChipInfo chip;
+    const int rc = query_chip(device, &chip, g_err);
+    if (rc) return rc;
+    if (n_cus) *n_cus = chip.n_cus;
+    if (lds_bytes_per_cu) *lds_bytes_per_cu = chip.lds_bytes;
+    if (max_resident_threads) *max_resident_threads = chip.max_resident_threads;
+    return BDDMMA_OK;
+}
 int bddmma_set_layout_threads(int n)
 {
     if (n < 0) return BDDMMA_ERR_INVALID_ARGUMENT;
@@ -134,6 +145,7 @@ int bddmma_solve_sweep_kind(const bddmma_solver* s) { return s && s->impl ? s->i
 int bddmma_precision(const bddmma_solver* s) { return s && s->impl ? s->impl->precision : -1; }
 int bddmma_device(const bddmma_solver* s) { return s && s->impl ? s->impl->device : -1; }
 uint64_t bddmma_device_bytes(const bddmma_solver* s) { return s && s->impl ? s->impl->dev_bytes : 0; }
+uint64_t bddmma_device_allocated_bytes(const bddmma_solver* s) { return s && s->impl ? s->impl->dev_alloc_bytes : 0; }
 
 int bddmma_num_bdds_per_var(const bddmma_solver* s, int32_t* out)
 {
@@ -708,11 +720,19 @@ struct bddmma_layout {
 int bddmma_layout_create(bddmma_layout** out, const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
                          const bddmma_options* opts)
 {
-    if (!out) return BDDMMA_ERR_INVALID_ARGUMENT;
+    return bddmma_layout_create_for_chip(out, instr, delims, n_bdds, opts, 4, 0, 0);
+}
+int bddmma_layout_create_for_chip(bddmma_layout** out, const bddmma_instruction* instr, const uint64_t* delims, uint64_t n_bdds,
+                                  const bddmma_options* opts, int real_size, uint32_t n_cus, uint32_t lds_bytes_per_cu)
+{
+    if (!out || (real_size != 4 && real_size != 8)) return BDDMMA_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     try {
         auto* l = new bddmma_layout();
-        int rc = build_layout(instr, delims, n_bdds, opts, l->L, g_err, true);
+        ChipInfo chip;
+        if (n_cus) chip.n_cus = n_cus;
+        if (lds_bytes_per_cu) chip.lds_bytes = lds_bytes_per_cu;
+        int rc = build_layout(instr, delims, n_bdds, opts, l->L, g_err, true, (uint32_t)real_size, chip);
         if (rc) { delete l; return rc; }
         *out = l;
         return BDDMMA_OK;

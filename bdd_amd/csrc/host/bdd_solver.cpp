@@ -100,7 +100,12 @@ bdd_store bdd_solver::transform_to_BDDs(const ilp_input& ilp) const
         // the reference tests contains("implication bdd") and then reads key "implication" (:119); accept both
         const bool implication = sb.bool_or("implication bdd", sb.bool_or("implication", false));
         const size_t len = (size_t)sb.number_or("split length", 0);
-        const auto [n, nv] = col.split_long_bdds(std::max(col.nr_variables(), ilp.nr_variables()), len, 256 * 2048 / 10, implication);
+        // getMaximumOccupancy() of the reference (bdd_preprocessor.cpp:21-30): a tenth of the device's resident threads, asked of the
+        // device the solver will run on (MI355X: 256 x 2048 / 10; that figure stands in when no device is visible, e.g. "export bdd lp" on a CPU box)
+        uint64_t threads = 0;
+        const int device = device_ >= 0 ? device_ : (int)config_.number_or("device", 0);
+        if (bddmma_device_chip(device, nullptr, nullptr, &threads) != BDDMMA_OK || threads == 0) threads = 256ull * 2048;
+        const auto [n, nv] = col.split_long_bdds(std::max(col.nr_variables(), ilp.nr_variables()), len, (size_t)(threads / 10), implication);
         (void)nv;
         log("[bdd preprocessor] Split " + std::to_string(n) + " BDDs");
         log("[bdd preprocessor] final #BDDs = " + std::to_string(col.nr_bdds()));

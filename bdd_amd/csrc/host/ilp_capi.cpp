@@ -16,6 +16,15 @@ struct bddilp_bdds { bdd_store col; };
 
 static thread_local std::string g_err;
 
+// getMaximumOccupancy() of the reference (bdd_preprocessor.cpp:21-30: device 0's resident threads / 10); MI355X's figure when no
+// device is visible — these entry points are host code and must work on a box without a GPU
+static size_t default_split_parallelism()
+{
+    uint64_t threads = 0;
+    if (bddmma_device_chip(0, nullptr, nullptr, &threads) != BDDMMA_OK || threads == 0) threads = 256ull * 2048;
+    return (size_t)(threads / 10);
+}
+
 template <typename F>
 static int guarded(int fail_code, F&& f)
 {
@@ -77,7 +86,7 @@ int bddilp_to_bdds(const bddilp* ilp, int split, uint64_t split_length, bddilp_b
     if (!ilp || !out) { g_err = "null argument"; return BDDILP_ERR_INVALID_ARGUMENT; }
     return guarded(BDDILP_ERR_INVALID_ARGUMENT, [&] {
         auto* b = new bddilp_bdds{to_bdds(ilp->ilp)};
-        if (split) b->col.split_long_bdds(std::max(b->col.nr_variables(), ilp->ilp.nr_variables()), split_length, 256 * 2048 / 10, split == 2);
+        if (split) b->col.split_long_bdds(std::max(b->col.nr_variables(), ilp->ilp.nr_variables()), split_length, default_split_parallelism(), split == 2);
         *out = b;
         return BDDILP_OK;
     });
@@ -104,7 +113,7 @@ int bddilp_bdds_split(bddilp_bdds* b, uint64_t nr_variables, uint64_t split_leng
                       uint64_t* nr_variables_after)
 {
     return guarded(BDDILP_ERR_INVALID_ARGUMENT, [&] {
-        const auto [n, nv] = b->col.split_long_bdds(nr_variables, split_length, 256 * 2048 / 10, with_implication_bdd != 0);
+        const auto [n, nv] = b->col.split_long_bdds(nr_variables, split_length, default_split_parallelism(), with_implication_bdd != 0);
         if (nr_split) *nr_split = n;
         if (nr_variables_after) *nr_variables_after = nv;
         return BDDILP_OK;

@@ -340,6 +340,7 @@ void build_seg_exchange(const HostLayout& L, uint32_t threads, uint32_t real_siz
 struct ChipInfo {
     uint32_t n_cus = 256;
     uint32_t lds_bytes = 160 * 1024;  // per CU
+    uint64_t max_resident_threads = 256ull * 2048;   // multiProcessorCount * maxThreadsPerMultiProcessor (the input stage's split-length rule)
 };
 
 // Returns BDDMMA_OK or an error code; `err` receives the message.

@@ -19,7 +19,8 @@ struct SolverBase {
     uint64_t n_vars = 0, n_bdds = 0, n_layers = 0, n_hops = 0, n_input_nodes = 0, n_slots = 0;
     int solve_sweep_kind = 0;  // bddmma_solve_sweep_kind (include/bdd_mma.h): which kernels run the narrow packs' solve sweeps
     uint32_t pack_width = 0, wide_pack_width = 0, wide_slot_base = 0;
-    uint64_t dev_bytes = 0;
+    uint64_t dev_bytes = 0;          // bytes of the arrays the solver holds
+    uint64_t dev_alloc_bytes = 0;    // bytes hipMalloc'd for them (arena capacity included: >= dev_bytes)
     bool fwd_valid = false, bwd_valid = false;  // forward_state_valid_ / backward_state_valid_ (bdd_cuda_base.h:205-206)
     uint64_t cost_epoch = 0;                    // counts the calls that changed arc costs other than through a solve sweep (update_costs, set_cost, gradient steps, ...)
     bool deterministic = false;

@@ -107,6 +107,8 @@ int query_chip(int device, ChipInfo* out, std::string& err)
     if (e != hipSuccess) { err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return BDDMMA_ERR_DEVICE; }
     if (prop.multiProcessorCount > 0) out->n_cus = (uint32_t)prop.multiProcessorCount;
     if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) out->lds_bytes = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
+    if (prop.multiProcessorCount > 0 && prop.maxThreadsPerMultiProcessor > 0)
+        out->max_resident_threads = (uint64_t)prop.multiProcessorCount * (uint64_t)prop.maxThreadsPerMultiProcessor;
     return BDDMMA_OK;
 }
 

@@ -24,6 +24,18 @@
 
 namespace bddmma {
 
+// one step of a host spin-wait (the polled bounds, run_solver's reader): the core's pause / yield hint
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __asm__ __volatile__("pause");
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    std::this_thread::yield();
+#endif
+}
+
 
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
@@ -184,6 +196,7 @@ struct SolverT final : SolverBase {
             HIPCHK(hipMalloc((void**)p, bytes));
             allocs.push_back(*p);
             dev_bytes += bytes;
+            dev_alloc_bytes += bytes;
             return BDDMMA_OK;
         }
         const uint64_t need = (bytes + 4095) / 4096 * 4096 + arena_skew;
@@ -193,6 +206,7 @@ struct SolverT final : SolverBase {
             HIPCHK(hipMalloc((void**)&a.base, a.size));
             allocs.push_back(a.base);
             arenas.push_back(a);
+            dev_alloc_bytes += a.size;
         }
         Arena& a = arenas.back();
         *p = reinterpret_cast<T*>(a.base + a.used);
@@ -275,8 +289,10 @@ struct SolverT final : SolverBase {
             // ~640 MiB; 1 M / 4.2 M nodes and double at 4.2 M: no difference.
             const uint64_t est = (uint64_t)n_slots * 2 * sizeof(REAL) + (uint64_t)n_layers * (5 * sizeof(REAL) + 24) + (uint64_t)n_vars * 24 +
                                  L.narrow_words_unique.size() * 4 + L.wide_words.size() * 8;
-            const uint64_t want = est + est / 2 + est / 8 + (16ull << 20);   // ~1.6 x: measured 1.45 x on the headline instance
-            if (want <= (640ull << 20)) arena_chunk = std::max<uint64_t>(want, 32ull << 20);
+            // ~1.6 x: measured 1.45 x on the headline instance.  Small instances get a small chunk (rounded up to 2 MiB; it was floored at
+            // 32 MiB through round 5: a farm of per-subproblem solvers then held 32 MiB each while bddmma_device_bytes reported ~1 MB).
+            const uint64_t want = est + est / 2 + est / 8 + std::min<uint64_t>(16ull << 20, est / 2 + (1ull << 20));
+            if (want <= (640ull << 20)) arena_chunk = (want + (2ull << 20) - 1) / (2ull << 20) * (2ull << 20);
 #ifdef BDDMMA_EXPERIMENTAL  // make EXPERIMENTAL=1: BDDMMA_EXP_ARENA="<chunk MiB>,<bytes between arrays>" (0: one hipMalloc per array) — tools/exp_r05_aa.sh ... _ad.sh
             if (const char* ar = std::getenv("BDDMMA_EXP_ARENA")) {
                 unsigned long long mib = 0, skew = 0;
@@ -415,7 +431,7 @@ struct SolverT final : SolverBase {
         opts_variant = opts ? opts->variant_flags : 0u;
         mixed_fwd = (opts_variant & 2u) == 0;
         // measured in double: 7.1 M nodes (490 MB resident) lose 12 % with non-temporal potentials, 10.5 M (720 MB) gain 4 %
-        nt_potentials = (sizeof(REAL) == 8 && dev_bytes > (640ull << 20)) ? 1u : 0u;
+        nt_potentials = (sizeof(REAL) == 8 && dev_bytes > (640ull << 20)) ? 1u : 0u;   // array bytes (the working set), not arena capacity
         exch_small = vars_per_bin <= EXS_MAX_VARS_PER_BIN;  // 256-thread workgroups (kernels.hpp: EXS_*)
         exch_medium = !exch_small && vars_per_bin <= EXM_MAX_VARS_PER_BIN;  // 512-thread workgroups (EXM_*)
         // `deterministic`: the scheduled reduction (kernels.hpp: k_exchange_seg; no atomics, fixed order) where every bin fits its tables
@@ -908,7 +924,7 @@ struct SolverT final : SolverBase {
         const auto t0 = std::chrono::steady_clock::now();
         uint32_t spins = 0;
         while (*w != lb_seq_expect[k]) {
-            __builtin_ia32_pause();
+            cpu_relax();
             if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) {
                 HIPCHK(hipStreamSynchronize(stream));
                 if (*w != lb_seq_expect[k]) { err = "lower bound: the reduce kernel did not report"; return BDDMMA_ERR_DEVICE; }
@@ -1091,7 +1107,7 @@ struct SolverT final : SolverBase {
                 } else if (now - idle_since > 1e-3) {
                     std::this_thread::sleep_for(std::chrono::microseconds(50));
                 } else {
-                    __builtin_ia32_pause();
+                    cpu_relax();
                 }
             } else {
                 idle_spins = 0;

@@ -156,7 +156,9 @@ def _parse_terms(s: str, what: str):
     return terms
 
 
-_BOUND_TOK = re.compile(rf"\s*(<=|>=|=|{_VAR}|[^\s<>=]+)")
+# operands and relations in turn; a lone `<` or `>` is a token of its own (refused below), exactly as host/ilp.cpp: scan_bound —
+# findall must never skip a character: `x < = 1` is an error, not the fixation `x = 1`
+_BOUND_TOK = re.compile(rf"\s*(<=|>=|=|{_VAR}|[^\s<>=]+|[<>])")
 
 
 def _parse_bound(ilp: "ILP", line: str, zeros: set, ones: set) -> None:
@@ -167,6 +169,9 @@ def _parse_bound(ilp: "ILP", line: str, zeros: set, ones: set) -> None:
 
     def bad(why):
         return ValueError(f"cannot read Bounds line '{line}': {why}")
+
+    if "".join(tok) != "".join(line.split()):      # the scanner consumed the whole line, or the line is refused
+        raise bad("unreadable characters")
 
     def value(t):
         if t in ("0", "+0", "0.0"):

@@ -89,6 +89,7 @@ class bdd_hip_parallel_mma:
         """which kernels run the narrow packs' solve sweeps (include/bdd_mma.h: BDDMMA_SWEEPS_*)"""
         return self.SWEEP_KINDS[int(self._L.bddmma_solve_sweep_kind(self._h))]
     def device_bytes(self): return int(self._L.bddmma_device_bytes(self._h))
+    def device_allocated_bytes(self): return int(self._L.bddmma_device_allocated_bytes(self._h))
 
     def nr_bdds(self, var=None):
         if var is None:

@@ -127,6 +127,11 @@ void bddmma_destroy(bddmma_solver* s);
 /* Number of HIP devices visible to the process (0 when there is none / no driver).  One host thread per device, each with its own
  * handles, is the multi-GPU model: independent instances, no collective (reference: device 0 hard-coded, include/cuda_utils.h:111-114). */
 int bddmma_device_count(void);
+/* What the layout rules and the input stage ask the chip (hipDeviceProp of `device`): compute units, LDS bytes per compute unit, and
+ * multiProcessorCount * maxThreadsPerMultiProcessor — the figure the reference's getMaximumOccupancy() derives its split length from
+ * (src/bdd_conversion/bdd_preprocessor.cpp:21-30: cudaGetDeviceProperties, / 10 there).  Any out pointer may be NULL.
+ * BDDMMA_ERR_DEVICE when there is no such device. */
+int bddmma_device_chip(int device, uint32_t* n_cus, uint32_t* lds_bytes_per_cu, uint64_t* max_resident_threads);
 /* Host threads one layout build (bddmma_create) may use: 0 = automatic (environment BDDMMA_THREADS, else min(cores, 32)).  A process that
  * builds one instance per GPU at the same time gives every build cores / #GPUs (the reference builds its layout on the device,
  * bdd_cuda_base.cu:146-391; here it is host work). */
@@ -325,13 +330,20 @@ int bddmma_time_iterations(bddmma_solver* s, double omega, uint64_t n, double* m
  * box the roofline is quoted next to. */
 #define BDDMMA_TRIAD_BYTES (1ull << 30)
 int bddmma_time_kernel(bddmma_solver* s, int kind, uint64_t reps, double* ms);
-/* HBM bytes held by the handle. */
+/* HBM bytes of the arrays the handle holds (its working set), and the bytes it has allocated for them: the
+ * arrays are carved out of few large allocations, so allocated >= held (what a farm of many small solvers
+ * must budget with). */
 uint64_t bddmma_device_bytes(const bddmma_solver* s);
+uint64_t bddmma_device_allocated_bytes(const bddmma_solver* s);
 
 /* ---- host-only layout inspection (no GPU needed; used by the CPU test-suite) ------------- */
 typedef struct bddmma_layout bddmma_layout;
 int bddmma_layout_create(bddmma_layout** out, const bddmma_instruction* instr, const uint64_t* bdd_delims,
                          uint64_t n_bdds, const bddmma_options* opts);
+/* The same for values of real_size bytes (4 / 8) on a chip with n_cus compute units and lds_bytes_per_cu of LDS each (0: MI355X, what
+ * bddmma_layout_create assumes): the layout bddmma_create builds on such a device (bddmma_device_chip), e.g. a CPX / DPX partition. */
+int bddmma_layout_create_for_chip(bddmma_layout** out, const bddmma_instruction* instr, const uint64_t* bdd_delims,
+                                  uint64_t n_bdds, const bddmma_options* opts, int real_size, uint32_t n_cus, uint32_t lds_bytes_per_cu);
 void bddmma_layout_destroy(bddmma_layout* l);
 uint64_t bddmma_layout_size(const bddmma_layout* l, int what);
 int bddmma_layout_copy(const bddmma_layout* l, int which, void* out);

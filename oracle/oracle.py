@@ -348,6 +348,18 @@ class RefCollection:
         self.R.ref_col_export(self.h, _p(instr), _p(delims))
         return BddCollection.from_arrays(instr, delims)
 
+    def flatten_dropin(self):
+        """(instructions [n, 3], delimiters) as LPMP::bdd_hip_parallel_mma<REAL>::flatten — the drop-in class's template constructor
+        instantiated with the reference's BDD::bdd_collection — produces them (bdd_amd/csrc/bdd_hip_parallel_mma.hpp)."""
+        self.R.ref_col_nr_instructions.restype = C.c_size_t
+        self.R.ref_col_flatten_dropin.restype = C.c_size_t
+        n = int(self.R.ref_col_nr_instructions(self.h))
+        instr = np.zeros((n, 3), np.uint64)
+        delims = np.zeros(self.nr_bdds() + 1, np.uint64)
+        got = int(self.R.ref_col_flatten_dropin(self.h, _p(instr), _p(delims)))
+        assert got == n, (got, n)
+        return instr, delims
+
 
 class RefMma:
     """MMA over the reference's bdd_branch_instruction<REAL,uint16_t> node code (oracle/ref_driver.cpp)."""

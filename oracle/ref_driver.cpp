@@ -22,6 +22,9 @@
 #include "bdd_collection/bdd_collection.h"
 #include "bdd_manager/bdd_mgr.h"
 #include "bdd_solver/bdd_branch_instruction.h"
+// the drop-in class of the product, for ONE purpose: its template constructor's flattening loop is instantiated below with the
+// reference's real BDD::bdd_collection; no bddmma_* entry point is called from here (nothing of the product is linked)
+#include "../bdd_amd/csrc/bdd_hip_parallel_mma.hpp"
 
 #include <sstream>
 #include <cstring>
@@ -314,6 +317,20 @@ void ref_col_export(void* c, uint64_t* instr, uint64_t* delims)
         }
     }
     delims[col.nr_bdds()] = k;
+}
+
+// the same export through the product's own template code: LPMP::bdd_hip_parallel_mma<REAL>::flatten(const BDD::bdd_collection&), the loop
+// its constructor runs before bddmma_create.  Returns the number of instructions written (instr: 3 words each; delims: nr_bdds + 1).
+size_t ref_col_flatten_dropin(void* c, uint64_t* instr, uint64_t* delims)
+{
+    const bdd_collection& col = *static_cast<bdd_collection*>(c);
+    std::vector<bddmma_instruction> in;
+    std::vector<uint64_t> de;
+    LPMP::bdd_hip_parallel_mma<float>::flatten(col, in, de);
+    static_assert(sizeof(bddmma_instruction) == 3 * sizeof(uint64_t), "bddmma_instruction is {lo, hi, index}");
+    std::memcpy(instr, in.data(), in.size() * sizeof(bddmma_instruction));
+    std::memcpy(delims, de.data(), de.size() * sizeof(uint64_t));
+    return in.size();
 }
 
 // text exports of the reference's bdd_collection (bdd_collection.h:663-830), for tests/golden/exports.json: the text is copied into

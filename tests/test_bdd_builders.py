@@ -73,3 +73,30 @@ def test_batched_builders_match_single():
         b.add_covering(r)
     np.testing.assert_array_equal(a.instr, b.instr)
     np.testing.assert_array_equal(a.delims, b.delims)
+
+
+@needs_ref
+def test_dropin_template_constructor_flattens_the_reference_collection():
+    """`bdd_hip_parallel_mma<REAL>(const BDD::bdd_collection&, costs)` with the REAL reference type
+    (include/bdd_collection/bdd_collection.h:206 `operator()(bdd_nr, offset)`, nr_bdd_nodes, offset).  oracle/ref_driver.cpp compiles
+    bdd_amd/csrc/bdd_hip_parallel_mma.hpp against -I/root/reference/include and runs the constructor's flattening loop
+    (static flatten(): no GPU) on collections built by the reference; the arrays bddmma_create would receive must equal the
+    reference-side export.  Several BDDs, so the storage offsets of the collection differ from the dense positions."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    rc = O.RefCollection()
+    for _ in range(12):
+        k = int(rng.integers(2, 8))
+        vs = np.sort(rng.choice(20, size=k, replace=False))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            rc.add_simplex(vs)
+        elif kind == 1:
+            rc.add_covering(vs)
+        else:
+            co = rng.integers(1, 5, size=k)
+            assert rc.add_linear(co, "<=", int(co.sum() // 2), vs) >= 0
+    ref = rc.export()
+    instr, delims = rc.flatten_dropin()
+    assert len(delims) == rc.nr_bdds() + 1 and rc.nr_bdds() == 12
+    np.testing.assert_array_equal(delims, ref.delims)
+    np.testing.assert_array_equal(instr, ref.instr)

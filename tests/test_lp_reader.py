@@ -123,7 +123,9 @@ def test_bounds_fix_variables_as_ilp_input_reduce(which):
 @pytest.mark.parametrize("which", [0, 1])
 @pytest.mark.parametrize("line,match", [("x1 = 2", "0 or 1"), ("x1 <= 0.5", "0 or 1"), ("nope = 1", "no row"), ("x1 free", "expected"),
                                         ("x1 < 1", "expected|0 or 1"), ("1 <= x1 <= 0", "above"), ("-1 <= x1", "0 or 1"), ("x1 = 0\n x1 >= 1", "0 and to 1"),
-                                        ("0 <= x1 >= 1", "expected")])
+                                        ("0 <= x1 >= 1", "expected"),
+                                        # malformed relations: no reader may skip the stray character and read a fixation
+                                        ("x1 < = 1", "expected"), ("x1 <= 1 <", "expected"), ("x1 > = 0", "expected"), ("> x1 = 1", "expected")])
 def test_bounds_lines_that_are_refused(which, line, match):
     name, read = readers()[which]
     with pytest.raises(ValueError, match=match):

@@ -11,7 +11,7 @@ followed directly by a VALU write of one of its data registers.
 The same check covers global_store_dwordx3 / x4 with an SGPR base (`saddr`), the form the 64-bit `big` paths can emit.
 
 usage: isa_lint.py <library.so>     exit code 1 on a hit; 0 (with a note) when llvm-objdump is not installed; 3 when the
-disassembly itself failed (the Makefile keeps the library then: a tool failure is not a finding)"""
+disassembly itself failed (the Makefile removes the library on ANY non-zero exit; `make LINT_OPTIONAL=1` keeps it on exit 3 only)"""
 import os
 import re
 import shutil
