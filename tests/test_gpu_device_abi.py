@@ -140,3 +140,26 @@ def test_every_device_overload_matches_its_host_twin(precision):
     for x, y in zip(a.get_solver_costs(), b.get_solver_costs()):
         np.testing.assert_array_equal(x, y)
     assert a.lower_bound() == b.lower_bound()
+
+
+def test_device_chip_query_and_allocated_bytes():
+    """bddmma_device_chip = the hipDeviceProp figures the layout rules and the input stage's split-length rule read (the reference:
+    cudaGetDeviceProperties, bdd_preprocessor.cpp:21-30); bddmma_device_allocated_bytes >= bddmma_device_bytes, and a tiny solver no
+    longer holds a 32 MiB arena."""
+    import ctypes as C
+
+    from bdd_amd import capi
+    L = capi.lib()
+    n, lds, thr = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+    capi.check(L.bddmma_device_chip(0, C.byref(n), C.byref(lds), C.byref(thr)), None)
+    prop = torch.cuda.get_device_properties(0)
+    assert n.value == prop.multi_processor_count
+    assert lds.value >= 64 * 1024 and thr.value == n.value * prop.max_threads_per_multi_processor
+    assert L.bddmma_device_chip(L.bddmma_device_count(), None, None, None) != 0
+    col, costs = random_set_cover(300, 200, 5, seed=2)
+    s = bdd_hip_parallel_mma(col, costs, precision="float")
+    held, alloc = s.device_bytes(), s.device_allocated_bytes()
+    assert 0 < held <= alloc <= held + (4 << 20), (held, alloc)
+    s.iterations(3)
+    assert np.isfinite(s.lower_bound())
+    s.close()

@@ -18,7 +18,7 @@ BOT = np.uint64(2**64 - 2)
 
 class Layout:
     def __init__(self, col, pack_width=0, wide_pack_width=0, vars_per_bin=0, stage_cap=0, waves_per_block=0, exchange_by_variable=0, pack_fill=0, pack_stagger=0,
-                 keep_bdd_order=0):
+                 keep_bdd_order=0, chip=None):
         L = capi.lib()
         instr = np.ascontiguousarray(col.instr, dtype=np.uint64)
         delims = np.ascontiguousarray(col.delims, dtype=np.uint64)
@@ -28,8 +28,12 @@ class Layout:
         opts.pack_fill = pack_fill
         opts.pack_stagger = pack_stagger
         opts.keep_bdd_order = keep_bdd_order
-        rc = L.bddmma_layout_create(C.byref(h), instr.ctypes.data_as(C.c_void_p), delims.ctypes.data_as(C.c_void_p),
-                                    col.nr_bdds(), C.byref(opts))
+        if chip is None:
+            rc = L.bddmma_layout_create(C.byref(h), instr.ctypes.data_as(C.c_void_p), delims.ctypes.data_as(C.c_void_p),
+                                        col.nr_bdds(), C.byref(opts))
+        else:   # (real_size, n_cus, lds_bytes_per_cu): the layout bddmma_create builds on such a device
+            rc = L.bddmma_layout_create_for_chip(C.byref(h), instr.ctypes.data_as(C.c_void_p), delims.ctypes.data_as(C.c_void_p),
+                                                 col.nr_bdds(), C.byref(opts), *chip)
         capi.check(rc, None)
         self.L, self.h = L, h
         self.pack_stagger = pack_stagger
@@ -795,3 +799,31 @@ def test_seg_exchange_refuses_what_it_cannot_hold():
     col, _ = random_set_cover(40, 400, 6, seed=1)              # 60 entries per variable: runs of more than 32 with 64 threads per 64 variables
     assert not seg_exchange(Layout(col, vars_per_bin=64), 64, 4)[0]
     assert not seg_exchange(Layout(col, exchange_by_variable=2), 256, 4)[0]
+
+
+def test_layout_for_a_smaller_chip_differs_where_the_rules_read_the_chip():
+    """the CPU-side layout entry point can be asked for the layout bddmma_create builds on the device at hand
+    (bddmma_device_chip -> bddmma_layout_create_for_chip).  ~2 200 narrow packs of 64 slots: one pack per workgroup where the chip holds
+    them all at once (256 CUs; layout.cpp: 3 700 packs per 256 CUs, scaled with the CU count), the streaming sweeps' four on a
+    32-CU partition.  Zeros mean MI355X: the same layout as bddmma_layout_create."""
+    from bdd_amd.instances import random_set_cover
+    col, _ = random_set_cover(150_000, 70_400, 10, seed=5)
+    default = Layout(col, pack_width=64)
+    same = Layout(col, pack_width=64, chip=(4, 0, 0))
+    small = Layout(col, pack_width=64, chip=(4, 32, 160 * 1024))
+    assert default.pack_width == 64 and 2048 <= default.np_n <= 3700
+    assert (default.wpb, same.wpb) == (1, 1) and small.wpb == 4
+    np.testing.assert_array_equal(default.nwords, same.nwords)
+    np.testing.assert_array_equal(default.cs_entry, same.cs_entry)
+    assert small.n_slots == default.n_slots and small.n_layers == default.n_layers
+    L, h = capi.lib(), C.c_void_p()
+    assert L.bddmma_layout_create_for_chip(C.byref(h), None, None, 0, None, 2, 0, 0) != 0   # real_size is 4 or 8
+
+
+def test_device_chip_query_without_a_device_is_an_error_not_a_default():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by tests/test_gpu_device_abi.py")
+    n, lds, thr = C.c_uint32(7), C.c_uint32(7), C.c_uint64(7)
+    assert capi.lib().bddmma_device_chip(0, C.byref(n), C.byref(lds), C.byref(thr)) != 0
+    assert (n.value, lds.value, thr.value) == (7, 7, 7)
