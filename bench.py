@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-precision", action="store_true")
     ap.add_argument("--no-lbfgs", action="store_true", dest="no_lbfgs", help="skip the L-BFGS leg (BASELINE.json configs[3]) after the timed region")
+    ap.add_argument("--no-configs", action="store_true", dest="no_configs", help="skip the BASELINE.json configs[1] leg (1.05 M nodes) after the timed region")
+    ap.add_argument("--repeats", type=int, default=4, help="further timed regions of exactly K steps after the one `value` is taken from (their rates: repeat_samples)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--deterministic", action="store_true")
     ap.add_argument("--event-stride", type=int, default=0, help="hipEvent pairs around every n-th iteration's launches (0: steps // 16)")
@@ -139,6 +141,7 @@ def main():
         # to time.  So the device is kept busy with the same iterations for args.clock_warm seconds first (untimed, counted in
         # lower_bound_after.iterations), then come the W warm-up steps and the K timed ones.
         pre = 0
+        t_pre = time.perf_counter()
         if "n" in pre_iterations:           # the second precision of the run: the same number of iterations as the first
             pre = pre_iterations["n"]
             if pre:
@@ -151,10 +154,14 @@ def main():
                 solver.synchronize()
                 pre += 64
             pre_iterations["n"] = pre
+            pre_iterations["s"] = time.perf_counter() - t_pre
         solver.iterations(args.warmup)
         solver.synchronize()
         dt = timed_region(lambda: solver.iterations(args.steps),
                           lambda: (solver.synchronize(), torch.cuda.synchronize()), dist)
+        # `value` is that region.  K = 20 steps are a 2.3 ms sample: the same region again, a few times, shows its spread (repeat_samples)
+        repeats = [timed_region(lambda: solver.iterations(args.steps), lambda: (solver.synchronize(), torch.cuda.synchronize()), dist)
+                   for _ in range(max(0, args.repeats))]
         # Kernel durations: the same K steps once more with hipEvent pairs on the solver's own stream around the launches of every
         # `stride`-th iteration (>= 16 samples per kernel class for any K >= 16).  An event pair per launch costs ~4 us of stream
         # time (-14 % it/s at stride 1), so the instrumented pass is kept out of `value`; its own rate is reported next to it.
@@ -163,6 +170,7 @@ def main():
                              lambda: (solver.synchronize(), torch.cuda.synchronize()), dist)
         prof = solver.get_profile()
         prof["ms_per_step_instrumented"] = dt_ev / args.steps * 1e3
+        prof["repeat_dt"] = repeats
         solver.set_profiling(False)
         return solver, dt, prof, solver.lower_bound()
 
@@ -200,7 +208,10 @@ def main():
     solver.close()
     lbfgs = None
     if rank == 0 and not args.no_lbfgs:
-        lbfgs = {p: lbfgs_rate(col, costs, p, local_rank, args) for p in ([args.precision] if args.no_second_precision else [args.precision, other])}
+        lbfgs = {p: lbfgs_rate(col, costs, p, local_rank, args, sizes) for p in ([args.precision] if args.no_second_precision else [args.precision, other])}
+    configs = None
+    if rank == 0 and not args.no_configs and (args.vars, args.rows, args.k) == (1_000_000, 500_000, 10):
+        configs = {"1m_f32": small_config(local_rank, "float"), "1m_f64": small_config(local_rank, "double")}
 
     if rank == 0:
         its = aggregate_rate(world, args.steps, dt)
@@ -235,8 +246,13 @@ def main():
             "roofline": roofline(prof, sizes, R, its / world, args, sfx, triad_gbs, copy_gbs, resident),
             "value_with_lower_bound_every_iteration": lb_rate,
             "value_with_lower_bound_every_iteration_host_loop": lb_rate_host_loop,
-            "lower_bound_after": {"iterations": pre_iterations.get("n", 0) + args.warmup + 2 * args.steps, "value": lb},
+            "lower_bound_after": {"iterations": pre_iterations.get("n", 0) + args.warmup + (2 + max(0, args.repeats)) * args.steps, "value": lb},
+            # what ran, untimed, before the K timed steps: the clock-warm loop (seconds / iterations of the same step), then the W warm-up steps
             "clock_warm_iterations": pre_iterations.get("n", 0),
+            "clock_warm_s": pre_iterations.get("s", 0.0),
+            "untimed_iterations_before_timed_region": pre_iterations.get("n", 0) + args.warmup,
+            # the timed region of `value` repeated: rates of `repeats` further regions of exactly K steps each (same barriers and syncs)
+            "repeat_samples": [aggregate_rate(world, args.steps, t) for t in prof.get("repeat_dt", [])],
         }
         if second is not None:
             dt2, prof2, lb2, _res2 = second
@@ -245,12 +261,16 @@ def main():
             out["value_" + sfx2] = its2
             out["ms_per_step_" + sfx2] = dt2 / args.steps * 1e3
             out["roofline_" + sfx2] = roofline(prof2, sizes, R2, its2 / world, args, sfx2, triad_gbs, copy_gbs, second[3])
-            out["lower_bound_after_" + sfx2] = {"iterations": pre_iterations.get("n", 0) + args.warmup + 2 * args.steps, "value": lb2,
+            out["lower_bound_after_" + sfx2] = {"iterations": pre_iterations.get("n", 0) + args.warmup + (2 + max(0, args.repeats)) * args.steps, "value": lb2,
                                                "rel_diff_to_" + sfx: abs(lb2 - lb) / max(abs(lb), 1e-300)}
         if lbfgs is not None:
             out["lbfgs"] = {"what": "BASELINE.json configs[3]: L-BFGS around the same solver on the same instance (history 5, the reference's default "
                                     "parameters), fresh solver, 20 untimed iterations that fill the history, then the timed ones; outside the timed "
                                     "region of `value`", **lbfgs}
+        if configs is not None:
+            out["configs"] = {"what": "the other single-GPU BASELINE.json configuration, outside the timed region of `value`: configs[1] = random set cover "
+                                      "k = 10, V = 1e5, B = 5e4 (1.05 M BDD nodes), same generator and seed; 2 000 timed iterations after 0.1 s of "
+                                      "clock-warm iterations; per-kernel times from hipEvent pairs on the solver's stream in a second pass", **configs}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(col, costs, args, sizes)
         print(json.dumps(out), flush=True)
@@ -259,7 +279,51 @@ def main():
         dist.destroy_process_group()
 
 
-def lbfgs_rate(col, costs, precision, device, args, iters=100):
+def lbfgs_bytes(sizes, R, m, trials):
+    """Algorithmic bytes of one L-BFGS iteration, SURVEY.md §8(d): the MMA iteration (B_iter) + the vector algebra of the two-loop
+    recursion, (2m + 6) R L' (L' = nr_layers: the dual vectors' length) + one extra sweep per lower_bound / bdds_solution evaluation —
+    `trials` bound evaluations (one per trial step) and one argmin-path sweep for the subgradient; an extra sweep reads the node
+    indices, the {lo, hi} costs and moves the potentials once each way: 12 N' + 2R N + 2R L'."""
+    extra = 12 * sizes["N_nt"] + 2 * R * sizes["N"] + 2 * R * sizes["L_nt"]
+    return iteration_bytes(sizes, R) + (2 * m + 6) * R * sizes["L_nt"] + (trials + 1.0) * extra
+
+
+def small_config(device, precision, vars_=100_000, rows=50_000, k=10, steps=2000):
+    """BASELINE.json configs[1] (1.05 M nodes) on the same box, outside the timed region: rate, whole-iteration roofline fraction and
+    the hipEvent time of each kernel class (BASELINE.md §3 quotes >= 45 k it/s / 0.40 for it; the driver's line never ran it before r6)."""
+    from bdd_amd.instances import random_set_cover_mt, set_cover_sizes
+    from bdd_amd.solver import bdd_hip_parallel_mma
+    sizes = set_cover_sizes(vars_, rows, k)
+    col, costs = random_set_cover_mt(vars_, rows, k, seed=12345)
+    s = bdd_hip_parallel_mma(col, costs, precision=precision, device=device)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.1:
+        s.iterations(256)
+        s.synchronize()
+    s.synchronize()
+    t0 = time.perf_counter()
+    s.iterations(steps)
+    s.synchronize()
+    dt = time.perf_counter() - t0
+    s.set_profiling(True, stride=max(1, steps // 64))
+    s.iterations(steps)
+    s.synchronize()
+    prof = s.get_profile()
+    s.set_profiling(False)
+    R = 4 if precision == "float" else 8
+    names = ["forward_mm", "backward_mm", "finish_delta"]
+    out = {"workload": f"random set cover (std::mt19937_64 seed 12345), row size {k}, V={vars_}, B={rows}: {sizes['N']} BDD nodes (BASELINE.json configs[1])",
+           "value": steps / dt, "unit": "iterations/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f32" if R == 4 else "f64",
+           "algorithmic_bytes_per_iteration": iteration_bytes(sizes, R),
+           "frac_whole_iteration": iteration_bytes(sizes, R) * steps / dt / 1e9 / HBM_PEAK_GBS,
+           "avg_launch_us": {names[i]: prof["total_ms"][i] / max(prof["launches"][i], 1) * 1e3 for i in range(3)},
+           "solve_sweeps": s.solve_sweep_kind(), "packs": s.nr_packs(), "hbm_resident_bytes": s.device_bytes(),
+           "lower_bound_after": {"value": s.lower_bound()}}
+    s.close()
+    return out
+
+
+def lbfgs_rate(col, costs, precision, device, args, sizes, iters=100):
     from bdd_amd.solver import bdd_hip_lbfgs, bdd_hip_parallel_mma
     s = bdd_hip_parallel_mma(col, costs, precision=precision, device=device, pack_width=args.pack_width, deterministic=args.deterministic,
                              vars_per_bin=args.vars_per_bin, stage_cap=args.stage_cap, waves_per_block=args.wpb)
@@ -278,8 +342,14 @@ def lbfgs_rate(col, costs, precision, device, args, iters=100):
     dt = time.perf_counter() - t0
     l.close()
     s.close()
+    R, m = (4 if precision == "float" else 8), 5
+    b = lbfgs_bytes(sizes, R, m, trials / iters)
     return {"value": iters / dt, "unit": "iterations/s", "ms_per_iteration": dt / iters * 1e3, "iterations": iters, "lbfgs_steps": steps,
-            "trial_steps_per_iteration": trials / iters, "lower_bound_after": {"iterations": 20 + iters, "value": lb}}
+            "trial_steps_per_iteration": trials / iters, "lower_bound_after": {"iterations": 20 + iters, "value": lb},
+            "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_iteration": b,
+                         "achieved": b * iters / dt / 1e9, "frac": b * iters / dt / 1e9 / HBM_PEAK_GBS,
+                         "basis": "SURVEY §8(d): B_iter + (2m + 6) R L' + (trial steps + 1) extra sweeps of 12 N' + 2R N + 2R L' bytes, m = 5, on "
+                                  "the wall clock of the loop (bound read-backs and host decisions included)"}}
 
 
 INFINITY_CACHE_BYTES = 256 << 20  # MI355X_MICROARCH.md "Infinity Cache (L3)"
@@ -301,7 +371,7 @@ def roofline(prof, sizes, R, its_per_gpu, args, sfx, triad_gbs, copy_gbs, reside
     dom = 0 if avg_ms[0] >= avg_ms[1] else 1
     b_sweep, b_exch, b_iter = sweep_bytes(sizes, R), exchange_bytes(sizes, R), iteration_bytes(sizes, R)
     achieved = b_sweep / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
-    traffic, traffic_exch, traffic_src = measured_traffic(names[dom], args, sfx)
+    traffic, traffic_exch, traffic_src, us_rocprof = measured_traffic(names[dom], args, sfx)
     counter_gbs = traffic / (avg_ms[dom] * 1e-3) / 1e9 if traffic and avg_ms[dom] > 0 else None
     whole = b_iter * its_per_gpu / 1e9
     hbm_only = hbm_only_fractions()
@@ -326,6 +396,11 @@ def roofline(prof, sizes, R, its_per_gpu, args, sfx, triad_gbs, copy_gbs, reside
         "whole_iteration_GBs": whole,
         "frac_whole_iteration": whole / HBM_PEAK_GBS,
         "avg_launch_ms": {names[i]: avg_ms[i] for i in range(3)},
+        # the same kernel's average in the committed rocprofv3 --kernel-trace --stats run (the hipEvent figure above carries ~2.6 us of
+        # event overhead per pair); frac_rocprof_duration = counter bytes / that duration / peak
+        "kernel_us_hipevent": avg_ms[dom] * 1e3,
+        "kernel_us_rocprof": us_rocprof,
+        "frac_rocprof_duration": (traffic / (us_rocprof * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic and us_rocprof else None,
         "ms_per_step_instrumented_pass": prof.get("ms_per_step_instrumented"),
         "timed_launches": {names[i]: prof["launches"][i] for i in range(3)},
         "stream_triad_GBs": triad_gbs,
@@ -345,11 +420,11 @@ def roofline(prof, sizes, R, its_per_gpu, args, sfx, triad_gbs, copy_gbs, reside
 def hbm_only_fractions():
     """frac_whole_iteration of the 105 M-node instance (V = 10 M, B = 5 M, k = 10: 4.5 / 7.2 GB resident, no Infinity-Cache help), measured
     with tools/kbench.py and committed in profiles/ (None if the file is missing)."""
-    for name in ("r04_hbm_only_105m.json", "r03_hbm_only_105m.json", "r02_hbm_only_105m.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            d = json.load(open(path))
-            return {"f32": d.get("f32"), "f64": d.get("f64"), "source": "profiles/" + name}
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_only_105m.json")), reverse=True):   # the newest round's
+        d = json.load(open(path))
+        return {"f32": d.get("f32"), "f64": d.get("f64"), "source": "profiles/" + os.path.basename(path), "sources_hash": d.get("_source_hash"),
+                "matches_these_sources": d.get("_source_hash") == source_hash() if d.get("_source_hash") else None}
     return None
 
 
@@ -388,8 +463,8 @@ def measured_traffic(kernel, args, sfx):
     sources it was measured on; (None, None, None) when no profile matches the workload or the sources changed since."""
     tag = {(1_000_000, 500_000, 10): "10m", (100_000, 50_000, 10): "1m"}.get((args.vars, args.rows, args.k))
     if tag is None or args.deterministic or args.pack_width or args.wpb or args.vars_per_bin or args.stage_cap:
-        return None, None, None
-    for rnd, dsfx in [(r, x) for r in ("r05", "r04", "r03", "r02") for x in dict.fromkeys((sfx, "f32"))]:   # a round's f32 directory holds both precisions
+        return None, None, None, None
+    for rnd, dsfx in [(r, x) for r in ("r06", "r05", "r04", "r03", "r02") for x in dict.fromkeys((sfx, "f32"))]:   # a round's f32 directory holds both precisions
         rel = os.path.join("profiles", f"{rnd}_{tag}_{dsfx}", "traffic.json")
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
@@ -399,28 +474,33 @@ def measured_traffic(kernel, args, sfx):
             continue
         want = "k_fwd_narrow" if kernel == "forward_mm" else "k_bwd_narrow"
         real = "float" if sfx == "f32" else "double"   # one profile holds both precisions: the default bench run times both
-        sweep = None
+        sweep = sweep_entry = None
+
+        def take(v):
+            nonlocal sweep, sweep_entry
+            sweep, sweep_entry = v["hbm_bytes"], v
+
         for name, v in d.items():   # third-generation streaming solve sweeps (a lane per layer): <REAL, waves per block>
             if isinstance(v, dict) and re.search(want + "3<" + real + r", \d+(?:, \w+)?>", name):   # <REAL, waves per block[, NT]>
-                sweep = v["hbm_bytes"]
+                take(v)
         if sweep is None:
             for name, v in d.items():   # second generation: <REAL, R, waves per block, GEN>
                 if isinstance(v, dict) and re.search(want + "2<" + real + r", \d+, \d+, \w+>", name):
-                    sweep = v["hbm_bytes"]
+                    take(v)
         if sweep is None:
             for name, v in d.items():
                 m = re.search(want + "<" + real + r", \d+, (\d+), \d+(?:, \w+)?>", name)   # <REAL, R, MODE, waves per block[, SEG]>; MODE 1 = solve
                 if m and m.group(1) == "1":
-                    sweep = v["hbm_bytes"]
+                    take(v)
         if sweep is None:
             for res in ("_res2", "_res"):   # small instances: the resident sweeps, second / first generation
                 for name, v in d.items():
                     if sweep is None and isinstance(v, dict) and re.search(want.replace("_narrow", res) + "<" + real + ",", name):
-                        sweep = v["hbm_bytes"]
+                        take(v)
         exch = next((v["hbm_bytes"] for name, v in d.items() if "k_exchange_reduce<" + real + "," in name and isinstance(v, dict)), None)
         if sweep is not None:
-            return sweep, exch, rel
-    return None, None, None
+            return sweep, exch, rel, sweep_entry.get("avg_us_rocprof")   # rocprofv3 --kernel-trace --stats average of the same kernel (collect_profiles.py)
+    return None, None, None, None
 
 
 def cpu_baseline(col, costs, args, sizes):
@@ -435,17 +515,20 @@ def cpu_baseline(col, costs, args, sizes):
     o = Oracle(col, costs, args.precision, threads=min(ncpu, 32))
     o.iteration()  # warm-up (first touch, backward_run)
     best, cores = 0.0, min(ncpu, 32)
+    scaling = {}
     for th in sorted({min(ncpu, t) for t in (16, 32, 64, 128, 256)}):
         o.set_threads(th)
         t1 = time.perf_counter()
         o.iteration()
         rate = 1.0 / (time.perf_counter() - t1)
+        scaling[str(th)] = rate
         if rate > best:
             best, cores = rate, th
     o.set_threads(1)
     t1 = time.perf_counter()
     o.iteration()
     single = 1.0 / (time.perf_counter() - t1)
+    scaling["1"] = single
     o.set_threads(cores)
     warm = 2 + len({min(ncpu, t) for t in (16, 32, 64, 128, 256)})
     n, t0 = 0, time.perf_counter()
@@ -467,6 +550,8 @@ def cpu_baseline(col, costs, args, sizes):
         "kind": "port",
         "single_thread_value": single,
         "value_per_core": n / el / cores,
+        # one iteration per thread count (it/s); the oracle's arrays are first touched in parallel over BDDs since r6 (pages on every NUMA node)
+        "thread_scaling_one_iteration_each": dict(sorted(scaling.items(), key=lambda kv: int(kv[0]))),
         "sample": f"{n} iterations of the same {sizes['N']}-node instance after {warm} warm-up / thread-count-probe "
                   f"iterations, oracle/mma_oracle.c with OpenMP over BDDs ({cores} of {ncpu} hardware threads: the "
                   f"fastest of 16..256), {args.precision}",

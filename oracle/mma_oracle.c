@@ -44,6 +44,23 @@
 #define RINF INFINITY
 #define RMIN(a, b) fminf_like_std((a), (b))
 static inline float fminf_like_std(float a, float b) { return b < a ? b : a; } /* std::min semantics */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* The loops over BDDs of the mm passes use schedule(runtime): dynamic, 64 unless the environment says otherwise (the reference:
+ * schedule(dynamic), bdd_parallel_mma_base.cpp:973,999).  MMA_ORACLE_SCHEDULE=static makes them static, 512 — the schedule the arrays
+ * were first touched with (oracle_create), for the timing leg of bench.py on multi-socket hosts. */
+static void oracle_default_schedule(void)
+{
+#ifdef _OPENMP
+    static int done = 0;
+    if (done) return;
+    done = 1;
+    const char* e = getenv("MMA_ORACLE_SCHEDULE");
+    if (e && e[0] == 's') omp_set_schedule(omp_sched_static, 512);
+    else omp_set_schedule(omp_sched_dynamic, 64);
+#endif
+}
 #include "mma_oracle_impl.h"
 #undef REAL
 #undef SUFFIX

@@ -62,7 +62,7 @@ def test_labels_follow_the_sizes_and_traffic_is_stamped():
     assert "not a BASELINE.json configuration" in bench.workload_name(set_cover_sizes(3000, 2000, 10), odd)
     assert bench.nodes_label(10_500_000) == "10.5M" and bench.nodes_label(1_050_000) == "1.05M"
     # committed PMC traffic is only quoted while the kernel sources it was measured on are unchanged
-    t, t_exch, src = bench.measured_traffic("forward_mm", a10, "f32")
+    t, t_exch, src, us_rocprof = bench.measured_traffic("forward_mm", a10, "f32")
     import json
     stamped = []
     import glob
@@ -71,3 +71,20 @@ def test_labels_follow_the_sizes_and_traffic_is_stamped():
     assert (t is not None) == (bench.source_hash() in stamped)
     if t is not None:
         assert src.startswith("profiles/") and 100e6 < t < 400e6 and (t_exch is None or 30e6 < t_exch < 200e6)
+        assert us_rocprof is None or 20.0 < us_rocprof < 200.0   # rocprofv3 average of the same kernel, stored beside its bytes since r6
+
+
+def test_lbfgs_bytes_and_hbm_only_source():
+    """the L-BFGS line carries a roofline on SURVEY §8(d)'s (2m + 6) R L' + sweep bytes; the HBM-only fraction quoted
+    in the line comes from the newest round's committed file."""
+    sys.path.insert(0, ROOT)
+    import glob
+    import bench
+    from bdd_amd.instances import set_cover_sizes
+    sz = set_cover_sizes(1_000_000, 500_000, 10)
+    extra = 12 * sz["N_nt"] + 2 * 4 * sz["N"] + 2 * 4 * sz["L_nt"]
+    assert bench.lbfgs_bytes(sz, 4, 5, 1.0) == 708_000_000 + 16 * 4 * sz["L_nt"] + 2 * extra
+    assert bench.lbfgs_bytes(sz, 8, 5, 1.25) == 1_140_000_000 + 16 * 8 * sz["L_nt"] + 2.25 * (12 * sz["N_nt"] + 16 * sz["N"] + 16 * sz["L_nt"])
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_only_105m.json")))[-1]
+    h = bench.hbm_only_fractions()
+    assert h["source"] == "profiles/" + os.path.basename(newest) and 0.3 < h["f32"] < 1.0 and 0.3 < h["f64"] < 1.0

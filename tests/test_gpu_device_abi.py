@@ -159,7 +159,7 @@ def test_device_chip_query_and_allocated_bytes():
     col, costs = random_set_cover(300, 200, 5, seed=2)
     s = bdd_hip_parallel_mma(col, costs, precision="float")
     held, alloc = s.device_bytes(), s.device_allocated_bytes()
-    assert 0 < held <= alloc <= held + (4 << 20), (held, alloc)
+    assert 0 < held <= alloc <= held + (8 << 20), (held, alloc)
     s.iterations(3)
     assert np.isfinite(s.lower_bound())
     s.close()

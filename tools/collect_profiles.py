@@ -29,6 +29,12 @@ for k, d in agg.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         f, w = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]), sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
         traffic[k] = {"fetch_kib_reported": f, "write_kib_reported": w, "hbm_bytes": (2 * f + w) * 1024}
+# the kernel-trace run's average duration of the same kernels, next to their bytes (bench.py: roofline.kernel_us_rocprof)
+for r in csv.DictReader(open(f"{dst}/kernel_stats.csv")):
+    k = r["Name"].split("(")[0]
+    if k in traffic:
+        traffic[k]["avg_us_rocprof"] = float(r["AverageNs"]) / 1e3
+        traffic[k]["calls_rocprof"] = int(r["Calls"])
 # stamp: bench.py quotes these bytes only while the kernel sources are the ones they were measured on
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
