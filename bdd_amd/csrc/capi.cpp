@@ -142,6 +142,7 @@ uint64_t bddmma_nr_bdd_nodes(const bddmma_solver* s) { return s && s->impl ? s->
 uint64_t bddmma_nr_hops(const bddmma_solver* s) { return s && s->impl ? s->impl->n_hops : 0; }
 uint64_t bddmma_nr_packs(const bddmma_solver* s) { return s && s->impl ? s->impl->n_packs_narrow + s->impl->n_packs_wide : 0; }
 int bddmma_solve_sweep_kind(const bddmma_solver* s) { return s && s->impl ? s->impl->solve_sweep_kind : -1; }
+int bddmma_fused_small(const bddmma_solver* s) { return s && s->impl ? (s->impl->fused_small ? 1 : 0) : -1; }
 int bddmma_precision(const bddmma_solver* s) { return s && s->impl ? s->impl->precision : -1; }
 int bddmma_device(const bddmma_solver* s) { return s && s->impl ? s->impl->device : -1; }
 uint64_t bddmma_device_bytes(const bddmma_solver* s) { return s && s->impl ? s->impl->dev_bytes : 0; }
@@ -211,13 +212,7 @@ int bddmma_iteration(bddmma_solver* s, double omega)
 }
 int bddmma_iterations(bddmma_solver* s, double omega, uint64_t n)
 {
-    return guarded(s, [&](SolverBase* b) {
-        for (uint64_t i = 0; i < n; ++i) {
-            int rc = b->iteration(omega);
-            if (rc) return rc;
-        }
-        return BDDMMA_OK;
-    });
+    return guarded(s, [&](SolverBase* b) { return b->iterations(omega, n); });
 }
 int bddmma_forward_mm(bddmma_solver* s, double omega, void* d, int on_device)
 {

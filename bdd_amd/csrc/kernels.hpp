@@ -33,4 +33,5 @@
 #include "kernels/narrow3.hpp"
 #include "kernels/wide.hpp"
 #include "kernels/exchange.hpp"
+#include "kernels/small.hpp"
 #include "kernels/elementwise.hpp"

@@ -15,7 +15,7 @@ namespace bddmma {
 // the launches of the iterations the host queued ahead see it and return (DevPtrs::stop), so the solver state is exactly the one
 // after the iteration that met the criterion.  No extra launch, no synchronisation; the host only watches `RunHost` (pinned) for
 // the bounds to print and for the end.  The wall-clock limit stays a host test.
-constexpr uint32_t RUN_RING = 64;
+constexpr uint32_t RUN_RING = 256;
 struct RunCtl {  // device memory
     double lb_initial, lb_first, lb_post, tolerance, slope;
     double time_limit;   // seconds since the start of run_solver (run_solver_util.h:45-55); tested on the device's constant 100 MHz clock
@@ -38,6 +38,36 @@ struct RunStep {  // argument of the launch that ends an iteration (ctl == nullp
     RunCtl* ctl;
     RunHost* host;
 };
+// The tests of run_solver_util.h:45-73 on the bound `t` of the iteration that has just ended, by ONE thread; `c` = the control block as it was
+// before the iteration.  Publishes the bound, advances the iteration count, latches `stop`.  Returns the stop reason (0: go on).
+// `publish` = false (k_iterate_small between the iterations of one launch): the bound goes to the ring but the host's view of the iteration
+// count waits for a later call — the one that stops the run or ends the launch publishes everything (one system-scope fence for all).
+__device__ __forceinline__ uint32_t run_ctl_finish(const RunStep& r, const RunCtl& c, double t, bool publish = true)
+{
+    RunCtl* ctl = r.ctl;
+    const uint64_t it = c.iter;
+    const double lb_prev = c.lb_post, lb_post = t;
+    const double lb_first = it == 0 ? lb_post : c.lb_first, lb_initial = c.lb_initial;
+    if (it == 0) ctl->lb_first = lb_post;
+    ctl->lb_post = lb_post;
+    ctl->iter = it + 1;
+    uint32_t reason = 0;
+    // the wall-clock limit first, as the reference tests it (:45-55) — on the device, so that no iteration queued behind the one that crossed
+    // the limit runs (ADVICE r2: the host-side test let up to window - 1 more iterations execute)
+    const double time_spent = (double)(__builtin_amdgcn_s_memrealtime() - c.t0) / RUN_TICKS_PER_SECOND;
+    if (time_spent > c.time_limit) reason = 1;
+    else if (__builtin_fabs(lb_prev - lb_post) < __builtin_fabs(c.tolerance * lb_prev)) reason = 2;           // run_solver_util.h:56-61
+    else if (__builtin_fabs(lb_prev - lb_post) < c.slope * __builtin_fabs(lb_initial - lb_first)) reason = 3;  // :62-67
+    else if (lb_post == __builtin_huge_val()) reason = 4;                                                       // :68-73
+    if (reason) { ctl->reason = reason; ctl->stop = (uint32_t)(it + 1 < (uint64_t)RUN_NOT_STOPPED ? it + 1 : (uint64_t)RUN_NOT_STOPPED - 1); }  // launches of iterations >= it + 1 are skipped
+    volatile RunHost* h = r.host;
+    h->lb[it % RUN_RING] = lb_post;
+    if (publish || reason) {
+        __threadfence_system();
+        h->state = (it + 1) | ((uint64_t)reason << 56);
+    }
+    return reason;
+}
 // Executed by every thread of ONE workgroup of 256, 512 or 1024 threads.  The sum has the shape and order of k_lb_reduce (1024
 // threads: 16 waves of strided partial sums, an in-wave tree, the 16 results added in order) whatever the workgroup size, so the
 // published bound equals lower_bound() bit for bit.
@@ -64,28 +94,9 @@ __device__ __forceinline__ void run_ctl_step(const RunStep& r)
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    RunCtl* ctl = r.ctl;
     double t = 0.0;
     for (uint32_t i = 0; i < 16; ++i) t += run_red[i];
-    const uint64_t it = c.iter;
-    const double lb_prev = c.lb_post, lb_post = t;
-    const double lb_first = it == 0 ? lb_post : c.lb_first, lb_initial = c.lb_initial;
-    if (it == 0) ctl->lb_first = lb_post;
-    ctl->lb_post = lb_post;
-    ctl->iter = it + 1;
-    uint32_t reason = 0;
-    // the wall-clock limit first, as the reference tests it (:45-55) — on the device, so that no iteration queued behind the one that crossed
-    // the limit runs (ADVICE r2: the host-side test let up to window - 1 more iterations execute)
-    const double time_spent = (double)(__builtin_amdgcn_s_memrealtime() - c.t0) / RUN_TICKS_PER_SECOND;
-    if (time_spent > c.time_limit) reason = 1;
-    else if (__builtin_fabs(lb_prev - lb_post) < __builtin_fabs(c.tolerance * lb_prev)) reason = 2;           // run_solver_util.h:56-61
-    else if (__builtin_fabs(lb_prev - lb_post) < c.slope * __builtin_fabs(lb_initial - lb_first)) reason = 3;  // :62-67
-    else if (lb_post == __builtin_huge_val()) reason = 4;                                                       // :68-73
-    if (reason) { ctl->reason = reason; ctl->stop = (uint32_t)(it + 1 < (uint64_t)RUN_NOT_STOPPED ? it + 1 : (uint64_t)RUN_NOT_STOPPED - 1); }  // launches of iterations >= it + 1 are skipped
-    volatile RunHost* h = r.host;
-    h->lb[it % RUN_RING] = lb_post;
-    __threadfence_system();
-    h->state = (it + 1) | ((uint64_t)reason << 56);
+    (void)run_ctl_finish(r, c, t);
 }
 
 template <typename REAL>

@@ -360,7 +360,6 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
     const uint32_t ng = !has_pack ? 0 : (hdr ? 1u : pk.pack_group_ptr[p + 1] - g0);
     const uint32_t r0 = hdr ? 0 : pk.quad_round_ptr[quad];
     const uint32_t n_rounds = hdr ? 1u : pk.quad_round_ptr[quad + 1] - r0;
-    P2* sDw = sD + (size_t)wave * pk.stage_cap;
     const uint32_t db = (uint32_t)wave * pk.stage_cap * (uint32_t)sizeof(P2);
     for (uint32_t k = n_rounds; k-- > 0;) {  // same rounds as the forward sweep, in reverse
         uint32_t gl0 = 0, cnt = 0, qs = q0;

@@ -54,6 +54,14 @@ struct SolverBase {
     virtual int lower_bound_fetch(int slot, double* lb) = 0;
     virtual int lower_bound_per_bdd(void* out, int on_device) = 0;
     virtual int iteration(double omega) = 0;
+    // n iterations; instances that fit one workgroup run them inside one launch (kernels/small.hpp), everything else calls iteration() n times
+    virtual int iterations(double omega, uint64_t n)
+    {
+        for (uint64_t i = 0; i < n; ++i)
+            if (int rc = iteration(omega)) return rc;
+        return BDDMMA_OK;
+    }
+    bool fused_small = false;   // whole iterations in one launch (diagnostics: bddmma_fused_small)
     // run_solver (include/run_solver_util.h:10-77) around iteration(): termination tests on the device, see solver_impl.hpp
     virtual int run_plain(uint64_t max_iter, double tolerance, double slope, double time_limit, int verbose, bddmma_run_result* res) = 0;
     virtual int forward_mm(double omega, void* delta, int on_device) = 0;

@@ -156,6 +156,12 @@ struct SolverT final : SolverBase {
     const uint32_t* n2_hdr_pack() const { return res_hdr_ok ? d_pack_hdr : nullptr; }
     const uint32_t* n2_hdr_quad() const { return res_hdr_ok ? d_quad_hdr : nullptr; }
     uint32_t srec_words = 0;
+    // instances that fit one workgroup: whole iterations in one launch (kernels/small.hpp: k_iterate_small)
+    bool small_ok = false, small_rl = false;
+    int small_nw = 1;
+    uint32_t small_lds = 0;
+    SmallDev small{};
+    uint32_t* d_small_lds = nullptr;
     // streaming solve sweeps, third generation: a lane per layer (kernels/narrow3.hpp: k_fwd_narrow3 / k_bwd_narrow3)
     bool use_narrow3 = false;
     uint32_t *d_lrec = nullptr, *d_lrec_off = nullptr;
@@ -619,6 +625,48 @@ struct SolverT final : SolverBase {
                 mixed_lds = std::max(narrow_dyn, wide_lds);
             }
         }
+        // Whole iterations in one launch (kernels/small.hpp) where every pack fits one workgroup: the second-generation resident records (their
+        // conditions: 64-slot packs, layers of <= 2 nodes, one stage group per pack and one staging round per quad), narrow packs only, the LDS-atomic
+        // exchange's arithmetic (not the deterministic / by-variable orders), all of it within the CU's LDS.  variant_flags bit 19: off.
+        if (use_res2 && res_hdr_ok && nb_.n_packs <= SMALL_MAX_PACKS && !wb_.n_packs && !hb_.n_packs && !deterministic && !entry_by_var && !big &&
+            L.var_ptr.size() == n_vars + 1 && L.ex.vpos.size() == n_layers && !(opts && (opts->variant_flags & 0x80000u))) {
+            const uint32_t np = nb_.n_packs;
+            std::vector<uint32_t> lds_off(n_layers);
+            uint32_t max_hops = 0;
+            bool ok = true;
+            for (uint32_t k = 0; k < (uint32_t)n_layers && ok; ++k) {
+                const uint32_t l = L.var_layers[k];
+                uint32_t p = 0;   // the pack whose layer range holds l (pack_hdr: [2] first layer, [3] layers)
+                while (p < np && !(l >= L.res.pack_hdr[8 * (size_t)p + 2] && l < L.res.pack_hdr[8 * (size_t)p + 2] + L.res.pack_hdr[8 * (size_t)p + 3])) ++p;
+                if (p == np || l - L.res.pack_hdr[8 * (size_t)p + 2] >= res2_nl) { ok = false; break; }
+                lds_off[k] = (p * res2_nl + (l - L.res.pack_hdr[8 * (size_t)p + 2])) * 2u * (uint32_t)sizeof(REAL);
+            }
+            for (uint32_t p = 0; p < np; ++p) max_hops = std::max(max_hops, L.res.pack_hdr[8 * (size_t)p + 5] & 0xFFFFu);
+            small = SmallDev{};
+            small.ns = res2_ns; small.nl = res2_nl; small.n_packs = np; small.wpb = wpb; small.n_quads = cdiv(np, wpb);
+            small.n_vars = (uint32_t)n_vars; small.n_entries = (uint32_t)n_layers; small.rec_words = res2_n_words;
+            small.rec_cap = max_hops * 1024u;
+            uint32_t bytes = small_lds_bytes((uint32_t)sizeof(REAL), np, (uint32_t)n_vars, (uint32_t)n_layers, small);
+            small_rl = bytes + 512 <= lds_cu;
+            if (!small_rl) {
+                small.rec_cap = 0;
+                bytes = small_lds_bytes((uint32_t)sizeof(REAL), np, (uint32_t)n_vars, (uint32_t)n_layers, small);
+            }
+            if (ok && bytes + 512 <= lds_cu) {
+                if ((rc = upload(&d_small_lds, lds_off))) return rc;
+                small.pack_hdr = d_pack_hdr; small.quad_hdr = d_quad_hdr; small.rec = d_res2_rec; small.rec_off = d_res2_rec_off;
+                small.var_ptr = d_var_ptr; small.var_lds = d_small_lds; small.var_ent = d_vpos;
+                small_lds = bytes;
+                small_nw = np <= 1 ? 1 : np <= 2 ? 2 : np <= 4 ? 4 : np <= 8 ? 8 : 16;
+#define SET_SMALL(NW_)                                                                                                                                  \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iterate_small<REAL, NW_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds)); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_iterate_small<REAL, NW_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+                switch (small_nw) { case 1: SET_SMALL(1) break; case 2: SET_SMALL(2) break; case 4: SET_SMALL(4) break; case 8: SET_SMALL(8) break; default: SET_SMALL(16) break; }
+#undef SET_SMALL
+                small_ok = true;
+                fused_small = true;
+            }
+        }
         solve_sweep_kind = !nb_.n_packs ? BDDMMA_SWEEPS_NONE : mixed ? BDDMMA_SWEEPS_MIXED : (use_res && use_res2) ? BDDMMA_SWEEPS_RESIDENT2 : use_res ? BDDMMA_SWEEPS_RESIDENT1
                            : use_narrow3 ? BDDMMA_SWEEPS_STREAMING3 : use_narrow2 ? BDDMMA_SWEEPS_STREAMING2 : BDDMMA_SWEEPS_STREAMING1;
         HIPCHK(hipStreamSynchronize(stream));
@@ -1008,10 +1056,50 @@ struct SolverT final : SolverBase {
         bwd_valid = true;
         return BDDMMA_OK;
     }
+    // ---- instances that fit one workgroup: n iterations inside one launch (kernels/small.hpp).  Not while event pairs are wanted per launch
+    // (profiling) or an L-BFGS wrapper wants x in layer order from the backward sweeps.
+    bool small_usable() const { return small_ok && !profiling && d_x_layer == nullptr; }
+    int launch_small(REAL omega, uint32_t n, const RunStep& rstep)
+    {
+        int rc;
+        if (!bwd_valid && (rc = backward_run())) return rc;  // bdd_cuda_parallel_mma.cu:211-212, as mma_forward
+        lb_cached = false;
+        ++lb_gen;
+        const DevPtrs<REAL> d = ptrs(d_delta_lay);
+        const PackDev pk = pdev(nb_, 0, 0);
+#define LAUNCH_SMALL(NW_)                                                                                                                       \
+    if (small_rl) hipLaunchKernelGGL((k_iterate_small<REAL, NW_, true>), dim3(1), dim3(64 * NW_), small_lds, stream, small, d, pk, omega, n, rstep); \
+    else hipLaunchKernelGGL((k_iterate_small<REAL, NW_, false>), dim3(1), dim3(64 * NW_), small_lds, stream, small, d, pk, omega, n, rstep)
+        switch (small_nw) { case 1: LAUNCH_SMALL(1); break; case 2: LAUNCH_SMALL(2); break; case 4: LAUNCH_SMALL(4); break; case 8: LAUNCH_SMALL(8); break; default: LAUNCH_SMALL(16); break; }
+#undef LAUNCH_SMALL
+        HIPCHK(hipGetLastError());
+        // the state the last iteration's four launches leave (mma_forward, exchange, mma_backward, exchange)
+        x_layer_valid = false;
+        fwd_valid = false;
+        bwd_valid = true;
+        delta_var_valid = false;
+        return BDDMMA_OK;
+    }
+    int iterations(double omega, uint64_t n) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (!small_usable() || run_stop) {
+            for (uint64_t i = 0; i < n; ++i)
+                if (int rc = iteration(omega)) return rc;
+            return BDDMMA_OK;
+        }
+        while (n) {
+            const uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 1u << 20);
+            if (int rc = launch_small((REAL)omega, chunk, RunStep{})) return rc;
+            n -= chunk;
+        }
+        return BDDMMA_OK;
+    }
     int iteration(double omega) override
     {
         HIPCHK(hipSetDevice(device));
         int rc;
+        if (small_usable() && !run_stop) return launch_small((REAL)omega, 1, RunStep{});
         prof_active = profiling && (prof_iter++ % prof_stride == 0);
         if ((rc = mma_forward((REAL)omega, d_delta_lay))) return rc;
         if ((rc = exchange())) return rc;
@@ -1062,17 +1150,24 @@ struct SolverT final : SolverBase {
         while (true) {
             // (the wall-clock limit is tested on the device with the other criteria, run_ctl_step: iterations queued behind the one that
             // crossed it return at once like those behind any other stop)
-            const uint64_t window = WINDOW;
+            // instances that fit one workgroup: SMALL_CHUNK iterations per launch, the tests inside the kernel after each (k_iterate_small); at most
+            // two chunks are outstanding, fewer bounds than the ring of published ones holds
+            constexpr uint64_t SMALL_CHUNK = 64;
+            static_assert(2 * SMALL_CHUNK < RUN_RING, "published bounds must not wrap before the host has read them");
+            const bool fused = small_usable();
+            const uint64_t window = fused ? SMALL_CHUNK + 1 : WINDOW;
             bool launched = false;
             while (queued < max_iter && queued - seen < window) {
                 run_iter = (uint32_t)std::min<uint64_t>(queued, RUN_NOT_STOPPED - 1);
-                rc = iteration(0.5);  // its last launch also reduces the bound and runs the tests (exchange(true))
+                const uint64_t n_launch = fused ? std::min<uint64_t>(SMALL_CHUNK, max_iter - queued) : 1;
+                // the sequential path's last launch also reduces the bound and runs the tests (exchange(true))
+                rc = fused ? launch_small(REAL(0.5), (uint32_t)n_launch, run_step) : iteration(0.5);
                 if (rc) {  // launches of this and earlier iterations may be in flight: drain them before the gate goes away
                     (void)hipStreamSynchronize(stream);
                     run_stop = nullptr;
                     return rc;
                 }
-                ++queued;
+                queued += n_launch;
                 launched = true;
             }
             if (queued == 0) break;  // max_iter == 0

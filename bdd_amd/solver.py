@@ -88,6 +88,9 @@ class bdd_hip_parallel_mma:
     def solve_sweep_kind(self) -> str:
         """which kernels run the narrow packs' solve sweeps (include/bdd_mma.h: BDDMMA_SWEEPS_*)"""
         return self.SWEEP_KINDS[int(self._L.bddmma_solve_sweep_kind(self._h))]
+    def fused_small(self) -> bool:
+        """whole iterations run inside one launch (the instance fits one workgroup; csrc/kernels/small.hpp)"""
+        return bool(self._L.bddmma_fused_small(self._h))
     def device_bytes(self): return int(self._L.bddmma_device_bytes(self._h))
     def device_allocated_bytes(self): return int(self._L.bddmma_device_allocated_bytes(self._h))
 

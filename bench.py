@@ -211,7 +211,8 @@ def main():
         lbfgs = {p: lbfgs_rate(col, costs, p, local_rank, args, sizes) for p in ([args.precision] if args.no_second_precision else [args.precision, other])}
     configs = None
     if rank == 0 and not args.no_configs and (args.vars, args.rows, args.k) == (1_000_000, 500_000, 10):
-        configs = {"1m_f32": small_config(local_rank, "float"), "1m_f64": small_config(local_rank, "double")}
+        configs = {"1m_f32": small_config(local_rank, "float"), "1m_f64": small_config(local_rank, "double"),
+                   "matching_8x8_f64": matching_config(local_rank, "double"), "matching_8x8_f32": matching_config(local_rank, "float")}
 
     if rank == 0:
         its = aggregate_rate(world, args.steps, dt)
@@ -268,9 +269,11 @@ def main():
                                     "parameters), fresh solver, 20 untimed iterations that fill the history, then the timed ones; outside the timed "
                                     "region of `value`", **lbfgs}
         if configs is not None:
-            out["configs"] = {"what": "the other single-GPU BASELINE.json configuration, outside the timed region of `value`: configs[1] = random set cover "
+            out["configs"] = {"what": "the other single-GPU BASELINE.json configurations, outside the timed region of `value`: configs[1] = random set cover "
                                       "k = 10, V = 1e5, B = 5e4 (1.05 M BDD nodes), same generator and seed; 2 000 timed iterations after 0.1 s of "
-                                      "clock-warm iterations; per-kernel times from hipEvent pairs on the solver's stream in a second pass", **configs}
+                                      "clock-warm iterations; per-kernel times from hipEvent pairs on the solver's stream in a second pass.  configs[0] = "
+                                      "the 8 x 8 bipartite matching of test_bdd_bipartite_matching_problem.cpp (16 BDDs, one workgroup: whole iterations "
+                                      "inside one launch, csrc/kernels/small.hpp) — iterations(n) and run_solver with its tests on the device", **configs}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(col, costs, args, sizes)
         print(json.dumps(out), flush=True)
@@ -321,6 +324,32 @@ def small_config(device, precision, vars_=100_000, rows=50_000, k=10, steps=2000
            "lower_bound_after": {"value": s.lower_bound()}}
     s.close()
     return out
+
+
+def matching_config(device, precision, n=8):
+    """BASELINE.json configs[0]: the n x n assignment problem (-2 on the diagonal, -1 elsewhere: optimum -2 n) — an instance that fits one
+    workgroup, so iterations run inside one launch; the rate of iterations(n) and of run_solver (bound and termination tests every iteration)."""
+    from bdd_amd import to_bdd_collection
+    from bdd_amd.instances import assignment_ilp
+    from bdd_amd.solver import bdd_hip_parallel_mma, run_solver
+    ilp = assignment_ilp(n)
+    col = to_bdd_collection(ilp)
+    s = bdd_hip_parallel_mma(col, ilp.objective, precision=precision, device=device)
+    s.iterations(5000)
+    s.synchronize()
+    t0 = time.perf_counter()
+    s.iterations(50000)
+    s.synchronize()
+    dt = time.perf_counter() - t0
+    lb = s.lower_bound()
+    fused = s.fused_small()
+    s.close()
+    s = bdd_hip_parallel_mma(col, ilp.objective, precision=precision, device=device)
+    rs = run_solver(s, max_iter=5000, tolerance=0.0, improvement_slope=0.0, time_limit=1e9)
+    s.close()
+    return {"workload": f"{n} x {n} bipartite matching, 2n simplex BDDs over n^2 variables (BASELINE.json configs[0])", "dtype": "f64" if precision == "double" else "f32",
+            "value": 50000 / dt, "unit": "iterations/s", "us_per_iteration": dt / 50000 * 1e6, "iterations_in_one_launch": fused,
+            "run_solver_us_per_iteration": rs["seconds"] / max(rs["iterations"], 1) * 1e6, "lower_bound": lb, "known_optimum": -2.0 * n}
 
 
 def lbfgs_rate(col, costs, precision, device, args, sizes, iters=100):
