@@ -37,6 +37,12 @@ __device__ __forceinline__ void pot_store(double v, rsrc_t rh, uint32_t voff, ui
     else hop_store<>(v, rh, voff, soff);
 }
 
+// Hops the prefetches of the hop pipeline run ahead.  One for float (two and three: nothing, round 5).  Two for double (round 6, same-box A/B of
+// whole builds, tools/exp_r06_o.sh: 10.5 M nodes 4 474 -> 4 644 it/s; the 16-byte pairs and 8-byte potentials of a double hop are twice the
+// bytes per request slot of the same record stream, and the registers are there: the double instantiation is LDS-bound at 4 waves per SIMD).
+#ifndef BDDMMA_N3_LOOKAHEAD
+#define BDDMMA_N3_LOOKAHEAD(REAL) (sizeof(REAL) == 8 ? 2 : BDDMMA_LOOKAHEAD)
+#endif
 template <typename REAL, int WPB, bool NT = false, int LA = BDDMMA_LOOKAHEAD>
 __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ lrec,
                                                  const uint32_t* __restrict__ lrec_off, uint32_t lrec_words, REAL omega, uint32_t block_id)
@@ -251,7 +257,7 @@ template <typename REAL, int WPB, bool NT = false>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N3_WAVES(REAL)))) k_fwd_narrow3(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ lrec, const uint32_t* __restrict__ lrec_off,
                                                           uint32_t lrec_words, REAL omega)
 {
-    fwd_narrow3_body<REAL, WPB, NT>(d, pk, lrec, lrec_off, lrec_words, omega, blockIdx.x);
+    fwd_narrow3_body<REAL, WPB, NT, BDDMMA_N3_LOOKAHEAD(REAL)>(d, pk, lrec, lrec_off, lrec_words, omega, blockIdx.x);
 }
 
 template <typename REAL, int WPB, bool NT = false, int LA = BDDMMA_LOOKAHEAD>
@@ -468,7 +474,7 @@ template <typename REAL, int WPB, bool NT = false>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N3_WAVES(REAL)))) k_bwd_narrow3(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ lrec, const uint32_t* __restrict__ lrec_off,
                                                           uint32_t lrec_words, REAL omega)
 {
-    bwd_narrow3_body<REAL, WPB, NT>(d, pk, lrec, lrec_off, lrec_words, omega, blockIdx.x);
+    bwd_narrow3_body<REAL, WPB, NT, BDDMMA_N3_LOOKAHEAD(REAL)>(d, pk, lrec, lrec_off, lrec_words, omega, blockIdx.x);
 }
 
 }  // namespace bddmma
