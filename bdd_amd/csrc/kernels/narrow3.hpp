@@ -37,9 +37,9 @@ __device__ __forceinline__ void pot_store(double v, rsrc_t rh, uint32_t voff, ui
     else hop_store<>(v, rh, voff, soff);
 }
 
-// Hops the prefetches of the hop pipeline run ahead.  One for float (two and three: nothing, round 5).  Two for double (round 6, same-box A/B of
-// whole builds, tools/exp_r06_o.sh: 10.5 M nodes 4 474 -> 4 644 it/s; the 16-byte pairs and 8-byte potentials of a double hop are twice the
-// bytes per request slot of the same record stream, and the registers are there: the double instantiation is LDS-bound at 4 waves per SIMD).
+// Hops the prefetches of the hop pipeline run ahead.  One for float (two and three: nothing, round 5).  Two for double: +0.8 % in a same-box A/B
+// over 36 solver objects (tools/exp_r06_r.sh: 4 612 / 4 620 / 4 482 against 4 576 / 4 589 / 4 481 it/s at 10.5 M nodes, process by process — the
+// process-to-process spread of 3 % is larger than the effect; a first single-sample reading of +4-6 % was that spread), three: -1 %, four: spills.
 #ifndef BDDMMA_N3_LOOKAHEAD
 #define BDDMMA_N3_LOOKAHEAD(REAL) (sizeof(REAL) == 8 ? 2 : BDDMMA_LOOKAHEAD)
 #endif
