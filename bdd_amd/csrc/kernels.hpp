@@ -32,7 +32,6 @@
 #include "kernels/narrow2.hpp"
 #include "kernels/narrow3.hpp"
 #include "kernels/wide.hpp"
-#include "kernels/wide3.hpp"
 #include "kernels/exchange.hpp"
 #include "kernels/small.hpp"
 #include "kernels/elementwise.hpp"

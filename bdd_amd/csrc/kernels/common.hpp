@@ -12,7 +12,6 @@ struct DevPtrs {
     const uint32_t* nwords;  // narrow node words: distinct pack sequences, pack p's at PackDev::pack_word_off[p]
     uint32_t n_nwords;
     const uint64_t* wwords;  // wide node words, indexed by slot - wide_slot_base
-    const uint32_t* wide_ent; // wide slots: entry index of the slot's layer (lpos[layer]), same indexing (kernels/wide3.hpp)
     uint32_t wide_slot_base;
     REAL* F;                 // cost from root, per slot
     REAL* T;                 // cost from terminal, per slot

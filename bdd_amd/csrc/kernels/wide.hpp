@@ -288,8 +288,10 @@ __device__ __forceinline__ void wide_load_vals(REAL (&v)[NPT], rsrc_t src, uint3
 // profiles/r05_wide_skip.txt, same box, two rounds): forward solve sweeps in float 25 000 rows of 18 variables 156 -> 147 us (2 883 -> 2 968 it/s),
 // 4 000 rows 58 -> 49.5 us (7 630 -> 8 100 it/s), rows of 16 and the knapsack benchmark +-1 %; in double rows of 18 gain 5 % and rows of 16 lose 4 %
 // (forward solve sweep 124 -> 141 us, reproducibly); plain sweeps lose 7-18 % (the branch costs them their counted waits), backward solve
-// sweeps gain on the small instance only.  The sweeps are bound by the latency of their own prefetches, whose registers the rotation at the end of
-// a hop touches (one hop of tolerance), not by instruction issue — which is why skipping three quarters of the lanes' work buys this little.
+// sweeps gain on the small instance only.  (Round 5 read this as "bound by the latency of their own prefetches, whose registers the rotation at
+// the end of a hop touches".  Round 6 built that fix — every load two hops old at its first use, three forms, `git show 1eaaed8:bdd_amd/csrc/
+// kernels/wide3.hpp`, profiles/r06_wide3.txt — and it was SLOWER (193 / 185 us against 134 / 183): the sweeps do not wait for memory either.  What
+// is left is the hop itself: two workgroup barriers, per-layer LDS minima and frontier pushes for 120 active of 512 slots — the packing.)
 #ifndef BDDMMA_WIDE_SKIP_FWD
 #define BDDMMA_WIDE_SKIP_FWD(REAL, MODE) ((MODE) == FWD_SOLVE && sizeof(REAL) == 4)
 #endif

@@ -60,7 +60,6 @@ struct SolverT final : SolverBase {
     uint32_t* d_pack_word_off = nullptr;
     uint32_t n_nwords = 0;
     uint64_t* d_wwords = nullptr;
-    uint32_t* d_wide_ent = nullptr;   // wide packs: entry index of every slot's layer (kernels/wide3.hpp)
     REAL *d_F = nullptr, *d_T = nullptr, *d_lohi = nullptr;  // d_lohi: {lo, hi} per layer, interleaved
     REAL* d_lo = nullptr;  // = d_lohi     (stride 2)
     REAL* d_hi = nullptr;  // = d_lohi + 1 (stride 2)
@@ -132,7 +131,6 @@ struct SolverT final : SolverBase {
     uint32_t wide_lds = 0, wide_threads = 256, wide_npt = 1;
     bool n3_nt = false;  // third-generation sweeps: the instantiation with non-temporal loads (double beyond the Infinity Cache's reach)
     uint32_t nt_potentials = 0;  // PackDev::nt_potentials (kernels.hpp: hop_store): double, footprint several times the Infinity Cache
-    bool use_wide3 = true;   // wide solve sweeps with two-hop prefetch distances (kernels/wide3.hpp; variant_flags bit 20: the wide2 form)
     bool mixed = false;      // narrow (streaming) and wide solve sweeps in one launch (kernels.hpp: k_fwd_mixed / k_bwd_mixed)
     // Measured on the knapsack benchmark (3 604 narrow + 389 wide packs): backward 44.7 -> 37.4 us in one launch.  The forward sweeps
     // did not gain at first (56.1 -> 58.6 us: both kinds were bound by same-address LDS pushes into the sink entries); with those
@@ -360,18 +358,6 @@ struct SolverT final : SolverBase {
         if ((rc = upload(&d_evar, L.ex.evar, 22))) return rc;
         if ((rc = upload(&d_bvar, L.ex.bvar, 23))) return rc;
         if ((rc = upload(&d_lpos, L.ex.lpos, 24))) return rc;
-        if (L.wide.n_packs() > 0) {
-            // the wide solve sweeps' per-slot entry index (kernels/wide3.hpp): lpos[first layer of the slot's hop + layer field of its word]
-            std::vector<uint32_t> went(L.wide_words.size(), 0u);
-            for (uint32_t q = 0; q + 1 < (uint32_t)L.wide.hop_node_off.size(); ++q) {
-                const uint32_t l0 = L.wide.hop_layer_off[q];
-                for (uint32_t s = L.wide.hop_node_off[q]; s < L.wide.hop_node_off[q + 1]; ++s) {
-                    const uint64_t w = L.wide_words[s - L.narrow_slots];
-                    went[s - L.narrow_slots] = L.ex.lpos[l0 + (uint32_t)((w >> (2 * WW_CHILD_BITS)) & WW_CHILD_MASK)];
-                }
-            }
-            if ((rc = upload(&d_wide_ent, went))) return rc;
-        }
         if ((rc = upload(&d_vpos, L.ex.vpos, 25))) return rc;
         if ((rc = upload(&d_bin_ptr, L.ex.bin_ptr, 26))) return rc;
         if ((rc = upload(&d_pack_group_ptr, L.ex.pack_group_ptr, 27))) return rc;
@@ -618,9 +604,7 @@ struct SolverT final : SolverBase {
                 err = "wide_pack_width " + std::to_string(wide_pack_width) + " needs " + std::to_string(wide_lds) + " B of LDS (> 160 KiB)";
                 return BDDMMA_ERR_UNSUPPORTED;
             }
-            use_wide3 = !(opts && (opts->variant_flags & 0x100000u));
 #define SET_LDS(K) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds))
-            SET_LDS((k_fwd_wide3<REAL, 1>)); SET_LDS((k_fwd_wide3<REAL, 2>)); SET_LDS((k_bwd_wide3<REAL, 1>)); SET_LDS((k_bwd_wide3<REAL, 2>));
 #define SET_LDS_N(N_) \
     SET_LDS((k_fwd_wide2<REAL, FWD_PLAIN, N_>)); SET_LDS((k_fwd_wide2<REAL, FWD_SOLVE, N_>)); SET_LDS((k_fwd_wide2<REAL, FWD_SOLUTION, N_>)); \
     SET_LDS((k_bwd_wide2<REAL, BWD_PLAIN, N_>)); SET_LDS((k_bwd_wide2<REAL, BWD_SOLVE, N_>)); SET_LDS((k_bwd_wide2<REAL, BWD_MARGINALS, N_>));
@@ -693,7 +677,7 @@ struct SolverT final : SolverBase {
     DevPtrs<REAL> ptrs(const REAL* delta_lay) const
     {
         DevPtrs<REAL> d;
-        d.nwords = d_nwords; d.n_nwords = n_nwords; d.wwords = d_wwords; d.wide_ent = d_wide_ent; d.wide_slot_base = wide_slot_base;
+        d.nwords = d_nwords; d.n_nwords = n_nwords; d.wwords = d_wwords; d.wide_slot_base = wide_slot_base;
         d.F = d_F; d.T = d_T; d.lohi = d_lohi;
         d.delta_lay = delta_lay; d.mm_binned = d_mm_binned; d.lpos = d_lpos; d.cs_entry = d_cs_entry; d.cs_slot = d_cs_slot;
         d.n_slots = (uint32_t)n_slots; d.n_layers = (uint32_t)n_layers; d.n_narrow_layers = n_narrow_layers;
@@ -757,10 +741,8 @@ struct SolverT final : SolverBase {
             const PackDev pk = pdev(wb_, nb_.n_packs);
             const dim3 g(wb_.n_packs), b(wide_threads);
             switch (wide_npt) {
-                case 1: if (MODE == FWD_SOLVE && use_wide3) hipLaunchKernelGGL((k_fwd_wide3<REAL, 1>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width);
-                        else hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 1>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
-                case 2: if (MODE == FWD_SOLVE && use_wide3) hipLaunchKernelGGL((k_fwd_wide3<REAL, 2>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width);
-                        else hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 2>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
+                case 1: hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 1>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
+                case 2: hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 2>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
                 default: hipLaunchKernelGGL((k_fwd_wide2<REAL, MODE, 4>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
             }
         }
@@ -834,10 +816,8 @@ struct SolverT final : SolverBase {
             const PackDev pk = pdev(wb_, nb_.n_packs);
             const dim3 g(wb_.n_packs), b(wide_threads);
             switch (wide_npt) {
-                case 1: if (MODE == BWD_SOLVE && use_wide3) hipLaunchKernelGGL((k_bwd_wide3<REAL, 1>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width);
-                        else hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 1>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
-                case 2: if (MODE == BWD_SOLVE && use_wide3) hipLaunchKernelGGL((k_bwd_wide3<REAL, 2>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width);
-                        else hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 2>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
+                case 1: hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 1>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
+                case 2: hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 2>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
                 default: hipLaunchKernelGGL((k_bwd_wide2<REAL, MODE, 4>), g, b, wide_lds, sw, d, pk, omega, wide_pack_width); break;
             }
         }

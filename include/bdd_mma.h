@@ -101,9 +101,7 @@ typedef struct bddmma_options {
                                           <= 2 nodes and <= 64 layers per hop that share their records, up to 16 M slots): the second / first
                                           generation instead (bit 13 lifts the sharing and size conditions of the third generation too)
                                   bit 19: four launches per iteration also for instances that fit one workgroup (rule: whole iterations in one
-                                          launch, k_iterate_small, for <= 16 narrow packs of 64 slots with layers of <= 2 nodes)
-                                  bit 20: the wide packs' solve sweeps in their second form (one-hop prefetch distances, k_*_wide2; rule: the
-                                          third form with two-hop distances and a per-slot entry index, k_*_wide3, for <= 2 nodes per thread) */
+                                          launch, k_iterate_small, for <= 16 narrow packs of 64 slots with layers of <= 2 nodes) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
                                   instance (NOTES.md section 6: the sweeps are bound by instructions issued, not by latency), kept for experiments */
