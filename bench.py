@@ -30,6 +30,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "HBM3E peak BW")
 KERNEL_SOURCES = ("bdd_amd/csrc/kernels.hpp", "bdd_amd/csrc/kernels/common.hpp", "bdd_amd/csrc/kernels/narrow.hpp", "bdd_amd/csrc/kernels/resident.hpp",
                   "bdd_amd/csrc/kernels/narrow2.hpp", "bdd_amd/csrc/kernels/narrow3.hpp", "bdd_amd/csrc/kernels/wide.hpp", "bdd_amd/csrc/kernels/exchange.hpp",
+                  "bdd_amd/csrc/kernels/small.hpp",
                   "bdd_amd/csrc/kernels/elementwise.hpp", "bdd_amd/csrc/solver_impl.hpp", "bdd_amd/csrc/layout.cpp")
 
 
