@@ -1,23 +1,13 @@
 #!/bin/bash
-# round 6, final collection on the shipped sources: GPU tests, rocprofv3 kernel stats + PMC passes of bench.py (10.5 M and 1.05 M nodes), kernel stats of the
-# L-BFGS loop, the HBM-only figure (105 M nodes), the default bench line and the driver's command line, instance-size sweep, small-instance rates
+# round 6, final collection on the shipped sources, part 1: GPU tests, rocprofv3 kernel stats + PMC passes of bench.py (10.5 M and 1.05 M nodes), kernel stats
+# of the L-BFGS loop.  Part 2 (tools/final_r06b.sh): the HBM-only figure, the bench lines, the size sweep, small-instance rates.
 mkdir -p gpurun_out/final
 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 > gpurun_out/final/gputest.txt
 bash tools/profile.sh r06_10m_f32 > gpurun_out/final/profile_10m.log 2>&1
 bash tools/profile.sh r06_1m_f32 --vars 100000 --rows 50000 > gpurun_out/final/profile_1m.log 2>&1
 bash tools/kstats.sh r06_lbfgs_f32 tools/lbfgs_prof.py float 200 > gpurun_out/final/kstats_lbfgs_f32.txt 2>&1
 bash tools/kstats.sh r06_lbfgs_f64 tools/lbfgs_prof.py double 200 > gpurun_out/final/kstats_lbfgs_f64.txt 2>&1
-timeout 1200 python tools/hbm_only.py gpurun_out/final/hbm_only_105m.json 3 > gpurun_out/final/hbm_only.txt 2>&1
-python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
-python bench.py --steps 20 --warmup 5 > gpurun_out/final/bench_20steps.json 2>/dev/null
-python bench.py --vars 100000 --rows 50000 --no-cpu-baseline > gpurun_out/final/bench_1m.json 2>/dev/null
-{
-for cfg in "100000 400" "400000 400" "1000000 400" "2000000 200" "4000000 100" "10000000 40"; do
-  set -- $cfg
-  for prec in float double; do
-    echo "V=$1 $prec: $(timeout 900 python tools/kbench.py --mt 1 --precision $prec --vars $1 --rows $(($1/2)) --iters $2 2>/dev/null | tail -2 | tr '\n' ' ')"
-  done
-done
-} > gpurun_out/final/size_sweep.txt 2>&1
-timeout 300 python tools/small_rate.py > gpurun_out/final/small_rate.txt 2>&1
-cat gpurun_out/final/gputest.txt gpurun_out/final/hbm_only.txt; tail -1 gpurun_out/final/bench_default.json | cut -c1-300
+# does a --pmc pass over the fused small-instance kernel return at all?  (bounded: 90 s)
+timeout 90 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/final/pmc_small -o pmc -- python tools/small_phases.py > gpurun_out/final/pmc_small.txt 2>&1; echo "pmc over k_iterate_small: exit $?" >> gpurun_out/final/pmc_small.txt
+rm -rf gpurun_out/final/pmc_small
+cat gpurun_out/final/gputest.txt; tail -3 gpurun_out/final/pmc_small.txt; ls gpurun_out/prof_r06_10m_f32 gpurun_out/prof_r06_1m_f32
