@@ -29,6 +29,19 @@ __device__ __forceinline__ void lds_ld2(REAL& a, REAL& b, const unsigned char* l
     b = p[1];
 }
 
+// Two neighbouring potentials with ONE load (round 6): the slots 2 lane, 2 lane + 1 of a hop (the forward sweep's copy of the next hop's
+// costs-from-terminal into LDS) or the nodes a, a + 1 of the lane's layer (the backward sweep's costs-from-root; LayerRecords: b = a + 1).  A hop
+// of these sweeps costs what its vector-memory instructions cost (a 4-byte-per-layer store added to the backward hop's seven instructions cost
+// 15 % of the sweep, profiles/r06_lbfgs_experiments.txt), and two 4-byte accesses of neighbouring addresses are one 8-byte access.  What lies
+// past the hop's last slot / behind a one-node layer comes back as whatever is there (or 0 past the descriptor's end) and is never used.
+template <typename REAL, bool NT>
+__device__ __forceinline__ void pot_pair_load(typename Pair<REAL>::type& v, rsrc_t rh, uint32_t voff, uint32_t soff)
+{
+    constexpr int AUX = NT ? 2 : BDDMMA_LD_POT_AUX;
+    if constexpr (sizeof(REAL) == 4) v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rh, voff, soff, AUX));
+    else v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rh, voff, soff, AUX));
+}
+
 // store of one potential (see hop_store: double-precision instances far beyond the Infinity Cache store F / T non-temporally)
 __device__ __forceinline__ void pot_store(float v, rsrc_t rh, uint32_t voff, uint32_t soff, uint32_t /*nt*/) { hop_store(v, rh, voff, soff); }
 __device__ __forceinline__ void pot_store(double v, rsrc_t rh, uint32_t voff, uint32_t soff, uint32_t nt)
@@ -90,7 +103,7 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
     uint32_t o[2 * D + 3];  // first slot of hops q .. q + 2D + 2
     uint32_t lb[D + 2];     // first layer of hops q .. q + D + 1
     u4v rc[2 * D + 1];      // records of hops q .. q + 2D
-    REAL tr[D + 1][2];      // costs-from-terminal of hops q + 2 .. q + D + 2, by slot (lane, lane + 64): copied to LDS one hop before they are read
+    P2 tr[D + 1];           // costs-from-terminal of hops q + 2 .. q + D + 2, slots (2 lane, 2 lane + 1): copied to LDS one hop before they are read
     P2 Lr[D + 1];           // {lo, hi} of the lane's layer in hops q .. q + D
 #pragma unroll
     for (int i = 0; i < 2 * D + 3; ++i) o[i] = 0;
@@ -117,15 +130,11 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
 #pragma unroll
         for (int i = 0; i < 2 * D; ++i) rc[i] = ldrec((uint32_t)i);  // (past the last hop: some other records, never used)
         {
-            REAL t1[2];
-            load_vals_p<REAL, 2, NT>(t1, Tp, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
+            P2 t1;
+            pot_pair_load<REAL, NT>(t1, hop_rsrc(Tp, o[1], o[2] - o[1]), 2u * (uint32_t)lane * S, o[1] * S);  // T of hop q0+1: straight into LDS
 #pragma unroll
-            for (int i = 0; i < D; ++i) load_vals_p<REAL, 2, NT>(tr[i], Tp, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const uint32_t j = lane + 64 * r;
-                if (j < o[2] - o[1]) lds_st<REAL>(sTw, j * S, t1[r]);
-            }
+            for (int i = 0; i < D; ++i) pot_pair_load<REAL, NT>(tr[i], hop_rsrc(Tp, o[i + 2], o[i + 3] - o[i + 2]), 2u * (uint32_t)lane * S, o[i + 2] * S);  // T of hop q0+2+i
+            if (2u * (uint32_t)lane < o[2] - o[1]) lds_st<P2>(sTw, 2u * (uint32_t)lane * S, t1);
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) hop_load(Lr[i], rs.lohi, (uint32_t)lane * (uint32_t)sizeof(P2), lb[i] * (uint32_t)sizeof(P2));
@@ -169,7 +178,7 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
         // ---- global prefetch: record of hop q+2D, T of hop q+D+2, arc costs of hop q+D
         rc[2 * D] = ldrec(q - q0 + 2 * D);
 #ifndef BDDMMA_EXP_NO_HOP_LOADS
-        load_vals_p<REAL, 2, NT>(tr[D], Tp, o[D + 2], o[D + 3] - o[D + 2], lane);
+        pot_pair_load<REAL, NT>(tr[D], hop_rsrc(Tp, o[D + 2], o[D + 3] - o[D + 2]), 2u * (uint32_t)lane * S, o[D + 2] * S);
         hop_load(Lr[D], rs.lohi, (uint32_t)lane * (uint32_t)sizeof(P2), lb[D] * (uint32_t)sizeof(P2));
 #endif
         const u4v ra = rc[0];
@@ -184,12 +193,8 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
         const uint32_t o_new = hw.node_off(q + 2 * D + 3);
         const uint32_t l_next = hw.layer_off(q + D + 2);
         // ---- set-up of the next hop's buffers (nothing above depends on it)
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint32_t j = lane + 64 * r;
-            if (j < n3) lds_st<REAL>(sTw, fn + j * S, tr[0][r]);  // T of hop q+2, gathered by hop q+1
-            lds_st<REAL>(sFw, fn + j * S, INF);
-        }
+        if (2u * (uint32_t)lane < n3) lds_st<P2>(sTw, fn + 2u * (uint32_t)lane * S, tr[0]);  // T of hop q+2, gathered by hop q+1
+        lds_st<P2>(sFw, fn + 2u * (uint32_t)lane * S, P2{INF, INF});
         wave_sync();
         // ---- arithmetic: the layer's two candidates per side, their minimum, the deferred difference, the new arc costs
         fa = (flags & LREC_REAL) ? fa : INF;
@@ -231,8 +236,7 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             Lr[i] = Lr[i + 1];
-            tr[i][0] = tr[i + 1][0];
-            tr[i][1] = tr[i + 1][1];
+            tr[i] = tr[i + 1];
         }
         ++q;
     };
@@ -307,7 +311,7 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
     uint32_t o[2 * D + 2];
     uint32_t lb[D + 2];
     u4v rc[2 * D + 1];
-    REAL fr[D + 1][2];  // costs-from-root of the lane's layer (nodes a, b) in hops q .. q-D
+    P2 fr[D + 1];       // costs-from-root of the lane's layer (nodes a, b = a + 1) in hops q .. q-D
     P2 Lr[D + 1];
 #pragma unroll
     for (int i = 0; i < 2 * D + 2; ++i) o[i] = 0;
@@ -317,15 +321,8 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
     // record of hop h of the pack (below the first hop: any record, never used)
     auto ldrec = [&](uint32_t qq) { return __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)lane * 16u, (rbase + (qq >= q0 ? qq - q0 : 0u) * 64u) * 16u, 0); };
     // costs-from-root of the two nodes of the lane's layer: slice of the hop [nb, nb + n), the record's store offsets (idle lanes / no second node: past the slice -> 0)
-    auto ldf = [&](REAL (&f)[2], const u4v& r, uint32_t nb, uint32_t n) {
-        const rsrc_t rh = hop_rsrc(Fp, nb, n);
-        if constexpr (NT) {
-            hop_load_nt(f[0], rh, r[3] & 0xFFFFu, nb * S);
-            hop_load_nt(f[1], rh, r[3] >> 16, nb * S);
-        } else {
-            hop_load(f[0], rh, r[3] & 0xFFFFu, nb * S);
-            hop_load(f[1], rh, r[3] >> 16, nb * S);
-        }
+    auto ldf = [&](P2& f, const u4v& r, uint32_t nb, uint32_t n) {   // node a's store offset; idle lanes: LREC_NO_STORE, past the slice -> 0
+        pot_pair_load<REAL, NT>(f, hop_rsrc(Fp, nb, n), r[3] & 0xFFFFu, nb * S);
     };
     const uint32_t sink = (W + 2 * (uint32_t)lane) * S;
     if (has_pack) {
@@ -397,8 +394,8 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
         const uint32_t o_new = (q >= q0 + 2 * D + 1) ? nb_of(q - 1 - 2 * D) : o[2 * D + 1];
         const uint32_t l_next = hw.layer_off(q >= q0 + D + 1 ? q - 1 - D : q0);
         // ---- arithmetic
-        const REAL fa = (flags & LREC_REAL) ? fr[0][0] : INF;
-        const REAL fb = (flags & LREC_TWO) ? fr[0][1] : INF;
+        const REAL fa = (flags & LREC_REAL) ? fr[0].x : INF;
+        const REAL fb = (flags & LREC_TWO) ? fr[0].y : INF;
         const REAL m0 = rmin((fa + c.x) + tla, (fb + c.x) + tlb);
         const REAL m1 = rmin((fa + c.y) + tha, (fb + c.y) + thb);
         const REAL mm = mm_diff1(m0, m1, omega);
@@ -441,8 +438,7 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             Lr[i] = Lr[i + 1];
-            fr[i][0] = fr[i + 1][0];
-            fr[i][1] = fr[i + 1][1];
+            fr[i] = fr[i + 1];
         }
     };
     while (q >= qs + HOP_UNROLL) {

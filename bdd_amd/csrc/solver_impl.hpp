@@ -1175,6 +1175,7 @@ struct SolverT final : SolverBase {
             const uint64_t done = st & ((1ull << 56) - 1);
             const int dev_reason = (int)(st >> 56);
             bool stop = false;
+            const bool progressed = done > seen;
             for (; seen < done && !stop; ++seen) {
                 lb_post = hr->lb[seen % RUN_RING];
                 if (verbose) std::printf("[bdd solver] iteration %llu, lower bound = %.10g, time = %.3f s\n", (unsigned long long)seen, lb_post, elapsed());
@@ -1182,12 +1183,15 @@ struct SolverT final : SolverBase {
             if (stop) break;
             if (dev_reason && seen == done) { reason = dev_reason; break; }
             if (seen == max_iter) break;
-            if (!launched && done == seen) {
-                // nothing new: spin for the first millisecond (an iteration is 20-250 us), then poll every 50 us without holding a core.
+            if (!launched && !progressed) {
+                // nothing new (no launch in this pass, no bound published since the last one): spin for the first millisecond (an iteration is 20-250 us), then poll every 50 us without holding a core.
                 // After 0.2 s without a published bound make sure the device is still alive: a blocking wait for the stream (harmless
                 // if an iteration is simply that long) — still nothing then means the queued launches were lost, which the checks
                 // behind the loop report.  (hipStreamQuery is not used for this: it was seen to report an idle stream with launches
-                // still queued, which ended runs early.)
+                // still queued, which ended runs early.)  A pass that SAW progress is not idle, whatever the clock says: through round 5 the
+                // test was "no launch in this pass", so a pass that found the window full at its start and all of it done at its read —
+                // with a 0.2 s old idle stamp, which takes a GPU shared by a dozen processes — synchronised an empty stream, found "nothing
+                // new" and ended the run early with reason 0 (soak of round 6: 1 of 32 loops; tests/tools/stress_run_solver.py: 15 of 3 200).
                 const double now = elapsed();
                 if (idle_spins++ == 0) idle_since = now;
                 if (now - idle_since > 0.2) {
@@ -1197,7 +1201,7 @@ struct SolverT final : SolverBase {
                         err = std::string("run_solver: ") + hipGetErrorString(e);
                         return BDDMMA_ERR_DEVICE;
                     }
-                    if ((hr->state & ((1ull << 56) - 1)) == seen) break;
+                    if ((hr->state & ((1ull << 56) - 1)) == seen && seen < queued) break;   // launches are outstanding and the idle stream has not run them
                     idle_spins = 0;
                 } else if (now - idle_since > 1e-3) {
                     std::this_thread::sleep_for(std::chrono::microseconds(50));
