@@ -50,6 +50,32 @@ __device__ __forceinline__ void pot_store(double v, rsrc_t rh, uint32_t voff, ui
     else hop_store<>(v, rh, voff, soff);
 }
 
+// The layer's one or two potentials (nodes a, b = a + 1) with as little store work as its shape allows: two-node layers write {a, b} with one
+// 8- / 16-byte store, one-node layers a with a 4- / 8-byte one — two instructions with complementary offsets (the other lanes' lie past the
+// slice and are dropped); in a uniform family a hop's layers are all of one kind, so one of the two has nothing to do.  (Merging the two stores of
+// every lane is not possible: a one-node layer's second value would land in the next layer's slot.)
+template <typename REAL>
+__device__ __forceinline__ void pot_store_layer(REAL a, REAL b, bool two, rsrc_t rh, uint32_t off_a, uint32_t soff, uint32_t nt)
+{
+    using P2 = typename Pair<REAL>::type;
+    const uint32_t off2 = two ? off_a : (uint32_t)LREC_NO_STORE, off1 = two ? (uint32_t)LREC_NO_STORE : off_a;
+    P2 v;
+    v.x = a;
+    v.y = b;
+    if constexpr (sizeof(REAL) == 4) {
+        using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(rh, 0, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rh, off2, soff, BDDMMA_ST_FT_AUX_F32);
+        pot_store(a, rh, off1, soff, nt);
+    } else {
+        using u4 = decltype(__builtin_amdgcn_raw_buffer_load_b128(rh, 0, 0, 0));
+        const u4 data = __builtin_bit_cast(u4, v);
+        if (nt) __builtin_amdgcn_raw_buffer_store_b128(data, rh, off2, soff, 2);  // uniform (a kernel argument)
+        else __builtin_amdgcn_raw_buffer_store_b128(data, rh, off2, soff, BDDMMA_ST_AUX);
+        asm volatile("s_nop 0" ::"v"(data) : "memory");  // wide store with an SGPR offset: the write-data hazard the compiler does not pad (hop_store(double2))
+        pot_store(a, rh, off1, soff, nt);
+    }
+}
+
 // Hops the prefetches of the hop pipeline run ahead.  One for float (two and three: nothing, round 5).  Two for double: +0.8 % in a same-box A/B
 // over 36 solver objects (tools/exp_r06_r.sh: 4 612 / 4 620 / 4 482 against 4 576 / 4 589 / 4 481 it/s at 10.5 M nodes, process by process — the
 // process-to-process spread of 3 % is larger than the effect; a first single-sample reading of +4-6 % was that spread), three: -1 %, four: spills.
@@ -218,8 +244,7 @@ __device__ __forceinline__ void fwd_narrow3_body(const DevPtrs<REAL>& d, const P
 #ifndef BDDMMA_EXP_NO_HOP_STORES
         {
             const rsrc_t rf = hop_rsrc(Fp, nb, o[1] - o[0]);  // LREC_NO_STORE lies past the slice
-            pot_store(fa, rf, ra[3] & 0xFFFFu, nb * S, pk.nt_potentials);
-            pot_store(fb, rf, ra[3] >> 16, nb * S, pk.nt_potentials);
+            pot_store_layer<REAL>(fa, fb, (flags & LREC_TWO) != 0, rf, ra[3] & 0xFFFFu, nb * S, pk.nt_potentials);
         }
 #endif
         wave_sync();
@@ -421,8 +446,7 @@ __device__ __forceinline__ void bwd_narrow3_body(const DevPtrs<REAL>& d, const P
 #ifndef BDDMMA_EXP_NO_HOP_STORES
         {
             const rsrc_t rt = hop_rsrc(Tp, nb, o[0] - o[1]);
-            pot_store(ta, rt, ra[3] & 0xFFFFu, nb * S, pk.nt_potentials);
-            pot_store(tb, rt, ra[3] >> 16, nb * S, pk.nt_potentials);
+            pot_store_layer<REAL>(ta, tb, (flags & LREC_TWO) != 0, rt, ra[3] & 0xFFFFu, nb * S, pk.nt_potentials);
         }
 #endif
         wave_sync();
