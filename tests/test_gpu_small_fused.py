@@ -156,3 +156,25 @@ def test_profiling_and_lbfgs_fall_back_to_the_launch_per_pass_path():
     for _ in range(8):
         lf.iteration(); lq.iteration()
     same_state(f, q)
+
+
+@pytest.mark.parametrize("opts", [dict(waves_per_block=2), dict(waves_per_block=4), dict(waves_per_block=8), dict(vars_per_bin=64), dict(keep_bdd_order=True),
+                                  dict(stage_cap=128), dict(pack_width=128), dict(resident_sweeps=1), dict(deterministic=True), dict(exchange_by_variable=2)],
+                         ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_layout_options_on_a_fused_instance(opts):
+    """The staging tables' LDS slots are quad-relative (packs per workgroup of the four-launch path): with 2 / 4 / 8 packs per quad the fused kernel's
+    prologue and epilogue map them to its own per-pack staging area.  Options under which the preconditions do not hold (several stage groups
+    per pack, packs of 128 slots, no resident records, the deterministic / by-variable exchanges) must fall back, not misbehave."""
+    col, costs = random_set_cover(146, 220, 8, seed=220)
+    f = bdd_hip_parallel_mma(col, costs, precision="float", **opts)
+    q = bdd_hip_parallel_mma(col, costs, precision="float", variant_flags=SEQ, **opts)
+    fused_expected = not any(k in opts for k in ("stage_cap", "pack_width", "resident_sweeps", "deterministic", "exchange_by_variable"))
+    assert f.fused_small() == fused_expected, opts
+    for k in (3, 8):
+        f.iterations(k)
+        q.iterations(k)
+        same_state(f, q)
+    rf = run_solver(f, max_iter=70, tolerance=0.0, improvement_slope=0.0, time_limit=1e9)
+    rq = run_solver(q, max_iter=70, tolerance=0.0, improvement_slope=0.0, time_limit=1e9)
+    assert rf["iterations"] == rq["iterations"] == 70 and rf["lb_final"] == rq["lb_final"]
+    same_state(f, q)
