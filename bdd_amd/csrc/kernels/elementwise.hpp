@@ -403,6 +403,47 @@ __global__ void __launch_bounds__(THREADS) k_project_entries(REAL* __restrict__ 
     const rsrc_t rx = make_rsrc(x, n_entries), rv = make_rsrc(bvar, n_entries);
     for (uint32_t i = tid; i < nv; i += THREADS) tile[i] = 0.0;
     __syncthreads();
+    // Bins of up to KEEP chunks (3 x 8 entries per thread: every bin of the automatic layout) keep their entries in registers between the
+    // accumulation and the subtraction — one read of the vector instead of two (round 6: 84 -> 53 MB per launch at 5 M entries).  Same
+    // additions into the same accumulators (LDS atomics on doubles, as before), same subtraction: the same results.
+    constexpr int KEEP = 3;
+    if (e1 - e0 <= (uint32_t)(KEEP * THREADS * U)) {   // uniform
+        REAL m[KEEP][U];
+        uint32_t lv[KEEP][U];
+#pragma unroll
+        for (int c = 0; c < KEEP; ++c) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t e = e0 + (uint32_t)c * THREADS * U + tid + u * THREADS;
+                bload(m[c][u], rx, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
+                lv[c][u] = bload_u16(rv, e < e1 ? e * 2u : OOB);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < KEEP; ++c) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t e = e0 + (uint32_t)c * THREADS * U + tid + u * THREADS;
+                if (e < e1) lds_add(&tile[lv[c][u]], (double)m[c][u]);
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < nv; i += THREADS) {
+            const int nb = nbdds[v0 + i];
+            const REAL s = REAL(tile[i]);
+            tile[i] = nb > 0 ? (double)(s / REAL(nb)) : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < KEEP; ++c) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t e = e0 + (uint32_t)c * THREADS * U + tid + u * THREADS;
+                bstore(m[c][u] - REAL(tile[lv[c][u]]), rx, e < e1 ? e * (uint32_t)sizeof(REAL) : OOB);
+            }
+        }
+        return;
+    }
     for (uint32_t base = e0; base < e1; base += THREADS * U) {
         REAL m[U];
         uint32_t lv[U];

@@ -1089,7 +1089,7 @@ struct SolverT final : SolverBase {
             return BDDMMA_OK;
         }
         while (n) {
-            const uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 1u << 20);
+            const uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 1u << 14);   // <= ~60 ms per launch: other processes' queues get the GPU in between
             if (int rc = launch_small((REAL)omega, chunk, RunStep{})) return rc;
             n -= chunk;
         }
