@@ -65,6 +65,7 @@ SIGNATURES = {
     "bddmma_nr_packs": (_U64, [_V]),
     "bddmma_solve_sweep_kind": (_I, [_V]),
     "bddmma_fused_small": (_I, [_V]),
+    "bddmma_nontemporal_loads": (_I, [_V]),
     "bddmma_precision": (_I, [_V]),
     "bddmma_device": (_I, [_V]),
     "bddmma_num_bdds_per_var": (_I, [_V, _V]),

@@ -143,6 +143,7 @@ uint64_t bddmma_nr_hops(const bddmma_solver* s) { return s && s->impl ? s->impl-
 uint64_t bddmma_nr_packs(const bddmma_solver* s) { return s && s->impl ? s->impl->n_packs_narrow + s->impl->n_packs_wide : 0; }
 int bddmma_solve_sweep_kind(const bddmma_solver* s) { return s && s->impl ? s->impl->solve_sweep_kind : -1; }
 int bddmma_fused_small(const bddmma_solver* s) { return s && s->impl ? (s->impl->fused_small ? 1 : 0) : -1; }
+int bddmma_nontemporal_loads(const bddmma_solver* s) { return s && s->impl ? (s->impl->nt_loads ? 1 : 0) : -1; }
 int bddmma_precision(const bddmma_solver* s) { return s && s->impl ? s->impl->precision : -1; }
 int bddmma_device(const bddmma_solver* s) { return s && s->impl ? s->impl->device : -1; }
 uint64_t bddmma_device_bytes(const bddmma_solver* s) { return s && s->impl ? s->impl->dev_bytes : 0; }

@@ -210,7 +210,7 @@ __device__ __forceinline__ void store_vals(const double (&v)[R], double* dst, ui
 #endif
 // SEG = false: no pack of the launch has a layer wider than two nodes — the segmented minimum is the DPP pair, its LDS variant and the
 // per-lane-group branch on the pack's step count are compiled out.
-template <typename REAL, int R, int MODE, int WPB, int LA = BDDMMA_LOOKAHEAD, bool SEG = true>
+template <typename REAL, int R, int MODE, int WPB, int LA = BDDMMA_LOOKAHEAD, bool SEG = true, bool NT = false>
 __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t block_id)
 {
     constexpr int W = 64 * R;
@@ -249,7 +249,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     NarrowRs<REAL> rs(d);
     rs.rebase_layers(d, l0);
     uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    if (hdr && MODE == FWD_SOLVE) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
+    if (hdr && MODE == FWD_SOLVE) stage_load_tables<REAL, WPB, (NT ? 2 : BDDMMA_LD_TAB_AUX)>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
     REAL* const Tp = d.T + slot_first;
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
@@ -289,9 +289,9 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
         for (int i = 0; i < 2 * D; ++i) load_words<R>(wr[i], d.nwords, o[i] + wd, o[i + 1] - o[i], lane);   // none past the last hop
         if (NEED_T) {
             REAL t1[R];
-            load_vals<REAL, R>(t1, Tp, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
+            load_vals_p<REAL, R, NT>(t1, Tp, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
 #pragma unroll
-            for (int i = 0; i < D; ++i) load_vals<REAL, R>(tr[i], Tp, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
+            for (int i = 0; i < D; ++i) load_vals_p<REAL, R, NT>(tr[i], Tp, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t j = lane + 64 * r;
@@ -324,7 +324,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             } else {
                 const uint32_t c0 = pk.cs_ptr[r0 + k];
                 cnt = pk.cs_ptr[r0 + k + 1] - c0;
-                stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
+                stage_load<REAL, WPB, (NT ? 2 : BDDMMA_LD_TAB_AUX)>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
             }
             if (hdr) {
                 qe = has_pack ? q1 : q;  // one group: the whole pack
@@ -351,7 +351,7 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             const uint32_t n3 = o[3] - o[2];  // slots of hop q+2
             // ---- global prefetch
             load_words<R>(wr[2 * D], d.nwords, o[2 * D] + wd, o[2 * D + 1] - o[2 * D], lane);
-            if (NEED_T) load_vals<REAL, R>(tr[D], Tp, o[D + 2], o[D + 3] - o[D + 2], lane);
+            if (NEED_T) load_vals_p<REAL, R, NT>(tr[D], Tp, o[D + 2], o[D + 3] - o[D + 2], lane);
             load_layer<REAL, R>(Lr[D], wr[D], lcur, rs);  // all padding past the last hop: no loads
             uint32_t (&wa)[R] = wr[0];
             HopLayer<REAL, R>& La = Lr[0];
@@ -487,13 +487,13 @@ __device__ __forceinline__ void fwd_narrow_body(const DevPtrs<REAL>& d, const Pa
 #ifndef BDDMMA_N1_WAVES
 #define BDDMMA_N1_WAVES(REAL, R, MODE, WPB) ((MODE) == 1 && sizeof(REAL) == 4 ? ((R) == 1 ? 6 : (R) == 2 && (WPB) == 1 ? 5 : 1) : 1)
 #endif
-template <typename REAL, int R, int MODE, int WPB, bool SEG = true>
+template <typename REAL, int R, int MODE, int WPB, bool SEG = true, bool NT = false>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N1_WAVES(REAL, R, MODE, WPB)))) k_fwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
 {
-    fwd_narrow_body<REAL, R, MODE, WPB, BDDMMA_LOOKAHEAD, SEG>(d, pk, omega, blockIdx.x);
+    fwd_narrow_body<REAL, R, MODE, WPB, BDDMMA_LOOKAHEAD, SEG, NT>(d, pk, omega, blockIdx.x);
 }
 
-template <typename REAL, int R, int MODE, int WPB, int LA = BDDMMA_LOOKAHEAD, bool SEG = true>
+template <typename REAL, int R, int MODE, int WPB, int LA = BDDMMA_LOOKAHEAD, bool SEG = true, bool NT = false>
 __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const PackDev& pk, REAL omega, uint32_t block_id)
 {
     constexpr int W = 64 * R;
@@ -526,7 +526,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     NarrowRs<REAL> rs(d);
     rs.rebase_layers(d, l0);
     uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    if (hdr && MODE == BWD_SOLVE) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
+    if (hdr && MODE == BWD_SOLVE) stage_load_tables<REAL, WPB, (NT ? 2 : BDDMMA_LD_TAB_AUX)>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
     REAL* const Tp = d.T + slot_first;
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
@@ -562,7 +562,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
         for (int i = 0; i < 2 * D; ++i) load_words<R>(wr[i], d.nwords, o[i + 1] + wd, o[i] - o[i + 1], lane);  // hop q1-1-i (none below q0)
         if (NEED_F) {
 #pragma unroll
-            for (int i = 0; i < D + 1; ++i) load_vals<REAL, R>(fr[i], Fp, o[i + 1], o[i] - o[i + 1], lane);   // F of hop q1-1-i
+            for (int i = 0; i < D + 1; ++i) load_vals_p<REAL, R, NT>(fr[i], Fp, o[i + 1], o[i] - o[i + 1], lane);   // F of hop q1-1-i
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) load_layer<REAL, R>(Lr[i], wr[i], hw.layer_off(q1 >= q0 + i + 1 ? q1 - 1 - i : q0), rs);
@@ -587,7 +587,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             } else {
                 const uint32_t c0 = pk.cs_ptr[r0 + k];
                 cnt = pk.cs_ptr[r0 + k + 1] - c0;
-                stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
+                stage_load<REAL, WPB, (NT ? 2 : BDDMMA_LD_TAB_AUX)>(sD, ent, esl, rs, c0, cnt, tid);
             }
             if (hdr) {
                 qs = has_pack ? q0 : q;  // one group: the whole pack
@@ -606,7 +606,7 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
             const uint32_t nb = o[1];
             // ---- prefetch: words of hop q-2D, F of hop q-D-1, layer data of hop q-D
             load_words<R>(wr[2 * D], d.nwords, o[2 * D + 1] + wd, o[2 * D] - o[2 * D + 1], lane);
-            if (NEED_F) load_vals<REAL, R>(fr[D + 1], Fp, o[D + 2], o[D + 1] - o[D + 2], lane);
+            if (NEED_F) load_vals_p<REAL, R, NT>(fr[D + 1], Fp, o[D + 2], o[D + 1] - o[D + 2], lane);
             load_layer<REAL, R>(Lr[D], wr[D], lcur, rs);  // all padding below the first hop: no loads
             uint32_t (&wa)[R] = wr[0];
             REAL (&fa)[R] = fr[0];
@@ -727,10 +727,10 @@ __device__ __forceinline__ void bwd_narrow_body(const DevPtrs<REAL>& d, const Pa
     if (lane == 0) d.lb_partial[pk.lb_base + p] = s;
 }
 
-template <typename REAL, int R, int MODE, int WPB, bool SEG = true>
+template <typename REAL, int R, int MODE, int WPB, bool SEG = true, bool NT = false>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N1_WAVES(REAL, R, MODE, WPB)))) k_bwd_narrow(DevPtrs<REAL> d, PackDev pk, REAL omega)
 {
-    bwd_narrow_body<REAL, R, MODE, WPB, BDDMMA_LOOKAHEAD, SEG>(d, pk, omega, blockIdx.x);
+    bwd_narrow_body<REAL, R, MODE, WPB, BDDMMA_LOOKAHEAD, SEG, NT>(d, pk, omega, blockIdx.x);
 }
 
 }  // namespace bddmma

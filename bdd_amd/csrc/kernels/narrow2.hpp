@@ -32,7 +32,7 @@ __device__ __forceinline__ void load_costs(typename Pair<REAL>::type (&c)[R], co
     for (int g = 0; g < R; ++g) hop_load(c[g], lohi, r[g][2] & 0xFFFFu, lbase * (uint32_t)sizeof(P2));
 }
 
-template <typename REAL, int R, int WPB, bool GEN, int LA = BDDMMA_LOOKAHEAD>
+template <typename REAL, int R, int WPB, bool GEN, int LA = BDDMMA_LOOKAHEAD, bool NT = false>
 __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ srec,
                                                  const uint32_t* __restrict__ srec_off, uint32_t srec_words, REAL omega, uint32_t block_id,
                                                  const uint32_t* __restrict__ hdr_pack = nullptr, const uint32_t* __restrict__ hdr_quad = nullptr)
@@ -76,7 +76,7 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
     NarrowRs<REAL> rs(d);
     rs.rebase_layers(d, l0);
     uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    if (hdr) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
+    if (hdr) stage_load_tables<REAL, WPB, (NT ? 2 : BDDMMA_LD_TAB_AUX)>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
     REAL* const Tp = d.T + slot_first;
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
@@ -110,9 +110,9 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
         for (int i = 0; i < 2 * D; ++i) load_recs<R>(rc[i], rr, rbase + (uint32_t)i * W, lane);  // (past the last hop: some other records, never used)
         {
             REAL t1[R];
-            load_vals<REAL, R>(t1, Tp, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
+            load_vals_p<REAL, R, NT>(t1, Tp, o[1], o[2] - o[1], lane);  // T of hop q0+1: straight into LDS
 #pragma unroll
-            for (int i = 0; i < D; ++i) load_vals<REAL, R>(tr[i], Tp, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
+            for (int i = 0; i < D; ++i) load_vals_p<REAL, R, NT>(tr[i], Tp, o[i + 2], o[i + 3] - o[i + 2], lane);  // T of hop q0+2+i
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t j = lane + 64 * r;
@@ -145,7 +145,7 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
             } else {
                 const uint32_t c0 = pk.cs_ptr[r0 + k];
                 cnt = pk.cs_ptr[r0 + k + 1] - c0;
-                stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
+                stage_load<REAL, WPB, (NT ? 2 : BDDMMA_LD_TAB_AUX)>(sD, ent, esl, rs, c0, cnt, tid);  // the delta pairs of the quad's k-th groups -> LDS
             }
             if (hdr) {
                 qe = has_pack ? q1 : q;  // one group: the whole pack
@@ -167,7 +167,7 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
             // ---- global prefetch: records of hop q+2D, T of hop q+D+2, arc costs of hop q+D
             load_recs<R>(rc[2 * D], rr, rbase + (q - q0 + 2 * D) * W, lane);
 #ifndef BDDMMA_EXP_NO_HOP_LOADS  // timing experiments only (wrong results): the hop loop without its streams from / to global memory
-            load_vals<REAL, R>(tr[D], Tp, o[D + 2], o[D + 3] - o[D + 2], lane);
+            load_vals_p<REAL, R, NT>(tr[D], Tp, o[D + 2], o[D + 3] - o[D + 2], lane);
             load_costs<REAL, R>(Lr[D], rc[D], rs.lohi, lb[D]);
 #endif
             u4v (&ra)[R] = rc[0];
@@ -267,14 +267,14 @@ __device__ __forceinline__ void fwd_narrow2_body(const DevPtrs<REAL>& d, const P
 #ifndef BDDMMA_N2_WAVES
 #define BDDMMA_N2_WAVES(REAL, R) ((R) <= 2 ? (sizeof(REAL) == 4 ? 5 : 4) : 1)
 #endif
-template <typename REAL, int R, int WPB, bool GEN>
+template <typename REAL, int R, int WPB, bool GEN, bool NT = false>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N2_WAVES(REAL, R)))) k_fwd_narrow2(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ srec, const uint32_t* __restrict__ srec_off,
                                                           uint32_t srec_words, REAL omega)
 {
-    fwd_narrow2_body<REAL, R, WPB, GEN>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x, pk.hdr_pack, pk.hdr_quad);
+    fwd_narrow2_body<REAL, R, WPB, GEN, BDDMMA_LOOKAHEAD, NT>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x, pk.hdr_pack, pk.hdr_quad);
 }
 
-template <typename REAL, int R, int WPB, bool GEN, int LA = BDDMMA_LOOKAHEAD>
+template <typename REAL, int R, int WPB, bool GEN, int LA = BDDMMA_LOOKAHEAD, bool NT = false>
 __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const PackDev& pk, const uint32_t* __restrict__ srec,
                                                  const uint32_t* __restrict__ srec_off, uint32_t srec_words, REAL omega, uint32_t block_id,
                                                  const uint32_t* __restrict__ hdr_pack = nullptr, const uint32_t* __restrict__ hdr_quad = nullptr)
@@ -308,7 +308,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
     NarrowRs<REAL> rs(d);
     rs.rebase_layers(d, l0);
     uint32_t ent[STAGE_ITERS], esl[STAGE_ITERS];
-    if (hdr) stage_load_tables<REAL, WPB>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
+    if (hdr) stage_load_tables<REAL, WPB, (NT ? 2 : BDDMMA_LD_TAB_AUX)>(ent, esl, rs, c0_h, cnt_h, tid);  // on their way while the pipeline is set up
     REAL* const Tp = d.T + slot_first;
     REAL* const Fp = d.F + slot_first;
     const REAL* const lohi_p = d.lohi + 2 * (size_t)l0;
@@ -346,7 +346,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
 #pragma unroll
         for (int i = 0; i < 2 * D; ++i) load_recs<R>(rc[i], rr, rec_of(q1 >= q0 + i + 1 ? q1 - 1 - i : q0), lane);  // hop q1-1-i
 #pragma unroll
-        for (int i = 0; i < D + 1; ++i) load_vals<REAL, R>(fr[i], Fp, o[i + 1], o[i] - o[i + 1], lane);            // F of hop q1-1-i
+        for (int i = 0; i < D + 1; ++i) load_vals_p<REAL, R, NT>(fr[i], Fp, o[i + 1], o[i] - o[i + 1], lane);            // F of hop q1-1-i
 #pragma unroll
         for (int i = 0; i < D; ++i) load_costs<REAL, R>(Lr[i], rc[i], rs.lohi, lb[i + 1]);                          // hop q1-1-i starts at layer lb[i+1]
     } else {
@@ -370,7 +370,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
             } else {
                 const uint32_t c0 = pk.cs_ptr[r0 + k];
                 cnt = pk.cs_ptr[r0 + k + 1] - c0;
-                stage_load<REAL, WPB>(sD, ent, esl, rs, c0, cnt, tid);
+                stage_load<REAL, WPB, (NT ? 2 : BDDMMA_LD_TAB_AUX)>(sD, ent, esl, rs, c0, cnt, tid);
             }
             if (hdr) {
                 qs = has_pack ? q0 : q;  // one group: the whole pack
@@ -391,7 +391,7 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
             const uint32_t stg = db + (lb[1] - gl0) * (uint32_t)sizeof(P2);  // hop q starts at layer lb[1]
             // ---- prefetch: records of hop q-2D, F of hop q-D-1, arc costs of hop q-D
             load_recs<R>(rc[2 * D], rr, rec_of(q >= q0 + 2 * D ? q - 2 * D : q0), lane);
-            load_vals<REAL, R>(fr[D + 1], Fp, o[D + 2], o[D + 1] - o[D + 2], lane);
+            load_vals_p<REAL, R, NT>(fr[D + 1], Fp, o[D + 2], o[D + 1] - o[D + 2], lane);
             load_costs<REAL, R>(Lr[D], rc[D], rs.lohi, lb[D + 1]);
             u4v (&ra)[R] = rc[0];
             REAL (&fa)[R] = fr[0];
@@ -490,11 +490,11 @@ __device__ __forceinline__ void bwd_narrow2_body(const DevPtrs<REAL>& d, const P
     if (lane == 0) d.lb_partial[pk.lb_base + p] = s;
 }
 
-template <typename REAL, int R, int WPB, bool GEN>
+template <typename REAL, int R, int WPB, bool GEN, bool NT = false>
 __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(BDDMMA_N2_WAVES(REAL, R)))) k_bwd_narrow2(DevPtrs<REAL> d, PackDev pk, const uint32_t* __restrict__ srec, const uint32_t* __restrict__ srec_off,
                                                           uint32_t srec_words, REAL omega)
 {
-    bwd_narrow2_body<REAL, R, WPB, GEN>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x, pk.hdr_pack, pk.hdr_quad);
+    bwd_narrow2_body<REAL, R, WPB, GEN, BDDMMA_LOOKAHEAD, NT>(d, pk, srec, srec_off, srec_words, omega, blockIdx.x, pk.hdr_pack, pk.hdr_quad);
 }
 
 }  // namespace bddmma

@@ -62,6 +62,7 @@ struct SolverBase {
         return BDDMMA_OK;
     }
     bool fused_small = false;   // whole iterations in one launch (diagnostics: bddmma_fused_small)
+    bool nt_loads = false;      // the solve sweeps' non-temporal instantiation (diagnostics: bddmma_nontemporal_loads)
     // run_solver (include/run_solver_util.h:10-77) around iteration(): termination tests on the device, see solver_impl.hpp
     virtual int run_plain(uint64_t max_iter, double tolerance, double slope, double time_limit, int verbose, bddmma_run_result* res) = 0;
     virtual int forward_mm(double omega, void* delta, int on_device) = 0;

@@ -130,6 +130,8 @@ struct SolverT final : SolverBase {
     } nb_, wb_, hb_;  // narrow, wide, huge packs
     uint32_t wide_lds = 0, wide_threads = 256, wide_npt = 1;
     bool n3_nt = false;  // third-generation sweeps: the instantiation with non-temporal loads (double beyond the Infinity Cache's reach)
+    bool beyond_cache = false;  // the arrays exceed what the Infinity Cache helps with (640 MiB)
+    bool n12_nt = false;  // ... and of the first- (float) / second-generation (double) sweeps that run beyond 16 M slots: packs of 128 slots, 4 / 8 per workgroup
     uint32_t nt_potentials = 0;  // PackDev::nt_potentials (kernels.hpp: hop_store): double, footprint several times the Infinity Cache
     bool mixed = false;      // narrow (streaming) and wide solve sweeps in one launch (kernels.hpp: k_fwd_mixed / k_bwd_mixed)
     // Measured on the knapsack benchmark (3 604 narrow + 389 wide packs): backward 44.7 -> 37.4 us in one launch.  The forward sweeps
@@ -410,6 +412,10 @@ struct SolverT final : SolverBase {
             }
 #undef SET_N_W
 #undef SET_N
+            if (pack_width == 128) {  // the non-temporal instantiations (n12_nt)
+                if (L.ex.waves_per_block == 4) { SET_N1((k_fwd_narrow<REAL, 2, FWD_SOLVE, 4, false, true>)) SET_N1((k_bwd_narrow<REAL, 2, BWD_SOLVE, 4, false, true>)) }
+                if (L.ex.waves_per_block == 8) { SET_N1((k_fwd_narrow<REAL, 2, FWD_SOLVE, 8, false, true>)) SET_N1((k_bwd_narrow<REAL, 2, BWD_SOLVE, 8, false, true>)) }
+            }
 #undef SET_N1
         }
         if ((rc = dalloc(&d_tmp0, n_layers))) return rc;
@@ -437,7 +443,8 @@ struct SolverT final : SolverBase {
         opts_variant = opts ? opts->variant_flags : 0u;
         mixed_fwd = (opts_variant & 2u) == 0;
         // measured in double: 7.1 M nodes (490 MB resident) lose 12 % with non-temporal potentials, 10.5 M (720 MB) gain 4 %
-        nt_potentials = (sizeof(REAL) == 8 && dev_bytes > (640ull << 20)) ? 1u : 0u;   // array bytes (the working set), not arena capacity
+        beyond_cache = dev_bytes > (640ull << 20);   // array bytes (the working set), not arena capacity
+        nt_potentials = (sizeof(REAL) == 8 && beyond_cache) ? 1u : 0u;
         exch_small = vars_per_bin <= EXS_MAX_VARS_PER_BIN;  // 256-thread workgroups (kernels.hpp: EXS_*)
         exch_medium = !exch_small && vars_per_bin <= EXM_MAX_VARS_PER_BIN;  // 512-thread workgroups (EXM_*)
         // `deterministic`: the scheduled reduction (kernels.hpp: k_exchange_seg; no atomics, fixed order) where every bin fits its tables
@@ -591,6 +598,20 @@ struct SolverT final : SolverBase {
 #undef SET_N3
             }
         }
+        // First / second (double only) generation where the third stops — beyond 16 M slots, i.e. beyond the Infinity Cache's reach: the same
+        // policy, the instantiation that loads potentials and staging tables non-temporally (round 5's build knobs BDDMMA_LD_POT_AUX / _TAB_AUX as a
+        // template parameter; profiles/r06_nt_loads.txt, alternating with the library before, it/s: float 21 M nodes 3 705 / 3 837 -> 3 823 / 4 006,
+        // 42 M 1 689 / 1 808 -> 1 836 / 1 891, 105 M 669 / 652 -> 671 / 661; double 21 M 1 938 / 2 090 -> 1 996 / 2 150, 42 M and 105 M +0-1 %).
+        // Packs of 128 slots, 4 / 8 per workgroup, layers of at most two nodes, no staggered packs: what instances of that size have (the other
+        // instantiations are not built).  variant_flags bit 20: whatever the footprint (the tests' way to these kernels).
+        if (nb_.n_packs && !use_res && !use_narrow3 && !wb_.n_packs && !hb_.n_packs && !narrow_seg && !narrow_gen && pack_width == 128 &&
+            (L.ex.waves_per_block == 4 || L.ex.waves_per_block == 8) && (beyond_cache || (opts && (opts->variant_flags & 0x100000u))))
+#ifndef BDDMMA_EXP_NO_N12_NT   // A/B builds (tools/build_variant.sh)
+            n12_nt = !use_narrow2 || sizeof(REAL) == 8;
+#else
+            n12_nt = false;
+#endif
+        nt_loads = n3_nt || n12_nt;
         if (wb_.n_packs) {
             // one workgroup per wide pack, thread t owns the nodes t + i * wide_threads of a hop (kernels.hpp: k_fwd_wide2)
             // two nodes of a hop per thread: half the wavefronts at the hop's two barriers and two independent chains per lane.  Wide-only
@@ -761,6 +782,8 @@ struct SolverT final : SolverBase {
     else if (res) hipLaunchKernelGGL((k_fwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
     else if (MODE == FWD_SOLVE && use_narrow3 && n3_nt && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_fwd_narrow3<REAL, (W_ == 8 ? 8 : 4), sizeof(REAL) == 8>), grid, block, dyn, stream, d, pk, d_lrec, d_lrec_off, lrec_words, omega); \
     else if (MODE == FWD_SOLVE && use_narrow3 && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_fwd_narrow3<REAL, (W_ == 8 ? 8 : 4)>), grid, block, dyn, stream, d, pk, d_lrec, d_lrec_off, lrec_words, omega); \
+    else if (MODE == FWD_SOLVE && use_narrow2 && n12_nt && R_ == 2 && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_fwd_narrow2<REAL, 2, (W_ == 8 ? 8 : 4), false, sizeof(REAL) == 8>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
+    else if (MODE == FWD_SOLVE && !use_narrow2 && n12_nt && R_ == 2 && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_fwd_narrow<REAL, 2, FWD_SOLVE, (W_ == 8 ? 8 : 4), false, true>), grid, block, dyn, stream, d, pk, omega); \
     else if (MODE == FWD_SOLVE && use_narrow2 && narrow_gen) hipLaunchKernelGGL((k_fwd_narrow2<REAL, R_, W_, true>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (MODE == FWD_SOLVE && use_narrow2) hipLaunchKernelGGL((k_fwd_narrow2<REAL, R_, W_, false>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (two_node) hipLaunchKernelGGL((k_fwd_narrow<REAL, R_, MODE, W_, MODE != FWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \
@@ -836,6 +859,8 @@ struct SolverT final : SolverBase {
     else if (res) hipLaunchKernelGGL((k_bwd_res<REAL, R_, W_>), grid, block, dyn, stream, rd.pack_hdr, rd.quad_hdr, rd.ns, rd.nl, pk.n_packs, pk.xcd_chunk, d.stop, d.run_iter, d, pk, omega);                           \
     else if (MODE == BWD_SOLVE && use_narrow3 && n3_nt && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_bwd_narrow3<REAL, (W_ == 8 ? 8 : 4), sizeof(REAL) == 8>), grid, block, dyn, stream, d, pk, d_lrec, d_lrec_off, lrec_words, omega); \
     else if (MODE == BWD_SOLVE && use_narrow3 && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_bwd_narrow3<REAL, (W_ == 8 ? 8 : 4)>), grid, block, dyn, stream, d, pk, d_lrec, d_lrec_off, lrec_words, omega); \
+    else if (MODE == BWD_SOLVE && use_narrow2 && n12_nt && R_ == 2 && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_bwd_narrow2<REAL, 2, (W_ == 8 ? 8 : 4), false, sizeof(REAL) == 8>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
+    else if (MODE == BWD_SOLVE && !use_narrow2 && n12_nt && R_ == 2 && (W_ == 4 || W_ == 8)) hipLaunchKernelGGL((k_bwd_narrow<REAL, 2, BWD_SOLVE, (W_ == 8 ? 8 : 4), false, true>), grid, block, dyn, stream, d, pk, omega); \
     else if (MODE == BWD_SOLVE && use_narrow2 && narrow_gen) hipLaunchKernelGGL((k_bwd_narrow2<REAL, R_, W_, true>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (MODE == BWD_SOLVE && use_narrow2) hipLaunchKernelGGL((k_bwd_narrow2<REAL, R_, W_, false>), grid, block, dyn, stream, d, pk, d_srec, d_srec_off, srec_words, omega); \
     else if (two_node) hipLaunchKernelGGL((k_bwd_narrow<REAL, R_, MODE, W_, MODE != BWD_SOLVE>), grid, block, dyn, stream, d, pk, omega); \

@@ -91,6 +91,9 @@ class bdd_hip_parallel_mma:
     def fused_small(self) -> bool:
         """whole iterations run inside one launch (the instance fits one workgroup; csrc/kernels/small.hpp)"""
         return bool(self._L.bddmma_fused_small(self._h))
+    def nontemporal_loads(self) -> bool:
+        """the solve sweeps run in the instantiation that loads potentials and staging tables non-temporally (footprint beyond the caches' reach)"""
+        return bool(self._L.bddmma_nontemporal_loads(self._h))
     def device_bytes(self): return int(self._L.bddmma_device_bytes(self._h))
     def device_allocated_bytes(self): return int(self._L.bddmma_device_allocated_bytes(self._h))
 

@@ -101,7 +101,10 @@ typedef struct bddmma_options {
                                           <= 2 nodes and <= 64 layers per hop that share their records, up to 16 M slots): the second / first
                                           generation instead (bit 13 lifts the sharing and size conditions of the third generation too)
                                   bit 19: four launches per iteration also for instances that fit one workgroup (rule: whole iterations in one
-                                          launch, k_iterate_small, for <= 16 narrow packs of 64 slots with layers of <= 2 nodes) */
+                                          launch, k_iterate_small, for <= 16 narrow packs of 64 slots with layers of <= 2 nodes)
+                                  bit 20: the streaming solve sweeps' instantiations that load potentials and staging tables non-temporally
+                                          whatever the footprint (rule: arrays beyond 640 MiB; first generation, and second in double,
+                                          packs of 128 slots, 4 / 8 per workgroup; the third generation's own: double beyond 640 MiB) */
     uint32_t pack_fill;        /* slots of a narrow pack's hop that further BDDs are packed into, in [2, pack_width] (default 0 = pack_width).
                                   Smaller values give more, emptier packs (more wavefronts for the same nodes); measured slower on every
                                   instance (NOTES.md section 6: the sweeps are bound by instructions issued, not by latency), kept for experiments */
@@ -167,6 +170,8 @@ int bddmma_solve_sweep_kind(const bddmma_solver* s);
 /* 1 when the instance fits one workgroup and bddmma_iterations / bddmma_run_solver run whole iterations inside one launch (sweeps, exchanges
  * and run_solver's tests with workgroup barriers in between, csrc/kernels/small.hpp; variant_flags bit 19 turns it off), else 0. */
 int bddmma_fused_small(const bddmma_solver* s);
+/* 1 when the narrow packs' solve sweeps run in the instantiation that loads what a sweep reads once (potentials, staging tables) non-temporally. */
+int bddmma_nontemporal_loads(const bddmma_solver* s);
 int bddmma_precision(const bddmma_solver* s);
 int bddmma_device(const bddmma_solver* s);
 /* nr_bdds(var): int32[nr_variables] (get_num_bdds_per_var, bdd_cuda_base.h:166) */

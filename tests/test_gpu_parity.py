@@ -827,6 +827,41 @@ def test_lane_per_layer_sweeps_are_the_rule_where_they_apply():
     assert bdd_hip_parallel_mma(col, costs, resident_sweeps=1, pack_width=64).solve_sweep_kind() in ("streaming2", "streaming1")
 
 
+@pytest.mark.parametrize("precision,flags,wpb,kind", [("float", 0x41000, 4, "streaming1"), ("float", 0x41000, 8, "streaming1"), ("double", 0x41000, 4, "streaming1"),
+                                                      ("double", 0x40000, 8, "streaming1"), ("double", 0x40000, 4, "streaming2")])
+def test_nontemporal_instantiations_of_the_first_and_second_generation(precision, flags, wpb, kind):
+    """Beyond 640 MiB of arrays the first- and (double) second-generation streaming sweeps of 128-slot packs run in the instantiation that loads
+    potentials and staging tables non-temporally (variant_flags bit 20 selects it on a small instance): a cache policy, so every result is
+    bit-equal to the default instantiation's; a fresh solver agrees with the oracle.  (Double with eight packs per workgroup: the second
+    generation's LDS exceeds 64 KiB and the first takes over, as at 21 M nodes and beyond.)  64-slot packs and the float second generation
+    have no such instantiation and report so."""
+    col, costs = random_set_cover(3000, 2400, 9, seed=17)
+    opts = dict(precision=precision, pack_width=128, waves_per_block=wpb, resident_sweeps=1, deterministic=True)
+    n = bdd_hip_parallel_mma(col, costs, variant_flags=flags | 0x100000, **opts)
+    c = bdd_hip_parallel_mma(col, costs, variant_flags=flags, **opts)
+    assert n.solve_sweep_kind() == c.solve_sweep_kind() == kind
+    assert n.nontemporal_loads() and not c.nontemporal_loads()
+    V = n.nr_variables()
+    dn, dc = (np.zeros(2 * V, n.value_type) for _ in range(2))
+    for _ in range(4):
+        n.forward_mm(0.5, dn); c.forward_mm(0.5, dc)
+        np.testing.assert_array_equal(dn, dc)
+        n.backward_mm(0.5, dn); c.backward_mm(0.5, dc)
+        np.testing.assert_array_equal(dn, dc)
+        assert n.lower_bound() == c.lower_bound()
+    n.iterations(6); c.iterations(6)
+    for a, b in zip(n.get_solver_costs(), c.get_solver_costs()):
+        np.testing.assert_array_equal(a, b)
+    assert n.lower_bound() == c.lower_bound()
+    s = bdd_hip_parallel_mma(col, costs, variant_flags=flags | 0x100000, **opts)
+    o = Oracle(col, costs, precision)
+    for _ in range(6):
+        s.iteration(); o.iteration()
+        assert close(s.lower_bound(), o.lower_bound(), precision, 10)
+    assert not bdd_hip_parallel_mma(col, costs, precision=precision, pack_width=64, resident_sweeps=1, variant_flags=flags | 0x100000).nontemporal_loads()
+    assert not bdd_hip_parallel_mma(col, costs, precision="float", pack_width=128, waves_per_block=4, resident_sweeps=1, variant_flags=0x40000 | 0x100000).nontemporal_loads()
+
+
 # ---------------------------------------------------------------- long BDDs: hop-window refills and several stage groups per pack
 @pytest.mark.parametrize("precision", ["double", "float"])
 @pytest.mark.parametrize("variant", [0, 0x2000])   # 0x2000: the second-generation streaming sweeps (per-lane records) although these packs share none
