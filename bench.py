@@ -514,12 +514,12 @@ def measured_traffic(kernel, args, sfx):
             if isinstance(v, dict) and re.search(want + "3<" + real + r", \d+(?:, \w+)?>", name):   # <REAL, waves per block[, NT]>
                 take(v)
         if sweep is None:
-            for name, v in d.items():   # second generation: <REAL, R, waves per block, GEN>
-                if isinstance(v, dict) and re.search(want + "2<" + real + r", \d+, \d+, \w+>", name):
+            for name, v in d.items():   # second generation: <REAL, R, waves per block, GEN[, NT]>
+                if isinstance(v, dict) and re.search(want + "2<" + real + r", \d+, \d+, \w+(?:, \w+)?>", name):
                     take(v)
         if sweep is None:
             for name, v in d.items():
-                m = re.search(want + "<" + real + r", \d+, (\d+), \d+(?:, \w+)?>", name)   # <REAL, R, MODE, waves per block[, SEG]>; MODE 1 = solve
+                m = re.search(want + "<" + real + r", \d+, (\d+), \d+(?:, \w+)*>", name)   # <REAL, R, MODE, waves per block[, SEG[, NT]]>; MODE 1 = solve
                 if m and m.group(1) == "1":
                     take(v)
         if sweep is None:
