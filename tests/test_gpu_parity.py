@@ -636,6 +636,28 @@ def test_full_size_properties(tag):
     assert abs(lf - o.lower_bound()) <= 1e-5 * abs(o.lower_bound())
 
 
+def test_twice_the_headline_size_runs_the_nontemporal_sweeps_by_rule_vs_oracle():
+    """21 M nodes (V = 2 M, B = 1 M, k = 10; 1.1 / 1.6 GB of arrays): beyond 16 M slots the third generation hands over to the first / second, and
+    beyond 640 MiB those run in the instantiation that loads potentials and staging tables non-temporally (SolverT::init: n12_nt) — chosen by
+    rule here, not by variant_flags bit 20 as in the small bit-equality test.  Bounds against the restated oracle at this size."""
+    col, costs = random_set_cover_mt(2_000_000, 1_000_000, 10, 12345)
+    assert col.nr_bdd_nodes() == 21_000_000
+    sf = bdd_hip_parallel_mma(col, costs, precision="float")
+    sd = bdd_hip_parallel_mma(col, costs, precision="double")
+    assert sf.solve_sweep_kind() == "streaming1" and sd.solve_sweep_kind() in ("streaming1", "streaming2")
+    assert sf.nontemporal_loads() and sd.nontemporal_loads()
+    o = Oracle(col, costs, "double", threads=min(os.cpu_count() or 1, 32))
+    assert abs(sd.lower_bound() - o.lower_bound()) <= 1e-9 * abs(o.lower_bound())
+    prev = sd.lower_bound()
+    for _ in range(3):
+        sf.iteration(); sd.iteration(); o.iteration()
+        assert abs(sd.lower_bound() - o.lower_bound()) <= 1e-9 * abs(o.lower_bound())
+        assert abs(sf.lower_bound() - o.lower_bound()) <= 1e-5 * abs(o.lower_bound())
+        assert sd.lower_bound() >= prev - 1e-9 * abs(prev)
+        prev = sd.lower_bound()
+    assert abs(sd.lower_bound_per_bdd().sum() - sd.lower_bound()) <= 1e-9 * abs(sd.lower_bound())
+
+
 # ---------------------------------------------------------------- general linear rows at the headline size (VERDICT r2 missing #2)
 def test_full_size_knapsack_and_covering_rows_vs_oracle():
     """10 M nodes of general <= rows with non-unit coefficients (layers up to ~77 nodes) mixed with covering rows — the instance
