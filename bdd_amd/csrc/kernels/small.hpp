@@ -36,19 +36,23 @@ struct SmallDev {
     const uint32_t* var_lds;    // byte offset of the entry's staging pair inside the staging area
     const uint32_t* var_ent;    // the entry's index in mm_binned / delta_lay
     uint32_t n_vars, n_entries;
-    uint32_t rec_cap;           // bytes of a pack's records kept in LDS (RL instantiation): 1 KiB per hop of the longest pack
+    uint32_t rec_cap;           // bytes of a pack's records kept in LDS (RL instantiation): 1 KiB per hop of the longest pack + one spare
     uint32_t off_regions, off_vp, off_vl, off_mm, off_misc, off_rec;  // byte offsets inside the dynamic LDS: pack regions | var_ptr copy | var_lds copy |
                                                                       // the last backward sweep's differences by (variable, bdd) | bounds + flag | records
 };
 // (rec_cap = 0: the records stay in global memory)
+// A pack's staging area and its {lo, hi} array carry ONE pair more than the nl the records address: the dummy pair at offset nl * 2 S that the
+// records rewritten in LDS (RL instantiation) point padding lanes and non-head lanes at, so that the hop's stores need no exec masks.
+__host__ __device__ inline uint32_t small_stage_stride(uint32_t nl) { return nl + 1u; }   // pairs per pack in the staging area
+__host__ __device__ inline uint32_t small_region_bytes(uint32_t real_size, uint32_t ns, uint32_t nl) { return res2_wave_bytes(real_size, ns, nl) + 2u * real_size; }
 inline uint32_t small_lds_bytes(uint32_t real_size, uint32_t n_packs, uint32_t n_vars, uint32_t n_entries, SmallDev& sm)
 {
     const uint32_t ns = sm.ns, nl = sm.nl;
     uint32_t *off_regions = &sm.off_regions, *off_vp = &sm.off_vp, *off_vl = &sm.off_vl, *off_misc = &sm.off_misc;
-    uint32_t o = n_packs * nl * 2u * real_size;   // staging area: a {lo, hi} pair per layer slot, nl per pack (the sweeps' own staging reserves stage_cap)
+    uint32_t o = n_packs * small_stage_stride(nl) * 2u * real_size;   // staging area: a {lo, hi} pair per layer slot, nl (+ the dummy) per pack (the sweeps' own staging reserves stage_cap)
     o = (o + 15u) & ~15u;
     *off_regions = o;
-    o += n_packs * res2_wave_bytes(real_size, ns, nl);
+    o += n_packs * small_region_bytes(real_size, ns, nl);
     o = (o + 15u) & ~15u;
     *off_vp = o;
     o += (n_vars + 1u) * 4u;
@@ -81,7 +85,8 @@ __global__ void __launch_bounds__(64 * NW) k_iterate_small(SmallDev sm, DevPtrs<
     // run_solver: launches queued behind the iteration that met a criterion do nothing (DevPtrs::stop / run_iter = this launch's first iteration)
     if (d.stop != nullptr && *d.stop <= d.run_iter) return;
     const REAL INF = inf_v<REAL>();
-    const uint32_t region = res2_wave_bytes(S, sm.ns, sm.nl);
+    const uint32_t region = small_region_bytes(S, sm.ns, sm.nl), dstride = small_stage_stride(sm.nl);
+    const uint32_t ll_dummy = sm.nl * 2u * S;   // the dummy pair of a pack's {lo, hi} array and of its staging area
     uint32_t* const vp = reinterpret_cast<uint32_t*>(dyn_lds + sm.off_vp);
     uint32_t* const vl = reinterpret_cast<uint32_t*>(dyn_lds + sm.off_vl);
     double* const lbp = reinterpret_cast<double*>(dyn_lds + sm.off_misc);          // per-pack bounds of the iteration
@@ -96,14 +101,31 @@ __global__ void __launch_bounds__(64 * NW) k_iterate_small(SmallDev sm, DevPtrs<
     const uint32_t slot0 = hp[0], layer0 = hp[2];
     const uint32_t nslots = has_pack ? hp[1] : 0, nlayers = has_pack ? hp[3] : 0, nh = has_pack ? (hp[5] & 0xFFFFu) : 0;
     const uint32_t rbase = sm.rec_off[has_pack ? p : 0];
-    const uint32_t db = p * sm.nl * (uint32_t)sizeof(P2);
+    const uint32_t db = p * dstride * (uint32_t)sizeof(P2);
     const uint32_t wb = sm.off_regions + p * region, wbF = wb + res2_f_off(S, sm.ns), wbC = wb + res2_c_off(S, sm.ns);
-    const uint32_t rl = sm.off_rec + p * sm.rec_cap;
+    const uint32_t rl = sm.off_rec + p * sm.rec_cap, rlane = rl + (uint32_t)lane * 16u;
+    const uint32_t nhm1 = nh ? nh - 1u : 0u;
     // ---- prologue: the state -> LDS
     if (has_pack) {
         wave_copy_to_lds(d.T + slot0, dyn_lds + wb, nslots * S, lane);
         wave_copy_to_lds(d.lohi + 2 * (size_t)layer0, dyn_lds + wbC, nlayers * (uint32_t)sizeof(P2), lane);
-        if (RL) wave_copy_to_lds(sm.rec + 4 * (size_t)rbase, dyn_lds + rl, nh * 1024u, lane);   // hop h's 64 records: 1 KiB at rl + 1024 h
+        if (RL) {
+            // hop h's 64 records: 1 KiB at rl + 1024 h — REWRITTEN on the way so that the hop loop needs no exec masks: padding lanes read and
+            // write the dummy pair and the spare entry ns + 2 of the costs-from-terminal (nothing reads either); both lanes of a two-node
+            // layer store the layer's new arc costs (the same pair to the same address — in LDS a duplicate costs nothing, the head-only
+            // rule of the streaming sweeps saves global bandwidth).  A padding lane is then the lane whose pair offset is the dummy's;
+            // .w keeps only the two-node flag, as the sign.
+            for (uint32_t h = 0; h < nh; ++h) {
+                u4v r = __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)lane * 16u, (rbase + h * 64u) * 16u, 0);
+                if (r[3] == RES2_PAD) {
+                    r[2] = ll_dummy | (((sm.ns + 2u) * S) << 16);
+                    r[3] = 0u;
+                } else {
+                    r[3] = (r[3] & 0x10000u) ? 0x80000000u : 0u;   // the two-node flag as the sign: one compare in the hop
+                }
+                lds_st<u4v>(dyn_lds, rl + h * 1024u + (uint32_t)lane * 16u, r);
+            }
+        }
     }
     for (uint32_t i = tid; i <= sm.n_vars; i += NT) vp[i] = sm.var_ptr[i];
     for (uint32_t i = tid; i < sm.n_entries; i += NT) vl[i] = sm.var_lds[i];
@@ -113,7 +135,7 @@ __global__ void __launch_bounds__(64 * NW) k_iterate_small(SmallDev sm, DevPtrs<
             const uint32_t c0 = sm.quad_hdr[4 * (size_t)q], cnt = sm.quad_hdr[4 * (size_t)q + 1];
             for (uint32_t i = tid; i < cnt; i += NT) {
                 const uint32_t e = d.cs_entry[c0 + i], sl = d.cs_slot[c0 + i];
-                sD[(size_t)(q * sm.wpb + sl / pk.stage_cap) * sm.nl + sl % pk.stage_cap] = reinterpret_cast<const P2*>(d.delta_lay)[e];   // quad-relative slot -> (pack, layer)
+                sD[(size_t)(q * sm.wpb + sl / pk.stage_cap) * dstride + sl % pk.stage_cap] = reinterpret_cast<const P2*>(d.delta_lay)[e];   // quad-relative slot -> (pack, layer)
             }
         }
     }
@@ -130,13 +152,28 @@ __global__ void __launch_bounds__(64 * NW) k_iterate_small(SmallDev sm, DevPtrs<
     // A thread's first variable (v = tid) with at most four entries is served from registers: its entries' addresses are read once, before the
     // iterations, so an exchange is one LDS round trip (the differences), the sums, the pair, the stores.  Other variables: the generic loop,
     // eight entries per batch of independent loads.  Same order of the additions in both: (variable, bdd).
+    // sum / (number of BDDs), rounded once like k_exchange_reduce's division: a count that is a power of two (every variable of an assignment
+    // problem sits in two BDDs) divides exactly by an exponent shift — one instruction instead of the ~10 of a correctly rounded division
+    auto mean_pair = [&](double lo, double hi, uint32_t n) -> P2 {
+        P2 pr;
+        if ((n & (n - 1u)) == 0u) {
+            const int sh = -(int)__builtin_ctz(n);
+            if constexpr (sizeof(REAL) == 4) { pr.x = __builtin_ldexpf(REAL(lo), sh); pr.y = __builtin_ldexpf(REAL(hi), sh); }
+            else { pr.x = __builtin_ldexp(REAL(lo), sh); pr.y = __builtin_ldexp(REAL(hi), sh); }
+        } else {
+            const REAL nb = REAL(n);
+            pr.x = REAL(lo) / nb;
+            pr.y = REAL(hi) / nb;
+        }
+        return pr;
+    };
     const uint32_t v_own = tid;
     uint32_t own_k0 = 0, own_n = 0, own_a[4] = {0u, 0u, 0u, 0u};
     if (v_own < sm.n_vars) {
         own_k0 = vp[v_own];
         own_n = vp[v_own + 1] - own_k0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) own_a[j] = (uint32_t)j < own_n ? vl[own_k0 + j] : 0u;
+        for (int j = 0; j < 4; ++j) own_a[j] = vl[own_k0 + ((uint32_t)j < own_n ? j : 0)];   // past the last entry: the first again (see the exchange)
     }
     auto exchange = [&](bool save_mm) {
         auto generic = [&](uint32_t v) {
@@ -159,10 +196,7 @@ __global__ void __launch_bounds__(64 * NW) k_iterate_small(SmallDev sm, DevPtrs<
                     }
                 }
             }
-            const REAL nb = REAL(k1 - k0);
-            P2 pr;
-            pr.x = REAL(lo) / nb;
-            pr.y = REAL(hi) / nb;
+            const P2 pr = mean_pair(lo, hi, k1 - k0);
             for (uint32_t kb = k0; kb < k1; kb += 8) {
                 uint32_t a[8];
 #pragma unroll
@@ -176,22 +210,19 @@ __global__ void __launch_bounds__(64 * NW) k_iterate_small(SmallDev sm, DevPtrs<
             REAL m[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) m[j] = lds_ld<REAL>(dyn_lds, own_a[j]);
+            // without branches: an entry past the variable's last reads its first entry's slot again and counts as 0 — adding +0.0 changes no
+            // sum, a NaN difference adds nothing either way (max(NaN, 0) = 0 as `NaN > 0` is false) — and stores the pair there once more
             double lo = 0.0, hi = 0.0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if ((uint32_t)j < own_n) {
-                    if (m[j] > 0) hi += (double)m[j];
-                    else if (m[j] < 0) lo += (double)(-m[j]);
-                    if (save_mm) mmE[own_k0 + j] = m[j];
-                }
+                const REAL x = (uint32_t)j < own_n ? m[j] : REAL(0);
+                if constexpr (sizeof(REAL) == 4) { hi += (double)__builtin_fmaxf(x, 0.0f); lo += (double)__builtin_fmaxf(-x, 0.0f); }
+                else { hi += __builtin_fmax(x, 0.0); lo += __builtin_fmax(-x, 0.0); }
+                if (save_mm && (uint32_t)j < own_n) mmE[own_k0 + j] = m[j];
             }
-            const REAL nb = REAL(own_n);
-            P2 pr;
-            pr.x = REAL(lo) / nb;
-            pr.y = REAL(hi) / nb;
+            const P2 pr = mean_pair(lo, hi, own_n);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if ((uint32_t)j < own_n) lds_st<P2>(dyn_lds, own_a[j], pr);
+            for (int j = 0; j < 4; ++j) lds_st<P2>(dyn_lds, own_a[j], pr);
         } else if (own_n > 4) {
             generic(v_own);
         }
@@ -206,42 +237,60 @@ __global__ void __launch_bounds__(64 * NW) k_iterate_small(SmallDev sm, DevPtrs<
 #else
         if (has_pack) {
 #endif
-            auto ldrec = [&](uint32_t h) -> u4v {
-                if (RL) return lds_ld<u4v>(dyn_lds, rl + (h < nh ? h : 0u) * 1024u + (uint32_t)lane * 16u);
-                return __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)lane * 16u, (rbase + h * 64u) * 16u, 0);
-            };
-            u4v r0 = ldrec(0), r1 = ldrec(1), r2 = ldrec(2), r3 = ldrec(3), r4 = ldrec(4), r5 = ldrec(5), r6 = ldrec(6), r7 = ldrec(7);
             for (uint32_t o = (uint32_t)lane; o < sm.ns + 64u; o += 64u) lds_st<REAL>(dyn_lds, wbF + o * S, INF);  // costs-from-root and the dummy entries
             wave_sync();
-            if (r0[3] != RES2_PAD) lds_st<REAL>(dyn_lds, wbF + (r0[2] >> 16), REAL(0));  // every node of hop 0 is a root (flush_costs_from_root)
-            wave_sync();
             auto hop = [&](const u4v& r) {
-                const bool real = r[3] != RES2_PAD;
-                const bool two = (r[3] & 0x10000u) != 0;
                 const uint32_t ll = r[2] & 0xFFFFu, fs = r[2] >> 16;
                 const REAL f = lds_ld<REAL>(dyn_lds, wbF + fs);
                 const REAL tl = lds_ld<REAL>(dyn_lds, wb + (r[0] & 0xFFFFu)), th = lds_ld<REAL>(dyn_lds, wb + (r[0] >> 16));
                 const P2 cc = lds_ld<P2>(dyn_lds, wbC + ll);
                 const P2 dd = lds_ld<P2>(dyn_lds, db + ll);
                 REAL m0 = (f + cc.x) + tl, m1 = (f + cc.y) + th;  // padding lanes: +inf
-                pair_min_aligned(m0, m1, two);
+                pair_min_aligned(m0, m1, RL ? (int32_t)r[3] < 0 : (r[3] & 0x10000u) != 0);
                 const REAL mm = mm_diff1(m0, m1, omega);
                 P2 nc;
                 nc.x = (cc.x + min0(mm)) + dd.x;
                 nc.y = (cc.y + min0_neg(mm)) + dd.y;
-                if ((r[3] & 0xFFFFu) != RES2_NO_STORE && real) lds_st<P2>(dyn_lds, wbC + ll, nc);  // the layer's head: new arc costs (every lane of the layer has read the old ones)
-                if (real) lds_st<REAL>(dyn_lds, db + ll, mm);                                       // every lane of a layer holds the same value
+                if constexpr (RL) {   // rewritten records: every lane stores (both lanes of a layer the same pair; padding lanes the dummy pair)
+                    lds_st<P2>(dyn_lds, wbC + ll, nc);
+                    lds_st<REAL>(dyn_lds, db + ll, mm);
+                } else {
+                    const bool real = r[3] != RES2_PAD;
+                    if ((r[3] & 0xFFFFu) != RES2_NO_STORE && real) lds_st<P2>(dyn_lds, wbC + ll, nc);  // the layer's head: new arc costs (every lane of the layer has read the old ones)
+                    if (real) lds_st<REAL>(dyn_lds, db + ll, mm);                                       // every lane of a layer holds the same value
+                }
                 lds_min(reinterpret_cast<REAL*>(dyn_lds + wb + (r[1] & 0xFFFFu)), f + nc.x);        // sinks / padding: the lane's own dummy entry
                 lds_min(reinterpret_cast<REAL*>(dyn_lds + wb + (r[1] >> 16)), f + nc.y);
                 wave_sync();
             };
+            if constexpr (RL) {
+                // records in LDS: one hop ahead is all the distance an LDS read needs; the record behind the pack's last hop is the spare KiB of
+                // its record area (never used)
+                uint32_t ra = rlane;
+                u4v ra_rec = lds_ld<u4v>(dyn_lds, ra), rb_rec;
+                if ((ra_rec[2] & 0xFFFFu) != ll_dummy) lds_st<REAL>(dyn_lds, wbF + (ra_rec[2] >> 16), REAL(0));  // every node of hop 0 is a root (flush_costs_from_root)
+                wave_sync();
+                for (uint32_t h = 0; h < nh; h += 2) {
+                    rb_rec = lds_ld<u4v>(dyn_lds, ra + 1024u);
+                    hop(ra_rec);
+                    if (h + 1 >= nh) break;
+                    ra_rec = lds_ld<u4v>(dyn_lds, ra + 2048u);
+                    hop(rb_rec);
+                    ra += 2048u;
+                }
+            } else {
+                auto ldrec = [&](uint32_t h) -> u4v { return __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)lane * 16u, (rbase + h * 64u) * 16u, 0); };
+                u4v r0 = ldrec(0), r1 = ldrec(1), r2 = ldrec(2), r3 = ldrec(3), r4 = ldrec(4), r5 = ldrec(5), r6 = ldrec(6), r7 = ldrec(7);
+                if (r0[3] != RES2_PAD) lds_st<REAL>(dyn_lds, wbF + (r0[2] >> 16), REAL(0));  // every node of hop 0 is a root (flush_costs_from_root)
+                wave_sync();
 #define SMALL_HOP(RK, HK)           \
     hop(RK);                        \
     RK = ldrec(h + (HK) + 8);       \
     if (h + (HK) + 1 >= nh) break;
-            for (uint32_t h = 0; h < nh; h += 16) {
-                SMALL_HOP(r0, 0) SMALL_HOP(r1, 1) SMALL_HOP(r2, 2) SMALL_HOP(r3, 3) SMALL_HOP(r4, 4) SMALL_HOP(r5, 5) SMALL_HOP(r6, 6) SMALL_HOP(r7, 7)
-                SMALL_HOP(r0, 8) SMALL_HOP(r1, 9) SMALL_HOP(r2, 10) SMALL_HOP(r3, 11) SMALL_HOP(r4, 12) SMALL_HOP(r5, 13) SMALL_HOP(r6, 14) SMALL_HOP(r7, 15)
+                for (uint32_t h = 0; h < nh; h += 16) {
+                    SMALL_HOP(r0, 0) SMALL_HOP(r1, 1) SMALL_HOP(r2, 2) SMALL_HOP(r3, 3) SMALL_HOP(r4, 4) SMALL_HOP(r5, 5) SMALL_HOP(r6, 6) SMALL_HOP(r7, 7)
+                    SMALL_HOP(r0, 8) SMALL_HOP(r1, 9) SMALL_HOP(r2, 10) SMALL_HOP(r3, 11) SMALL_HOP(r4, 12) SMALL_HOP(r5, 13) SMALL_HOP(r6, 14) SMALL_HOP(r7, 15)
+                }
             }
         }
         __syncthreads();
@@ -256,44 +305,62 @@ __global__ void __launch_bounds__(64 * NW) k_iterate_small(SmallDev sm, DevPtrs<
 #else
         if (has_pack) {
 #endif
-            // k-th hop processed = hop nh - 1 - k of the pack; past the first hop: any record (never used)
-            auto ldrec = [&](uint32_t k) -> u4v {
-                const uint32_t h = k < nh ? nh - 1u - k : 0u;
-                if (RL) return lds_ld<u4v>(dyn_lds, rl + h * 1024u + (uint32_t)lane * 16u);
-                return __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)lane * 16u, (rbase + h * 64u) * 16u, 0);
-            };
-            u4v r0 = ldrec(0), r1 = ldrec(1), r2 = ldrec(2), r3 = ldrec(3), r4 = ldrec(4), r5 = ldrec(5), r6 = ldrec(6), r7 = ldrec(7);
             auto hop = [&](const u4v& r) {
-                const bool real = r[3] != RES2_PAD;
-                const bool two = (r[3] & 0x10000u) != 0;
                 const uint32_t ll = r[2] & 0xFFFFu, fs = r[2] >> 16;
                 const REAL f = lds_ld<REAL>(dyn_lds, wbF + fs);  // padding lanes: whatever the dummy entry holds; their results go nowhere
                 const REAL tl = lds_ld<REAL>(dyn_lds, wb + (r[0] & 0xFFFFu)), th = lds_ld<REAL>(dyn_lds, wb + (r[0] >> 16));
                 const P2 cc = lds_ld<P2>(dyn_lds, wbC + ll);
                 const P2 dd = lds_ld<P2>(dyn_lds, db + ll);
                 REAL m0 = (f + cc.x) + tl, m1 = (f + cc.y) + th;
-                pair_min_aligned(m0, m1, two);
+                pair_min_aligned(m0, m1, RL ? (int32_t)r[3] < 0 : (r[3] & 0x10000u) != 0);
                 const REAL mm = mm_diff1(m0, m1, omega);
                 P2 nc;
                 nc.x = (cc.x + min0(mm)) + dd.x;
                 nc.y = (cc.y + min0_neg(mm)) + dd.y;
                 const REAL t = rmin(nc.y + th, nc.x + tl);
-                if ((r[3] & 0xFFFFu) != RES2_NO_STORE && real) lds_st<P2>(dyn_lds, wbC + ll, nc);
-                if (real) {
+                if constexpr (RL) {   // rewritten records: no exec masks (padding lanes: the dummy pair, the spare entry ns + 2)
+                    lds_st<P2>(dyn_lds, wbC + ll, nc);
                     lds_st<REAL>(dyn_lds, db + ll, mm);
                     lds_st<REAL>(dyn_lds, wb + fs, t);
+                } else {
+                    const bool real = r[3] != RES2_PAD;
+                    if ((r[3] & 0xFFFFu) != RES2_NO_STORE && real) lds_st<P2>(dyn_lds, wbC + ll, nc);
+                    if (real) {
+                        lds_st<REAL>(dyn_lds, db + ll, mm);
+                        lds_st<REAL>(dyn_lds, wb + fs, t);
+                    }
                 }
                 wave_sync();
             };
-            for (uint32_t h = 0; h < nh; h += 16) {  // h counts the hops processed, from the pack's last hop upwards
-                SMALL_HOP(r0, 0) SMALL_HOP(r1, 1) SMALL_HOP(r2, 2) SMALL_HOP(r3, 3) SMALL_HOP(r4, 4) SMALL_HOP(r5, 5) SMALL_HOP(r6, 6) SMALL_HOP(r7, 7)
-                SMALL_HOP(r0, 8) SMALL_HOP(r1, 9) SMALL_HOP(r2, 10) SMALL_HOP(r3, 11) SMALL_HOP(r4, 12) SMALL_HOP(r5, 13) SMALL_HOP(r6, 14) SMALL_HOP(r7, 15)
+            if constexpr (RL) {
+                // from the pack's last hop upwards; the record read "before" hop 0 lies in front of the record area (any LDS contents, never used)
+                uint32_t ra = rlane + nhm1 * 1024u;
+                u4v ra_rec = lds_ld<u4v>(dyn_lds, ra), rb_rec;
+                for (uint32_t k = 0; k < nh; k += 2) {
+                    rb_rec = lds_ld<u4v>(dyn_lds, ra - 1024u);
+                    hop(ra_rec);
+                    if (k + 1 >= nh) break;
+                    ra_rec = lds_ld<u4v>(dyn_lds, ra - 2048u);
+                    hop(rb_rec);
+                    ra -= 2048u;
+                }
+            } else {
+                // k-th hop processed = hop nh - 1 - k of the pack; past the first hop: any record (never used)
+                auto ldrec = [&](uint32_t k) -> u4v {
+                    const uint32_t h = k < nhm1 ? nhm1 - k : 0u;
+                    return __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)lane * 16u, (rbase + h * 64u) * 16u, 0);
+                };
+                u4v r0 = ldrec(0), r1 = ldrec(1), r2 = ldrec(2), r3 = ldrec(3), r4 = ldrec(4), r5 = ldrec(5), r6 = ldrec(6), r7 = ldrec(7);
+                for (uint32_t h = 0; h < nh; h += 16) {  // h counts the hops processed, from the pack's last hop upwards
+                    SMALL_HOP(r0, 0) SMALL_HOP(r1, 1) SMALL_HOP(r2, 2) SMALL_HOP(r3, 3) SMALL_HOP(r4, 4) SMALL_HOP(r5, 5) SMALL_HOP(r6, 6) SMALL_HOP(r7, 7)
+                    SMALL_HOP(r0, 8) SMALL_HOP(r1, 9) SMALL_HOP(r2, 10) SMALL_HOP(r3, 11) SMALL_HOP(r4, 12) SMALL_HOP(r5, 13) SMALL_HOP(r6, 14) SMALL_HOP(r7, 15)
+                }
             }
 #undef SMALL_HOP
             // lower bound contribution of this pack: sum of root costs-from-terminal (bdd_cuda_base.cu:1243-1251); every node of the first hop is a root
             if (run.ctl != nullptr || it + 1 == n_iters) {   // (uniform) the bound: run_solver's tests, or the state the launch leaves
             const u4v rroot = RL ? lds_ld<u4v>(dyn_lds, rl + (uint32_t)lane * 16u) : __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)lane * 16u, rbase * 16u, 0);
-            double lb = rroot[3] != RES2_PAD ? (double)lds_ld<REAL>(dyn_lds, wb + (rroot[2] >> 16)) : 0.0;
+            double lb = (RL ? (rroot[2] & 0xFFFFu) != ll_dummy : rroot[3] != RES2_PAD) ? (double)lds_ld<REAL>(dyn_lds, wb + (rroot[2] >> 16)) : 0.0;
             for (int off2 = 32; off2 > 0; off2 >>= 1) lb += __shfl_down(lb, off2);
             if (lane == 0) lbp[p] = lb;
             }
@@ -339,7 +406,7 @@ __global__ void __launch_bounds__(64 * NW) k_iterate_small(SmallDev sm, DevPtrs<
             const uint32_t c0 = sm.quad_hdr[4 * (size_t)q], cnt = sm.quad_hdr[4 * (size_t)q + 1];
             for (uint32_t i = tid; i < cnt; i += NT) {
                 const uint32_t e = d.cs_entry[c0 + i], sl = d.cs_slot[c0 + i];
-                const_cast<P2*>(reinterpret_cast<const P2*>(d.delta_lay))[e] = sD[(size_t)(q * sm.wpb + sl / pk.stage_cap) * sm.nl + sl % pk.stage_cap];
+                const_cast<P2*>(reinterpret_cast<const P2*>(d.delta_lay))[e] = sD[(size_t)(q * sm.wpb + sl / pk.stage_cap) * small_stage_stride(sm.nl) + sl % pk.stage_cap];
             }
         }
     }

@@ -660,13 +660,13 @@ struct SolverT final : SolverBase {
                 uint32_t p = 0;   // the pack whose layer range holds l (pack_hdr: [2] first layer, [3] layers)
                 while (p < np && !(l >= L.res.pack_hdr[8 * (size_t)p + 2] && l < L.res.pack_hdr[8 * (size_t)p + 2] + L.res.pack_hdr[8 * (size_t)p + 3])) ++p;
                 if (p == np || l - L.res.pack_hdr[8 * (size_t)p + 2] >= res2_nl) { ok = false; break; }
-                lds_off[k] = (p * res2_nl + (l - L.res.pack_hdr[8 * (size_t)p + 2])) * 2u * (uint32_t)sizeof(REAL);
+                lds_off[k] = (p * small_stage_stride(res2_nl) + (l - L.res.pack_hdr[8 * (size_t)p + 2])) * 2u * (uint32_t)sizeof(REAL);
             }
             for (uint32_t p = 0; p < np; ++p) max_hops = std::max(max_hops, L.res.pack_hdr[8 * (size_t)p + 5] & 0xFFFFu);
             small = SmallDev{};
             small.ns = res2_ns; small.nl = res2_nl; small.n_packs = np; small.wpb = wpb; small.n_quads = cdiv(np, wpb);
             small.n_vars = (uint32_t)n_vars; small.n_entries = (uint32_t)n_layers; small.rec_words = res2_n_words;
-            small.rec_cap = max_hops * 1024u;
+            small.rec_cap = (max_hops + 1u) * 1024u;   // + the spare KiB the forward sweep's one-hop-ahead read lands in behind the last hop
             uint32_t bytes = small_lds_bytes((uint32_t)sizeof(REAL), np, (uint32_t)n_vars, (uint32_t)n_layers, small);
             small_rl = bytes + 512 <= lds_cu;
             if (!small_rl) {
