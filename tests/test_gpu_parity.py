@@ -850,7 +850,8 @@ def test_lane_per_layer_sweeps_are_the_rule_where_they_apply():
 
 
 @pytest.mark.parametrize("precision,flags,wpb,kind", [("float", 0x41000, 4, "streaming1"), ("float", 0x41000, 8, "streaming1"), ("double", 0x41000, 4, "streaming1"),
-                                                      ("double", 0x40000, 8, "streaming1"), ("double", 0x40000, 4, "streaming2")])
+                                                      ("double", 0x40000, 8, "streaming1"), ("double", 0x40000, 4, "streaming2"),
+                                                      ("float", 0x41000 | 0x4000, 8, "streaming1"), ("double", 0x40000 | 0x4000, 4, "streaming2")])   # bit 14: 64-bit staging addresses
 def test_nontemporal_instantiations_of_the_first_and_second_generation(precision, flags, wpb, kind):
     """Beyond 640 MiB of arrays the first- and (double) second-generation streaming sweeps of 128-slot packs run in the instantiation that loads
     potentials and staging tables non-temporally (variant_flags bit 20 selects it on a small instance): a cache policy, so every result is
