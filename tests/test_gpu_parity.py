@@ -636,6 +636,45 @@ def test_full_size_properties(tag):
     assert abs(lf - o.lower_bound()) <= 1e-5 * abs(o.lower_bound())
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_nontemporal_instantiations_fuzz(seed):
+    """The non-temporal instantiations on random uniform-row instances (covering / simplex / at-most-one rows of 2-24 variables and a few of 70-150:
+    one- and two-node layers side by side, several stage groups per pack, ragged pack ends), random packs per workgroup, bin size, BDD order,
+    exchange and staging-address width — forced by variant_flags bit 20, against the oracle per iteration and in the min-marginals."""
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    V = int(rng.integers(60, 400))
+    col = BddCollection()
+    for _ in range(int(rng.integers(300, 1200))):
+        k = int(rng.integers(2, min(V, int(rng.choice([6, 10, 24]))) + 1))
+        vs = np.sort(rng.choice(V, size=k, replace=False))
+        [col.add_covering, col.add_simplex, lambda v: col.add_linear(np.ones(len(v), int), "<=", 1, v)][int(rng.integers(0, 3))](vs)
+    for _ in range(int(rng.choice([0, 0, 12]))):
+        (col.add_covering if rng.random() < 0.5 else col.add_simplex)(np.sort(rng.choice(V, size=int(rng.integers(70, min(V, 150))), replace=False)))
+    costs = rng.normal(0, 4, col.nr_variables()).round(3)
+    base = dict(pack_width=128, waves_per_block=int(rng.choice([4, 8])), resident_sweeps=1, vars_per_bin=int(rng.choice([0, 64, 256])),
+                keep_bdd_order=int(rng.integers(0, 3)), deterministic=bool(rng.integers(0, 2)))
+    wide = int(rng.choice([0, 0x4000]))
+    ran = 0
+    for precision in ("double", "float"):
+        # float: the first generation (bit 12) is the one with the instantiation; double: first or second
+        gen = 0x1000 if precision == "float" else int(rng.choice([0, 0x1000, 0x2000]))
+        s = bdd_hip_parallel_mma(col, costs, precision=precision, variant_flags=0x40000 | 0x100000 | gen | wide, **base)
+        if s.solve_sweep_kind() not in ("streaming1", "streaming2") or not s.nontemporal_loads():
+            continue   # layers wider than two nodes / staggered packs in this draw: the general forms have no such instantiation
+        ran += 1
+        o = Oracle(col, costs, precision)
+        for _ in range(int(rng.integers(3, 20))):
+            s.iteration(); o.iteration()
+            assert close(s.lower_bound(), o.lower_bound(), precision, 10), (base, precision, gen, wide)
+        perm = oracle_layer_perm(s, o)
+        _, mm0, mm1 = s.min_marginals_cuda(get_sorted=False)
+        omm = o.min_marginals()
+        tol = dict(rtol=1e-9, atol=1e-8) if precision == "double" else dict(rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(mm0[perm], omm[:, 0], err_msg=str(base), **tol)
+        np.testing.assert_allclose(mm1[perm], omm[:, 1], err_msg=str(base), **tol)
+    assert ran >= 1, "no draw reached the non-temporal instantiations"
+
+
 def test_twice_the_headline_size_runs_the_nontemporal_sweeps_by_rule_vs_oracle():
     """21 M nodes (V = 2 M, B = 1 M, k = 10; 1.1 / 1.6 GB of arrays): beyond 16 M slots the third generation hands over to the first / second, and
     beyond 640 MiB those run in the instantiation that loads potentials and staging tables non-temporally (SolverT::init: n12_nt) — chosen by
