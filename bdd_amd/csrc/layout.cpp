@@ -845,6 +845,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         uint32_t auto_cap = W;
         for (uint32_t p = 0; p < L.narrow.n_packs(); ++p)
             auto_cap = std::max(auto_cap, L.narrow.hop_layer_off[L.narrow.pack_hop_ptr[p + 1]] - L.narrow.hop_layer_off[L.narrow.pack_hop_ptr[p]]);
+        const uint32_t raw_cap = auto_cap;   // the largest pack's layers: beyond 640 its packs have several stage groups
         auto_cap = std::min<uint32_t>(640, (auto_cap + 63) / 64 * 64);
         X.stage_cap = opts && opts->stage_cap ? opts->stage_cap : auto_cap;
         if (X.vars_per_bin < 64 || X.vars_per_bin > max_vb) {
@@ -859,6 +860,91 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         // stage groups: runs of hops of a narrow pack holding <= stage_cap layers
         const PackSet& N = L.narrow;
         const uint32_t Pn = N.n_packs();
+        // packs per workgroup (the rules read like this since rounds 2-5; a function of the stage groups' size because the rule for that size below asks
+        // what they would choose)
+        auto choose_wpb = [&](uint32_t stage_cap) -> uint32_t {
+            uint32_t wpb = opts && opts->waves_per_block ? opts->waves_per_block : 4;
+            // small instances: keep at least ~512 workgroups so that every CU has work
+            if (!(opts && opts->waves_per_block))
+                while (wpb > 1 && Pn / wpb < 512) wpb /= 2;
+            // large instances: 8.  The entries a workgroup stages per bin form one run in the entry arrays; with four packs per workgroup a run is
+            // (layers of four packs) / bins entries long — 10 at 10.5 M nodes float, 1 at 105 M, where the sweeps fall from 5.7 to 4.2 TB/s on their
+            // counter bytes.  Eight packs double it.  Measured (tools/kbench.py --wpb 4 / 8, one box each, it/s): 10.5 M nodes float (run 10.4) 8 546 /
+            // 8 488, double (5.2) 4 225 / 4 251; 15.8 M 4 437 / 4 414 and 2 659 / 2 707; 21 M 3 516 / 3 557 and 1 832 / 1 868; 42 M 1 620 / 1 632 and
+            // 884 / 906; 105 M 596 / 630 and 314 / 331.  With the sweeps starting from the resident headers (PackDev::hdr_pack; later in the round)
+            // the double 10.5 M case is a tie (4 276 / 4 273, 4 319 / 4 263: four packs keep the per-lane records, eight exceed their 64 KB), 105 M
+            // still 599 / 640 and 318 / 332.  Rule: 8 when the run of four packs is shorter than 4.5 entries.
+            if (!(opts && opts->waves_per_block) && wpb == 4 && Pn >= 8 * 512 && X.n_bins > 0) {
+                const double run4 = (double)L.n_layers / ((double)Pn / 4.0) / (double)X.n_bins;
+                // (LDS of a sweep workgroup of eight, as SolverT::init adds it up: staging pairs + frontier / potentials / hop window per wave + the
+                // segmented-minimum scratch)
+                const uint64_t lds8 = 8ull * stage_cap * 2 * real_size + 8ull * (3ull * (W + 2) * real_size + 2 * 64 * 4 + 2) + 8ull * 128 * real_size;
+                if (run4 < 4.5 && lds8 <= 150 * 1024) wpb = 8;
+            }
+            // Instances of a few thousand narrow packs and nothing else are candidates for the resident sweeps, whose workgroups should be all in
+            // flight at once: one pack per workgroup packs the CUs' LDS best (a wave's 12-21 KB region; k_fwd_res2).  The entry arrays of such an
+            // instance stay in cache, so the longer runs of cooperative staging buy nothing there (1.05 M nodes, streaming: 28.0 k it/s with 1, 2 or 4).
+            // (64-slot packs, up to ~1.45 x what the chip holds at once in float; beyond that the streaming sweeps run, which want their 4: 3.1 M
+            // nodes 16.3 k it/s with 4, 16.0 k with 1; 4.2 M, packs of 128: 14.6 k / 13.8 k)
+            // Only where those sweeps can be chosen at all (SolverT::init: layers of at most two nodes, resident sweeps not switched off) — the
+            // streaming sweeps of any other instance keep their four packs per workgroup and the staging runs that go with them.  3 700 packs
+            // on 256 CUs, scaled with the CU count.
+            bool two_node_layers = true;
+            for (uint8_t st : L.narrow.pack_steps) two_node_layers = two_node_layers && st < 2;
+            if (!(opts && opts->waves_per_block) && W == 64 && (uint64_t)Pn * 256 <= 3700ull * chip.n_cus && L.wide.n_packs() == 0 && L.huge.n_packs() == 0 &&
+                two_node_layers && !(opts && opts->resident_sweeps == 1))
+                wpb = 1;
+            // Instances with a sizeable share of wide packs (>= 10 % of the node slots): their solve sweeps share the narrow packs' launch
+            // (k_fwd_mixed / k_bwd_mixed), so a wide pack gets 64 * waves_per_block threads — more than its hop width leaves threads idle
+            // behind every barrier.  Knapsack benchmark (wide packs of 65-77 nodes): 4 -> 2 packs per workgroup 16.1 k -> 18.1 k it/s
+            // (float), 14.5 k -> 16.5 k (double); 1: 18.0 k / 15.4 k; 8: 12.8 k / 10.7 k.
+            if (!(opts && opts->waves_per_block) && L.wide.n_packs() > 0 && !L.wide.hop_node_off.empty()) {
+                const uint64_t wide_slots = L.wide.hop_node_off.back() - L.wide.hop_node_off.front();
+                if (wide_slots * 10 >= (uint64_t)L.n_slots) {
+                    uint32_t fit = 1;
+                    while (fit < 4 && 64u * fit < L.wide_pack_width) fit *= 2;
+                    wpb = std::min(wpb, fit);
+                }
+            }
+            // Staggered packs: one pack per workgroup.  The waves of a workgroup share its LDS and meet at the barriers of the staging rounds, and
+            // staggered packs differ in length and in what their hops cost (BDDs start and end anywhere inside them), so a workgroup of four lives as
+            // long as its slowest pack; uniform packs finish together.  Measured on the round-3 kernels, 10 M nodes, 4 -> 1 packs per workgroup, it/s
+            // float / double: 20 k knapsack + 250 k covering rows 5 458 -> 6 110 / 2 862 -> 3 293, 10 k + 400 k 5 641 -> 6 886 / 2 961 -> 3 512, 30 k +
+            // 100 k 5 342 -> 5 234 / 3 152 -> 3 418, 40 k knapsack rows of 14 variables 4 734 -> 4 890 / 3 300 -> 3 740, of 10 variables 11 595 ->
+            // 12 972 / 9 885 -> 10 173.  Not staggered: random set cover keeps 4 (8 127 vs 7 717 / 4 351 vs 3 926 with one), the 1 M-node knapsack
+            // instance its 2 (19 189 vs 18 475).  (The hop counts alone do not tell: grouping staggered packs by four pads them by < 10 %.)
+            if (!(opts && opts->waves_per_block) && wpb > 1) {
+                bool staggered = false;
+                for (uint16_t r : N.hop_root)
+                    if (r != NO_ROOT) { staggered = true; break; }
+                if (staggered) wpb = 1;
+            }
+            return wpb;
+        };
+        // Several stage groups per pack (rows of more than ~20 variables in 64-slot packs) in ONE round of workgroups where a smaller staging area allows
+        // it.  The sweeps of such instances are latency-bound and bimodal: ~105 us when every workgroup of the launch is resident at once, ~135 us when a
+        // second, nearly empty round follows (double, 10.5 M nodes; profiles/r06_stage_groups.txt: 33 shapes x 6 group sizes).  What decides is the LDS
+        // of the forward sweep's workgroup — packs per workgroup x (stage_cap pairs + the second generation's static arrays, (4 (W + 2) + 2 W) values + 768 B)
+        // + ~0.6 KB the hardware keeps per workgroup (fitted: 14 workgroups of 11 072 B share a CU, 13 of 12 096 B do not) — against the CU's LDS, and the
+        // register budget's 16 (double) / 20 (float) waves per CU.  Fewer, larger groups win whenever the launch fits one round anyway (fewer staging
+        // rounds per pack), and a change from three rounds to two measured as a loss (-3..-5 %), so: only when the rule's size needs more than one round and
+        // a smaller one needs exactly one — double 10.5 M nodes, rows of 40 / 44 / 50 / 56 variables +11 / +14 / +22 / +11 %, 5.25 M nodes rows of 24 / 28
+        // +19 / +11 %, 21 M nodes rows of 80 / 100 +6 / +16 %; float is never LDS-limited here and keeps its 640.  64-slot packs, narrow packs only.
+        if (!(opts && opts->stage_cap) && Pn && W == 64 && L.wide.n_packs() == 0 && L.huge.n_packs() == 0 && raw_cap > X.stage_cap) {
+            const uint32_t wpb = choose_wpb(X.stage_cap);
+            const uint64_t n_wg = ((uint64_t)Pn + wpb - 1) / wpb;
+            auto one_round = [&](uint32_t cap) {
+                const uint64_t per_wg = (uint64_t)wpb * ((uint64_t)cap * 2 * real_size + (4ull * (W + 2) + 2ull * W) * real_size + 768) + 640;
+                const uint64_t per_cu = std::min<uint64_t>(chip.lds_bytes / per_wg, std::max<uint32_t>(1, (real_size == 8 ? 16u : 20u) / wpb));
+                return n_wg <= per_cu * chip.n_cus;
+            };
+            if (!one_round(X.stage_cap))
+                for (uint32_t cap = X.stage_cap - 64; cap >= 256 && cap >= W; cap -= 64)
+                    if (one_round(cap)) {
+                        if (choose_wpb(cap) == wpb) X.stage_cap = cap;
+                        break;
+                    }
+        }
         X.pack_group_ptr.assign(Pn + 1, 0);
         std::vector<uint32_t> layer_group(Lin, 0);
         const uint32_t narrow_layers = Pn ? N.hop_layer_off.back() : 0;  // narrow layers come first
@@ -932,62 +1018,7 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         // cooperative staging tables
         // default: 4 packs per workgroup (measured after the node words became shared: 4 beats 8 in float by 5-8 %:
         // 28 KB of LDS per workgroup instead of 57 KB, i.e. 5 instead of 4 waves per SIMD)
-        X.waves_per_block = opts && opts->waves_per_block ? opts->waves_per_block : 4;
-        // small instances: keep at least ~512 workgroups so that every CU has work
-        if (!(opts && opts->waves_per_block))
-            while (X.waves_per_block > 1 && Pn / X.waves_per_block < 512) X.waves_per_block /= 2;
-        // large instances: 8.  The entries a workgroup stages per bin form one run in the entry arrays; with four packs per workgroup a run is
-        // (layers of four packs) / bins entries long — 10 at 10.5 M nodes float, 1 at 105 M, where the sweeps fall from 5.7 to 4.2 TB/s on their
-        // counter bytes.  Eight packs double it.  Measured (tools/kbench.py --wpb 4 / 8, one box each, it/s): 10.5 M nodes float (run 10.4) 8 546 /
-        // 8 488, double (5.2) 4 225 / 4 251; 15.8 M 4 437 / 4 414 and 2 659 / 2 707; 21 M 3 516 / 3 557 and 1 832 / 1 868; 42 M 1 620 / 1 632 and
-        // 884 / 906; 105 M 596 / 630 and 314 / 331.  With the sweeps starting from the resident headers (PackDev::hdr_pack; later in the round)
-        // the double 10.5 M case is a tie (4 276 / 4 273, 4 319 / 4 263: four packs keep the per-lane records, eight exceed their 64 KB), 105 M
-        // still 599 / 640 and 318 / 332.  Rule: 8 when the run of four packs is shorter than 4.5 entries.
-        if (!(opts && opts->waves_per_block) && X.waves_per_block == 4 && Pn >= 8 * 512 && X.n_bins > 0) {
-            const double run4 = (double)L.n_layers / ((double)Pn / 4.0) / (double)X.n_bins;
-            // (LDS of a sweep workgroup of eight, as SolverT::init adds it up: staging pairs + frontier / potentials / hop window per wave + the
-            // segmented-minimum scratch)
-            const uint64_t lds8 = 8ull * X.stage_cap * 2 * real_size + 8ull * (3ull * (W + 2) * real_size + 2 * 64 * 4 + 2) + 8ull * 128 * real_size;
-            if (run4 < 4.5 && lds8 <= 150 * 1024) X.waves_per_block = 8;
-        }
-        // Instances of a few thousand narrow packs and nothing else are candidates for the resident sweeps, whose workgroups should be all in
-        // flight at once: one pack per workgroup packs the CUs' LDS best (a wave's 12-21 KB region; k_fwd_res2).  The entry arrays of such an
-        // instance stay in cache, so the longer runs of cooperative staging buy nothing there (1.05 M nodes, streaming: 28.0 k it/s with 1, 2 or 4).
-        // (64-slot packs, up to ~1.45 x what the chip holds at once in float; beyond that the streaming sweeps run, which want their 4: 3.1 M
-        // nodes 16.3 k it/s with 4, 16.0 k with 1; 4.2 M, packs of 128: 14.6 k / 13.8 k)
-        // Only where those sweeps can be chosen at all (SolverT::init: layers of at most two nodes, resident sweeps not switched off) — the
-        // streaming sweeps of any other instance keep their four packs per workgroup and the staging runs that go with them.  3 700 packs
-        // on 256 CUs, scaled with the CU count.
-        bool two_node_layers = true;
-        for (uint8_t st : L.narrow.pack_steps) two_node_layers = two_node_layers && st < 2;
-        if (!(opts && opts->waves_per_block) && W == 64 && (uint64_t)Pn * 256 <= 3700ull * chip.n_cus && L.wide.n_packs() == 0 && L.huge.n_packs() == 0 &&
-            two_node_layers && !(opts && opts->resident_sweeps == 1))
-            X.waves_per_block = 1;
-        // Instances with a sizeable share of wide packs (>= 10 % of the node slots): their solve sweeps share the narrow packs' launch
-        // (k_fwd_mixed / k_bwd_mixed), so a wide pack gets 64 * waves_per_block threads — more than its hop width leaves threads idle
-        // behind every barrier.  Knapsack benchmark (wide packs of 65-77 nodes): 4 -> 2 packs per workgroup 16.1 k -> 18.1 k it/s
-        // (float), 14.5 k -> 16.5 k (double); 1: 18.0 k / 15.4 k; 8: 12.8 k / 10.7 k.
-        if (!(opts && opts->waves_per_block) && L.wide.n_packs() > 0 && !L.wide.hop_node_off.empty()) {
-            const uint64_t wide_slots = L.wide.hop_node_off.back() - L.wide.hop_node_off.front();
-            if (wide_slots * 10 >= (uint64_t)L.n_slots) {
-                uint32_t fit = 1;
-                while (fit < 4 && 64u * fit < L.wide_pack_width) fit *= 2;
-                X.waves_per_block = std::min(X.waves_per_block, fit);
-            }
-        }
-        // Staggered packs: one pack per workgroup.  The waves of a workgroup share its LDS and meet at the barriers of the staging rounds, and
-        // staggered packs differ in length and in what their hops cost (BDDs start and end anywhere inside them), so a workgroup of four lives as
-        // long as its slowest pack; uniform packs finish together.  Measured on the round-3 kernels, 10 M nodes, 4 -> 1 packs per workgroup, it/s
-        // float / double: 20 k knapsack + 250 k covering rows 5 458 -> 6 110 / 2 862 -> 3 293, 10 k + 400 k 5 641 -> 6 886 / 2 961 -> 3 512, 30 k +
-        // 100 k 5 342 -> 5 234 / 3 152 -> 3 418, 40 k knapsack rows of 14 variables 4 734 -> 4 890 / 3 300 -> 3 740, of 10 variables 11 595 ->
-        // 12 972 / 9 885 -> 10 173.  Not staggered: random set cover keeps 4 (8 127 vs 7 717 / 4 351 vs 3 926 with one), the 1 M-node knapsack
-        // instance its 2 (19 189 vs 18 475).  (The hop counts alone do not tell: grouping staggered packs by four pads them by < 10 %.)
-        if (!(opts && opts->waves_per_block) && X.waves_per_block > 1) {
-            bool staggered = false;
-            for (uint16_t r : N.hop_root)
-                if (r != NO_ROOT) { staggered = true; break; }
-            if (staggered) X.waves_per_block = 1;
-        }
+        X.waves_per_block = choose_wpb(X.stage_cap);
         if (X.waves_per_block != 1 && X.waves_per_block != 2 && X.waves_per_block != 4 && X.waves_per_block != 8) {
             err = "waves_per_block must be 1, 2, 4 or 8";
             return BDDMMA_ERR_INVALID_ARGUMENT;

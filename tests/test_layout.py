@@ -820,6 +820,23 @@ def test_layout_for_a_smaller_chip_differs_where_the_rules_read_the_chip():
     assert L.bddmma_layout_create_for_chip(C.byref(h), None, None, 0, None, 2, 0, 0) != 0   # real_size is 4 or 8
 
 
+@pytest.mark.parametrize("packs,real_size,want", [(80, 8, 640), (100, 8, 448), (116, 8, 384), (126, 8, 320), (140, 8, 640), (100, 4, 640)])
+def test_stage_groups_shrink_to_fit_the_launch_into_one_round_of_workgroups(packs, real_size, want):
+    """layout.cpp (round 6): rows of 50 variables are 32 BDDs per 64-slot pack and 1 600 layers per pack — three stage groups of <= 640.  On an 8-CU chip
+    with 160 KB of LDS per CU the forward sweep's one-pack workgroups (16 B per staged pair + 3 904 B static + ~0.6 KB) fit 11 per CU with groups of
+    640 layers, 13 with 448, 15 with 384, 16 (the register budget) with 320: the rule takes the LARGEST size that puts every workgroup of the launch on
+    the chip at once, keeps 640 where that already fits (80 packs <= 88) or no size achieves it (140 > 128), and never fires in float (20 per CU either way).
+    An explicit stage_cap is never overridden."""
+    from bdd_amd.instances import random_set_cover
+    col, _ = random_set_cover(4000, 32 * packs, 50, seed=packs)
+    chip = (real_size, 8, 160 * 1024)
+    lay = Layout(col, pack_width=64, chip=chip)
+    assert lay.np_n == packs and lay.wpb == 1
+    assert lay.stage_cap == want
+    assert Layout(col, pack_width=64, stage_cap=640, chip=chip).stage_cap == 640
+    check_roundtrip(col, pack_width=64, chip=chip)
+
+
 def test_device_chip_query_without_a_device_is_an_error_not_a_default():
     import torch
     if torch.cuda.is_available():
