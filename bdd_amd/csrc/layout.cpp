@@ -933,17 +933,23 @@ static int build_layout_w(const bddmma_instruction* instr, const uint64_t* delim
         if (!(opts && opts->stage_cap) && Pn && W == 64 && L.wide.n_packs() == 0 && L.huge.n_packs() == 0 && raw_cap > X.stage_cap) {
             const uint32_t wpb = choose_wpb(X.stage_cap);
             const uint64_t n_wg = ((uint64_t)Pn + wpb - 1) / wpb;
-            auto one_round = [&](uint32_t cap) {
+            auto per_cu = [&](uint32_t cap) {
                 const uint64_t per_wg = (uint64_t)wpb * ((uint64_t)cap * 2 * real_size + (4ull * (W + 2) + 2ull * W) * real_size + 768) + 640;
-                const uint64_t per_cu = std::min<uint64_t>(chip.lds_bytes / per_wg, std::max<uint32_t>(1, (real_size == 8 ? 16u : 20u) / wpb));
-                return n_wg <= per_cu * chip.n_cus;
+                return std::min<uint64_t>(chip.lds_bytes / per_wg, std::max<uint32_t>(1, (real_size == 8 ? 16u : 20u) / wpb));
             };
-            if (!one_round(X.stage_cap))
-                for (uint32_t cap = X.stage_cap - 64; cap >= 256 && cap >= W; cap -= 64)
+            auto one_round = [&](uint32_t cap) { return n_wg <= per_cu(cap) * chip.n_cus; };
+            const uint32_t cap0 = X.stage_cap;
+            if (!one_round(cap0))
+                for (uint32_t cap = cap0 - 64; cap >= 256 && cap >= W; cap -= 64)
                     if (one_round(cap)) {
                         if (choose_wpb(cap) == wpb) X.stage_cap = cap;
                         break;
                     }
+            // ... and where no size gets the launch into one round: one step down (640 -> 576 layers) if that is what lets a CU hold a THIRD workgroup
+            // instead of two — four packs per workgroup in double are 57 KB with groups of 640 layers, 53 KB with 576 — half as many resident waves
+            // again for groups 10 % smaller (10.5 M nodes, rows of 28 / 32 / 36 variables: +7 %; rows of 24: 0)
+            if (X.stage_cap == cap0 && !one_round(cap0) && cap0 >= 128 + W && per_cu(cap0) == 2 && per_cu(cap0 - 64) == 3 && choose_wpb(cap0 - 64) == wpb)
+                X.stage_cap = cap0 - 64;
         }
         X.pack_group_ptr.assign(Pn + 1, 0);
         std::vector<uint32_t> layer_group(Lin, 0);

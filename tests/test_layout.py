@@ -835,6 +835,16 @@ def test_stage_groups_shrink_to_fit_the_launch_into_one_round_of_workgroups(pack
     assert lay.stage_cap == want
     assert Layout(col, pack_width=64, stage_cap=640, chip=chip).stage_cap == 640
     check_roundtrip(col, pack_width=64, chip=chip)
+    # four packs per workgroup: 57 KB with groups of 640 layers (two workgroups per CU), 53 KB with 576 (three) — where no size fits the launch into one round
+    # the rule takes that one step; a launch that fits anyway, and float, keep 640
+    four = Layout(col, pack_width=64, waves_per_block=4, chip=chip)
+    assert four.wpb == 4
+    n_wg = (packs + 3) // 4
+    per_cu = lambda cap: min(160 * 1024 // (4 * (cap * 2 * real_size + (4 * 66 + 128) * real_size + 768) + 640), (16 if real_size == 8 else 20) // 4)
+    fits = [cap for cap in range(640, 255, -64) if n_wg <= 8 * per_cu(cap)]
+    want4 = 640 if fits[:1] == [640] else fits[0] if fits else 576 if (per_cu(640), per_cu(576)) == (2, 3) else 640
+    assert four.stage_cap == want4, (n_wg, four.stage_cap, want4)
+    assert want4 == {(80, 8): 576, (100, 8): 384, (116, 8): 384, (126, 8): 384, (140, 8): 576}.get((packs, real_size), 640)
 
 
 def test_device_chip_query_without_a_device_is_an_error_not_a_default():
