@@ -1,7 +1,8 @@
 #!/bin/bash
-mkdir -p gpurun_out/r06q
-for i in 1 2; do for v in base n3la3; do
-  if [ $v = base ]; then unset BDDMMA_LIB; else export BDDMMA_LIB=build/lib$v.so; fi
-  echo "[$v] $(timeout 300 python tools/kbench.py --mt 1 --precision double --iters 1000 2>&1 | tail -1)"
-done; done > gpurun_out/r06q/la3.txt 2>&1
-cat gpurun_out/r06q/la3.txt
+# round 6: does the one-round boundary show in the third-generation sweeps (k = 10, double: 4 workgroups of 4 packs per CU = 1 024 workgroups = 4 096 packs = V 524 k)?
+mkdir -p gpurun_out/r06z
+for v in 400000 440000 480000 500000 520000 530000 540000 560000 600000 700000 800000; do
+  for prec in double float; do
+    echo "V=$v $prec: $(timeout 300 python tools/kbench.py --mt 1 --precision $prec --vars $v --rows $((v/2)) --iters 300 2>/dev/null | tail -2 | tr '\n' ' ' | cut -c1-200)"
+  done
+done > gpurun_out/r06z/quant.txt 2>&1
